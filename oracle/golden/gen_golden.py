@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REFERENCE shaders (container-only; needs /root/reference + kaleido).
+
+Runs oracle/golden/harness.js inside kaleido's HeadlessChrome/SwiftShader (software GL), which loads the
+reference's shader files from /root/reference at run time, and stores inputs + outputs as small ``.npz``
+fixtures under tests/golden/. Only data (arrays, uniform values) is stored -- no reference source.
+
+SwiftShader caveat: advectionShader output is corrupted for air pixels that share a
+2x2 pixel quad with a wall pixel, so every fixture here keeps wall/air boundaries on even x and even y.
+
+usage:  python oracle/golden/gen_golden.py [fixture ...]     (default: all)
+"""
+from __future__ import annotations
+
+import base64
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import wxpkg  # noqa: E402
+
+pkg = wxpkg.load_package()
+OUT_DIR = os.path.join(ROOT, "tests", "golden")
+REF_SAVE = "/root/reference/saves/100 X 100 Test.weathersandbox"
+
+
+def kaleido_exe() -> str:
+    import kaleido
+    return os.path.join(os.path.dirname(kaleido.__file__), "executable", "kaleido")
+
+
+def run_harness(job: dict, timeout: float = 600.0) -> dict:
+    """One harness run; ``job`` is passed as gd.layout.wx."""
+    req = {"data": {"data": [], "layout": {"wx": job}}, "format": "json", "width": job["X"], "height": job["Y"], "scale": 1}
+    cmd = [kaleido_exe(), "plotly", "--plotlyjs=" + os.path.join(HERE, "harness.js"), "--disable-gpu",
+           "--allow-file-access-from-files", "--disable-breakpad", "--disable-dev-shm-usage", "--no-sandbox"]
+    p = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    try:
+        p.stdin.write((json.dumps(req) + "\n").encode())
+        p.stdin.flush()
+        t0 = time.time()
+        result = None
+        while time.time() - t0 < timeout:
+            line = p.stdout.readline()
+            if not line:
+                break
+            try:
+                msg = json.loads(line.decode())
+            except Exception:
+                continue
+            if "result" in msg and msg.get("result") is not None:
+                result = msg
+                break
+            if msg.get("code", 0) != 0:
+                raise RuntimeError(f"kaleido error: {msg}")
+        if result is None:
+            raise RuntimeError("no result from kaleido")
+    finally:
+        try:
+            p.stdin.close()
+        except Exception:
+            pass
+        p.kill()
+        p.wait()
+    res = result["result"]
+    if isinstance(res, str):
+        res = json.loads(res)
+    if "error" in res:
+        raise RuntimeError("harness: " + res["error"])
+    return res
+
+
+def _dec(s: str, dtype) -> np.ndarray:
+    return np.frombuffer(base64.b64decode(s), dtype=dtype).copy()
+
+
+def js_uniforms(u: dict) -> dict:
+    o = {}
+    for k, v in u.items():
+        if k == "initial_T":
+            continue
+        o[k] = list(v) if isinstance(v, tuple) else v
+    return o
+
+
+def run_fixture(name, X, Y, base, water, wall, drops, u, *, niter, dump_iters, perpass_iter=None, precip=False,
+                iter0=0, keep=("base_cur", "water_cur", "wall_cur", "light_0", "light_1", "water_0", "base_disp")):
+    tmp = tempfile.mkdtemp(prefix="wxgold_")
+    np.ascontiguousarray(base, np.float32).tofile(os.path.join(tmp, "base.f32"))
+    np.ascontiguousarray(water, np.float32).tofile(os.path.join(tmp, "water.f32"))
+    np.ascontiguousarray(wall, np.int8).tofile(os.path.join(tmp, "wall.i8"))
+    n_drops = 0 if drops is None else len(drops)
+    if n_drops:
+        np.ascontiguousarray(drops, np.float32).tofile(os.path.join(tmp, "drops.f32"))
+    job = {
+        "X": X, "Y": Y, "n_drops": n_drops, "dir": "file://" + tmp + "/",
+        "uniforms": js_uniforms(u), "initial_T": [float(v) for v in u["initial_T"]],
+        "niter": niter, "dump_iters": list(dump_iters), "precip": bool(precip), "iter0": iter0,
+    }
+    if perpass_iter is not None:
+        job["perpass_iter"] = perpass_iter
+    probe = run_harness({"X": X, "Y": Y, "probe": True, "n_drops": 0})
+    varyings = _dec(probe["probe"], np.float32).reshape(Y, X, 4)
+    res = run_harness(job)
+    print(f"[{name}] renderer={res['renderer']!r} err={res['err']} {res['niter']} it, "
+          f"{res['ms_after_first']:.1f} ms after first -> {1000.0 * (res['niter'] - 1) / max(res['ms_after_first'], 1e-9):.1f} it/s")
+    out = {
+        "X": X, "Y": Y, "iter0": iter0, "niter": niter, "precip": int(bool(precip)),
+        "in_base": np.asarray(base, np.float32).reshape(Y, X, 4), "in_water": np.asarray(water, np.float32).reshape(Y, X, 4),
+        "in_wall": np.asarray(wall, np.int8).reshape(Y, X, 4),
+        "initial_T": np.asarray(u["initial_T"], np.float32),
+        # simShader.vert varyings (fragCoord.xy, texCoord.xy) as interpolated by the reference's rasteriser here
+        "varyings": varyings,
+        "uniforms_json": json.dumps(js_uniforms(u)),
+        "renderer": res["renderer"], "its_per_s": 1000.0 * (res["niter"] - 1) / max(res["ms_after_first"], 1e-9),
+    }
+    if n_drops:
+        out["in_drops"] = np.asarray(drops, np.float32).reshape(n_drops, 5)
+    shapes = {"curl": (Y, X), "vort": (Y, X, 2), "precip_dep": (Y, X, 2), "drops": (-1, 5), "precip_drops": (-1, 5), "lightning": (4,)}
+    for it, d in res["dumps"].items():
+        for k, v in d.items():
+            if k not in keep and k not in ("drops", "lightning", "precip_fb", "precip_dep"):
+                continue
+            dt = np.int8 if "wall" in k else np.float32
+            out[f"it{it}_{k}"] = _dec(v, dt).reshape(shapes.get(k, (Y, X, 4)))
+    for k, v in res.get("perpass", {}).items():
+        dt = np.int8 if "wall" in k else np.float32
+        out[f"pp_{k}"] = _dec(v, dt).reshape(shapes.get(k, (Y, X, 4)))
+    if "inactiveDroplets" in res:
+        out["inactiveDroplets"] = res["inactiveDroplets"]
+    os.makedirs(OUT_DIR, exist_ok=True)
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# fixtures
+# ------------------------------------------------------------------------------------------------
+def save100_quad_aligned():
+    """The reference's only save, with terrain snapped to even x/y: sea and coast thickened to rows 0-1,
+    the 20-column island raised to rows 0-3."""
+    sf = pkg.codec.load(REF_SAVE)
+    base, water, wall = sf.base.copy(), sf.water.copy(), sf.wall.copy()
+    air1 = wall[1, :, 1] != 0
+    for arr in (base, water, wall):
+        arr[1, air1] = arr[0, air1]
+    island = ~air1
+    for y in (2, 3):
+        for arr in (base, water, wall):
+            arr[y, island] = arr[1, island]
+    return sf, base, water, wall
+
+
+def fx_save100(precip: bool):
+    sf, base, water, wall = save100_quad_aligned()
+    gui = pkg.params.merge_settings(sf.settings)
+    u = pkg.params.uniforms_from_gui(gui, sf.Y)
+    name = "save100qa_precip" if precip else "save100qa"
+    if precip:  # particle state / feedback over 50 iterations; grid fields are covered by save100qa
+        return run_fixture(name, sf.X, sf.Y, base, water, wall, sf.droplets, u, niter=50, dump_iters=[1, 10, 50],
+                           precip=True, keep=("base_cur",))
+    return run_fixture(name, sf.X, sf.Y, base, water, wall, None, u,
+                       niter=50, dump_iters=[1, 10, 50], perpass_iter=0, precip=False,
+                       keep=("base_cur", "water_cur", "wall_cur", "light_0", "light_1"))
+
+
+def synth_terrain(X, Y, rng):
+    """Quad-aligned terrain with every wall type, snow, vegetation, moist warm air and cloud."""
+    gui = dict(pkg.params.GUI_DEFAULTS)
+    gui["sunAngle"] = 60.0
+    u = pkg.params.uniforms_from_gui(gui, Y)
+    T0 = u["initial_T"]
+    base = np.zeros((Y, X, 4), np.float32)
+    water = np.zeros((Y, X, 4), np.float32)
+    wall = np.zeros((Y, X, 4), np.int8)
+    height = np.full(X, 2)
+    height[8:20] = 4
+    height[12:16] = 8
+    height[28:40] = 2
+    height[40:44] = 6
+    types = np.full(X, 2)  # sea
+    types[6:24] = 1  # land island with hill
+    types[28:34] = 4  # urban
+    types[34:40] = 6  # industrial
+    types[40:44] = 1
+    types[44:48] = 3  # fire
+    types[48:52] = 5  # runway
+    types[52:56] = 0  # inert
+    for x in range(X):
+        h = height[x]
+        wall[:h, x, 0] = types[x]
+        wall[:h, x, 1] = 0
+        wall[:h, x, 2] = np.arange(-(h - 1), 1)
+        wall[:h, x, 3] = {1: 60 + (x % 7) * 9, 3: 90, 4: 40, 6: 10}.get(int(types[x]), 0)
+        wall[h:, x, 0] = types[x]
+        wall[h:, x, 1] = np.minimum(np.arange(1, Y - h + 1), 127)
+        wall[h:, x, 2] = np.minimum(np.arange(1, Y - h + 1), 127)
+        if types[x] == 2:
+            base[:h, x, 3] = 298.15 + 0.05 * (x % 5)
+            water[:h, x, 0] = 1002.0
+            water[:h, x, 2] = 100.0
+        else:
+            base[:h, x, 3] = 1000.0
+            water[:h, x, 0] = 1001.0
+            water[:h, x, 2] = 5.0 + (x % 11) * 3.0  # soil moisture
+            water[:h, x, 3] = 12.0 if 12 <= x < 16 else 0.0  # snow on the hill
+    yy = np.arange(Y)[:, None]
+    air = wall[..., 1] != 0
+    base[..., 3] = np.where(air, T0[:Y][:, None] + rng.normal(0, 0.3, (Y, X)).astype(np.float32) + 2.0 * np.exp(-((yy - 10) / 6.0) ** 2), base[..., 3])
+    base[..., 0] = np.where(air, rng.normal(0, 0.02, (Y, X)), 0).astype(np.float32)
+    base[..., 1] = np.where(air, rng.normal(0, 0.02, (Y, X)), 0).astype(np.float32)
+    base[..., 2] = np.where(air, rng.normal(0, 0.002, (Y, X)), base[..., 2]).astype(np.float32)
+    realT = base[..., 3] - ((yy + 0.5) / Y) * u["dryLapse"]
+    maxw = (realT / 250.0) ** 17
+    tot = maxw * (0.7 + 0.5 * rng.random((Y, X)))
+    water[..., 0] = np.where(air, tot, water[..., 0]).astype(np.float32)
+    water[..., 1] = np.where(air, np.maximum(tot - maxw, 0), water[..., 1]).astype(np.float32)
+    water[..., 2] = np.where(air, 0.05 * rng.random((Y, X)), water[..., 2]).astype(np.float32)
+    water[..., 3] = np.where(air, 0.3 * rng.random((Y, X)) * (yy < 14), water[..., 3]).astype(np.float32)
+    water[4:6, 44:48, 3] = 5.0  # flames above the fire cells
+    return gui, u, base, water, wall
+
+
+def fx_synth64():
+    rng = np.random.default_rng(1234)
+    X, Y = 64, 48
+    gui, u, base, water, wall = synth_terrain(X, Y, rng)
+    # iterations 95..104: crosses iterNum%100==0 (soil smoothing, vegetation, fire spread) and %20==0 (sea T)
+    return run_fixture("synth64", X, Y, base, water, wall, None, u, niter=10, dump_iters=[1, 5, 6, 10],
+                       perpass_iter=5, precip=False, iter0=95,
+                       keep=("base_cur", "water_cur", "wall_cur", "light_0", "light_1", "water_0"))
+
+
+def fx_precip64():
+    """Particle pass: hand-built droplet set over a cloudy field (spawn / grow / freeze / melt / deposit)."""
+    rng = np.random.default_rng(99)
+    X, Y = 64, 48
+    gui, u, base, water, wall = synth_terrain(X, Y, rng)
+    yy = np.arange(Y)[:, None]
+    air = wall[..., 1] != 0
+    # dense cloud deck (warm below, cold above) so inactive droplets do spawn
+    deck = air & (yy >= 14) & (yy < 40)
+    water[..., 1] = np.where(deck, 1.2 + 2.5 * rng.random((Y, X)), water[..., 1]).astype(np.float32)
+    water[..., 0] = np.where(deck, water[..., 0] + water[..., 1], water[..., 0]).astype(np.float32)
+    u["spawnChanceMult"] = 0.02
+    u["enablePrecipitation"] = 1
+    n = 256
+    drops = np.zeros((n, 5), np.float32)
+    drops[:, 0] = rng.random(n)
+    drops[:, 1] = rng.random(n)
+    drops[:, 2] = -10.0 + rng.random(n)
+    drops[:, 3] = rng.random(n)
+    drops[:, 4] = rng.random(n)
+    k = 96  # active ones
+    drops[:k, 0] = rng.uniform(-0.98, 0.98, k)
+    drops[:k, 1] = rng.uniform(-0.9, 0.9, k)
+    drops[:k, 2] = rng.uniform(0.0, 0.6, k)  # water
+    drops[:k, 3] = np.where(rng.random(k) < 0.5, rng.uniform(0.0, 0.8, k), 0.0)  # ice
+    drops[:k, 4] = np.where(drops[:k, 3] > 0, rng.uniform(0.2, 1.0, k), 1.0)
+    drops[:8, 2] = 0.01  # too small -> evaporate
+    drops[:8, 3] = 0.01
+    drops[8:16, 1] = -0.97  # inside the ground -> deposit
+    drops[16:20, 1] = -0.999
+    return run_fixture("precip64", X, Y, base, water, wall, drops, u, niter=4, dump_iters=[1, 2, 4],
+                       perpass_iter=0, precip=True,
+                       keep=("base_cur", "water_cur", "wall_cur", "light_0", "light_1"))
+
+
+FIXTURES = {
+    "save100qa": lambda: fx_save100(False),
+    "save100qa_precip": lambda: fx_save100(True),
+    "synth64": fx_synth64,
+    "precip64": fx_precip64,
+}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(FIXTURES)
+    for nm in names:
+        FIXTURES[nm]()

