@@ -1,0 +1,167 @@
+/*
+ * wxsim.h -- C ABI of the MI355X-native simulation engine (libwxsim.so).
+ *
+ * Drop-in boundary for the reference's "simulation step + field readback" seam
+ * (niels747/2D-Weather-Sandbox has no FFI/plugin API: the seam is draw()'s simulation block and the
+ * gl.readPixels / gl.getBufferSubData call sites, all talking to module-scope WebGL objects).
+ * Every entry point cites the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * WX_E_* code, the message is available from wx_last_error(); no exceptions cross the ABI.
+ * One caller thread per handle (the reference is single-threaded JS issuing an in-order GL command
+ * stream). All grids are row-major with y = 0 at the BOTTOM, x fastest, 4 interleaved channels per
+ * cell -- byte-identical to the reference's textures, readPixels results and save files
+ * (app.js:1297-1312, 6586-6593).
+ */
+#ifndef WXSIM_H
+#define WXSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WX_ABI_VERSION 1
+
+/* error codes */
+#define WX_OK 0
+#define WX_E_INVALID (-1)   /* bad argument */
+#define WX_E_DEVICE (-2)    /* HIP runtime error (message in wx_last_error) */
+#define WX_E_NOMEM (-3)
+#define WX_E_RANGE (-4)     /* rectangle / particle range outside the grid (no wrap, as readPixels) */
+#define WX_E_STATE (-5)     /* call sequence error (e.g. step before upload) */
+
+/* Uniform values of the simulation programs (what gl.uniform* pushes):
+ *   velocityShader.frag:14-16, boundaryShader.frag:22-38, advectionShader.frag:21-43,
+ *   lightingShader.frag:22-29, precipitationShader.vert:31-48; host side app.js:3401-3443
+ *   (setGuiUniforms), app.js:5479-5635 (constants), app.js:6557-6561 (sun), app.js:5804-5808 (brush),
+ *   app.js:3335 (airplane). All values are fp32 exactly as the GL uniform would hold them. */
+typedef struct wx_params {
+  float dragMultiplier, wind;
+  float vorticity, landEvaporation, waterEvaporation, dynamicWaterTemperature;
+  float evapHeat, waterWeight;
+  float sunAngle;  /* solar zenith angle, rad (app.js:6538-6539) */
+  float dryLapse;  /* simHeight * dryLapseRate / 1000 (app.js:5439) */
+  float meltingHeat, condensationRate, globalDrying, globalHeating, soundingForcing;
+  float globalEffectsStartAlt, globalEffectsEndAlt; /* normalised by simHeight (app.js:3425-3426) */
+  float waterTemperature;                           /* K (app.js:3427) */
+  float sunIntensity;                               /* W/m2 (app.js:6550) */
+  float greenhouseGases, waterGreenHouseEffect, IR_rate;
+  float aboveZeroThreshold, subZeroThreshold, spawnChanceMult, snowDensity, fallSpeed;
+  float growthRate0C, growthRate_30C, freezingRate, meltingRate, evapRate;
+  float inactiveDroplets; /* < 0: keep the engine's own measured value (app.js:5957-5966) */
+  float userInputValues[4]; /* xpos ypos intensity brushSize (advectionShader.frag:21) */
+  float userInputMove[2];
+  int32_t userInputType;    /* -1 none (app.js:5749) */
+  int32_t wrapHorizontally;
+  float airplaneValues[4];
+  int32_t enablePrecipitation; /* guiControls.enablePrecipitation (app.js:5936) */
+  int32_t quad_scale;          /* 0: fragCoord = (x+.5, y+.5) exactly (the reference author's intent,
+                                  app.js:4766-4769); 1: model the *1.0000001 quad UV scale */
+  uint32_t pass_mask;          /* WX_PASS_* bits; WX_PASS_ALL = the reference loop */
+} wx_params;
+
+#define WX_PASS_VELOCITY 1u
+#define WX_PASS_VORTICITY 2u   /* curl + vorticity */
+#define WX_PASS_BOUNDARY 4u
+#define WX_PASS_ADVECTION 8u
+#define WX_PASS_PRESSURE 16u
+#define WX_PASS_LIGHTING 32u
+#define WX_PASS_PRECIPITATION 64u
+#define WX_PASS_ALL 0x7Fu
+#define WX_PASS_DRY (WX_PASS_VELOCITY | WX_PASS_ADVECTION | WX_PASS_PRESSURE)
+
+/* Fields for wx_read_rect / wx_device_ptr. "FB0"/"FB1" are the reference's frameBuff_0 / frameBuff_1
+ * (app.js:5243-5252); which one a consumer reads is listed in SURVEY.md section 3.5. */
+enum {
+  WX_FIELD_BASE_CUR = 0,   /* baseTexture_0: post-pressure state (FB0; weather stations, save) */
+  WX_FIELD_BASE_DISP = 1,  /* baseTexture_1: post-advection, pre-pressure (FB1; display, sounding) */
+  WX_FIELD_WATER_0 = 2,    /* waterTexture_0: post-boundary (what a save stores, app.js:6587-6589) */
+  WX_FIELD_WATER_CUR = 3,  /* waterTexture_1: post-advection (current) */
+  WX_FIELD_WALL_CUR = 4,   /* wallTexture_0 */
+  WX_FIELD_WALL_DISP = 5,  /* wallTexture_1 */
+  WX_FIELD_LIGHT_0 = 6,    /* lightTexture_0 (the one boundaryShader samples, app.js:5868-5869) */
+  WX_FIELD_LIGHT_1 = 7,
+  WX_FIELD_CURL = 8,       /* R32F */
+  WX_FIELD_VORT = 9,       /* RG32F vortForce */
+  WX_FIELD_PRECIP_FB = 10, /* RGBA32F precipitationFeedbackTexture */
+  WX_FIELD_PRECIP_DEP = 11,/* RG32F precipitationDepositionTexture */
+  WX_FIELD_LIGHTNING = 12, /* 1x1 RGBA32F lightningDataTexture */
+  WX_FIELD_COUNT = 13
+};
+
+/* destination element types of wx_read_rect */
+enum { WX_DTYPE_F32 = 0, WX_DTYPE_I8 = 1, WX_DTYPE_I32 = 2 };
+
+typedef struct wx_sim wx_sim;
+
+/* Replaces texture/FBO creation app.js:5149-5317 and particle buffers app.js:4891-5002.
+ * Allocates both ping-pong copies of every field on the current HIP device. */
+int wx_create(int X, int Y, int n_droplets, wx_sim **out);
+
+/* Column-slab variant (no reference counterpart: the reference is single-GPU). The handle owns columns
+ * [x0, x0 + X_owned) of a periodic domain X_global wide and stores `halo` ghost columns on each side
+ * (local width X_owned + 2*halo; local column i is global column (x0 - halo + i) mod X_global). */
+int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_droplets, wx_sim **out);
+
+void wx_destroy(wx_sim *s);
+const char *wx_last_error(const wx_sim *s); /* also valid with s == NULL for create failures */
+int wx_abi_version(void);
+
+/* Replaces setupTextures() app.js:5189-5234 (the same data goes into BOTH _0 and _1) and
+ * setupPrecipitationBuffers() app.js:4915-5002. Host arrays are copied; the caller keeps ownership.
+ * Resets even=true, light/curl/vort/feedback/lightning = 0; iterNum is NOT reset (the reference keeps
+ * it across KeyL reloads, app.js:4628-4640). Arrays cover the handle's LOCAL width. drops may be NULL. */
+int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wall, const float *drops);
+
+/* Replaces the uniform pushes (see wx_params) plus the `initial_Tv` / realWorldSounding_* arrays
+ * (app.js:5444-5474, 5485-5537). initial_T has Y+1 entries; sounding arrays Y+1 entries or NULL (= 0).
+ * Takes effect at the next wx_step. */
+int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const float *sounding_T,
+                  const float *sounding_W, const float *sounding_Vel);
+
+/* Replaces the loop body app.js:5830-6005: n_iter iterations, enqueued asynchronously on the handle's
+ * stream; iterNum++ per iteration; the 600-iteration inactive-droplet count (app.js:5957-5966) is
+ * refreshed on the device without a host round trip. */
+int wx_step(wx_sim *s, int n_iter);
+int wx_sync(wx_sim *s);
+
+/* iterNum global (app.js:440) */
+int64_t wx_get_iter(const wx_sim *s);
+int wx_set_iter(wx_sim *s, int64_t iter);
+
+/* Replaces every gl.readPixels of SURVEY.md section 3.5 (app.js:1084-1092, 3931-3943, 3020-3065,
+ * 1840-1906, 4215-4237, 4347-4357, 5958-5961, 5986-5988, 6584-6593). Rows bottom-up, no wrap
+ * (WX_E_RANGE outside the local grid); float fields accept WX_DTYPE_F32, wall fields WX_DTYPE_I8 or
+ * WX_DTYPE_I32 (both are used by the reference: app.js:6593 vs 3943). Synchronises the stream. */
+int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, int dtype);
+
+/* Replaces gl.getBufferSubData on the transform-feedback buffers (app.js:5019, 5086, 6597):
+ * 5 floats per droplet (pos.xy, mass.xy, density) from the destination buffer of the last step. */
+int wx_read_particles(wx_sim *s, int first, int count, float *dst);
+
+/* ---- plumbing for hosts that own device memory / streams (PyTorch, multi-GPU halo exchange) ---- */
+int wx_set_stream(wx_sim *s, void *hip_stream);     /* NULL = legacy default stream */
+void *wx_device_ptr(wx_sim *s, int field);          /* device address of a field's current storage */
+int wx_local_width(const wx_sim *s);                /* X_owned + 2*halo */
+/* Halo exchange of the state carried across iterations (base_0, wall_0, water_1, both light textures):
+ * pack the `halo` outermost OWNED columns of one side into a contiguous device buffer / unpack a
+ * neighbour's buffer into this handle's ghost columns. side: 0 = left (low x), 1 = right. */
+size_t wx_halo_bytes(const wx_sim *s);
+int wx_halo_pack(wx_sim *s, int side, void *dev_buf);
+int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf);
+
+/* Per-kernel device time from HIP events recorded on the handle's stream around every launch.
+ * wx_profile(s, 1) starts collecting, wx_profile_read returns accumulated milliseconds and launch counts
+ * for up to `cap` kernels (names via wx_kernel_name) and resets the accumulators. */
+int wx_profile(wx_sim *s, int enable);
+int wx_profile_read(wx_sim *s, int cap, float *ms, int *launches);
+int wx_kernel_count(void);
+const char *wx_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WXSIM_H */

@@ -14,7 +14,7 @@
  *   - integer modulo by zero (boundaryShader.frag:462 when vegetationGrowthRate > 100) -> condition false
  *   - sounding index y-1 < 0 (advectionShader.frag:59-61, row 0) -> clamped to 0
  *   - sin/cos of the uniform sunAngle are evaluated once on the host (sinf/cosf) per pass
- *   - pow(x, 2.0) in precipitationShader.vert:109 evaluated as x*x
+ *   - pow(x, c) with constant c in {17, 4, 2, 0.5}: fixed multiply chains / sqrt (see pow17, pow4)
  *   - unassigned IR_up (lightingShader.frag:90, air above an INERT wall) = 0
  *   - additive particle splats are summed in droplet-index order
  */
@@ -129,10 +129,23 @@ static inline float map_rangeC(float v, float min1, float max1, float min2, floa
 }
 static inline float CtoK(float c) { return c + 273.15f; }
 static inline float KtoC(float k) { return k - 273.15f; }
-/* common.glsl:177-180 */
-static inline float maxWater(float T) { return powf(T / 250.0f, 17.0f); }
-/* common.glsl:258-261 */
-static inline float IR_emitted(float T) { return powf(T * 0.01f, 4.0f) * 5.670374419f; }
+/* pow() with the constant exponents the grid passes use. GLSL pow is not correctly rounded on any GPU
+ * (SURVEY Appendix A), so its value is only defined to a few ulp; the restatement fixes ONE evaluation
+ * order built from exactly-rounded fp32 multiplies / sqrt, which CPU and GPU reproduce bit for bit. */
+static inline float pow17(float x)
+{
+  const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
+  return x16 * x;
+}
+static inline float pow4(float x)
+{
+  const float x2 = x * x;
+  return x2 * x2;
+}
+/* common.glsl:177-180: pow(T / 250.0, 17.0) */
+static inline float maxWater(float T) { return pow17(T / 250.0f); }
+/* common.glsl:258-261: pow(T * 0.01, 4.) * IR_constant */
+static inline float IR_emitted(float T) { return pow4(T * 0.01f) * 5.670374419f; }
 
 /* common.glsl:103-111 */
 uint32_t wxo_hash(uint32_t x)
@@ -1021,7 +1034,7 @@ void wxo_lighting(const wxo_params *p, const float *base_in, const float *water_
         float net_heating = 0.0f;
         if (fy < resY - 2.0f) {
           float reflection =
-            fminf(powf(water[CLOUD] * 0.0010f + water[PRECIPITATION] * 0.00020f, 0.5f) * cellHeightCompensation, 1.0f);
+            fminf(sqrtf(water[CLOUD] * 0.0010f + water[PRECIPITATION] * 0.00020f) * cellHeightCompensation, 1.0f); /* pow(x, 0.5) */
           reflection += 0.0002f;
           const float absorbtion = fminf(water[SMOKE] * 0.020f * cellHeightCompensation, 1.0f);
           const float lightReflected = sunlight * reflection;
