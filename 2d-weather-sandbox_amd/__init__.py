@@ -1,9 +1,10 @@
 """MI355X-native engine for the 2D-Weather-Sandbox simulation iteration (hot path only).
 
 The directory name (``2d-weather-sandbox_amd``) is not a Python identifier; import it through
-``__graft_entry__.load_package()`` (or ``tests/conftest.py``), which registers it as
+``wxpkg.load_package()`` (tests/conftest.py, __graft_entry__.py, bench.py do), which registers it as
 ``weather_sandbox_amd``.
 """
-from . import codec, params  # noqa: F401
+from . import codec, engine, params, sim, synth  # noqa: F401
+from .sim import WeatherSim  # noqa: F401
 
-__all__ = ["codec", "params"]
+__all__ = ["codec", "engine", "params", "sim", "synth", "WeatherSim"]

@@ -1,0 +1,469 @@
+// wx_kernels.h -- per-pass HIP kernels (one launch per reference draw call) and utility kernels.
+//
+// These are the parity baseline: each kernel is one reference pass with one thread per cell, coalesced
+// float4 / char4 traffic and neighbour reads served by L1/L2. The fused LDS-tiled kernels in
+// wx_fused.h compute exactly the same per-cell arithmetic (wx_cells.h) with less HBM traffic.
+#pragma once
+#include "wx_cells.h"
+
+namespace wx {
+
+constexpr int BX = 64; // one wavefront per row segment: 64 lanes x 16 B = 1 KiB coalesced
+constexpr int BY = 4;
+
+struct GridPtrs {
+  const float4 *base, *water;
+  const char4 *wall;
+  const float2 *vort;
+  const float4 *light;
+  const float4 *fb;
+  const float2 *dep;
+};
+
+__device__ __forceinline__ size_t cidx(int x, int y, int X) { return (size_t)y * X + x; }
+
+// ---- velocity: base_0, wall_0 -> base_1, wall_1 (app.js:5832-5839) ----
+__global__ __launch_bounds__(BX *BY) void k_velocity(Geo g, Uni u, const float4 *__restrict__ base_in, const char4 *__restrict__ wall_in,
+                                                      float4 *__restrict__ base_out, char4 *__restrict__ wall_out)
+{
+  const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+  if (x >= g.X || y >= g.Y) return;
+  const int xr = (x + 1 == g.X) ? 0 : x + 1, yu = (y + 1 == g.Y) ? 0 : y + 1;
+  const float4 b = base_in[cidx(x, y, g.X)];
+  const char4 w = wall_in[cidx(x, y, g.X)];
+  const float Pr = base_in[cidx(xr, y, g.X)].z, Pu = base_in[cidx(x, yu, g.X)].z;
+  base_out[cidx(x, y, g.X)] = velocity_cell(u, b, Pr, Pu, w.y);
+  wall_out[cidx(x, y, g.X)] = w;
+}
+
+// ---- curl (app.js:5842-5847) ----
+__global__ __launch_bounds__(BX *BY) void k_curl(Geo g, const float4 *__restrict__ base_in, float *__restrict__ curl_out)
+{
+  const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+  if (x >= g.X || y >= g.Y) return;
+  const int xr = (x + 1 == g.X) ? 0 : x + 1, yu = (y + 1 == g.Y) ? 0 : y + 1;
+  const float4 c = base_in[cidx(x, y, g.X)];
+  curl_out[cidx(x, y, g.X)] = curl_cell(c.x, c.y, base_in[cidx(xr, y, g.X)].y, base_in[cidx(x, yu, g.X)].x);
+}
+
+// ---- vorticity (app.js:5850-5855) ----
+__global__ __launch_bounds__(BX *BY) void k_vorticity(Geo g, const float *__restrict__ curl_in, float2 *__restrict__ vort_out)
+{
+  const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+  if (x >= g.X || y >= g.Y) return;
+  const int xr = (x + 1 == g.X) ? 0 : x + 1, yu = (y + 1 == g.Y) ? 0 : y + 1;
+  const int xl = (x == 0) ? g.X - 1 : x - 1, yd = (y == 0) ? g.Y - 1 : y - 1;
+  vort_out[cidx(x, y, g.X)] = vorticity_cell(curl_in[cidx(x, y, g.X)], curl_in[cidx(xl, y, g.X)], curl_in[cidx(xr, y, g.X)],
+                                             curl_in[cidx(x, yd, g.X)], curl_in[cidx(x, yu, g.X)]);
+}
+
+// ---- boundary (app.js:5858-5878) ----
+struct GBoundaryAcc {
+  GridPtrs p;
+  int X, Y, x, y;
+  __device__ __forceinline__ size_t at(int dx, int dy) const { return cidx(wrapi(x + dx, X), wrapi(y + dy, Y), X); }
+  __device__ __forceinline__ float4 base(int dx, int dy) const { return p.base[at(dx, dy)]; }
+  __device__ __forceinline__ float4 water(int dx, int dy) const { return p.water[at(dx, dy)]; }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return p.wall[at(dx, dy)]; }
+  __device__ __forceinline__ float2 vort(int dx, int dy) const { return p.vort[at(dx, dy)]; }
+  __device__ __forceinline__ float4 light(int dy) const
+  {
+    int yy = y + dy;
+    yy = yy < 0 ? 0 : (yy > Y - 1 ? Y - 1 : yy);
+    return p.light[cidx(x, yy, X)];
+  }
+  __device__ __forceinline__ float4 fb() const { return p.fb ? p.fb[cidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ float2 dep() const { return p.dep ? p.dep[cidx(x, y, X)] : make_float2(0.f, 0.f); }
+};
+
+__global__ __launch_bounds__(BX *BY) void k_boundary(Geo g, Uni u, const float *__restrict__ initial_T, GridPtrs in, float4 *__restrict__ base_out,
+                                                      float4 *__restrict__ water_out, char4 *__restrict__ wall_out)
+{
+  const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+  if (x >= g.X || y >= g.Y) return;
+  GBoundaryAcc a{in, g.X, g.Y, x, y};
+  float4 b, w;
+  char4 wl;
+  boundary_cell(u, g, initial_T, x, y, a, b, w, wl);
+  const size_t i = cidx(x, y, g.X);
+  base_out[i] = b;
+  water_out[i] = w;
+  wall_out[i] = wl;
+}
+
+// ---- advection (app.js:5881-5890) ----
+struct GAdvectAcc {
+  GridPtrs p;
+  int X, Y, x, y;
+  __device__ __forceinline__ size_t at(int dx, int dy) const { return cidx(wrapi(x + dx, X), wrapi(y + dy, Y), X); }
+  __device__ __forceinline__ size_t at_off(int dx, int dy) const { return cidx(wrapmod(x + dx, X), wrapmod(y + dy, Y), X); }
+  __device__ __forceinline__ float4 base(int dx, int dy) const { return p.base[at(dx, dy)]; }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return p.wall[at(dx, dy)]; }
+  __device__ __forceinline__ float4 base_off(int dx, int dy) const { return p.base[at_off(dx, dy)]; }
+  __device__ __forceinline__ float4 water_off(int dx, int dy) const { return p.water[at_off(dx, dy)]; }
+  __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return p.wall[at_off(dx, dy)]; }
+};
+
+__global__ __launch_bounds__(BX *BY) void k_advection(Geo g, Uni u, const float *__restrict__ initial_T, const float *__restrict__ snd_T,
+                                                       const float *__restrict__ snd_W, const float *__restrict__ snd_Vel, GridPtrs in,
+                                                       float4 *__restrict__ base_out, float4 *__restrict__ water_out, char4 *__restrict__ wall_out)
+{
+  const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+  if (x >= g.X || y >= g.Y) return;
+  GAdvectAcc a{in, g.X, g.Y, x, y};
+  float4 b, w;
+  char4 wl;
+  advection_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, x, y, a, b, w, wl);
+  const size_t i = cidx(x, y, g.X);
+  base_out[i] = b;
+  water_out[i] = w;
+  wall_out[i] = wl;
+}
+
+// ---- pressure (app.js:5893-5900) ----
+__global__ __launch_bounds__(BX *BY) void k_pressure(Geo g, const float4 *__restrict__ base_in, const char4 *__restrict__ wall_in,
+                                                      float4 *__restrict__ base_out, char4 *__restrict__ wall_out)
+{
+  const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+  if (x >= g.X || y >= g.Y) return;
+  const int xl = (x == 0) ? g.X - 1 : x - 1, yd = (y == 0) ? g.Y - 1 : y - 1;
+  const float4 b = base_in[cidx(x, y, g.X)];
+  const float4 bd = base_in[cidx(x, yd, g.X)];
+  const char4 wd = wall_in[cidx(x, yd, g.X)];
+  base_out[cidx(x, y, g.X)] = pressure_cell(b, base_in[cidx(xl, y, g.X)].x, bd.y, bd.w, wd.x, wd.y);
+  wall_out[cidx(x, y, g.X)] = wall_in[cidx(x, y, g.X)];
+}
+
+// ---- lighting (app.js:5903-5930) ----
+struct GLightAcc {
+  const float4 *base_, *water_;
+  const char4 *wall_;
+  const float4 *light_;
+  int X, Y, x, y;
+  __device__ __forceinline__ float T(int dy) const { return base_[cidx(x, wrapi(y + dy, Y), X)].w; }
+  __device__ __forceinline__ float4 water() const { return water_[cidx(x, y, X)]; }
+  __device__ __forceinline__ char4 wall() const { return wall_[cidx(x, y, X)]; }
+  __device__ __forceinline__ float4 light_at(int dx, int j) const { return light_[cidx(wrapmod(x + dx, X), j, X)]; }
+};
+
+__global__ __launch_bounds__(BX *BY) void k_lighting(Geo g, Uni u, const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
+                                                      const char4 *__restrict__ wall_in, const float4 *__restrict__ light_in,
+                                                      float4 *__restrict__ light_out)
+{
+  const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+  if (x >= g.X || y >= g.Y) return;
+  GLightAcc a{base_in, water_in, wall_in, light_in, g.X, g.Y, x, y};
+  light_out[cidx(x, y, g.X)] = lighting_cell(u, g, x, y, a);
+}
+
+// ---- pass-through copies for masked-off passes (pass_mask) ----
+__global__ void k_copy16(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void k_copy4(const char4 *__restrict__ src, char4 *__restrict__ dst, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Particles: precipitationShader.vert:66-293 + point rasterisation with ONE,ONE blending
+// (app.js:5940-5953). One thread per droplet; splats are fp32 atomic adds (order-nondeterministic,
+// exactly like the reference's blend unit). Whole-domain handles only.
+// ------------------------------------------------------------------------------------------------
+struct DevState {
+  float inactiveDroplets; // the `inactiveDroplets` uniform, refreshed on the device every 600 iterations
+  float lightning[4];     // lightningDataTexture (1x1 RGBA32F)
+};
+
+// common.glsl:103-111
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x)
+{
+  x += (x << 10u);
+  x ^= (x >> 6u);
+  x += (x << 3u);
+  x ^= (x >> 11u);
+  x += (x << 15u);
+  return x;
+}
+// common.glsl:126-137
+__device__ __forceinline__ float random2d(float sx, float sy)
+{
+  uint32_t h = hash_u32(__float_as_uint(sx) + hash_u32(__float_as_uint(sy)));
+  h &= 0x007FFFFFu;
+  h |= 0x3F800000u;
+  const float r2 = __uint_as_float(h);
+  return r2 - 1.0f * floorf(r2 / 1.0f);
+}
+// pow(x, 1./3.) for x > 0 as a fixed sequence of exactly-rounded operations (bit-reproducible CPU/GPU):
+// bit-level seed + 4 Newton steps.
+__device__ __forceinline__ float det_cbrt(float x)
+{
+  float y = __uint_as_float(__float_as_uint(x) / 3u + 709921077u);
+#pragma unroll
+  for (int i = 0; i < 4; i++) y = (2.0f * y + x / (y * y)) / 3.0f;
+  return y;
+}
+
+__device__ __forceinline__ size_t texel(int X, int Y, float u_, float v_)
+{
+  const int ix = wrapmod((int)floorf(u_ * (float)X), X);
+  const int iy = wrapmod((int)floorf(v_ * (float)Y), Y);
+  return cidx(ix, iy, X);
+}
+
+__device__ __forceinline__ void atomic_add_f(float *p, float v)
+{
+  if (v != 0.0f) unsafeAtomicAdd(p, v);
+}
+
+__global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops, const float *__restrict__ drops_in,
+                                                        const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
+                                                        const DevState *__restrict__ st, float *__restrict__ drops_out, float4 *fb, float2 *dep)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n_drops;
+  const int X = g.X, Y = g.Y;
+  const float resX = (float)X, resY = (float)Y;
+  const float initalMass = 0.15f;
+  bool count_inactive = false;
+
+  float feedback[4] = {0.f, 0.f, 0.f, 0.f}, deposition[2] = {0.f, 0.f};
+  float size = 1.0f, gposx = -2.0f, gposy = -2.0f; // default: clipped
+
+  if (live) {
+    const float dpx = drops_in[5 * (size_t)i], dpy = drops_in[5 * (size_t)i + 1];
+    const float m0 = drops_in[5 * (size_t)i + 2], m1 = drops_in[5 * (size_t)i + 3];
+    const float density = drops_in[5 * (size_t)i + 4];
+    float newPosx = dpx, newPosy = dpy, newM0 = m0, newM1 = m1, newDensity = density;
+    bool isActive = true, spawned = false, lightningSpawned = false;
+    float tcx = 0.f, tcy = 0.f, realTemp = 0.f;
+    float4 base = make_float4(0.f, 0.f, 0.f, 0.f), water = base;
+
+    if (m0 < 0.0f) { // inactive :72-162
+      tcx = random2d(m0, dpx + u.iterNum * 0.3754f);
+      tcy = random2d(m1, dpx + u.iterNum * 0.073162f);
+      const size_t t = texel(X, Y, tcx, tcy);
+      base = base_in[t];
+      water = water_in[t];
+      realTemp = base.w - tcy * u.dryLapse;
+      const float threshold = (realTemp > CtoK(0.0f)) ? u.aboveZeroThreshold : u.subZeroThreshold;
+      if (water.y > threshold && base.w < 500.0f) {
+        const float spawnChance = ((water.y - threshold) / (st->inactiveDroplets + 10.0f)) * resX * resY * u.spawnChanceMult;
+        const float c10 = water.y * 10.0f;
+        const float pw = c10 * c10; // pow(x, 2.0)
+        const float nrmRand = pw - floorf(pw);
+        if (spawnChance > nrmRand) {
+          spawned = true;
+          newPosx = (tcx - 0.5f) * 2.0f;
+          newPosy = (tcy - 0.5f) * 2.0f;
+          if (realTemp < CtoK(0.0f)) {
+            newM0 = 0.0f;
+            newM1 = initalMass;
+            feedback[1] += newM1 * u.meltingHeat;
+            newDensity = u.snowDensity;
+            const float cloudPlusPrecipDensity = water.y + water.z;
+            const float lightningSpawnChance = fmaxf((cloudPlusPrecipDensity - 2.5f) * 0.0033f, 0.0f);
+            if (st->lightning[2] < u.iterNum - 30.0f && random2d(base.w * 0.2324f, water.x * 7.7f) < lightningSpawnChance) {
+              lightningSpawned = true;
+              isActive = false;
+              size = 1.0f;
+              feedback[0] = tcx;
+              feedback[1] = tcy;
+              feedback[2] = u.iterNum;
+              feedback[3] = clampf(cloudPlusPrecipDensity / 10.0f + (random2d(tcx, tcy) - 0.5f), 0.01f, 4.0f);
+              gposx = -1.0f + g.texX * 3.0f;
+              gposy = -1.0f + g.texY;
+            }
+          } else {
+            newM0 = initalMass;
+            newM1 = 0.0f;
+            newDensity = 1.0f;
+          }
+          feedback[2] -= initalMass;
+        }
+      }
+      if (spawned) {
+        if (!lightningSpawned) {
+          size = 1.0f;
+          gposx = newPosx;
+          gposy = newPosy;
+        }
+      } else {
+        isActive = false;
+        count_inactive = true; // feedback[MASS] = 1 into texel (0,0): wave-aggregated below
+      }
+    }
+
+    if (isActive) { // :164-288
+      if (!spawned) {
+        tcx = dpx / 2.0f + 0.5f;
+        tcy = dpy / 2.0f + 0.5f;
+        const size_t t = texel(X, Y, tcx, tcy);
+        water = water_in[t];
+        base = base_in[t];
+        realTemp = base.w - tcy * u.dryLapse;
+      }
+      const float totalMass = newM0 + newM1;
+      if (totalMass < 0.04f) {
+        feedback[1] = -(totalMass * u.evapHeat);
+        feedback[2] = totalMass;
+        newM0 = -2.0f - dpx;
+        newM1 = dpy;
+      } else if (newPosy < -1.0f || water.x > 1000.0f) {
+        if (base_in[texel(X, Y, tcx, tcy + g.texY)].w > 500.0f) newPosy += g.texY * 1.0f;
+        deposition[0] = newM0;
+        deposition[1] = newM1;
+        newM0 = -2.0f - dpx;
+        newM1 = dpy;
+      } else {
+        const float surfaceArea = det_cbrt(totalMass);
+        const float growthRate = fmaxf(map_range(realTemp, CtoK(0.0f), CtoK(-30.0f), u.growthRate0C, u.growthRate_30C), u.growthRate0C);
+        float growth = water.y * growthRate * surfaceArea;
+        if (realTemp < CtoK(0.0f) && water.y > 0.0f && density == 1.0f) growth += surfaceArea * water.z * 0.0030f;
+        feedback[2] -= growth * 1.0f;
+        if (realTemp < CtoK(0.0f)) {
+          newM1 += growth;
+          feedback[1] += growth * u.meltingHeat;
+          const float freezing = fminf((CtoK(0.0f) - realTemp) * u.freezingRate * surfaceArea, newM0);
+          newM0 -= freezing;
+          newM1 += freezing;
+          feedback[1] += freezing * u.meltingHeat;
+        } else {
+          newM0 += growth;
+          const float melting = fminf((realTemp - CtoK(0.0f)) * u.meltingRate * surfaceArea, newM1);
+          newM1 -= melting;
+          newM0 += melting;
+          feedback[1] -= melting * u.meltingHeat;
+          newDensity = fminf(newDensity + (melting / totalMass) * 1.00f, 1.0f);
+        }
+        float dropletTemp = base.w - tcy * u.dryLapse;
+        if (newM1 > 0.0f) dropletTemp = fminf(dropletTemp, CtoK(0.0f));
+        const float evapAndSubli = fmaxf((maxWater(dropletTemp) - water.x) * surfaceArea * u.evapRate, 0.0f);
+        const float evap = fminf(newM0, evapAndSubli);
+        const float subli = fminf(newM1, evapAndSubli - evap);
+        newM0 -= evap;
+        newM1 -= subli;
+        feedback[2] += evap;
+        feedback[2] += subli;
+        feedback[1] -= evap * u.evapHeat;
+        feedback[1] -= subli * u.evapHeat;
+        feedback[1] -= subli * u.meltingHeat;
+
+        newPosx += base.x / resX * 2.0f;
+        newPosy += base.y / resY * 2.0f;
+        newPosy -= u.fallSpeed * newDensity * sqrtf(totalMass / surfaceArea);
+        {
+          const float t = newPosx + 1.0f;
+          newPosx = (t - 2.0f * floorf(t / 2.0f)) - 1.0f;
+        }
+        feedback[0] = totalMass;
+      }
+      const float pntSize = 12.0f, pntSurface = 12.0f * 12.0f;
+      feedback[0] /= pntSurface;
+      feedback[1] /= pntSurface;
+      feedback[2] /= pntSurface;
+      deposition[0] /= pntSize;
+      deposition[1] /= pntSize;
+      size = pntSize;
+      gposx = newPosx;
+      gposy = newPosy;
+    }
+
+    drops_out[5 * (size_t)i + 0] = newPosx;
+    drops_out[5 * (size_t)i + 1] = newPosy;
+    drops_out[5 * (size_t)i + 2] = newM0;
+    drops_out[5 * (size_t)i + 3] = newM1;
+    drops_out[5 * (size_t)i + 4] = fmaxf(newDensity, 0.0f);
+  }
+
+  // inactive-droplet count: the reference blends +1 into texel (0,0) per droplet
+  // (precipitationShader.vert:158-159); here one atomic per wavefront carries the lane count
+  {
+    const unsigned long long m = __ballot(count_inactive);
+    if (m != 0ull) {
+      const int lane = threadIdx.x & 63;
+      if (lane == __ffsll((long long)m) - 1) unsafeAtomicAdd(&fb[0].x, (float)__popcll(m));
+    }
+  }
+  if (!live || count_inactive) return;
+
+  // point sprite: clip test on the centre, then every pixel whose centre lies in [w - size/2, w + size/2)
+  if (!(gposx >= -1.0f && gposx <= 1.0f && gposy >= -1.0f && gposy <= 1.0f)) return;
+  const float xw = (gposx + 1.0f) * 0.5f * resX, yw = (gposy + 1.0f) * 0.5f * resY;
+  int i0, i1, j0, j1;
+  if (size <= 1.0f) {
+    i0 = i1 = (int)floorf(xw);
+    j0 = j1 = (int)floorf(yw);
+  } else {
+    const float h = size * 0.5f;
+    i0 = (int)ceilf(xw - h - 0.5f);
+    i1 = i0 + (int)size - 1;
+    j0 = (int)ceilf(yw - h - 0.5f);
+    j1 = j0 + (int)size - 1;
+  }
+  for (int j = j0; j <= j1; j++) {
+    if (j < 0 || j >= Y) continue;
+    for (int ii = i0; ii <= i1; ii++) {
+      if (ii < 0 || ii >= X) continue;
+      float *f = reinterpret_cast<float *>(fb + cidx(ii, j, X));
+      atomic_add_f(f + 0, feedback[0]);
+      atomic_add_f(f + 1, feedback[1]);
+      atomic_add_f(f + 2, feedback[2]);
+      atomic_add_f(f + 3, feedback[3]);
+      float *d = reinterpret_cast<float *>(dep + cidx(ii, j, X));
+      atomic_add_f(d + 0, deposition[0]);
+      atomic_add_f(d + 1, deposition[1]);
+    }
+  }
+}
+
+// lightningLocationShader.frag:24-38 + the 600-iteration inactive count (app.js:5957-5966), one thread
+__global__ void k_lightning(float iterNum, int refresh_inactive, const float4 *__restrict__ fb, DevState *st)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (refresh_inactive) st->inactiveDroplets = fb[0].x;
+  const float4 n = fb[1]; // texel (1,0)
+  if (n.z < fmaxf(iterNum - 1.0f, 1.0f) || n.z > iterNum) return; // discard
+  st->lightning[0] = n.x;
+  st->lightning[1] = n.y;
+  st->lightning[2] = n.z;
+  st->lightning[3] = n.w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// halo pack / unpack of the state carried across iterations (base_0, wall_0, water_1, light_0, light_1)
+// buffer layout: [base h*Y float4][water h*Y float4][light0 h*Y float4][light1 h*Y float4][wall h*Y char4]
+// ------------------------------------------------------------------------------------------------
+struct HaloPtrs {
+  float4 *base, *water, *light0, *light1;
+  char4 *wall;
+};
+__global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, int x_start, float4 *buf16, char4 *buf4)
+{
+  const int n = h * Y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int y = i / h, c = i - y * h;
+    const size_t s = cidx(x_start + c, y, X);
+    buf16[i] = f.base[s];
+    buf16[n + i] = f.water[s];
+    buf16[2 * n + i] = f.light0[s];
+    buf16[3 * n + i] = f.light1[s];
+    buf4[i] = f.wall[s];
+  }
+}
+__global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, int x_start, const float4 *buf16, const char4 *buf4)
+{
+  const int n = h * Y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int y = i / h, c = i - y * h;
+    const size_t s = cidx(x_start + c, y, X);
+    f.base[s] = buf16[i];
+    f.water[s] = buf16[n + i];
+    f.light0[s] = buf16[2 * n + i];
+    f.light1[s] = buf16[3 * n + i];
+    f.wall[s] = buf4[i];
+  }
+}
+
+} // namespace wx

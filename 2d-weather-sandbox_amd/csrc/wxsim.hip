@@ -1,0 +1,680 @@
+// wxsim.hip -- libwxsim.so: the C ABI of include/wxsim.h on top of the HIP kernels (gfx950 only).
+//
+// Host side of the hot path: texture set, ping-pong bookkeeping and per-iteration launch sequence that
+// restate the reference's draw() simulation block (app.js:5830-6005), plus the readback entry points.
+// There is NO CPU fallback: every entry point that computes needs a HIP device and fails with
+// WX_E_DEVICE otherwise.
+#include "../../include/wxsim.h"
+#include "wx_fused.h"
+#include "wx_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace wx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum KernelId {
+  K_VELOCITY = 0,
+  K_CURL,
+  K_VORTICITY,
+  K_BOUNDARY,
+  K_ADVECTION,
+  K_PRESSURE,
+  K_LIGHTING,
+  K_PRECIP,
+  K_LIGHTNING,
+  K_COPY,
+  K_HALO,
+  K_FUSED_VCVB, // velocity + curl + vorticity + boundary
+  K_FUSED_APL,  // advection + pressure + lighting
+  K_COUNT
+};
+const char *const kKernelNames[K_COUNT] = {"velocity", "curl", "vorticity", "boundary", "advection", "pressure", "lighting",
+                                           "precipitation", "lightning", "copy", "halo", "fused_vel_curl_vort_boundary",
+                                           "fused_advect_pressure_light"};
+
+struct ProfRec {
+  hipEvent_t a, b;
+  int kid;
+};
+
+} // namespace
+
+struct wx_sim {
+  int X = 0, Y = 0;      // local width (owned + 2*halo), height
+  int Xg = 0, x0 = 0;    // global width, global x of the first OWNED column
+  int halo = 0, n_drops = 0;
+  bool uploaded = false, have_params = false;
+  int even = 1;          // app.js `even`
+  int drop_cur = 0;      // particle buffer holding the latest state
+  int64_t iter = 0;
+  int fused = 0;         // 1: fused LDS-tiled kernels (env WX_FUSED overrides); 0: one kernel per reference pass
+  wx_params p{};
+  Geo geo{};
+  Uni uni{};
+  hipStream_t stream = nullptr;
+  // device storage
+  float4 *base[2] = {nullptr, nullptr}, *water[2] = {nullptr, nullptr}, *light[2] = {nullptr, nullptr};
+  char4 *wall[2] = {nullptr, nullptr};
+  float *curl = nullptr;
+  float2 *vort = nullptr, *dep = nullptr;
+  float4 *fb = nullptr;
+  float *drops[2] = {nullptr, nullptr};
+  float *initial_T = nullptr, *snd_T = nullptr, *snd_W = nullptr, *snd_Vel = nullptr;
+  DevState *state = nullptr;
+  bool fb_dirty = false; // feedback/deposition hold non-zero data (particles ran last iteration)
+  // profiling
+  bool profiling = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  double prof_ms[K_COUNT] = {0};
+  int prof_n[K_COUNT] = {0};
+  std::string err;
+};
+
+namespace {
+
+int fail(wx_sim *s, int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (s)
+    s->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(s, expr)                                                                                  \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return fail((s), WX_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));           \
+  } while (0)
+
+size_t ncell(const wx_sim *s) { return (size_t)s->X * s->Y; }
+
+hipEvent_t get_event(wx_sim *s)
+{
+  if (!s->ev_pool.empty()) {
+    hipEvent_t e = s->ev_pool.back();
+    s->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+struct ProfScope {
+  wx_sim *s;
+  ProfRec r;
+  bool on;
+  ProfScope(wx_sim *s_, int kid) : s(s_), on(s_->profiling)
+  {
+    if (on) {
+      r.kid = kid;
+      r.a = get_event(s);
+      r.b = get_event(s);
+      hipEventRecord(r.a, s->stream);
+    }
+  }
+  ~ProfScope()
+  {
+    if (on) {
+      hipEventRecord(r.b, s->stream);
+      s->prof.push_back(r);
+    }
+  }
+};
+
+void collect_profile(wx_sim *s)
+{
+  if (s->prof.empty()) return;
+  hipStreamSynchronize(s->stream);
+  for (auto &r : s->prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      s->prof_ms[r.kid] += ms;
+      s->prof_n[r.kid] += 1;
+    }
+    s->ev_pool.push_back(r.a);
+    s->ev_pool.push_back(r.b);
+  }
+  s->prof.clear();
+}
+
+dim3 grid2d(const wx_sim *s) { return dim3((s->X + BX - 1) / BX, (s->Y + BY - 1) / BY); }
+
+void build_geo(wx_sim *s)
+{
+  Geo &g = s->geo;
+  g.X = s->X;
+  g.Y = s->Y;
+  g.Xg = s->Xg;
+  int xoff = (s->x0 - s->halo) % s->Xg;
+  if (xoff < 0) xoff += s->Xg;
+  g.xoff = xoff;
+  if (s->p.quad_scale) {
+    // app.js:4770-4788: the quad's U runs 0 .. f32(res * 1.0000001)
+    g.sx = (float)((double)s->Xg * 1.0000001) / (float)s->Xg;
+    g.sy = (float)((double)s->Y * 1.0000001) / (float)s->Y;
+  } else {
+    g.sx = 1.0f;
+    g.sy = 1.0f;
+  }
+  g.texX = (float)(1.0 / (double)s->Xg); // app.js:5436-5437
+  g.texY = (float)(1.0 / (double)s->Y);
+}
+
+void build_uni(wx_sim *s)
+{
+  const wx_params &p = s->p;
+  Uni &u = s->uni;
+  u.dragMultiplier = p.dragMultiplier;
+  u.wind = p.wind;
+  u.vorticity = p.vorticity;
+  u.landEvaporation = p.landEvaporation;
+  u.waterEvaporation = p.waterEvaporation;
+  u.dynamicWaterTemperature = p.dynamicWaterTemperature;
+  u.evapHeat = p.evapHeat;
+  u.waterWeight = p.waterWeight;
+  u.dryLapse = p.dryLapse;
+  u.meltingHeat = p.meltingHeat;
+  u.condensationRate = p.condensationRate;
+  u.globalDrying = p.globalDrying;
+  u.globalHeating = p.globalHeating;
+  u.soundingForcing = p.soundingForcing;
+  u.globalEffectsStartAlt = p.globalEffectsStartAlt;
+  u.globalEffectsEndAlt = p.globalEffectsEndAlt;
+  u.waterTemperature = p.waterTemperature;
+  u.sunIntensity = p.sunIntensity;
+  u.greenhouseGases = p.greenhouseGases;
+  u.waterGreenHouseEffect = p.waterGreenHouseEffect;
+  u.IR_rate = p.IR_rate;
+  u.aboveZeroThreshold = p.aboveZeroThreshold;
+  u.subZeroThreshold = p.subZeroThreshold;
+  u.spawnChanceMult = p.spawnChanceMult;
+  u.snowDensity = p.snowDensity;
+  u.fallSpeed = p.fallSpeed;
+  u.growthRate0C = p.growthRate0C;
+  u.growthRate_30C = p.growthRate_30C;
+  u.freezingRate = p.freezingRate;
+  u.meltingRate = p.meltingRate;
+  u.evapRate = p.evapRate;
+  for (int i = 0; i < 4; i++) u.userInputValues[i] = p.userInputValues[i];
+  for (int i = 0; i < 2; i++) u.userInputMove[i] = p.userInputMove[i];
+  u.userInputType = p.userInputType;
+  u.wrapHorizontally = p.wrapHorizontally;
+  for (int i = 0; i < 4; i++) u.airplaneValues[i] = p.airplaneValues[i];
+  // sin/cos of the uniform sunAngle, evaluated once here instead of per fragment
+  u.cos_a = cosf(p.sunAngle);
+  u.sin_a = sinf(p.sunAngle);
+  u.sin_ma = sinf(-p.sunAngle);
+}
+
+template <class T> int dalloc(wx_sim *s, T **p, size_t n)
+{
+  HIPCHK(s, hipMalloc((void **)p, n * sizeof(T)));
+  HIPCHK(s, hipMemset(*p, 0, n * sizeof(T)));
+  return WX_OK;
+}
+
+int copy_field(wx_sim *s, const float4 *src, float4 *dst)
+{
+  ProfScope ps(s, K_COPY);
+  hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, s->stream, src, dst, ncell(s));
+  return WX_OK;
+}
+int copy_wall(wx_sim *s, const char4 *src, char4 *dst)
+{
+  ProfScope ps(s, K_COPY);
+  hipLaunchKernelGGL(k_copy4, dim3(2048), dim3(256), 0, s->stream, src, dst, ncell(s));
+  return WX_OK;
+}
+
+// One iteration with the reference's pass structure (one kernel per draw call).
+int iterate_per_pass(wx_sim *s, unsigned mask, bool precip)
+{
+  const dim3 grid = grid2d(s), block(BX, BY);
+  const Geo g = s->geo;
+  Uni u = s->uni;
+  u.iterNum = (float)s->iter; // iterNum is passed as float (app.js:5859) and cast int(iterNum) in the shaders
+  u.iterI = (int)u.iterNum;
+
+  // 1 velocity: base_0, wall_0 -> base_1, wall_1
+  if (mask & WX_PASS_VELOCITY) {
+    ProfScope ps(s, K_VELOCITY);
+    hipLaunchKernelGGL(k_velocity, grid, block, 0, s->stream, g, u, s->base[0], s->wall[0], s->base[1], s->wall[1]);
+  } else {
+    copy_field(s, s->base[0], s->base[1]);
+    copy_wall(s, s->wall[0], s->wall[1]);
+  }
+  // 2, 3 curl + vorticity
+  if (mask & WX_PASS_VORTICITY) {
+    {
+      ProfScope ps(s, K_CURL);
+      hipLaunchKernelGGL(k_curl, grid, block, 0, s->stream, g, s->base[1], s->curl);
+    }
+    {
+      ProfScope ps(s, K_VORTICITY);
+      hipLaunchKernelGGL(k_vorticity, grid, block, 0, s->stream, g, s->curl, s->vort);
+    }
+  }
+  // 4 boundary: base_1, water_1, vort, wall_1, light_0 (always _0), feedback, deposition -> base_0, water_0, wall_0
+  if (mask & WX_PASS_BOUNDARY) {
+    GridPtrs in{s->base[1], s->water[1], s->wall[1], s->vort, s->light[0], s->fb_dirty ? s->fb : nullptr,
+                s->fb_dirty ? s->dep : nullptr};
+    ProfScope ps(s, K_BOUNDARY);
+    hipLaunchKernelGGL(k_boundary, grid, block, 0, s->stream, g, u, s->initial_T, in, s->base[0], s->water[0], s->wall[0]);
+  } else {
+    copy_field(s, s->base[1], s->base[0]);
+    copy_field(s, s->water[1], s->water[0]);
+    copy_wall(s, s->wall[1], s->wall[0]);
+  }
+  // 5 advection: _0 -> _1
+  if (mask & WX_PASS_ADVECTION) {
+    GridPtrs in{s->base[0], s->water[0], s->wall[0], nullptr, nullptr, nullptr, nullptr};
+    ProfScope ps(s, K_ADVECTION);
+    hipLaunchKernelGGL(k_advection, grid, block, 0, s->stream, g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, s->base[1],
+                       s->water[1], s->wall[1]);
+  } else {
+    copy_field(s, s->base[0], s->base[1]);
+    copy_field(s, s->water[0], s->water[1]);
+    copy_wall(s, s->wall[0], s->wall[1]);
+  }
+  // 6 pressure: base_1, wall_1 -> base_0, wall_0
+  if (mask & WX_PASS_PRESSURE) {
+    ProfScope ps(s, K_PRESSURE);
+    hipLaunchKernelGGL(k_pressure, grid, block, 0, s->stream, g, s->base[1], s->wall[1], s->base[0], s->wall[0]);
+  } else {
+    copy_field(s, s->base[1], s->base[0]);
+    copy_wall(s, s->wall[1], s->wall[0]);
+  }
+  // 7 lighting: base_1 (pre-pressure!), water_1, wall_1, light_src -> light_dst ; even = !even
+  const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
+  if (mask & WX_PASS_LIGHTING) {
+    ProfScope ps(s, K_LIGHTING);
+    hipLaunchKernelGGL(k_lighting, grid, block, 0, s->stream, g, u, s->base[1], s->water[1], s->wall[1], s->light[src], s->light[dst]);
+  }
+  (void)precip;
+  return WX_OK;
+}
+
+// The same iteration as two fused kernels (wx_fused.h); results are bit-identical to iterate_per_pass.
+int iterate_fused(wx_sim *s, unsigned mask)
+{
+  const Geo g = s->geo;
+  Uni u = s->uni;
+  u.iterNum = (float)s->iter;
+  u.iterI = (int)u.iterNum;
+  const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
+  {
+    FusedAIn in{s->base[0], s->wall[0], s->water[1], s->light[0], s->fb_dirty ? s->fb : nullptr, s->fb_dirty ? s->dep : nullptr};
+    ProfScope ps(s, K_FUSED_VCVB);
+    launch_fused_a(g, u, mask, s->initial_T, in, s->base[1], s->water[0], s->wall[1], s->curl, s->stream);
+  }
+  {
+    FusedBIn in{s->base[1], s->water[0], s->wall[1], s->light[src]};
+    ProfScope ps(s, K_FUSED_APL);
+    launch_fused_b(g, u, mask, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, s->base[0], s->base[1], s->water[1], s->wall[0],
+                   s->light[dst], s->stream);
+  }
+  return WX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int wx_abi_version(void) { return WX_ABI_VERSION; }
+
+const char *wx_last_error(const wx_sim *s) { return s ? s->err.c_str() : g_create_error.c_str(); }
+
+int wx_kernel_count(void) { return K_COUNT; }
+const char *wx_kernel_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }
+
+int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_droplets, wx_sim **out)
+{
+  if (!out) return fail(nullptr, WX_E_INVALID, "wx_create: out is NULL");
+  *out = nullptr;
+  if (X_global < 2 || Y < 4 || X_owned < 1 || X_owned > X_global || halo < 0 || n_droplets < 0 || X_global > 65535 * 16 || Y > 65535)
+    return fail(nullptr, WX_E_INVALID, "wx_create: bad geometry X_global=%d Y=%d X_owned=%d halo=%d n_droplets=%d", X_global, Y, X_owned, halo,
+                n_droplets);
+  if (halo > 0 && X_owned < halo) return fail(nullptr, WX_E_INVALID, "wx_create_slab: X_owned (%d) < halo (%d)", X_owned, halo);
+  if (halo == 0 && X_owned != X_global)
+    return fail(nullptr, WX_E_INVALID, "wx_create_slab: a slab narrower than the domain needs halo > 0");
+  if (n_droplets > 0 && X_owned != X_global) return fail(nullptr, WX_E_INVALID, "particles are only supported on whole-domain handles");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, WX_E_DEVICE, "no HIP device available (%s): libwxsim has no CPU fallback", hipGetErrorString(e));
+  wx_sim *s = new wx_sim();
+  s->X = X_owned + 2 * halo;
+  s->Y = Y;
+  s->Xg = X_global;
+  s->x0 = x0;
+  s->halo = halo;
+  s->n_drops = n_droplets;
+  if (const char *f = getenv("WX_FUSED")) s->fused = atoi(f);
+  if (!kHaveFused) s->fused = 0;
+  const size_t n = ncell(s);
+  int rc = WX_OK;
+  for (int i = 0; i < 2 && rc == WX_OK; i++) {
+    if ((rc = dalloc(s, &s->base[i], n))) break;
+    if ((rc = dalloc(s, &s->water[i], n))) break;
+    if ((rc = dalloc(s, &s->light[i], n))) break;
+    if ((rc = dalloc(s, &s->wall[i], n))) break;
+    if ((rc = dalloc(s, &s->drops[i], (size_t)(n_droplets > 0 ? n_droplets : 1) * 5))) break;
+  }
+  if (rc == WX_OK) rc = dalloc(s, &s->curl, n);
+  if (rc == WX_OK) rc = dalloc(s, &s->vort, n);
+  if (rc == WX_OK) rc = dalloc(s, &s->fb, n);
+  if (rc == WX_OK) rc = dalloc(s, &s->dep, n);
+  if (rc == WX_OK) rc = dalloc(s, &s->initial_T, (size_t)Y + 8);
+  if (rc == WX_OK) rc = dalloc(s, &s->snd_T, (size_t)Y + 8);
+  if (rc == WX_OK) rc = dalloc(s, &s->snd_W, (size_t)Y + 8);
+  if (rc == WX_OK) rc = dalloc(s, &s->snd_Vel, (size_t)Y + 8);
+  if (rc == WX_OK) rc = dalloc(s, &s->state, 1);
+  if (rc != WX_OK) {
+    g_create_error = s->err;
+    wx_destroy(s);
+    return rc == WX_E_DEVICE ? WX_E_NOMEM : rc;
+  }
+  s->p.pass_mask = WX_PASS_ALL;
+  build_geo(s);
+  *out = s;
+  return WX_OK;
+}
+
+int wx_create(int X, int Y, int n_droplets, wx_sim **out) { return wx_create_slab(X, Y, 0, X, 0, n_droplets, out); }
+
+void wx_destroy(wx_sim *s)
+{
+  if (!s) return;
+  if (s->stream) hipStreamSynchronize(s->stream);
+  else hipDeviceSynchronize();
+  for (auto &r : s->prof) {
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  for (auto e : s->ev_pool) hipEventDestroy(e);
+  for (int i = 0; i < 2; i++) {
+    hipFree(s->base[i]);
+    hipFree(s->water[i]);
+    hipFree(s->light[i]);
+    hipFree(s->wall[i]);
+    hipFree(s->drops[i]);
+  }
+  hipFree(s->curl);
+  hipFree(s->vort);
+  hipFree(s->fb);
+  hipFree(s->dep);
+  hipFree(s->initial_T);
+  hipFree(s->snd_T);
+  hipFree(s->snd_W);
+  hipFree(s->snd_Vel);
+  hipFree(s->state);
+  delete s;
+}
+
+int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wall, const float *drops)
+{
+  if (!s) return WX_E_INVALID;
+  if (!base || !water || !wall) return fail(s, WX_E_INVALID, "wx_upload: NULL grid array");
+  const size_t n = ncell(s);
+  for (int i = 0; i < 2; i++) {
+    HIPCHK(s, hipMemcpyAsync(s->base[i], base, n * 16, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(s, hipMemcpyAsync(s->water[i], water, n * 16, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(s, hipMemcpyAsync(s->wall[i], wall, n * 4, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->light[i], 0, n * 16, s->stream));
+    if (drops && s->n_drops > 0)
+      HIPCHK(s, hipMemcpyAsync(s->drops[i], drops, (size_t)s->n_drops * 20, hipMemcpyHostToDevice, s->stream));
+  }
+  HIPCHK(s, hipMemsetAsync(s->curl, 0, n * 4, s->stream));
+  HIPCHK(s, hipMemsetAsync(s->vort, 0, n * 8, s->stream));
+  HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 16, s->stream));
+  HIPCHK(s, hipMemsetAsync(s->dep, 0, n * 8, s->stream));
+  HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
+  HIPCHK(s, hipStreamSynchronize(s->stream)); // the caller keeps ownership of the host arrays
+  s->fb_dirty = false;
+  s->even = 1;
+  s->drop_cur = 0;
+  s->uploaded = true;
+  return WX_OK;
+}
+
+int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const float *sounding_T, const float *sounding_W,
+                  const float *sounding_Vel)
+{
+  if (!s || !p) return WX_E_INVALID;
+  if (!initial_T && !s->have_params) return fail(s, WX_E_INVALID, "wx_set_params: initial_T is required on the first call");
+  s->p = *p;
+  build_geo(s);
+  build_uni(s);
+  const size_t nb = ((size_t)s->Y + 1) * 4;
+  if (initial_T) HIPCHK(s, hipMemcpyAsync(s->initial_T, initial_T, nb, hipMemcpyHostToDevice, s->stream));
+  if (sounding_T) HIPCHK(s, hipMemcpyAsync(s->snd_T, sounding_T, nb, hipMemcpyHostToDevice, s->stream));
+  if (sounding_W) HIPCHK(s, hipMemcpyAsync(s->snd_W, sounding_W, nb, hipMemcpyHostToDevice, s->stream));
+  if (sounding_Vel) HIPCHK(s, hipMemcpyAsync(s->snd_Vel, sounding_Vel, nb, hipMemcpyHostToDevice, s->stream));
+  if (p->inactiveDroplets >= 0.0f)
+    HIPCHK(s, hipMemcpyAsync(&s->state->inactiveDroplets, &p->inactiveDroplets, 4, hipMemcpyHostToDevice, s->stream));
+  HIPCHK(s, hipStreamSynchronize(s->stream));
+  s->have_params = true;
+  return WX_OK;
+}
+
+int wx_step(wx_sim *s, int n_iter)
+{
+  if (!s) return WX_E_INVALID;
+  if (n_iter < 0) return fail(s, WX_E_INVALID, "wx_step: n_iter < 0");
+  if (!s->uploaded || !s->have_params) return fail(s, WX_E_STATE, "wx_step before wx_upload / wx_set_params");
+  const unsigned mask = s->p.pass_mask;
+  const bool precip = (mask & WX_PASS_PRECIPITATION) && s->p.enablePrecipitation && s->n_drops > 0;
+  const size_t n = ncell(s);
+  for (int it = 0; it < n_iter; it++) {
+    if (s->fused)
+      iterate_fused(s, mask);
+    else
+      iterate_per_pass(s, mask, precip);
+    const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
+    s->even = !s->even;
+    // 8 clear feedback + deposition (app.js:5933-5934); skipped while they are known to be zero
+    if (s->fb_dirty || precip) {
+      hipMemsetAsync(s->fb, 0, n * 16, s->stream);
+      hipMemsetAsync(s->dep, 0, n * 8, s->stream);
+      s->fb_dirty = false;
+    }
+    // 9, 10 precipitation + lightning location (app.js:5936-5983)
+    if (precip) {
+      Uni u = s->uni;
+      u.iterNum = (float)s->iter;
+      u.iterI = (int)u.iterNum;
+      {
+        ProfScope ps(s, K_PRECIP);
+        hipLaunchKernelGGL(k_precipitation, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, u, s->n_drops, s->drops[src],
+                           s->base[1], s->water[1], s->state, s->drops[dst], s->fb, s->dep);
+      }
+      {
+        ProfScope ps(s, K_LIGHTNING);
+        hipLaunchKernelGGL(k_lightning, dim3(1), dim3(64), 0, s->stream, u.iterNum, (int)(s->iter % 600 == 0), s->fb, s->state);
+      }
+      s->drop_cur = dst;
+      s->fb_dirty = true;
+    }
+    s->iter++;
+  }
+  HIPCHK(s, hipGetLastError());
+  return WX_OK;
+}
+
+int wx_sync(wx_sim *s)
+{
+  if (!s) return WX_E_INVALID;
+  HIPCHK(s, hipStreamSynchronize(s->stream));
+  return WX_OK;
+}
+
+int64_t wx_get_iter(const wx_sim *s) { return s ? s->iter : -1; }
+int wx_set_iter(wx_sim *s, int64_t iter)
+{
+  if (!s || iter < 0) return WX_E_INVALID;
+  s->iter = iter;
+  return WX_OK;
+}
+
+static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int *elem)
+{
+  switch (field) {
+  case WX_FIELD_BASE_CUR: *ptr = s->base[0]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_BASE_DISP: *ptr = s->base[1]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_WATER_0: *ptr = s->water[0]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_WATER_CUR: *ptr = s->water[1]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_WALL_CUR: *ptr = s->wall[0]; *channels = 4; *elem = 1; return 0;
+  case WX_FIELD_WALL_DISP: *ptr = s->wall[1]; *channels = 4; *elem = 1; return 0;
+  case WX_FIELD_LIGHT_0: *ptr = s->light[0]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_LIGHT_1: *ptr = s->light[1]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_CURL: *ptr = s->curl; *channels = 1; *elem = 4; return 0;
+  case WX_FIELD_VORT: *ptr = s->vort; *channels = 2; *elem = 4; return 0;
+  case WX_FIELD_PRECIP_FB: *ptr = s->fb; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_PRECIP_DEP: *ptr = s->dep; *channels = 2; *elem = 4; return 0;
+  default: return -1;
+  }
+}
+
+int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, int dtype)
+{
+  if (!s || !dst) return WX_E_INVALID;
+  if (field == WX_FIELD_LIGHTNING) {
+    if (dtype != WX_DTYPE_F32 || x != 0 || y != 0 || w != 1 || h != 1) return fail(s, WX_E_RANGE, "lightning data is a 1x1 f32 texture");
+    HIPCHK(s, hipMemcpyAsync(dst, s->state->lightning, 16, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return WX_OK;
+  }
+  const void *ptr;
+  int ch, el;
+  if (field_info(s, field, &ptr, &ch, &el)) return fail(s, WX_E_INVALID, "wx_read_rect: unknown field %d", field);
+  if (w <= 0 || h <= 0 || x < 0 || y < 0 || x + w > s->X || y + h > s->Y)
+    return fail(s, WX_E_RANGE, "wx_read_rect: rect (%d,%d %dx%d) outside %dx%d (no wrap)", x, y, w, h, s->X, s->Y);
+  const bool is_wall = (el == 1);
+  if (is_wall ? (dtype != WX_DTYPE_I8 && dtype != WX_DTYPE_I32) : (dtype != WX_DTYPE_F32))
+    return fail(s, WX_E_INVALID, "wx_read_rect: dtype %d does not fit field %d", dtype, field);
+  const size_t texel = (size_t)ch * el;
+  const char *src = (const char *)ptr + ((size_t)y * s->X + x) * texel;
+  if (is_wall && dtype == WX_DTYPE_I32) {
+    std::vector<int8_t> tmp((size_t)w * h * 4);
+    HIPCHK(s, hipMemcpy2DAsync(tmp.data(), (size_t)w * texel, src, (size_t)s->X * texel, (size_t)w * texel, h, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    int32_t *d = (int32_t *)dst;
+    for (size_t i = 0; i < tmp.size(); i++) d[i] = tmp[i];
+    return WX_OK;
+  }
+  HIPCHK(s, hipMemcpy2DAsync(dst, (size_t)w * texel, src, (size_t)s->X * texel, (size_t)w * texel, h, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(s, hipStreamSynchronize(s->stream));
+  return WX_OK;
+}
+
+int wx_read_particles(wx_sim *s, int first, int count, float *dst)
+{
+  if (!s || !dst) return WX_E_INVALID;
+  if (first < 0 || count < 0 || first + count > s->n_drops) return fail(s, WX_E_RANGE, "wx_read_particles: [%d, %d) outside 0..%d", first, first + count, s->n_drops);
+  if (count == 0) return WX_OK;
+  HIPCHK(s, hipMemcpyAsync(dst, s->drops[s->drop_cur] + 5 * (size_t)first, (size_t)count * 20, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(s, hipStreamSynchronize(s->stream));
+  return WX_OK;
+}
+
+int wx_set_stream(wx_sim *s, void *hip_stream)
+{
+  if (!s) return WX_E_INVALID;
+  HIPCHK(s, hipStreamSynchronize(s->stream));
+  s->stream = (hipStream_t)hip_stream;
+  return WX_OK;
+}
+
+void *wx_device_ptr(wx_sim *s, int field)
+{
+  if (!s) return nullptr;
+  if (field == WX_FIELD_LIGHTNING) return s->state->lightning;
+  const void *ptr;
+  int ch, el;
+  if (field_info(s, field, &ptr, &ch, &el)) return nullptr;
+  return const_cast<void *>(ptr);
+}
+
+int wx_local_width(const wx_sim *s) { return s ? s->X : 0; }
+
+size_t wx_halo_bytes(const wx_sim *s) { return s ? (size_t)s->halo * s->Y * (4 * 16 + 4) : 0; }
+
+static int halo_xstart(const wx_sim *s, int side, bool pack)
+{
+  if (pack) return side == 0 ? s->halo : s->X - 2 * s->halo; // outermost OWNED columns
+  return side == 0 ? 0 : s->X - s->halo;                     // ghost columns
+}
+
+int wx_halo_pack(wx_sim *s, int side, void *dev_buf)
+{
+  if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
+  if (s->halo == 0) return fail(s, WX_E_STATE, "handle has no halo");
+  const int n = s->halo * s->Y;
+  HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->wall[0]};
+  ProfScope ps(s, K_HALO);
+  hipLaunchKernelGGL(k_halo_pack, dim3((n + 255) / 256), dim3(256), 0, s->stream, f, s->X, s->Y, s->halo, halo_xstart(s, side, true),
+                     (float4 *)dev_buf, (char4 *)((char *)dev_buf + (size_t)n * 64));
+  HIPCHK(s, hipGetLastError());
+  return WX_OK;
+}
+
+int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
+{
+  if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
+  if (s->halo == 0) return fail(s, WX_E_STATE, "handle has no halo");
+  const int n = s->halo * s->Y;
+  HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->wall[0]};
+  ProfScope ps(s, K_HALO);
+  hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256), dim3(256), 0, s->stream, f, s->X, s->Y, s->halo, halo_xstart(s, side, false),
+                     (const float4 *)dev_buf, (const char4 *)((const char *)dev_buf + (size_t)n * 64));
+  HIPCHK(s, hipGetLastError());
+  return WX_OK;
+}
+
+int wx_profile(wx_sim *s, int enable)
+{
+  if (!s) return WX_E_INVALID;
+  collect_profile(s);
+  s->profiling = enable != 0;
+  if (enable) {
+    for (int k = 0; k < K_COUNT; k++) {
+      s->prof_ms[k] = 0;
+      s->prof_n[k] = 0;
+    }
+  }
+  return WX_OK;
+}
+
+int wx_profile_read(wx_sim *s, int cap, float *ms, int *launches)
+{
+  if (!s || !ms || !launches) return WX_E_INVALID;
+  collect_profile(s);
+  for (int k = 0; k < K_COUNT && k < cap; k++) {
+    ms[k] = (float)s->prof_ms[k];
+    launches[k] = s->prof_n[k];
+    s->prof_ms[k] = 0;
+    s->prof_n[k] = 0;
+  }
+  return WX_OK;
+}
+
+} // extern "C"

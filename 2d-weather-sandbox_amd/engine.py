@@ -1,0 +1,222 @@
+"""ctypes binding of libwxsim.so (the C ABI of include/wxsim.h).
+
+This is the ONLY compute path of the package: if the HIP library is missing or no GPU is present the
+calls fail loudly (RuntimeError) -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+from .params import WxParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libwxsim.so")
+
+FIELD_IDS = {
+    "BASE_CUR": 0, "BASE_DISP": 1, "WATER_0": 2, "WATER_CUR": 3, "WALL_CUR": 4, "WALL_DISP": 5,
+    "LIGHT_0": 6, "LIGHT_1": 7, "CURL": 8, "VORT": 9, "PRECIP_FB": 10, "PRECIP_DEP": 11, "LIGHTNING": 12,
+}
+FIELD_CHANNELS = {"CURL": 1, "VORT": 2, "PRECIP_DEP": 2}
+DTYPE_F32, DTYPE_I8, DTYPE_I32 = 0, 1, 2
+
+# every symbol include/wxsim.h declares
+EXPORTS = [
+    "wx_create", "wx_create_slab", "wx_destroy", "wx_last_error", "wx_abi_version", "wx_upload", "wx_set_params",
+    "wx_step", "wx_sync", "wx_get_iter", "wx_set_iter", "wx_read_rect", "wx_read_particles", "wx_set_stream",
+    "wx_device_ptr", "wx_local_width", "wx_halo_bytes", "wx_halo_pack", "wx_halo_unpack", "wx_profile",
+    "wx_profile_read", "wx_kernel_count", "wx_kernel_name",
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile libwxsim.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "wxsim.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "libwxsim.so"])
+    return LIB_PATH
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the simulation step.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.wx_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    L.wx_create_slab.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.wx_destroy.argtypes = [vp]
+    L.wx_destroy.restype = None
+    L.wx_last_error.argtypes = [vp]
+    L.wx_last_error.restype = C.c_char_p
+    L.wx_abi_version.restype = i32
+    L.wx_upload.argtypes = [vp, vp, vp, vp, vp]
+    L.wx_set_params.argtypes = [vp, C.POINTER(WxParams), vp, vp, vp, vp]
+    L.wx_step.argtypes = [vp, i32]
+    L.wx_sync.argtypes = [vp]
+    L.wx_get_iter.argtypes = [vp]
+    L.wx_get_iter.restype = i64
+    L.wx_set_iter.argtypes = [vp, i64]
+    L.wx_read_rect.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32]
+    L.wx_read_particles.argtypes = [vp, i32, i32, vp]
+    L.wx_set_stream.argtypes = [vp, vp]
+    L.wx_device_ptr.argtypes = [vp, i32]
+    L.wx_device_ptr.restype = vp
+    L.wx_local_width.argtypes = [vp]
+    L.wx_halo_bytes.argtypes = [vp]
+    L.wx_halo_bytes.restype = C.c_size_t
+    L.wx_halo_pack.argtypes = [vp, i32, vp]
+    L.wx_halo_unpack.argtypes = [vp, i32, vp]
+    L.wx_profile.argtypes = [vp, i32]
+    L.wx_profile_read.argtypes = [vp, i32, vp, vp]
+    L.wx_kernel_count.restype = i32
+    L.wx_kernel_name.argtypes = [i32]
+    L.wx_kernel_name.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+class WxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libwxsim error {code}: {msg}")
+        self.code = code
+
+
+class Handle:
+    """Thin RAII wrapper of a ``wx_sim*``."""
+
+    def __init__(self, X: int, Y: int, n_droplets: int = 0, *, X_global: Optional[int] = None, x0: int = 0, halo: int = 0):
+        L = lib()
+        h = C.c_void_p()
+        if X_global is None:
+            rc = L.wx_create(X, Y, n_droplets, C.byref(h))
+        else:
+            rc = L.wx_create_slab(X_global, Y, x0, X, halo, n_droplets, C.byref(h))
+        if rc != 0:
+            raise WxError(rc, (L.wx_last_error(None) or b"").decode())
+        self._h = h
+        self.X_owned, self.Y, self.n_droplets, self.halo = X, Y, n_droplets, halo
+        self.X = L.wx_local_width(h)
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise WxError(rc, (lib().wx_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().wx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state ----
+    def upload(self, base, water, wall, drops=None):
+        n = self.X * self.Y * 4
+        base = np.ascontiguousarray(base, np.float32).reshape(-1)
+        water = np.ascontiguousarray(water, np.float32).reshape(-1)
+        wall = np.ascontiguousarray(wall, np.int8).reshape(-1)
+        if not (base.size == water.size == wall.size == n):
+            raise ValueError(f"grid arrays must hold {self.Y}x{self.X}x4 values")
+        d = None
+        if drops is not None and self.n_droplets > 0:
+            drops = np.ascontiguousarray(drops, np.float32).reshape(-1)
+            if drops.size != self.n_droplets * 5:
+                raise ValueError("drops must hold n_droplets x 5 values")
+            d = drops.ctypes.data
+        self._chk(lib().wx_upload(self._h, base.ctypes.data, water.ctypes.data, wall.ctypes.data, d))
+
+    def set_params(self, p: WxParams, initial_T=None, snd_T=None, snd_W=None, snd_Vel=None):
+        arrs = []
+        for a in (initial_T, snd_T, snd_W, snd_Vel):
+            if a is None:
+                arrs.append(None)
+            else:
+                a = np.ascontiguousarray(a, np.float32)
+                if a.size < self.Y + 1:
+                    raise ValueError("profile arrays need Y+1 entries")
+                arrs.append(a)
+        ptr = [None if a is None else a.ctypes.data for a in arrs]
+        self._chk(lib().wx_set_params(self._h, C.byref(p), *ptr))
+
+    def step(self, n: int = 1):
+        self._chk(lib().wx_step(self._h, int(n)))
+
+    def sync(self):
+        self._chk(lib().wx_sync(self._h))
+
+    @property
+    def iter(self) -> int:
+        return lib().wx_get_iter(self._h)
+
+    @iter.setter
+    def iter(self, v: int):
+        self._chk(lib().wx_set_iter(self._h, int(v)))
+
+    # ---- readback ----
+    def read_rect(self, field: str, x: int = 0, y: int = 0, w: Optional[int] = None, h: Optional[int] = None, *, int32: bool = False):
+        w = self.X - x if w is None else w
+        h = self.Y - y if h is None else h
+        if field == "LIGHTNING":
+            out = np.zeros(4, np.float32)
+            self._chk(lib().wx_read_rect(self._h, 12, 0, 0, 1, 1, out.ctypes.data, DTYPE_F32))
+            return out
+        ch = FIELD_CHANNELS.get(field, 4)
+        if field.startswith("WALL"):
+            out = np.zeros((max(h, 0), max(w, 0), ch), np.int32 if int32 else np.int8)
+            dt = DTYPE_I32 if int32 else DTYPE_I8
+        else:
+            out = np.zeros((max(h, 0), max(w, 0), ch), np.float32)
+            dt = DTYPE_F32
+        self._chk(lib().wx_read_rect(self._h, FIELD_IDS[field], x, y, w, h, out.ctypes.data, dt))
+        return out
+
+    def read_particles(self, first: int = 0, count: Optional[int] = None):
+        count = self.n_droplets - first if count is None else count
+        out = np.zeros((max(count, 0), 5), np.float32)
+        self._chk(lib().wx_read_particles(self._h, first, count, out.ctypes.data))
+        return out
+
+    # ---- plumbing ----
+    def set_stream(self, stream_ptr: int):
+        self._chk(lib().wx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def device_ptr(self, field: str) -> int:
+        return lib().wx_device_ptr(self._h, FIELD_IDS[field])
+
+    def halo_bytes(self) -> int:
+        return lib().wx_halo_bytes(self._h)
+
+    def halo_pack(self, side: int, dev_ptr: int):
+        self._chk(lib().wx_halo_pack(self._h, side, C.c_void_p(dev_ptr)))
+
+    def halo_unpack(self, side: int, dev_ptr: int):
+        self._chk(lib().wx_halo_unpack(self._h, side, C.c_void_p(dev_ptr)))
+
+    def profile(self, enable: bool):
+        self._chk(lib().wx_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        L = lib()
+        n = L.wx_kernel_count()
+        ms = (C.c_float * n)()
+        cnt = (C.c_int * n)()
+        self._chk(L.wx_profile_read(self._h, n, ms, cnt))
+        return {L.wx_kernel_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(n) if cnt[k] > 0}

@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference's simulation seam.
+
+The reference has no class for this: ``mainScript(base, water, wall, drops)`` (app.js:1495) creates
+module-scope GL objects, ``draw()`` (app.js:5686) runs ``guiControls.IterPerFrame`` iterations per frame
+(app.js:5830-6005), consumers call ``gl.readPixels`` and ``prepareDownload()`` writes a save
+(app.js:6575-6628). ``WeatherSim`` restates exactly that surface on top of the C ABI (engine.py).
+"""
+from __future__ import annotations
+
+import datetime as _dt
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+from . import codec, params
+from .engine import Handle
+
+TIME_PER_ITERATION = 0.00008  # hours of simulated time per iteration (app.js:449)
+
+
+class WeatherSim:
+    def __init__(self, X: int, Y: int, base, water, wall, droplets=None, settings: Optional[Dict[str, Any]] = None, *,
+                 sun_angle_deg: Optional[float] = None, quad_scale: int = 0, pass_mask: int = params.PASS_ALL):
+        """``mainScript``: take the four initial arrays + saved settings (app.js:1495, 3375-3399, 5189-5317)."""
+        self.X, self.Y = int(X), int(Y)
+        self.gui = params.merge_settings(settings)
+        n_drops = 0 if droplets is None else int(np.asarray(droplets).size // 5)
+        self._h = Handle(self.X, self.Y, n_drops)
+        self._h.upload(base, water, wall, droplets)
+        self._quad_scale = int(quad_scale)
+        self._pass_mask = int(pass_mask)
+        self._manual_sun = sun_angle_deg
+        self._inactive_pushed = False
+        # startSimulation(): clock from the saved month / time of day (app.js:3902-3910)
+        month = float(self.gui["month"])
+        self.sim_datetime = _dt.datetime(2000, int(month), 1) + _dt.timedelta(days=(month % 1) * 30.417 - 1 + 1e-9,
+                                                                           hours=float(self.gui["timeOfDay"]))
+        self.brush = {"userInputType": -1, "userInputValues": (0.0, 0.0, 0.0, 0.0), "userInputMove": (0.0, 0.0)}
+        self.airplane = (0.0, 0.0, 0.0, 0.0)
+        self._push_uniforms()
+
+    # ---- construction helpers ----
+    @classmethod
+    def from_save(cls, sf: "codec.SaveFile | str", **kw) -> "WeatherSim":
+        """``loadData()`` (app.js:1256-1366)."""
+        if isinstance(sf, str):
+            sf = codec.load(sf)
+        return cls(sf.X, sf.Y, sf.base, sf.water, sf.wall, sf.droplets, sf.settings, **kw)
+
+    # ---- parameters ----
+    def uniforms(self) -> Dict[str, Any]:
+        u = params.uniforms_from_gui(self.gui, self.Y, sun_angle_deg=self._manual_sun, quad_scale=self._quad_scale,
+                                     pass_mask=self._pass_mask)
+        u.update(self.brush)
+        u["airplaneValues"] = self.airplane
+        # keep the engine's own 600-iteration measurement after the first push (app.js:5957-5966)
+        u["inactiveDroplets"] = -1.0 if self._inactive_pushed else 0.0
+        return u
+
+    def _push_uniforms(self):
+        u = self.uniforms()
+        p = params.fill_struct(params.WxParams(), u)
+        self._h.set_params(p, u["initial_T"], u.get("sounding_T"), u.get("sounding_W"), u.get("sounding_Vel"))
+        self._inactive_pushed = True
+
+    def set_gui(self, **changes):
+        """Change guiControls entries and push the uniforms (dat.GUI onChange + setGuiUniforms, app.js:3401-3443)."""
+        for k in changes:
+            if k not in params.GUI_DEFAULTS:
+                raise KeyError(k)
+        self.gui.update(changes)
+        self._push_uniforms()
+
+    def set_brush(self, input_type: int, x: float, y: float, intensity: float, brush_size: float, move=(0.0, 0.0)):
+        """Per-frame brush uniforms (app.js:5749-5808); input_type -1 = mouse released."""
+        self.brush = {"userInputType": int(input_type), "userInputValues": (x, y, intensity, brush_size * 0.5),
+                      "userInputMove": tuple(move)}
+        self._push_uniforms()
+
+    def update_sunlight(self, delta_hours: Optional[float]):
+        """``updateSunlight(deltaT_hours)`` (app.js:6510-6561): advance the clock, recompute the sun."""
+        if delta_hours is not None:
+            self.sim_datetime += _dt.timedelta(hours=delta_hours)
+            t = self.sim_datetime
+            self.gui["timeOfDay"] = t.hour + t.minute / 60.0 + t.second / 3600.0
+            self.gui["month"] = t.month + t.day / 30.5 + t.hour / 720.0
+        self.gui["sunAngle"] = params.sun_angle_from_time(self.gui["timeOfDay"], self.gui["month"], self.gui["latitude"])
+        self._manual_sun = None
+        self._push_uniforms()
+
+    # ---- the frame loop ----
+    def step(self, n_iter: Optional[int] = None):
+        """Simulation part of ``draw()``: sun update for the frame, then n iterations (app.js:5814-6005)."""
+        n = int(self.gui["IterPerFrame"]) if n_iter is None else int(n_iter)
+        if self.gui.get("dayNightCycle") and self._manual_sun is None:
+            self.update_sunlight(TIME_PER_ITERATION * n)
+        self._h.step(n)
+
+    def sync(self):
+        self._h.sync()
+
+    @property
+    def iter_num(self) -> int:
+        return self._h.iter
+
+    @iter_num.setter
+    def iter_num(self, v: int):
+        self._h.iter = v
+
+    # ---- readback (gl.readPixels / getBufferSubData call sites) ----
+    def read_rect(self, field: str, x=0, y=0, w=None, h=None, **kw):
+        return self._h.read_rect(field, x, y, w, h, **kw)
+
+    def read_particles(self, first=0, count=None):
+        return self._h.read_particles(first, count)
+
+    def measure_station(self, x: int, y: int):
+        """Weatherstation.measure (app.js:1084-1092): FB0 base 1x3 and water 1x2 starting at (x, y-1)."""
+        return self.read_rect("BASE_CUR", x, y - 1, 1, 3), self.read_rect("WATER_0", x, y - 1, 1, 2)
+
+    def sounding_column(self, x: int):
+        """soundingGraph.draw (app.js:3931-3943): FB1 column reads; wall as Int32."""
+        return (self.read_rect("BASE_DISP", x, 0, 1, self.Y), self.read_rect("WATER_CUR", x, 0, 1, self.Y),
+                self.read_rect("WALL_DISP", x, 0, 1, self.Y, int32=True))
+
+    def inactive_droplets(self) -> float:
+        """readPixels(0,0) of the feedback texture (app.js:5958-5961)."""
+        return float(self.read_rect("PRECIP_FB", 0, 0, 1, 1)[0, 0, 0])
+
+    def lightning(self):
+        return self.read_rect("LIGHTNING")
+
+    def to_save(self) -> codec.SaveFile:
+        """``prepareDownload()`` (app.js:6584-6613): FB0 = base_0, water_0 (post-boundary!), wall_0 + particles.
+        Deviation: the reference always stores particle buffer 0; this stores the current buffer."""
+        gui = {k: v for k, v in self.gui.items()}
+        return codec.SaveFile(self.X, self.Y, self.read_rect("BASE_CUR"), self.read_rect("WATER_0"), self.read_rect("WALL_CUR"),
+                              self.read_particles() if self._h.n_droplets else np.zeros((0, 5), np.float32), [], gui)
+
+    # ---- profiling ----
+    def profile(self, enable: bool):
+        self._h.profile(enable)
+
+    def profile_read(self):
+        return self._h.profile_read()
+
+    @property
+    def handle(self) -> Handle:
+        return self._h

@@ -1,0 +1,130 @@
+"""Synthetic initial states for the BASELINE.json configurations.
+
+``terrain_grid`` restates what the reference's setup pass produces for a new simulation
+(shaders/fragment/setupShader.frag:36-92: multi-octave value noise terrain, sea below, land with soil
+moisture / vegetation / snow above, initial sounding with a 2 K / 20 K dew-point depression), with the
+terrain snapped to even x / even y steps (SwiftShader-safe). ``dry_grid`` is the
+config-2 state: inert floor, dry air with small temperature noise.
+``init_rain_drops`` restates initRainDrops() (app.js:4901-4913) with a seeded generator.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import params
+
+
+def _frac(x):
+    return x - np.floor(x)
+
+
+def _rand(n):
+    # setupShader.frag:26  fract(sin(n) * 43758.5453123)
+    return _frac(np.sin(n) * 43758.5453123)
+
+
+def _noise(p):
+    # setupShader.frag:28-33
+    fl = np.floor(p)
+    fc = p - fl
+    return _rand(fl) * (1.0 - fc) + _rand(fl + 1.0) * fc - 0.5
+
+
+def terrain_height(X: int, seed: float = 0.5, height_mult: float = 0.3) -> np.ndarray:
+    """Normalised terrain height per column (setupShader.frag:44-61)."""
+    fx = np.arange(X, dtype=np.float64) + 0.5
+    if height_mult < 0.05:
+        return np.zeros(X)
+    if height_mult < 0.10:
+        return np.full(X, 0.005)
+    var = fx * 0.001
+    h = np.zeros(X)
+    i = 2.0
+    while i < 1000.0:
+        h += _noise(var * i + _rand(seed + i) * 10.0) * 0.5 / i
+        i *= 1.5
+    return h * height_mult
+
+
+def terrain_grid(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: float = 0.3, snap: int = 2):
+    """(base, water, wall) of a new simulation (setupShader.frag:36-92), terrain snapped to ``snap`` cells."""
+    gui = params.merge_settings(None) if gui is None else gui
+    sim_h = float(gui["simHeight"])
+    dry_lapse = sim_h * float(gui["dryLapseRate"]) / 1000.0
+    T0 = params.initial_temperature_profile(Y, sim_h, dry_lapse)
+    h = terrain_height(X, seed, height_mult)
+    if snap > 1:  # snap in x: constant over `snap` columns
+        h = np.repeat(h[::snap], snap)[:X]
+    texY = 1.0 / Y
+    # rows that are wall: texCoord.y < texelSize.y or texCoord.y < height  -> row index < max(1, height*Y - 0.5)
+    nrows = np.maximum(1, np.ceil(h * Y - 0.5).astype(np.int64))
+    if snap > 1:
+        nrows = ((nrows + snap - 1) // snap) * snap  # even thickness
+    nrows = np.minimum(nrows, Y - 8)
+    yy = np.arange(Y)[:, None]
+    is_wall = yy < nrows[None, :]
+    is_sea = (h < texY)[None, :] & is_wall
+    is_land = is_wall & ~is_sea
+
+    base = np.zeros((Y, X, 4), np.float32)
+    water = np.zeros((Y, X, 4), np.float32)
+    wall = np.zeros((Y, X, 4), np.int8)
+
+    # air: initial sounding (setupShader.frag:78-89)
+    tcy = (yy + 0.5) / Y
+    T_air = T0[:Y][:, None].astype(np.float64)
+    realT = T_air - tcy * dry_lapse
+    dew = np.where(tcy < 0.20, realT - 2.0, realT - 20.0)
+    tot = (dew / 250.0) ** 17
+    cloud = np.maximum(tot - (realT / 250.0) ** 17, 0.0)
+    air = ~is_wall
+    base[..., 3] = np.where(air, T_air, 0.0)
+    water[..., 0] = np.where(air, tot, 0.0)
+    water[..., 1] = np.where(air, cloud, 0.0)
+
+    # walls (setupShader.frag:63-77)
+    base[..., 3] = np.where(is_sea, 25.0 + 273.15, base[..., 3])
+    base[..., 3] = np.where(is_land, 1000.0, base[..., 3])
+    water[..., 0] = np.where(is_sea, 1002.0, water[..., 0])
+    water[..., 0] = np.where(is_land, 1001.0, water[..., 0])
+    water[..., 2] = np.where(is_land, 25.0, water[..., 2])
+    water[..., 2] = np.where(is_sea, 100.0, water[..., 2])
+    fx = np.arange(X, dtype=np.float64) + 0.5
+    veg = 110.0 - (yy + 0.5) * 2.0 + (_noise(fx * 0.01 + _rand(seed) * 10.0) * 150.0)[None, :]
+    wall[..., 3] = np.where(is_land, np.clip(np.trunc(veg), 0, 127), 0).astype(np.int8)
+    height_m = h * sim_h
+    snow = np.clip((height_m - 2000.0) * 100.0 / 3000.0, 0.0, 100.0)
+    water[..., 3] = np.where(is_land, snow[None, :], water[..., 3])
+
+    wall[..., 0] = np.where((h < texY)[None, :], 2, 1).astype(np.int8)  # type, extended upward like the boundary pass does
+    vdist = yy - nrows[None, :] + 1  # 1 for the first air row, 0 for the top wall row, negative below
+    wall[..., 2] = np.clip(vdist, -127, 127).astype(np.int8)
+    wall[..., 1] = np.where(is_wall, 0, np.clip(vdist, 1, 127)).astype(np.int8)
+    return base, water, wall
+
+
+def dry_grid(X: int, Y: int, gui=None, seed: int = 1234, noise_K: float = 0.05):
+    """BASELINE config 2: inert floor row, dry still air, T = initial_T[y] + N(0, noise_K)."""
+    gui = params.merge_settings(None) if gui is None else gui
+    sim_h = float(gui["simHeight"])
+    dry_lapse = sim_h * float(gui["dryLapseRate"]) / 1000.0
+    T0 = params.initial_temperature_profile(Y, sim_h, dry_lapse)
+    rng = np.random.Generator(np.random.Philox(seed))
+    base = np.zeros((Y, X, 4), np.float32)
+    water = np.zeros((Y, X, 4), np.float32)
+    wall = np.zeros((Y, X, 4), np.int8)
+    base[..., 3] = T0[:Y][:, None] + rng.normal(0.0, noise_K, (Y, X)).astype(np.float32)
+    yy = np.arange(Y)[:, None]
+    wall[..., 1] = np.clip(yy, 0, 127)
+    wall[..., 2] = np.clip(yy, -127, 127)
+    base[0, :, 3] = 1000.0
+    water[0, :, 0] = 1001.0
+    return base, water, wall
+
+
+def init_rain_drops(n: int, seed: int = 7) -> np.ndarray:
+    """initRainDrops() (app.js:4901-4913): inactive droplets whose fields are random seeds."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    d = rng.random((n, 5)).astype(np.float32)
+    d[:, 2] = -10.0 + d[:, 2]
+    return d

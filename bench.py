@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Mcell-steps/s of the simulation iteration on MI355X.
+
+`python bench.py --gpus N --steps K --warmup W`. A "step" is ONE simulation iteration (all grid passes +
+lighting; BASELINE.json configs[2]) over the 16384 x 2048 synthetic terrain grid; for N > 1 the same grid
+is cut into N column slabs (strong scaling) with one halo exchange per iteration over RCCL.
+Prints one JSON line on rank 0 (contract in the task description): throughput with inputs resident in HBM,
+plus `roofline` (dominant kernel, HIP-event timed on the engine's stream) and `cpu_baseline` (the CPU
+oracle timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+# Algorithmic (compulsory) bytes per cell and launch for each kernel -- DESIGN.md section 4.
+# fp32 RGBA texel = 16 B, wall RGBA8I = 4 B, curl 4 B, vortForce 8 B.
+ALGO_BYTES = {
+    "velocity": 20 + 20, "curl": 16 + 4, "vorticity": 4 + 8, "boundary": 60 + 36, "advection": 36 + 36,
+    "pressure": 20 + 20, "lighting": 52 + 16,
+    "fused_vel_curl_vort_boundary": 52 + 36 + 4, "fused_advect_pressure_light": 52 + 68,
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--X", type=int, default=16384)
+    ap.add_argument("--Y", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, budget_s=12.0):
+    """Time the CPU oracle (OpenMP, all host cores) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import wx_oracle
+    wx_oracle.build()
+    X, Y = 2048, 512
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 50.0
+    u = pkg.params.uniforms_from_gui(gui, Y)
+    u["enablePrecipitation"] = 0
+    o = wx_oracle.OracleSim(X, Y, 0)
+    o.upload(base, water, wall)
+    o.set_params(u)
+    o.step(1)
+    t0 = time.perf_counter()
+    o.step(2)
+    per = (time.perf_counter() - t0) / 2
+    n = max(3, min(400, int(budget_s / max(per, 1e-6))))
+    t0 = time.perf_counter()
+    o.step(n)
+    dt = time.perf_counter() - t0
+    return {"value": X * Y * n / dt / 1e6, "unit": "Mcell-steps/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"CPU oracle (C/OpenMP restatement, not the reference itself), {X}x{Y} terrain grid, {n} iterations, {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import wxpkg
+    pkg = wxpkg.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    X, Y = a.X, a.Y
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 50.0  # fixed sun ('MANUAL_ANGLE'), day side
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+
+    if world == 1:
+        base, water, wall = pkg.synth.terrain_grid(X, Y)
+        h = pkg.engine.Handle(X, Y, 0)
+        h.upload(base, water, wall)
+        del base, water, wall
+        h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+        stepper = h
+        step = lambda n: h.step(n)
+        sync = lambda: (h.sync(), torch.cuda.synchronize())
+        barrier = lambda: None
+    else:
+        from weather_sandbox_amd import slab
+        drv = slab.SlabSim.from_generator(pkg, X, Y, u, rank, world, torch.device("cuda", local_rank))
+        stepper = drv.handle
+        step = drv.step
+        sync = lambda: (drv.sync(), torch.cuda.synchronize())
+        barrier = dist.barrier
+
+    step(a.warmup)
+    sync()
+    barrier()
+    stepper.profile(True)
+    sync()
+    t0 = time.perf_counter()
+    step(a.steps)
+    sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = stepper.profile_read()
+    stepper.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        cells = X * Y
+        value = cells * a.steps / dt / 1e6
+        local_cells = stepper.X * Y
+        dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else None
+        roof = None
+        if dom:
+            name, (ms, cnt) = dom
+            avg_ms = ms / cnt
+            achieved = ALGO_BYTES.get(name, 0) * local_cells / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": cnt,
+                    "algo_bytes_per_cell": ALGO_BYTES.get(name, 0),
+                    "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()}}
+        out = {
+            "metric": "Mcell-steps/s", "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{X}x{Y} terrain grid, all six grid passes + lighting, particles off (BASELINE configs[2])",
+                       "grid": [X, Y], "decomposition": "none" if world == 1 else f"{world} x-slabs, 1 halo exchange / iteration (RCCL send/recv)",
+                       "iteration_algorithmic_bytes_per_cell": 72},
+            "iteration_roofline_frac_A_wet": cells * a.steps * 72 / dt / 1e9 / (HBM_PEAK_GBS * world),
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

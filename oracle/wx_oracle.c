@@ -14,7 +14,8 @@
  *   - integer modulo by zero (boundaryShader.frag:462 when vegetationGrowthRate > 100) -> condition false
  *   - sounding index y-1 < 0 (advectionShader.frag:59-61, row 0) -> clamped to 0
  *   - sin/cos of the uniform sunAngle are evaluated once on the host (sinf/cosf) per pass
- *   - pow(x, c) with constant c in {17, 4, 2, 0.5}: fixed multiply chains / sqrt (see pow17, pow4)
+ *   - pow(x, c) with constant c in {17, 4, 2, 0.5, 1/3}: fixed multiply chains / sqrt / Newton cbrt
+ *     (see pow17, pow4, det_cbrt)
  *   - unassigned IR_up (lightingShader.frag:90, air above an INERT wall) = 0
  *   - additive particle splats are summed in droplet-index order
  */
@@ -147,6 +148,8 @@ static inline float maxWater(float T) { return pow17(T / 250.0f); }
 /* common.glsl:258-261: pow(T * 0.01, 4.) * IR_constant */
 static inline float IR_emitted(float T) { return pow4(T * 0.01f) * 5.670374419f; }
 
+static inline uint32_t f2u(float f);
+static inline float u2f(uint32_t u);
 /* common.glsl:103-111 */
 uint32_t wxo_hash(uint32_t x)
 {
@@ -168,6 +171,14 @@ static inline float u2f(uint32_t u)
   float f;
   memcpy(&f, &u, 4);
   return f;
+}
+/* pow(x, 1./3.) for x > 0 (precipitationShader.vert:195) as a fixed sequence of exactly-rounded
+ * operations: bit-level seed + 4 Newton steps (bit-reproducible on CPU and GPU, ~1 ulp) */
+static inline float det_cbrt(float x)
+{
+  float y = u2f(f2u(x) / 3u + 709921077u);
+  for (int i = 0; i < 4; i++) y = (2.0f * y + x / (y * y)) / 3.0f;
+  return y;
 }
 /* common.glsl:126-137 */
 float wxo_random2d(float sx, float sy)
@@ -1254,7 +1265,7 @@ void wxo_precipitation(const wxo_params *p, float iterNum, int n_drops, const fl
         newMass[0] = -2.0f - dropPosition[0];
         newMass[1] = dropPosition[1];
       } else {
-        const float surfaceArea = powf(totalMass, 1.0f / 3.0f);
+        const float surfaceArea = det_cbrt(totalMass);
         const float growthRate =
           fmaxf(map_range(realTemp, CtoK(0.0f), CtoK(-30.0f), p->growthRate0C, p->growthRate_30C), p->growthRate0C);
         float growth = water[CLOUD] * growthRate * surfaceArea;

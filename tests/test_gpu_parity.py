@@ -1,0 +1,194 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle and the golden vectors.
+
+Bars: every grid field BIT-EXACT against the oracle (the grid passes use only exactly-rounded fp32
+operations in a fixed order, see csrc/wx_cells.h); particle feedback to fp32 summation-order tolerance;
+against the SwiftShader goldens the calibrated envelope of tests/test_oracle_golden.py (the goldens were
+rendered with SwiftShader's own fragCoord interpolation, which the product does not imitate).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ULP_T = 3.0518e-05
+GRID_FIELDS = ["BASE_CUR", "BASE_DISP", "WATER_0", "WATER_CUR", "WALL_CUR", "WALL_DISP", "LIGHT_0", "LIGHT_1"]
+
+
+@pytest.fixture(scope="module")
+def E(pkg):
+    from weather_sandbox_amd import engine
+    engine.build()
+    return engine
+
+
+def _make_pair(pkg, oracle, E, X, Y, base, water, wall, u, drops=None, iter0=0):
+    nd = 0 if drops is None else len(drops)
+    h = E.Handle(X, Y, nd)
+    h.upload(base, water, wall, drops)
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    h.set_params(p, u["initial_T"])
+    h.iter = iter0
+    o = oracle.OracleSim(X, Y, nd)
+    o.upload(base, water, wall, drops)
+    o.set_params(u)
+    o.iter = iter0
+    return h, o
+
+
+def _assert_grid_equal(h, o, fields=GRID_FIELDS):
+    for f in fields:
+        a, b = h.read_rect(f), o.field(f)
+        assert np.array_equal(a, b), f"{f}: {np.count_nonzero(a != b)} of {a.size} values differ, max |d| = {np.abs(a.astype(np.float64) - b).max()}"
+
+
+@pytest.mark.parametrize("name", ["save100qa", "synth64"])
+@pytest.mark.parametrize("quad_scale", [0, 1])
+def test_bit_exact_vs_oracle_on_golden_inputs(pkg, oracle, golden, E, name, quad_scale):
+    g, u = golden(name)
+    u = dict(u, quad_scale=quad_scale, enablePrecipitation=0)
+    X, Y = int(g["X"]), int(g["Y"])
+    h, o = _make_pair(pkg, oracle, E, X, Y, g["in_base"], g["in_water"], g["in_wall"], u, iter0=int(g["iter0"]))
+    done = 0
+    for it in (1, 2, 10, 50):
+        h.step(it - done)
+        o.step(it - done)
+        done = it
+        _assert_grid_equal(h, o)
+    assert h.iter == o.iter == int(g["iter0"]) + 50
+
+
+def test_vs_swiftshader_goldens(pkg, golden, E):
+    """HIP (quad_scale=1) straight against the reference's own output, 50 iterations of the save."""
+    g, u = golden("save100qa")
+    u = dict(u, quad_scale=1, enablePrecipitation=0)
+    X, Y = int(g["X"]), int(g["Y"])
+    h = E.Handle(X, Y, 0)
+    h.upload(g["in_base"], g["in_water"], g["in_wall"])
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    done = 0
+    # tolerance: SwiftShader interpolates fragCoord differently (a few 1e-6 cells), plus pow() ulps
+    tol = {1: (5e-7, 4 * ULP_T, 1e-4), 10: (5e-6, 2e-3, 5e-4), 50: (3e-5, 5e-3, 2e-3)}
+    for it in (1, 10, 50):
+        h.step(it - done)
+        done = it
+        tv, tT, tw = tol[it]
+        assert np.array_equal(h.read_rect("WALL_CUR"), g[f"it{it}_wall_cur"]), "wall masks must be bit-exact"
+        b, rb = h.read_rect("BASE_CUR"), g[f"it{it}_base_cur"]
+        assert np.abs(b[..., :3] - rb[..., :3]).max() <= tv
+        assert np.abs(b[..., 3] - rb[..., 3]).max() <= tT
+        assert np.abs(h.read_rect("WATER_CUR") - g[f"it{it}_water_cur"]).max() <= tw
+
+
+@pytest.mark.parametrize("X,Y", [(512, 128), (192, 96), (130, 50)])
+def test_bit_exact_terrain_grid(pkg, oracle, E, X, Y):
+    """setupShader-style terrain with default settings, all grid passes + lighting; ragged sizes included."""
+    S = pkg.synth
+    base, water, wall = S.terrain_grid(X, Y)
+    rng = np.random.default_rng(5)
+    air = wall[..., 1] != 0
+    base[..., 0] += np.where(air, rng.normal(0, 0.05, (Y, X)), 0).astype(np.float32)
+    base[..., 1] += np.where(air, rng.normal(0, 0.05, (Y, X)), 0).astype(np.float32)
+    water[..., 0] *= np.where(air, 1.0 + 0.4 * rng.random((Y, X)), 1.0).astype(np.float32)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 40.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+    h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u, iter0=90)
+    for _ in range(3):
+        h.step(7)
+        o.step(7)
+        _assert_grid_equal(h, o)
+
+
+def test_dry_config_pass_mask(pkg, oracle, E):
+    """BASELINE config 2: pressure + velocity + advection only."""
+    X, Y = 256, 128
+    base, water, wall = pkg.synth.dry_grid(X, Y)
+    base[40:60, 100:140, 3] += 3.0  # a warm bubble so something moves
+    base[..., 2] += np.random.default_rng(3).normal(0, 1e-3, (Y, X)).astype(np.float32)
+    u = pkg.params.uniforms_from_gui(pkg.params.merge_settings(None), Y, pass_mask=pkg.params.PASS_DRY)
+    h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
+    h.step(25)
+    o.step(25)
+    _assert_grid_equal(h, o, ["BASE_CUR", "BASE_DISP", "WATER_CUR", "WALL_CUR"])
+    assert np.abs(h.read_rect("BASE_CUR")[..., 0]).max() > 1e-4
+
+
+def test_particles_vs_oracle(pkg, oracle, golden, E):
+    g, u = golden("precip64")
+    u = dict(u, quad_scale=0, enablePrecipitation=1)
+    X, Y = int(g["X"]), int(g["Y"])
+    h, o = _make_pair(pkg, oracle, E, X, Y, g["in_base"], g["in_water"], g["in_wall"], u, drops=g["in_drops"])
+    h.step(1)
+    o.step(1)
+    # particle state: per-droplet arithmetic is order independent -> bit-exact
+    assert np.array_equal(h.read_particles(), o.field("DROPS"))
+    # splats: atomic adds in arbitrary order vs droplet-index order
+    fb, ofb = h.read_rect("PRECIP_FB"), o.field("PRECIP_FB")
+    assert np.abs(fb - ofb).max() <= 1e-7 * max(1.0, np.abs(ofb).max())
+    assert fb[0, 0, 0] == ofb[0, 0, 0]  # inactive count is an exact integer sum
+    assert np.abs(h.read_rect("PRECIP_DEP") - o.field("PRECIP_DEP")).max() <= 1e-7
+    assert np.array_equal(h.read_rect("LIGHTNING"), o.field("LIGHTNING"))
+    # grid fields of that iteration did not depend on feedback yet -> still bit-exact
+    _assert_grid_equal(h, o)
+    h.step(3)
+    o.step(3)
+    d, od = h.read_particles(), o.field("DROPS")
+    assert np.array_equal(d[:, 2] >= 0, od[:, 2] >= 0)
+    assert np.abs(d - od).max() <= 1e-5  # feedback summation order feeds back into T, cloud
+    assert np.abs(h.read_rect("BASE_CUR")[..., 3] - o.field("BASE_CUR")[..., 3]).max() <= 1e-3
+
+
+def test_read_rect_contract(pkg, golden, E):
+    g, u = golden("synth64")
+    X, Y = int(g["X"]), int(g["Y"])
+    h = E.Handle(X, Y, 0)
+    h.upload(g["in_base"], g["in_water"], g["in_wall"])
+    assert np.array_equal(h.read_rect("BASE_CUR", 3, 5, 7, 2), g["in_base"][5:7, 3:10])
+    assert np.array_equal(h.read_rect("BASE_DISP"), g["in_base"])  # upload fills both ping-pong copies
+    assert np.array_equal(h.read_rect("WATER_0", 0, 0, X, 1), g["in_water"][:1])
+    w8 = h.read_rect("WALL_DISP", 10, 0, 1, Y)
+    w32 = h.read_rect("WALL_DISP", 10, 0, 1, Y, int32=True)
+    assert w8.dtype == np.int8 and w32.dtype == np.int32 and np.array_equal(w8, w32)
+    assert np.array_equal(w8[:, 0], g["in_wall"][:, 10])
+    with pytest.raises(E.WxError) as ei:  # no wrap, like readPixels
+        h.read_rect("BASE_CUR", X - 2, 0, 4, 1)
+    assert ei.value.code == -4
+    with pytest.raises(E.WxError) as ei:
+        h.step(1)  # no params yet
+    assert ei.value.code == -5
+    with pytest.raises(E.WxError):
+        h.read_particles(0, 1)
+
+
+def test_full_size_invariants(pkg, E):
+    """BASELINE size (16384 x 2048): x-shift equivariance, determinism, no NaN, water >= 0."""
+    X, Y = 16384, 2048
+    S = pkg.synth
+    base, water, wall = S.terrain_grid(X, Y)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 50.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+
+    def run(b, w, wl, n):
+        h = E.Handle(X, Y, 0)
+        h.upload(b, w, wl)
+        h.set_params(p, u["initial_T"])
+        h.step(n)
+        out = h.read_rect("BASE_CUR"), h.read_rect("WATER_CUR"), h.read_rect("WALL_CUR")
+        h.close()
+        return out
+
+    n = 12
+    b0, w0, wl0 = run(base, water, wall, n)
+    assert np.isfinite(b0).all() and np.isfinite(w0).all()
+    assert (w0[..., 0] >= 0).all() and (w0[..., 1] >= 0).all()
+    assert np.abs(b0[..., 1]).max() > 0  # something happened
+    # periodic in x: shifting the input by a multiple of 80 columns (industrial stacks use x % 80) shifts the output
+    k = 80 * 37
+    b1, w1, wl1 = run(np.roll(base, k, 1), np.roll(water, k, 1), np.roll(wall, k, 1), n)
+    assert np.array_equal(np.roll(b0, k, 1), b1)
+    assert np.array_equal(np.roll(w0, k, 1), w1)
+    assert np.array_equal(np.roll(wl0, k, 1), wl1)
