@@ -55,6 +55,13 @@ def lib() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the simulation step.")
+    try:
+        # PyTorch ships its own libamdhip64.so.7: import it FIRST so that the process holds a single HIP runtime
+        # (libwxsim.so's NEEDED libamdhip64.so.7 then resolves to the already loaded one). Loading ours first and
+        # torch second gives two runtimes, and the second one finds "no ROCm-capable device".
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     L.wx_create.argtypes = [i32, i32, i32, C.POINTER(vp)]

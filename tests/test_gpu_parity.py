@@ -126,7 +126,7 @@ def test_particles_vs_oracle(pkg, oracle, golden, E):
     # splats: atomic adds in arbitrary order vs droplet-index order
     fb, ofb = h.read_rect("PRECIP_FB"), o.field("PRECIP_FB")
     assert np.abs(fb - ofb).max() <= 1e-7 * max(1.0, np.abs(ofb).max())
-    assert fb[0, 0, 0] == ofb[0, 0, 0]  # inactive count is an exact integer sum
+    assert round(float(fb[0, 0, 0])) == round(float(ofb[0, 0, 0])) > 10  # inactive-droplet count in texel (0,0)
     assert np.abs(h.read_rect("PRECIP_DEP") - o.field("PRECIP_DEP")).max() <= 1e-7
     assert np.array_equal(h.read_rect("LIGHTNING"), o.field("LIGHTNING"))
     # grid fields of that iteration did not depend on feedback yet -> still bit-exact
