@@ -58,13 +58,15 @@ struct wx_sim {
   int even = 1;          // app.js `even`
   int drop_cur = 0;      // particle buffer holding the latest state
   int64_t iter = 0;
-  int fused = 0;         // 1: fused LDS-tiled kernels (env WX_FUSED overrides); 0: one kernel per reference pass
+  int fused = 1;         // 1: fused LDS-tiled kernels (default); WX_FUSED=0 in the environment: one kernel per reference pass
   wx_params p{};
   Geo geo{};
   Uni uni{};
   hipStream_t stream = nullptr;
   // device storage
-  float4 *base[2] = {nullptr, nullptr}, *water[2] = {nullptr, nullptr}, *light[2] = {nullptr, nullptr};
+  float4 *base[3] = {nullptr, nullptr, nullptr}; // [2]: post-advection base of the fused path (= baseTexture_1)
+  float4 *water[2] = {nullptr, nullptr}, *light[2] = {nullptr, nullptr};
+  bool ran_fused = false; // the last iteration used the fused ping-pong (field mapping differs)
   char4 *wall[2] = {nullptr, nullptr};
   float *curl = nullptr;
   float2 *vort = nullptr, *dep = nullptr;
@@ -314,7 +316,9 @@ int iterate_per_pass(wx_sim *s, unsigned mask, bool precip)
 }
 
 // The same iteration as two fused kernels (wx_fused.h); results are bit-identical to iterate_per_pass.
-int iterate_fused(wx_sim *s, unsigned mask)
+// write_disp: also store the post-advection base (the reference's baseTexture_1, read by the particle pass and
+// by display-side consumers) -- needed only for the last iteration of a wx_step call or when particles run.
+int iterate_fused(wx_sim *s, bool write_disp)
 {
   const Geo g = s->geo;
   Uni u = s->uni;
@@ -324,13 +328,13 @@ int iterate_fused(wx_sim *s, unsigned mask)
   {
     FusedAIn in{s->base[0], s->wall[0], s->water[1], s->light[0], s->fb_dirty ? s->fb : nullptr, s->fb_dirty ? s->dep : nullptr};
     ProfScope ps(s, K_FUSED_VCVB);
-    launch_fused_a(g, u, mask, s->initial_T, in, s->base[1], s->water[0], s->wall[1], s->curl, s->stream);
+    launch_fused_a(g, u, s->initial_T, in, s->base[1], s->water[0], s->wall[1], s->curl, s->stream);
   }
   {
     FusedBIn in{s->base[1], s->water[0], s->wall[1], s->light[src]};
     ProfScope ps(s, K_FUSED_APL);
-    launch_fused_b(g, u, mask, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, s->base[0], s->base[1], s->water[1], s->wall[0],
-                   s->light[dst], s->stream);
+    launch_fused_b(g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, s->base[0], s->base[2], s->water[1], s->wall[0], s->light[dst],
+                   write_disp, s->stream);
   }
   return WX_OK;
 }
@@ -379,6 +383,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
     if ((rc = dalloc(s, &s->wall[i], n))) break;
     if ((rc = dalloc(s, &s->drops[i], (size_t)(n_droplets > 0 ? n_droplets : 1) * 5))) break;
   }
+  if (rc == WX_OK) rc = dalloc(s, &s->base[2], n);
   if (rc == WX_OK) rc = dalloc(s, &s->curl, n);
   if (rc == WX_OK) rc = dalloc(s, &s->vort, n);
   if (rc == WX_OK) rc = dalloc(s, &s->fb, n);
@@ -418,6 +423,7 @@ void wx_destroy(wx_sim *s)
     hipFree(s->wall[i]);
     hipFree(s->drops[i]);
   }
+  hipFree(s->base[2]);
   hipFree(s->curl);
   hipFree(s->vort);
   hipFree(s->fb);
@@ -450,6 +456,7 @@ int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wa
   HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
   HIPCHK(s, hipStreamSynchronize(s->stream)); // the caller keeps ownership of the host arrays
   s->fb_dirty = false;
+  s->ran_fused = false;
   s->even = 1;
   s->drop_cur = 0;
   s->uploaded = true;
@@ -484,11 +491,14 @@ int wx_step(wx_sim *s, int n_iter)
   const unsigned mask = s->p.pass_mask;
   const bool precip = (mask & WX_PASS_PRECIPITATION) && s->p.enablePrecipitation && s->n_drops > 0;
   const size_t n = ncell(s);
+  // the fused kernels implement the full grid-pass set; any other pass_mask runs the per-pass kernels
+  const bool fused = s->fused && (mask & 0x3Fu) == 0x3Fu;
   for (int it = 0; it < n_iter; it++) {
-    if (s->fused)
-      iterate_fused(s, mask);
+    if (fused)
+      iterate_fused(s, precip || it == n_iter - 1);
     else
       iterate_per_pass(s, mask, precip);
+    s->ran_fused = fused;
     const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
     s->even = !s->even;
     // 8 clear feedback + deposition (app.js:5933-5934); skipped while they are known to be zero
@@ -505,7 +515,7 @@ int wx_step(wx_sim *s, int n_iter)
       {
         ProfScope ps(s, K_PRECIP);
         hipLaunchKernelGGL(k_precipitation, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, u, s->n_drops, s->drops[src],
-                           s->base[1], s->water[1], s->state, s->drops[dst], s->fb, s->dep);
+                           fused ? s->base[2] : s->base[1], s->water[1], s->state, s->drops[dst], s->fb, s->dep);
       }
       {
         ProfScope ps(s, K_LIGHTNING);
@@ -539,11 +549,12 @@ static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int
 {
   switch (field) {
   case WX_FIELD_BASE_CUR: *ptr = s->base[0]; *channels = 4; *elem = 4; return 0;
-  case WX_FIELD_BASE_DISP: *ptr = s->base[1]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_BASE_DISP: *ptr = s->ran_fused ? s->base[2] : s->base[1]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_WATER_0: *ptr = s->water[0]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_WATER_CUR: *ptr = s->water[1]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_WALL_CUR: *ptr = s->wall[0]; *channels = 4; *elem = 1; return 0;
-  case WX_FIELD_WALL_DISP: *ptr = s->wall[1]; *channels = 4; *elem = 1; return 0;
+  // wallTexture_1 (post-advection) == wallTexture_0 after the pressure pass-through; the fused path keeps one copy
+  case WX_FIELD_WALL_DISP: *ptr = s->ran_fused ? s->wall[0] : s->wall[1]; *channels = 4; *elem = 1; return 0;
   case WX_FIELD_LIGHT_0: *ptr = s->light[0]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_LIGHT_1: *ptr = s->light[1]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_CURL: *ptr = s->curl; *channels = 1; *elem = 4; return 0;

@@ -21,6 +21,19 @@ def E(pkg):
     return engine
 
 
+@pytest.fixture(params=[1, 0], ids=["fused", "perpass"])
+def fused(request):
+    """Both kernel sets go through every parity test: WX_FUSED is read by wx_create."""
+    import os
+    old = os.environ.get("WX_FUSED")
+    os.environ["WX_FUSED"] = str(request.param)
+    yield request.param
+    if old is None:
+        os.environ.pop("WX_FUSED", None)
+    else:
+        os.environ["WX_FUSED"] = old
+
+
 def _make_pair(pkg, oracle, E, X, Y, base, water, wall, u, drops=None, iter0=0):
     nd = 0 if drops is None else len(drops)
     h = E.Handle(X, Y, nd)
@@ -43,7 +56,7 @@ def _assert_grid_equal(h, o, fields=GRID_FIELDS):
 
 @pytest.mark.parametrize("name", ["save100qa", "synth64"])
 @pytest.mark.parametrize("quad_scale", [0, 1])
-def test_bit_exact_vs_oracle_on_golden_inputs(pkg, oracle, golden, E, name, quad_scale):
+def test_bit_exact_vs_oracle_on_golden_inputs(pkg, oracle, golden, E, name, quad_scale, fused):
     g, u = golden(name)
     u = dict(u, quad_scale=quad_scale, enablePrecipitation=0)
     X, Y = int(g["X"]), int(g["Y"])
@@ -57,7 +70,7 @@ def test_bit_exact_vs_oracle_on_golden_inputs(pkg, oracle, golden, E, name, quad
     assert h.iter == o.iter == int(g["iter0"]) + 50
 
 
-def test_vs_swiftshader_goldens(pkg, golden, E):
+def test_vs_swiftshader_goldens(pkg, golden, E, fused):
     """HIP (quad_scale=1) straight against the reference's own output, 50 iterations of the save."""
     g, u = golden("save100qa")
     u = dict(u, quad_scale=1, enablePrecipitation=0)
@@ -80,7 +93,7 @@ def test_vs_swiftshader_goldens(pkg, golden, E):
 
 
 @pytest.mark.parametrize("X,Y", [(512, 128), (192, 96), (130, 50)])
-def test_bit_exact_terrain_grid(pkg, oracle, E, X, Y):
+def test_bit_exact_terrain_grid(pkg, oracle, E, X, Y, fused):
     """setupShader-style terrain with default settings, all grid passes + lighting; ragged sizes included."""
     S = pkg.synth
     base, water, wall = S.terrain_grid(X, Y)
@@ -114,7 +127,7 @@ def test_dry_config_pass_mask(pkg, oracle, E):
     assert np.abs(h.read_rect("BASE_CUR")[..., 0]).max() > 1e-4
 
 
-def test_particles_vs_oracle(pkg, oracle, golden, E):
+def test_particles_vs_oracle(pkg, oracle, golden, E, fused):
     g, u = golden("precip64")
     u = dict(u, quad_scale=0, enablePrecipitation=1)
     X, Y = int(g["X"]), int(g["Y"])
@@ -161,7 +174,7 @@ def test_read_rect_contract(pkg, golden, E):
         h.read_particles(0, 1)
 
 
-def test_full_size_invariants(pkg, E):
+def test_full_size_invariants(pkg, E, fused):
     """BASELINE size (16384 x 2048): x-shift equivariance, determinism, no NaN, water >= 0."""
     X, Y = 16384, 2048
     S = pkg.synth
