@@ -174,8 +174,11 @@ def test_read_rect_contract(pkg, golden, E):
         h.read_particles(0, 1)
 
 
-def test_full_size_invariants(pkg, E, fused):
-    """BASELINE size (16384 x 2048): x-shift equivariance, determinism, no NaN, water >= 0."""
+def test_full_size_invariants(pkg, E):
+    """BASELINE size (16384 x 2048): the two independently written kernel sets (fused LDS-tiled vs one kernel
+    per reference pass) agree BIT FOR BIT, runs are deterministic, fields stay finite / non-negative, and the
+    solution is periodic in x (shift equivariance)."""
+    import os
     X, Y = 16384, 2048
     S = pkg.synth
     base, water, wall = S.terrain_grid(X, Y)
@@ -184,24 +187,42 @@ def test_full_size_invariants(pkg, E, fused):
     u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
     u["enablePrecipitation"] = 0
     p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    fields = ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1", "WATER_0", "BASE_DISP", "CURL")
 
-    def run(b, w, wl, n):
-        h = E.Handle(X, Y, 0)
+    def run(b, w, wl, n, fused):
+        os.environ["WX_FUSED"] = str(fused)
+        try:
+            h = E.Handle(X, Y, 0)
+        finally:
+            os.environ.pop("WX_FUSED", None)
         h.upload(b, w, wl)
         h.set_params(p, u["initial_T"])
         h.step(n)
-        out = h.read_rect("BASE_CUR"), h.read_rect("WATER_CUR"), h.read_rect("WALL_CUR")
+        out = {f: h.read_rect(f) for f in fields}
         h.close()
         return out
 
     n = 12
-    b0, w0, wl0 = run(base, water, wall, n)
-    assert np.isfinite(b0).all() and np.isfinite(w0).all()
+    r_f = run(base, water, wall, n, 1)
+    r_p = run(base, water, wall, n, 0)
+    for f in fields:
+        assert np.array_equal(r_f[f], r_p[f]), f"fused and per-pass kernels differ in {f}"
+    del r_p
+    b0, w0, wl0 = r_f["BASE_CUR"], r_f["WATER_CUR"], r_f["WALL_CUR"]
+    assert np.isfinite(b0).all() and np.isfinite(w0).all() and np.isfinite(r_f["LIGHT_0"]).all()
     assert (w0[..., 0] >= 0).all() and (w0[..., 1] >= 0).all()
-    assert np.abs(b0[..., 1]).max() > 0  # something happened
-    # periodic in x: shifting the input by a multiple of 80 columns (industrial stacks use x % 80) shifts the output
+    assert np.abs(b0[..., :2]).max() > 1e-3  # the flow developed
+    # determinism
+    r_2 = run(base, water, wall, n, 1)
+    assert all(np.array_equal(r_f[f], r_2[f]) for f in fields)
+    del r_2
+    # periodic in x: shifting the input by a multiple of 80 columns (industrial stacks use x % 80) shifts the
+    # output. Masks and water are exactly equivariant; the back-trace `fragCoord - v` is evaluated at the
+    # absolute x like in the reference, so its rounding depends on x (ulp(16384.5) = 1e-3 cell): velocity,
+    # pressure and temperature are equivariant to a few ulp, not bit for bit.
     k = 80 * 37
-    b1, w1, wl1 = run(np.roll(base, k, 1), np.roll(water, k, 1), np.roll(wall, k, 1), n)
-    assert np.array_equal(np.roll(b0, k, 1), b1)
-    assert np.array_equal(np.roll(w0, k, 1), w1)
-    assert np.array_equal(np.roll(wl0, k, 1), wl1)
+    r_s = run(np.roll(base, k, 1), np.roll(water, k, 1), np.roll(wall, k, 1), n, 1)
+    assert np.array_equal(np.roll(wl0, k, 1), r_s["WALL_CUR"])
+    assert np.abs(np.roll(w0, k, 1) - r_s["WATER_CUR"]).max() <= 1e-5
+    d = np.abs(np.roll(b0, k, 1) - r_s["BASE_CUR"])
+    assert d[..., :3].max() <= 1e-6 and d[..., 3].max() <= 1e-4
