@@ -46,8 +46,11 @@ def terrain_height(X: int, seed: float = 0.5, height_mult: float = 0.3) -> np.nd
     return h * height_mult
 
 
-def terrain_grid(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: float = 0.3, snap: int = 2):
-    """(base, water, wall) of a new simulation (setupShader.frag:36-92), terrain snapped to ``snap`` cells."""
+def terrain_grid(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: float = 0.3, snap: int = 2, cols=None):
+    """(base, water, wall) of a new simulation (setupShader.frag:36-92), terrain snapped to ``snap`` cells.
+
+    ``cols=(start, count)`` returns only the columns ``(start + i) mod X`` (a slab with its ghost columns) of the
+    X-wide domain; every quantity is a function of the global column, so slabs tile the whole-domain result."""
     gui = params.merge_settings(None) if gui is None else gui
     sim_h = float(gui["simHeight"])
     dry_lapse = sim_h * float(gui["dryLapseRate"]) / 1000.0
@@ -61,6 +64,11 @@ def terrain_grid(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: float
     if snap > 1:
         nrows = ((nrows + snap - 1) // snap) * snap  # even thickness
     nrows = np.minimum(nrows, Y - 8)
+    gcol = np.arange(X)
+    if cols is not None:
+        gcol = (cols[0] + np.arange(cols[1])) % X
+        h, nrows = h[gcol], nrows[gcol]
+        X = int(cols[1])
     yy = np.arange(Y)[:, None]
     is_wall = yy < nrows[None, :]
     is_sea = (h < texY)[None, :] & is_wall
@@ -89,7 +97,7 @@ def terrain_grid(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: float
     water[..., 0] = np.where(is_land, 1001.0, water[..., 0])
     water[..., 2] = np.where(is_land, 25.0, water[..., 2])
     water[..., 2] = np.where(is_sea, 100.0, water[..., 2])
-    fx = np.arange(X, dtype=np.float64) + 0.5
+    fx = gcol.astype(np.float64) + 0.5
     veg = 110.0 - (yy + 0.5) * 2.0 + (_noise(fx * 0.01 + _rand(seed) * 10.0) * 150.0)[None, :]
     wall[..., 3] = np.where(is_land, np.clip(np.trunc(veg), 0, 127), 0).astype(np.int8)
     height_m = h * sim_h

@@ -134,8 +134,9 @@ def _vp(a: Optional[np.ndarray]):
 class OracleSim:
     """Whole-simulation oracle object (texture set + ping-pong of app.js:5830-6005)."""
 
-    def __init__(self, X: int, Y: int, n_drops: int = 0):
+    def __init__(self, X: int, Y: int, n_drops: int = 0, X_global: Optional[int] = None, x_off: int = 0):
         self.X, self.Y, self.n_drops = X, Y, n_drops
+        self.X_global, self.x_off = (X if X_global is None else X_global), x_off
         self._h = lib().wxo_create(X, Y, n_drops)
         self.pass_mask = 0x7F
 
@@ -161,7 +162,7 @@ class OracleSim:
         lib().wxo_upload(self._h, base, water, wall, _vp(d))
 
     def set_params(self, u: Dict[str, Any]):
-        p = make_params(u, self.X, self.Y)
+        p = make_params(u, self.X, self.Y, self.X_global, self.x_off)
         self._vary_keep = getattr(p, "_keep", None)
         self.pass_mask = int(u.get("pass_mask", 0x7F))
         T0 = np.ascontiguousarray(u["initial_T"], np.float32)
@@ -180,6 +181,13 @@ class OracleSim:
     @iter.setter
     def iter(self, v: int):
         lib().wxo_set_iter(self._h, v)
+
+    def view(self, name: str) -> np.ndarray:
+        """Writable no-copy view of a grid field (used by the slab halo exchange test engine)."""
+        fid, dt, ch = FIELDS[name]
+        ptr = lib().wxo_field(self._h, fid)
+        ct = C.c_float if dt == np.float32 else C.c_int8
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), (self.Y, self.X, ch))
 
     def field(self, name: str) -> np.ndarray:
         if name == "LIGHTNING":

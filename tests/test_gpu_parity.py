@@ -226,3 +226,57 @@ def test_full_size_invariants(pkg, E):
     assert np.abs(np.roll(w0, k, 1) - r_s["WATER_CUR"]).max() <= 1e-5
     d = np.abs(np.roll(b0, k, 1) - r_s["BASE_CUR"])
     assert d[..., :3].max() <= 1e-6 and d[..., 3].max() <= 1e-4
+
+
+@pytest.mark.parametrize("nslab,halo", [(2, 12), (4, 6)])
+def test_slab_handles_equal_whole_domain(pkg, E, fused, nslab, halo):
+    """wx_create_slab + wx_halo_pack/unpack: N slab handles on one GPU, halos copied device-to-device in ring
+    order, against the undecomposed handle -- bit for bit. (The multi-process RCCL path uses the same calls;
+    its exchange logic is covered by tests/test_slab_gloo.py.)"""
+    import torch
+    X, Y, n_iter = 256, 64, 9
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    rng = np.random.default_rng(2)
+    air = wall[..., 1] != 0
+    base[..., 0] += np.where(air, rng.normal(0, 0.2, (Y, X)), 0).astype(np.float32)
+    base[..., 1] += np.where(air, rng.normal(0, 0.1, (Y, X)), 0).astype(np.float32)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 35.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=1)
+    u["enablePrecipitation"] = 0
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    whole = E.Handle(X, Y, 0)
+    whole.upload(base, water, wall)
+    whole.set_params(p, u["initial_T"])
+    xo = X // nslab
+    slabs, bufs = [], []
+    for r in range(nslab):
+        h = E.Handle(xo, Y, 0, X_global=X, x0=r * xo, halo=halo)
+        idx = (r * xo - halo + np.arange(xo + 2 * halo)) % X
+        h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]))
+        h.set_params(p, u["initial_T"])
+        assert h.halo_bytes() == halo * Y * 68
+        slabs.append(h)
+        bufs.append([torch.empty(h.halo_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2)])
+    per = halo // 6
+    done = 0
+    while done < n_iter:
+        k = min(per, n_iter - done)
+        for h in slabs:
+            h.step(k)
+        done += k
+        for r, h in enumerate(slabs):
+            h.halo_pack(0, bufs[r][0].data_ptr())
+            h.halo_pack(1, bufs[r][1].data_ptr())
+        for h in slabs:
+            h.sync()
+        for r, h in enumerate(slabs):
+            h.halo_unpack(0, bufs[(r - 1) % nslab][1].data_ptr())  # left ghosts <- left neighbour's right edge
+            h.halo_unpack(1, bufs[(r + 1) % nslab][0].data_ptr())
+        for h in slabs:
+            h.sync()
+    whole.step(n_iter)
+    for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1"):
+        ref = whole.read_rect(f)
+        for r, h in enumerate(slabs):
+            assert np.array_equal(h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]), (f, r)
