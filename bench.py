@@ -76,10 +76,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if os.environ.get("WX_BENCH_SHARE_GPU"):  # plumbing test on a 1-GPU box: all ranks on cuda:0, gloo transport
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("WX_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     X, Y = a.X, a.Y
