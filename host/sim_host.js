@@ -1,0 +1,258 @@
+/*
+ * sim_host.js -- Node.js host for the MI355X engine: the reference's simulation seam in JavaScript.
+ *
+ * app.js cannot be require()d under Node (DOM everywhere), so this file restates, call for call, the parts
+ * of it that belong to the hot path and binds them to the N-API addon instead of WebGL:
+ *   loadData()            app.js:1256-1366   -> loadSave()
+ *   settings merge        app.js:3378-3399 + libraries/dat.gui.min.js:136-150 -> mergeSettings()
+ *   derived constants     app.js:5436-5476   -> uniformsFromGui()
+ *   setGuiUniforms()      app.js:3401-3443   -> WeatherSim.pushUniforms()
+ *   updateSunlight()      app.js:6510-6561   -> WeatherSim.updateSunlight()
+ *   draw() simulation     app.js:5814-6005   -> WeatherSim.frame()
+ *   readPixels consumers  SURVEY.md 3.5      -> WeatherSim.readRect() & friends
+ *   prepareDownload()     app.js:6575-6628   -> WeatherSim.toSave()
+ * Rendering / UI / audio stay where they are in the reference.
+ *
+ * CLI:  node host/sim_host.js <in.weathersandbox> <iterations> [out.weathersandbox] [--sun-fixed] [--dump out.bin]
+ */
+'use strict';
+const fs = require('fs');
+const path = require('path');
+const zlib = require('zlib');
+
+const SAVE_FILE_VERSION_ID = 263574036; // app.js:345
+const LEGACY_VERSION_ID = 1939327491;
+const TIME_PER_ITERATION = 0.00008; // app.js:449
+const DEG2RAD = 0.0174533, RAD2DEG = 57.2957795; // app.js:340-341
+
+const GUI_DEFAULTS = { // app.js:347-407
+  vorticity: 0.005, dragMultiplier: 0.001, wind: 0.0, globalEffectsStartAlt: 0, globalEffectsEndAlt: 10000, globalDrying: 0.0,
+  globalHeating: 0.0, soundingForcing: 0.0, sunIntensity: 1.0, waterTemperature: 25.0, dynamicWaterTemperature: true,
+  landEvaporation: 0.00005, waterEvaporation: 0.0001, evapHeat: 2.90, meltingHeat: 0.43, condensationRate: 0.0050, waterWeight: 0.25,
+  inactiveDroplets: 0, aboveZeroThreshold: 1.0, subZeroThreshold: 0.005, spawnChance: 0.00005, snowDensity: 0.2, fallSpeed: 0.0003,
+  growthRate0C: 0.0001, growthRate_30C: 0.001, freezingRate: 0.01, meltingRate: 0.01, evapRate: 0.0008, displayMode: 'DISP_REAL',
+  wrapHorizontally: true, SmoothCam: true, camSpeed: 0.01, exposure: 1.0, timeOfDay: 9.9, latitude: 45.0, month: 6.65, sunAngle: 9.9,
+  dayNightCycle: true, greenhouseGases: 0.001, waterGreenHouseEffect: 0.0015, IR_rate: 1.0, tool: 'TOOL_NONE', brushSize: 20,
+  wholeWidth: false, intensity: 0.01, showGraph: false, realDewPoint: false, enablePrecipitation: true, showDrops: false, paused: false,
+  IterPerFrame: 10, auto_IterPerFrame: true, sound: true, dryLapseRate: 10.0, simHeight: 12000, twelveHourClock: false,
+  lengthUnit: 'LENGTH_UNIT_METRIC', tempUnit: 'TEMP_UNIT_C', windUnit: 'SPEED_UNIT_KMH'
+};
+
+const FIELD = {BASE_CUR: 0, BASE_DISP: 1, WATER_0: 2, WATER_CUR: 3, WALL_CUR: 4, WALL_DISP: 5, LIGHT_0: 6, LIGHT_1: 7, CURL: 8, VORT: 9,
+               PRECIP_FB: 10, PRECIP_DEP: 11, LIGHTNING: 12};
+
+function loadAddon()
+{
+  return require(path.join(__dirname, 'wxsim_napi.node')); // throws if libwxsim.so / the GPU is missing
+}
+
+// ---- .weathersandbox codec (app.js:1261-1344, 6610-6621; pako 1.0.3 == RFC 1950 zlib) ----
+function decodeSave(buf)
+{
+  const version = buf.readUInt32LE(0);
+  if (version !== SAVE_FILE_VERSION_ID && version !== LEGACY_VERSION_ID) throw new Error('Incompatible file!');
+  const raw = zlib.inflateSync(buf.slice(4));
+  const X = raw.readUInt16LE(0), Y = raw.readUInt16LE(2);
+  let off = 4;
+  const n = X * Y * 4;
+  function f32(count) { const a = new Float32Array(raw.buffer.slice(raw.byteOffset + off, raw.byteOffset + off + count * 4)); off += count * 4; return a; }
+  const base = f32(n), water = f32(n);
+  const wall = new Int8Array(raw.buffer.slice(raw.byteOffset + off, raw.byteOffset + off + n));
+  off += n;
+  const ndBytes = Math.floor((X * Y) / 25 * 4 * 5);
+  const nd = Math.floor(ndBytes / 20);
+  const droplets = f32(nd * 5);
+  off += ndBytes - nd * 20;
+  const stations = [];
+  let settings = null;
+  if (version === SAVE_FILE_VERSION_ID) {
+    const ns = raw.readInt16LE(off);
+    off += 2;
+    for (let i = 0; i < ns; i++) stations.push([raw.readInt16LE(off + 4 * i), raw.readInt16LE(off + 4 * i + 2)]);
+    off += ns * 4;
+    const txt = raw.slice(off).toString('utf8');
+    settings = txt.trim().length ? JSON.parse(txt) : null;
+  }
+  return {X: X, Y: Y, base: base, water: water, wall: wall, droplets: droplets, stations: stations, settings: settings, version: version};
+}
+function loadSave(file) { return decodeSave(fs.readFileSync(file)); }
+
+function encodeSave(sf)
+{
+  const head = Buffer.alloc(4);
+  head.writeUInt16LE(sf.X, 0);
+  head.writeUInt16LE(sf.Y, 2);
+  const ns = Buffer.alloc(2 + sf.stations.length * 4);
+  ns.writeUInt16LE(sf.stations.length, 0);
+  sf.stations.forEach(function(s, i) { ns.writeInt16LE(s[0], 2 + 4 * i); ns.writeInt16LE(s[1], 4 + 4 * i); });
+  const b = function(t) { return Buffer.from(t.buffer, t.byteOffset, t.byteLength); };
+  const body = Buffer.concat([head, b(sf.base), b(sf.water), b(sf.wall), b(sf.droplets), ns, Buffer.from(JSON.stringify(sf.settings || {}), 'utf8')]);
+  const ver = Buffer.alloc(4);
+  ver.writeUInt32LE(SAVE_FILE_VERSION_ID, 0);
+  return Buffer.concat([ver, zlib.deflateSync(body)]);
+}
+
+// ---- settings merge: missing numeric (or a saved -1) -> default, missing boolean -> false ----
+function mergeSettings(saved)
+{
+  if (saved == null) return Object.assign({}, GUI_DEFAULTS);
+  const out = Object.assign({}, saved);
+  Object.keys(GUI_DEFAULTS).forEach(function(k) {
+    const d = GUI_DEFAULTS[k];
+    if (typeof d === 'boolean') { if (!(k in out)) out[k] = false; }
+    else if (typeof d === 'number') { if (!(k in out) || out[k] === -1) out[k] = d; }
+    else if (!(k in out)) out[k] = d;
+  });
+  return out;
+}
+
+// ---- derived parameters ----
+function initialTemperatureProfile(Y, simHeight, dryLapse)
+{ // app.js:5467-5474 (float64 math, then Float32Array as gl.uniform4fv)
+  const T = new Float32Array(Y + 1);
+  for (let y = 0; y < Y + 1; y++) {
+    const altitude = y / (Y + 1) * simHeight;
+    const realTemp = Math.max(15.0 + (altitude - 0) * (-70.0 - 15.0) / (12000 - 0), -60);
+    T[y] = (realTemp + 273.15) + (y / Y) * dryLapse;
+  }
+  return T;
+}
+function sunFromAngle(sunAngleDeg, sunIntensityGui)
+{ // app.js:6538-6550
+  return {
+    zenith: (sunAngleDeg - 90) * DEG2RAD,
+    intensity: sunIntensityGui * Math.pow(Math.max(Math.sin((180.0 - sunAngleDeg) * DEG2RAD), 0.0), 0.1) * 1300.0
+  };
+}
+function sunAngleFromTime(timeOfDay, month, latitude)
+{ // app.js:6522-6536
+  const tod = (timeOfDay / 24.0) * 2.0 * Math.PI - Math.PI / 2.0;
+  const tiltDeg = Math.sin(month * 0.5236 - 1.92) * 23.5;
+  const t = tiltDeg * DEG2RAD, l = latitude * DEG2RAD;
+  let ang = Math.asin(Math.sin(t) * Math.sin(l) + Math.cos(t) * Math.cos(l) * Math.sin(tod)) * RAD2DEG;
+  if (latitude - tiltDeg < 0.0) ang = 180.0 - ang;
+  return ang;
+}
+function uniformsFromGui(gui, Y, opts)
+{
+  opts = opts || {};
+  const simH = gui.simHeight;
+  const dryLapse = simH * gui.dryLapseRate / 1000.0; // app.js:5439
+  const sun = sunFromAngle(opts.sunAngleDeg != null ? opts.sunAngleDeg : gui.sunAngle, gui.sunIntensity);
+  return {
+    dragMultiplier: gui.dragMultiplier, wind: gui.wind, vorticity: gui.vorticity, landEvaporation: gui.landEvaporation,
+    waterEvaporation: gui.waterEvaporation, dynamicWaterTemperature: gui.dynamicWaterTemperature ? 1.0 : 0.0, evapHeat: gui.evapHeat,
+    waterWeight: gui.waterWeight, sunAngle: sun.zenith, dryLapse: dryLapse, meltingHeat: gui.meltingHeat, condensationRate: gui.condensationRate,
+    globalDrying: gui.globalDrying, globalHeating: gui.globalHeating, soundingForcing: gui.soundingForcing,
+    globalEffectsStartAlt: gui.globalEffectsStartAlt / simH, globalEffectsEndAlt: gui.globalEffectsEndAlt / simH,
+    waterTemperature: gui.waterTemperature + 273.15, sunIntensity: sun.intensity, greenhouseGases: gui.greenhouseGases,
+    waterGreenHouseEffect: gui.waterGreenHouseEffect, IR_rate: gui.IR_rate, aboveZeroThreshold: gui.aboveZeroThreshold,
+    subZeroThreshold: gui.subZeroThreshold, spawnChanceMult: gui.spawnChance, snowDensity: gui.snowDensity, fallSpeed: gui.fallSpeed,
+    growthRate0C: gui.growthRate0C, growthRate_30C: gui.growthRate_30C, freezingRate: gui.freezingRate, meltingRate: gui.meltingRate,
+    evapRate: gui.evapRate, inactiveDroplets: 0.0, userInputValues: [0, 0, 0, 0], userInputMove: [0, 0], userInputType: -1,
+    wrapHorizontally: gui.wrapHorizontally ? 1 : 0, airplaneValues: [0, 0, 0, 0], enablePrecipitation: gui.enablePrecipitation ? 1 : 0,
+    quad_scale: opts.quadScale || 0, pass_mask: opts.passMask != null ? opts.passMask : 0x7F,
+    initial_T: initialTemperatureProfile(Y, simH, dryLapse)
+  };
+}
+
+// ---- the simulation object: mainScript() + draw()'s simulation block + readbacks ----
+function WeatherSim(sf, opts)
+{
+  opts = opts || {};
+  this.addon = opts.addon || loadAddon();
+  this.X = sf.X;
+  this.Y = sf.Y;
+  this.gui = mergeSettings(sf.settings);
+  this.nDroplets = sf.droplets ? Math.floor(sf.droplets.length / 5) : 0;
+  this.opts = opts;
+  this.manualSun = opts.sunFixed ? this.gui.sunAngle : null; // updateSunlight('MANUAL_ANGLE')
+  this.h = this.addon.create(this.X, this.Y, this.nDroplets);
+  this.addon.upload(this.h, sf.base, sf.water, sf.wall, this.nDroplets ? sf.droplets : null);
+  // startSimulation(): clock from month / timeOfDay (app.js:3902)
+  const m = this.gui.month;
+  this.simDateTime = new Date(2000, Math.floor(m) - 1, (m % 1) * 30.417);
+  this.simDateTime = new Date(this.simDateTime.getTime() + this.gui.timeOfDay * 3600 * 1000);
+  this.brush = {userInputType: -1, userInputValues: [0, 0, 0, 0], userInputMove: [0, 0]};
+  this.inactivePushed = false;
+  this.pushUniforms();
+}
+WeatherSim.prototype.pushUniforms = function() {
+  const u = uniformsFromGui(this.gui, this.Y, {sunAngleDeg: this.manualSun, quadScale: this.opts.quadScale, passMask: this.opts.passMask});
+  Object.assign(u, this.brush);
+  u.inactiveDroplets = this.inactivePushed ? -1.0 : 0.0; // keep the engine's 600-iteration measurement (app.js:5957-5966)
+  this.addon.setParams(this.h, u, u.initial_T);
+  this.inactivePushed = true;
+};
+WeatherSim.prototype.setGui = function(changes) { Object.assign(this.gui, changes); this.pushUniforms(); };
+WeatherSim.prototype.setBrush = function(type, x, y, intensity, brushSize, move) { // app.js:5749-5808
+  this.brush = {userInputType: type, userInputValues: [x, y, intensity, brushSize * 0.5], userInputMove: move || [0, 0]};
+  this.pushUniforms();
+};
+WeatherSim.prototype.updateSunlight = function(deltaHours) { // app.js:6510-6561
+  if (deltaHours != null) {
+    this.simDateTime = new Date(this.simDateTime.getTime() + deltaHours * 3600 * 1000);
+    const t = this.simDateTime;
+    this.gui.timeOfDay = t.getHours() + t.getMinutes() / 60. + t.getSeconds() / 3600.;
+    this.gui.month = t.getMonth() + 1 + t.getDate() / 30.5 + t.getHours() / 720.;
+  }
+  this.gui.sunAngle = sunAngleFromTime(this.gui.timeOfDay, this.gui.month, this.gui.latitude);
+  this.manualSun = null;
+  this.pushUniforms();
+};
+// one animation frame: `IterPerFrame` iterations (app.js:5814-6005)
+WeatherSim.prototype.frame = function(nIter) {
+  const n = nIter != null ? nIter : this.gui.IterPerFrame;
+  if (this.gui.paused) return;
+  if (this.gui.dayNightCycle && this.manualSun == null) this.updateSunlight(TIME_PER_ITERATION * n);
+  this.addon.step(this.h, n);
+};
+WeatherSim.prototype.sync = function() { this.addon.sync(this.h); };
+WeatherSim.prototype.iterNum = function() { return this.addon.getIter(this.h); };
+WeatherSim.prototype.readRect = function(field, x, y, w, h, Type) {
+  const id = typeof field === 'string' ? FIELD[field] : field;
+  const ch = id === FIELD.CURL ? 1 : (id === FIELD.VORT || id === FIELD.PRECIP_DEP) ? 2 : 4;
+  const isWall = id === FIELD.WALL_CUR || id === FIELD.WALL_DISP;
+  const dst = new (Type || (isWall ? Int8Array : Float32Array))(w * h * ch);
+  return this.addon.readRect(this.h, id, x, y, w, h, dst);
+};
+WeatherSim.prototype.measureStation = function(x, y) { // Weatherstation.measure, app.js:1084-1092
+  return {base: this.readRect('BASE_CUR', x, y - 1, 1, 3), water: this.readRect('WATER_0', x, y - 1, 1, 2)};
+};
+WeatherSim.prototype.soundingColumn = function(x) { // soundingGraph.draw, app.js:3931-3943 (wall as Int32Array)
+  return {base: this.readRect('BASE_DISP', x, 0, 1, this.Y), water: this.readRect('WATER_CUR', x, 0, 1, this.Y),
+          wall: this.readRect('WALL_DISP', x, 0, 1, this.Y, Int32Array)};
+};
+WeatherSim.prototype.readParticles = function() {
+  return this.nDroplets ? this.addon.readParticles(this.h, 0, this.nDroplets, new Float32Array(this.nDroplets * 5)) : new Float32Array(0);
+};
+WeatherSim.prototype.toSave = function() { // prepareDownload(): FB0 = base_0, water_0, wall_0 (app.js:6584-6593)
+  return {X: this.X, Y: this.Y, base: this.readRect('BASE_CUR', 0, 0, this.X, this.Y), water: this.readRect('WATER_0', 0, 0, this.X, this.Y),
+          wall: this.readRect('WALL_CUR', 0, 0, this.X, this.Y), droplets: this.readParticles(), stations: [], settings: this.gui};
+};
+WeatherSim.prototype.destroy = function() { this.addon.destroy(this.h); };
+
+module.exports = {WeatherSim: WeatherSim, loadSave: loadSave, decodeSave: decodeSave, encodeSave: encodeSave, mergeSettings: mergeSettings,
+                  uniformsFromGui: uniformsFromGui, initialTemperatureProfile: initialTemperatureProfile, sunFromAngle: sunFromAngle,
+                  sunAngleFromTime: sunAngleFromTime, GUI_DEFAULTS: GUI_DEFAULTS, FIELD: FIELD};
+
+if (require.main === module) {
+  const args = process.argv.slice(2);
+  const flags = args.filter(function(a) { return a.startsWith('--'); });
+  const pos = args.filter(function(a) { return !a.startsWith('--'); });
+  if (pos.length < 2) {
+    console.error('usage: node sim_host.js <in.weathersandbox> <iterations> [out.weathersandbox] [--sun-fixed] [--selftest]');
+    process.exit(2);
+  }
+  const sf = loadSave(pos[0]);
+  const sim = new WeatherSim(sf, {sunFixed: flags.indexOf('--sun-fixed') >= 0});
+  const n = parseInt(pos[1], 10);
+  const t0 = Date.now();
+  let left = n;
+  while (left > 0) { const k = Math.min(left, sim.gui.IterPerFrame); sim.frame(k); left -= k; }
+  sim.sync();
+  const dt = (Date.now() - t0) / 1000;
+  console.log(JSON.stringify({X: sf.X, Y: sf.Y, iterations: n, iterNum: sim.iterNum(), seconds: dt, McellStepsPerS: sf.X * sf.Y * n / dt / 1e6}));
+  if (pos[2]) fs.writeFileSync(pos[2], encodeSave(sim.toSave()));
+  sim.destroy();
+}

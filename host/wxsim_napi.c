@@ -1,0 +1,359 @@
+/*
+ * wxsim_napi.c -- thin Node.js N-API (raw C, N-API v8 / Node 12+) shim over the C ABI of include/wxsim.h.
+ *
+ * This is the binding a maintainer of the reference adds so that app.js' per-frame simulation block
+ * (app.js:5830-6005) and its gl.readPixels consumers call the MI355X engine instead of WebGL:
+ *   JS (host/sim_host.js)  ->  this N-API addon  ->  libwxsim.so (C ABI)  ->  HIP kernels.
+ * libwxsim.so is dlopen()ed at require() time from ../2d-weather-sandbox_amd/csrc (or $WXSIM_LIB).
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/wxsim.h"
+
+static struct {
+  void *dl;
+  int (*create)(int, int, int, wx_sim **);
+  void (*destroy)(wx_sim *);
+  const char *(*last_error)(const wx_sim *);
+  int (*abi_version)(void);
+  int (*upload)(wx_sim *, const float *, const float *, const int8_t *, const float *);
+  int (*set_params)(wx_sim *, const wx_params *, const float *, const float *, const float *, const float *);
+  int (*step)(wx_sim *, int);
+  int (*sync)(wx_sim *);
+  int64_t (*get_iter)(const wx_sim *);
+  int (*set_iter)(wx_sim *, int64_t);
+  int (*read_rect)(wx_sim *, int, int, int, int, int, void *, int);
+  int (*read_particles)(wx_sim *, int, int, float *);
+} L;
+
+#define NAPI_CALL(env, call)                                                        \
+  do {                                                                              \
+    if ((call) != napi_ok) {                                                        \
+      napi_throw_error((env), NULL, "N-API call failed: " #call);                   \
+      return NULL;                                                                  \
+    }                                                                               \
+  } while (0)
+
+static napi_value throw_wx(napi_env env, wx_sim *s, int rc, const char *what)
+{
+  char buf[640];
+  snprintf(buf, sizeof(buf), "%s failed (%d): %s", what, rc, L.last_error ? L.last_error(s) : "");
+  napi_throw_error(env, NULL, buf);
+  return NULL;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv)
+{
+  size_t argc = want;
+  if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+    napi_throw_type_error(env, NULL, "wrong number of arguments");
+    return -1;
+  }
+  return 0;
+}
+
+static wx_sim *get_handle(napi_env env, napi_value v)
+{
+  void *p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+    napi_throw_type_error(env, NULL, "expected a simulation handle");
+    return NULL;
+  }
+  return *(wx_sim **)p;
+}
+
+static void finalize_handle(napi_env env, void *data, void *hint)
+{
+  wx_sim **slot = (wx_sim **)data;
+  if (*slot) L.destroy(*slot);
+  free(slot);
+}
+
+static void *typed_data(napi_env env, napi_value v, napi_typedarray_type want, size_t *len)
+{
+  bool is = false;
+  napi_typedarray_type t;
+  void *data = NULL;
+  if (napi_is_typedarray(env, v, &is) != napi_ok || !is) return NULL;
+  if (napi_get_typedarray_info(env, v, &t, len, &data, NULL, NULL) != napi_ok || t != want) return NULL;
+  return data;
+}
+
+/* create(X, Y, nDroplets) -> handle   [replaces texture/FBO/particle-buffer creation, app.js:5149-5317, 4891-5002] */
+static napi_value Create(napi_env env, napi_callback_info info)
+{
+  napi_value a[3];
+  if (get_args(env, info, 3, a)) return NULL;
+  int32_t X, Y, N;
+  NAPI_CALL(env, napi_get_value_int32(env, a[0], &X));
+  NAPI_CALL(env, napi_get_value_int32(env, a[1], &Y));
+  NAPI_CALL(env, napi_get_value_int32(env, a[2], &N));
+  wx_sim *s = NULL;
+  int rc = L.create(X, Y, N, &s);
+  if (rc) return throw_wx(env, NULL, rc, "wx_create");
+  wx_sim **slot = (wx_sim **)malloc(sizeof(*slot));
+  *slot = s;
+  napi_value ext;
+  NAPI_CALL(env, napi_create_external(env, slot, finalize_handle, NULL, &ext));
+  return ext;
+}
+
+static napi_value Destroy(napi_env env, napi_callback_info info)
+{
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  void *p = NULL;
+  if (napi_get_value_external(env, a[0], &p) == napi_ok && p && *(wx_sim **)p) {
+    L.destroy(*(wx_sim **)p);
+    *(wx_sim **)p = NULL;
+  }
+  return NULL;
+}
+
+/* upload(h, Float32Array base, Float32Array water, Int8Array wall, Float32Array drops|null)  [setupTextures()] */
+static napi_value Upload(napi_env env, napi_callback_info info)
+{
+  napi_value a[5];
+  if (get_args(env, info, 5, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  size_t n;
+  const float *base = (const float *)typed_data(env, a[1], napi_float32_array, &n);
+  const float *water = (const float *)typed_data(env, a[2], napi_float32_array, &n);
+  const int8_t *wall = (const int8_t *)typed_data(env, a[3], napi_int8_array, &n);
+  const float *drops = (const float *)typed_data(env, a[4], napi_float32_array, &n);
+  if (!base || !water || !wall) {
+    napi_throw_type_error(env, NULL, "upload: base/water must be Float32Array, wall Int8Array");
+    return NULL;
+  }
+  int rc = L.upload(s, base, water, wall, drops);
+  if (rc) return throw_wx(env, s, rc, "wx_upload");
+  return NULL;
+}
+
+static int get_f(napi_env env, napi_value obj, const char *k, float *out)
+{
+  napi_value v;
+  double d;
+  bool has = false;
+  if (napi_has_named_property(env, obj, k, &has) != napi_ok || !has) return 0;
+  if (napi_get_named_property(env, obj, k, &v) != napi_ok || napi_get_value_double(env, v, &d) != napi_ok) return 0;
+  *out = (float)d;
+  return 1;
+}
+static void get_fv(napi_env env, napi_value obj, const char *k, float *out, uint32_t n)
+{
+  napi_value arr, e;
+  bool has = false;
+  if (napi_has_named_property(env, obj, k, &has) != napi_ok || !has) return;
+  if (napi_get_named_property(env, obj, k, &arr) != napi_ok) return;
+  for (uint32_t i = 0; i < n; i++) {
+    double d;
+    if (napi_get_element(env, arr, i, &e) == napi_ok && napi_get_value_double(env, e, &d) == napi_ok) out[i] = (float)d;
+  }
+}
+
+/* setParams(h, uniformsObject, Float32Array initial_T [, snd_T, snd_W, snd_Vel])   [gl.uniform* pushes] */
+static napi_value SetParams(napi_env env, napi_callback_info info)
+{
+  napi_value a[6];
+  size_t argc = 6;
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, NULL, NULL));
+  if (argc < 3) {
+    napi_throw_type_error(env, NULL, "setParams(handle, uniforms, initial_T[, sndT, sndW, sndVel])");
+    return NULL;
+  }
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  wx_params p;
+  memset(&p, 0, sizeof(p));
+  p.userInputType = -1;
+  p.pass_mask = WX_PASS_ALL;
+  napi_value o = a[1];
+#define F(name) get_f(env, o, #name, &p.name)
+  F(dragMultiplier); F(wind); F(vorticity); F(landEvaporation); F(waterEvaporation); F(dynamicWaterTemperature);
+  F(evapHeat); F(waterWeight); F(sunAngle); F(dryLapse); F(meltingHeat); F(condensationRate); F(globalDrying);
+  F(globalHeating); F(soundingForcing); F(globalEffectsStartAlt); F(globalEffectsEndAlt); F(waterTemperature);
+  F(sunIntensity); F(greenhouseGases); F(waterGreenHouseEffect); F(IR_rate); F(aboveZeroThreshold); F(subZeroThreshold);
+  F(spawnChanceMult); F(snowDensity); F(fallSpeed); F(growthRate0C); F(growthRate_30C); F(freezingRate); F(meltingRate);
+  F(evapRate); F(inactiveDroplets);
+#undef F
+  get_fv(env, o, "userInputValues", p.userInputValues, 4);
+  get_fv(env, o, "userInputMove", p.userInputMove, 2);
+  get_fv(env, o, "airplaneValues", p.airplaneValues, 4);
+  float t;
+  if (get_f(env, o, "userInputType", &t)) p.userInputType = (int32_t)t;
+  if (get_f(env, o, "wrapHorizontally", &t)) p.wrapHorizontally = (int32_t)t;
+  if (get_f(env, o, "enablePrecipitation", &t)) p.enablePrecipitation = (int32_t)t;
+  if (get_f(env, o, "quad_scale", &t)) p.quad_scale = (int32_t)t;
+  if (get_f(env, o, "pass_mask", &t)) p.pass_mask = (uint32_t)t;
+  size_t n;
+  const float *T0 = (const float *)typed_data(env, a[2], napi_float32_array, &n);
+  const float *snd[3] = {NULL, NULL, NULL};
+  for (size_t i = 3; i < argc && i < 6; i++) snd[i - 3] = (const float *)typed_data(env, a[i], napi_float32_array, &n);
+  int rc = L.set_params(s, &p, T0, snd[0], snd[1], snd[2]);
+  if (rc) return throw_wx(env, s, rc, "wx_set_params");
+  return NULL;
+}
+
+/* step(h, nIter)   [the loop body app.js:5830-6005, asynchronous] */
+static napi_value Step(napi_env env, napi_callback_info info)
+{
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  int32_t n;
+  NAPI_CALL(env, napi_get_value_int32(env, a[1], &n));
+  int rc = L.step(s, n);
+  if (rc) return throw_wx(env, s, rc, "wx_step");
+  return NULL;
+}
+
+static napi_value Sync(napi_env env, napi_callback_info info)
+{
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  int rc = L.sync(s);
+  if (rc) return throw_wx(env, s, rc, "wx_sync");
+  return NULL;
+}
+
+static napi_value GetIter(napi_env env, napi_callback_info info)
+{
+  napi_value a[1], r;
+  if (get_args(env, info, 1, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  NAPI_CALL(env, napi_create_double(env, (double)L.get_iter(s), &r));
+  return r;
+}
+
+static napi_value SetIter(napi_env env, napi_callback_info info)
+{
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  double d;
+  NAPI_CALL(env, napi_get_value_double(env, a[1], &d));
+  int rc = L.set_iter(s, (int64_t)d);
+  if (rc) return throw_wx(env, s, rc, "wx_set_iter");
+  return NULL;
+}
+
+/* readRect(h, field, x, y, w, h, dstTypedArray)  [every gl.readPixels of SURVEY 3.5]; dst type selects dtype */
+static napi_value ReadRect(napi_env env, napi_callback_info info)
+{
+  napi_value a[7];
+  if (get_args(env, info, 7, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  int32_t v[5];
+  for (int i = 0; i < 5; i++) NAPI_CALL(env, napi_get_value_int32(env, a[1 + i], &v[i]));
+  bool is = false;
+  napi_typedarray_type t;
+  size_t len;
+  void *data;
+  if (napi_is_typedarray(env, a[6], &is) != napi_ok || !is ||
+      napi_get_typedarray_info(env, a[6], &t, &len, &data, NULL, NULL) != napi_ok) {
+    napi_throw_type_error(env, NULL, "readRect: dst must be a typed array");
+    return NULL;
+  }
+  int dtype = t == napi_float32_array ? WX_DTYPE_F32 : t == napi_int8_array ? WX_DTYPE_I8 : t == napi_int32_array ? WX_DTYPE_I32 : -1;
+  int ch = (v[0] == WX_FIELD_CURL) ? 1 : (v[0] == WX_FIELD_VORT || v[0] == WX_FIELD_PRECIP_DEP) ? 2 : 4;
+  if (dtype < 0 || len < (size_t)v[3] * v[4] * ch) {
+    napi_throw_range_error(env, NULL, "readRect: destination too small or of unsupported type");
+    return NULL;
+  }
+  int rc = L.read_rect(s, v[0], v[1], v[2], v[3], v[4], data, dtype);
+  if (rc) return throw_wx(env, s, rc, "wx_read_rect");
+  return a[6];
+}
+
+/* readParticles(h, first, count, Float32Array dst)  [gl.getBufferSubData, app.js:5019, 5086, 6597] */
+static napi_value ReadParticles(napi_env env, napi_callback_info info)
+{
+  napi_value a[4];
+  if (get_args(env, info, 4, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  int32_t first, count;
+  NAPI_CALL(env, napi_get_value_int32(env, a[1], &first));
+  NAPI_CALL(env, napi_get_value_int32(env, a[2], &count));
+  size_t len;
+  float *dst = (float *)typed_data(env, a[3], napi_float32_array, &len);
+  if (!dst || len < (size_t)count * 5) {
+    napi_throw_range_error(env, NULL, "readParticles: dst must be a Float32Array of count*5");
+    return NULL;
+  }
+  int rc = L.read_particles(s, first, count, dst);
+  if (rc) return throw_wx(env, s, rc, "wx_read_particles");
+  return a[3];
+}
+
+static napi_value AbiVersion(napi_env env, napi_callback_info info)
+{
+  napi_value r;
+  NAPI_CALL(env, napi_create_int32(env, L.abi_version(), &r));
+  return r;
+}
+
+static int load_lib(napi_env env)
+{
+  const char *path = getenv("WXSIM_LIB");
+  char buf[4096];
+  if (!path) {
+    Dl_info di;
+    if (dladdr((void *)&load_lib, &di) && di.dli_fname) {
+      snprintf(buf, sizeof(buf), "%s", di.dli_fname);
+      char *slash = strrchr(buf, '/');
+      if (slash) *slash = 0;
+      strncat(buf, "/../2d-weather-sandbox_amd/csrc/libwxsim.so", sizeof(buf) - strlen(buf) - 1);
+      path = buf;
+    }
+  }
+  L.dl = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+  if (!L.dl) {
+    char msg[4600];
+    snprintf(msg, sizeof(msg), "cannot load libwxsim.so (%s): %s -- there is no CPU fallback", path ? path : "?", dlerror());
+    napi_throw_error(env, NULL, msg);
+    return -1;
+  }
+#define SYM(field, name)                                          \
+  *(void **)&L.field = dlsym(L.dl, name);                         \
+  if (!L.field) {                                                 \
+    napi_throw_error(env, NULL, "libwxsim.so lacks symbol " name); \
+    return -1;                                                    \
+  }
+  SYM(create, "wx_create") SYM(destroy, "wx_destroy") SYM(last_error, "wx_last_error") SYM(abi_version, "wx_abi_version")
+  SYM(upload, "wx_upload") SYM(set_params, "wx_set_params") SYM(step, "wx_step") SYM(sync, "wx_sync") SYM(get_iter, "wx_get_iter")
+  SYM(set_iter, "wx_set_iter") SYM(read_rect, "wx_read_rect") SYM(read_particles, "wx_read_particles")
+#undef SYM
+  return 0;
+}
+
+static napi_value Init(napi_env env, napi_value exports)
+{
+  if (load_lib(env)) return NULL;
+  napi_property_descriptor d[] = {
+    {"create", 0, Create, 0, 0, 0, napi_default, 0},       {"destroy", 0, Destroy, 0, 0, 0, napi_default, 0},
+    {"upload", 0, Upload, 0, 0, 0, napi_default, 0},       {"setParams", 0, SetParams, 0, 0, 0, napi_default, 0},
+    {"step", 0, Step, 0, 0, 0, napi_default, 0},           {"sync", 0, Sync, 0, 0, 0, napi_default, 0},
+    {"getIter", 0, GetIter, 0, 0, 0, napi_default, 0},     {"setIter", 0, SetIter, 0, 0, 0, napi_default, 0},
+    {"readRect", 0, ReadRect, 0, 0, 0, napi_default, 0},   {"readParticles", 0, ReadParticles, 0, 0, 0, napi_default, 0},
+    {"abiVersion", 0, AbiVersion, 0, 0, 0, napi_default, 0},
+  };
+  NAPI_CALL(env, napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d));
+  return exports;
+}
+
+NAPI_MODULE(wxsim_napi, Init)

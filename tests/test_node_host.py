@@ -1,0 +1,69 @@
+"""Node.js host (host/sim_host.js + the N-API addon): JS-side logic on CPU, end-to-end on the GPU."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE = shutil.which("node")
+HAVE_HEADERS = os.path.exists("/usr/include/node/node_api.h")
+
+needs_node = pytest.mark.skipif(NODE is None, reason="node is not installed")
+
+
+@needs_node
+def test_js_host_logic_matches_python(pkg):
+    out = json.loads(subprocess.check_output([NODE, os.path.join(ROOT, "host", "selftest.js")]))
+    assert out["ok"]
+    u = pkg.params.uniforms_from_gui(pkg.params.merge_settings({"sunAngle": 67.45275198770811, "sunIntensity": 1}), 100)
+    assert np.array_equal(np.asarray(out["initial_T"], np.float32), u["initial_T"][:4])
+    assert out["sunAngle"] == u["sunAngle"] and out["sunIntensity"] == u["sunIntensity"]
+
+
+@needs_node
+@pytest.mark.skipif(not HAVE_HEADERS, reason="node headers missing")
+def test_addon_builds_loads_and_fails_loudly_without_gpu(pkg):
+    from weather_sandbox_amd import engine
+    engine.build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    js = ("const m=require('%s'); console.log(m.abiVersion());"
+          "try{m.create(64,32,0); console.log('created')}catch(e){console.log('ERR '+e.message)}" % os.path.join(ROOT, "host", "wxsim_napi.node"))
+    out = subprocess.check_output([NODE, "-e", js]).decode().split("\n")
+    assert out[0] == "1"
+    import torch
+    if not torch.cuda.is_available():
+        assert out[1].startswith("ERR") and "no CPU fallback" in out[1]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_host_end_to_end_equals_python_host(pkg, golden, tmp_path):
+    """save in -> N iterations through JS/N-API/C-ABI/HIP -> save out == the same run through the Python host."""
+    g, u = golden("save100qa_precip")
+    settings = {"vorticity": 0.007, "dragMultiplier": 0.01, "wind": -0.0001, "globalDrying": 1e-05, "evapHeat": 1.9, "meltingHeat": 0.6,
+                "waterWeight": 0.5, "subZeroThreshold": 0.01, "spawnChance": 2e-05, "freezingRate": 0.0025, "meltingRate": 0.0025,
+                "evapRate": 0.0005, "sunAngle": 67.45275198770811, "timeOfDay": 11.44416, "month": 6.67, "dayNightCycle": True,
+                "enablePrecipitation": True, "wrapHorizontally": True, "IterPerFrame": 26, "sunIntensity": 1, "latitude": 45}
+    sf = pkg.codec.SaveFile(int(g["X"]), int(g["Y"]), g["in_base"], g["in_water"], g["in_wall"], g["in_drops"], [], settings)
+    src, dst = str(tmp_path / "in.weathersandbox"), str(tmp_path / "out.weathersandbox")
+    pkg.codec.save(src, sf)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    n = 60
+    out = subprocess.check_output([NODE, os.path.join(ROOT, "host", "sim_host.js"), src, str(n), dst, "--sun-fixed"])
+    info = json.loads(out.decode().strip().split("\n")[-1])
+    assert info["iterNum"] == n
+    got = pkg.codec.load(dst)
+    sim = pkg.WeatherSim.from_save(sf, sun_angle_deg=settings["sunAngle"])
+    left = n
+    while left > 0:
+        k = min(left, 26)
+        sim.step(k)
+        left -= k
+    ref = sim.to_save()
+    assert np.array_equal(got.wall, ref.wall)
+    assert np.array_equal(got.base, ref.base) and np.array_equal(got.water, ref.water)
+    assert got.droplets.shape == ref.droplets.shape
+    assert got.settings["vorticity"] == 0.007
