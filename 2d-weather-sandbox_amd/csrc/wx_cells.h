@@ -76,8 +76,16 @@ struct Uni {
   int userInputType;
   int wrapHorizontally;
   float airplaneValues[4];
-  // derived on the host once per wx_set_params: sin/cos of the uniform sunAngle
-  float cos_a, sin_a, sin_ma;
+  // derived on the host once per wx_set_params (same fp32 expressions the shaders evaluate per fragment)
+  float cos_a, sin_a, sin_ma;      // sin/cos of the uniform sunAngle
+  float vel_keep;                  // 1. - dragMultiplier * 0.0002          (velocityShader.frag:52)
+  float wind_add;                  // wind * 0.000001                       (velocityShader.frag:60)
+  float snd_dragk;                 // 1.0 - map_rangeC(soundingForcing, 0.1, 1.0, 0.0, 0.001)   (advectionShader.frag:171)
+  float snd_velk;                  // map_rangeC(soundingForcing, 0.9, 1.0, 0.0, 0.001)         (advectionShader.frag:174)
+  float a_texX, a_texY;            // vec2(1.) / resolution                 (advectionShader.frag:69)
+  float a_invTexY;                 // 1.0 / texelSize.y                     (advectionShader.frag:162)
+  float a_aspect;                  // texelSize.y / texelSize.x             (advectionShader.frag:247)
+  float chc;                       // cellHeightCompensation = 300. / resolution.y (lightingShader.frag:44)
   // per iteration
   float iterNum;
   int iterI; // int(iterNum)
@@ -119,15 +127,15 @@ __device__ __forceinline__ char4 pack_wall(const int w[4])
 {
   return make_char4((signed char)sat8(w[0]), (signed char)sat8(w[1]), (signed char)sat8(w[2]), (signed char)sat8(w[3]));
 }
-__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__host__ __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 // mix(): lowered as a + t*(b-a), the form pinned by the golden vectors (see oracle/wx_oracle.c)
 __device__ __forceinline__ float mixf(float a, float b, float t) { return a + t * (b - a); }
 // common.glsl:99-101
-__device__ __forceinline__ float map_range(float v, float min1, float max1, float min2, float max2)
+__host__ __device__ __forceinline__ float map_range(float v, float min1, float max1, float min2, float max2)
 {
   return min2 + (v - min1) * (max2 - min2) / (max1 - min1);
 }
-__device__ __forceinline__ float map_rangeC(float v, float min1, float max1, float min2, float max2)
+__host__ __device__ __forceinline__ float map_rangeC(float v, float min1, float max1, float min2, float max2)
 {
   return clampf(map_range(v, min1, max1, min2, max2), fminf(min2, max2), fmaxf(min2, max2));
 }
@@ -159,9 +167,9 @@ __device__ __forceinline__ float4 velocity_cell(const Uni &u, float4 b, float Pr
   } else {
     b.x += b.z - Pr;
     b.y += b.z - Pu;
-    b.x *= 1.0f - u.dragMultiplier * 0.0002f;
-    b.y *= 1.0f - u.dragMultiplier * 0.0002f;
-    b.x += u.wind * 0.000001f;
+    b.x *= u.vel_keep;
+    b.y *= u.vel_keep;
+    b.x += u.wind_add;
   }
   return b;
 }
@@ -538,8 +546,7 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
 {
   const CellCoord cc = cellcoord(g, x, y);
   const float fx = cc.fx, fy = cc.fy, tcx = cc.tcx, tcy = cc.tcy;
-  // advectionShader.frag:69: texelSize = vec2(1.) / resolution (in-shader fp32 division)
-  const float a_texX = 1.0f / (float)g.Xg, a_texY = 1.0f / (float)g.Y;
+  const float a_texY = u.a_texY; // advectionShader.frag:69: texelSize = vec2(1.) / resolution
   const char4 w0 = a.wall(0, 0);
   int wl[4] = {w0.x, w0.y, w0.z, w0.w};
   float4 b, w;
@@ -631,7 +638,7 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
       w.x -= clampf(u.globalDrying, 0.0f, fmaxf(w.x - maxWater(fmaxf(realTemp - 20.0f, CtoK(-80.0f))), 0.0f));
       b.w += u.globalHeating;
 
-      const int si = (int)(tcy * (1.0f / a_texY));
+      const int si = (int)(tcy * u.a_invTexY);
       const int si1 = si - 1 < 0 ? 0 : si - 1; // index -1 is undefined in the reference -> clamp
       const float sT = (snd_T[si] + snd_T[si1]) / 2.0f;
       const float sW = (snd_W[si] + snd_W[si1]) / 2.0f;
@@ -641,11 +648,10 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
       b.w -= Tdiff * 0.001f * u.soundingForcing;
       const float Wdiff = w.x - sW;
       w.x -= Wdiff * 0.001f * u.soundingForcing;
-      const float dragk = 1.0f - map_rangeC(u.soundingForcing, 0.1f, 1.0f, 0.0f, 0.001f);
-      b.x *= dragk;
-      b.y *= dragk;
+      b.x *= u.snd_dragk;
+      b.y *= u.snd_dragk;
       const float velDiff = b.x - sV;
-      b.x -= velDiff * map_rangeC(u.soundingForcing, 0.9f, 1.0f, 0.0f, 0.001f);
+      b.x -= velDiff * u.snd_velk;
     }
     w.x = fmaxf(w.x, 0.0f);
   } else { // wall :189-227
@@ -685,7 +691,7 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
         vmx = absHorizontalDist(u.userInputValues[0], tcx);
       else
         vmx = fabsf(u.userInputValues[0] - tcx);
-      vmx *= a_texY / a_texX;
+      vmx *= u.a_aspect;
       const float distFromMouse = sqrtf(vmx * vmx + vmy * vmy);
       weight = smoothstepf(brushR, 0.0f, distFromMouse);
       if (distFromMouse < brushR) inBrush = true;
@@ -773,7 +779,7 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
             b.x = 0.0f;
             b.y = 0.0f;
             b.z = 0.0f;
-            b.w = initial_T[(int)(tcy * (1.0f / a_texY))];
+            b.w = initial_T[(int)(tcy * u.a_invTexY)];
             w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
           }
         }
@@ -790,7 +796,7 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
       vpx = absHorizontalDist(u.airplaneValues[0], tcx);
     else
       vpx = fabsf(u.airplaneValues[0] - tcx);
-    vpx *= a_texY / a_texX;
+    vpx *= u.a_aspect;
     vpx *= (float)g.Y;
     vpy *= (float)g.Y;
     if (u.airplaneValues[3] < 0.0f) vpy += -1.0f;
@@ -828,7 +834,7 @@ __device__ __forceinline__ float4 lighting_cell(const Uni &u, const Geo &g, int 
   const int Y = g.Y;
   const float resY = (float)Y;
   if (fy >= resY - 1.0f) return make_float4(u.sunIntensity, 0.0f, 0.0f, 0.0f); // :40-41
-  const float cellHeightCompensation = 300.0f / resY;
+  const float cellHeightCompensation = u.chc;
 
   // :48-49 LINEAR tap at texCoord + (sin a, cos a) texels, S=REPEAT T=CLAMP_TO_EDGE. The filter weights are
   // the exact fp32 fractions of the offset (weight precision is implementation defined in GL).

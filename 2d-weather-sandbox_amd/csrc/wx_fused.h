@@ -10,6 +10,11 @@
 //   requested)  ~= 196 B vs ~380 B for the reference's pass structure.
 // The per-cell arithmetic is the same wx_cells.h code as the per-pass kernels: results are bit-identical.
 //
+// LDS layout: one fp32 PLANE per channel (structure of arrays, odd row stride). A wavefront reading one
+// channel of 64 neighbouring cells touches 64 consecutive banks -- conflict free -- whereas a single-channel
+// read out of an array of float4 is a 4-way bank conflict (measured: 56 % of the LDS cycles of the first
+// version). Unused channels of an accessor call are dead code and cost nothing.
+//
 // Ping-pong in fused mode (a tile may not overwrite what neighbouring tiles still read as halo):
 //   A: base[0], wall[0], water[1], light[0]  ->  base[1] (post-boundary), water[0], wall[1], curl
 //   B: base[1], water[0], wall[1], light[src] -> base[0] (post-pressure), wall[0], water[1], light[dst],
@@ -20,6 +25,7 @@
 namespace wx {
 
 constexpr int TX = 64, TY = 16, NT = 256;
+constexpr int RPT = TY / (NT / TX); // tile rows per thread
 constexpr bool kHaveFused = true;
 
 struct FusedAIn {
@@ -35,28 +41,47 @@ struct FusedBIn {
 };
 
 __device__ __forceinline__ size_t fidx(int x, int y, int X) { return (size_t)y * X + x; }
+// wrap for i in [-n, 2n): tile halos of grids at least as large as the halo
+__device__ __forceinline__ int wrapfast(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
+
+// fp32 plane set of a float4 field
+template <int H, int W> struct Planes4 {
+  float x[H][W], y[H][W], z[H][W], w[H][W];
+  __device__ __forceinline__ void put(int r, int c, float4 v)
+  {
+    x[r][c] = v.x;
+    y[r][c] = v.y;
+    z[r][c] = v.z;
+    w[r][c] = v.w;
+  }
+  __device__ __forceinline__ float4 get(int r, int c) const { return make_float4(x[r][c], y[r][c], z[r][c], w[r][c]); }
+};
 
 // ================================================================================================
 // kernel A
 // ================================================================================================
 namespace fa {
 constexpr int HL = 2, HR = 3, HD = 2, HU = 3; // halo of the base_0 tile: velocity is needed on [-2,+2]^2 and reads P at +1
-constexpr int BW = TX + HL + HR, BH = TY + HD + HU;
-constexpr int WW = TX + 4, WH = TY + 4;       // wall tile, halo 2
-constexpr int CW = TX + 3, CH = TY + 3;       // curl on x,y in [-2,+1]
-constexpr int VW = TX + 1, VH = TY + 1;       // vortForce on x,y in [-1,0]
+constexpr int BW = TX + HL + HR, BH = TY + HD + HU; // 69 x 21
+constexpr int WW = TX + 4, WH = TY + 4;             // wall tile, halo 2
+constexpr int CW = TX + 3, CH = TY + 3;             // curl on x,y in [-2,+1]
+constexpr int VW = TX + 1, VH = TY + 1;             // vortForce on x,y in [-1,0]
+struct Smem {
+  Planes4<BH, BW> b;
+  char4 w[WH][WW + 1];
+  float c[CH][CW];
+  float vx[VH][VW], vy[VH][VW];
+};
 } // namespace fa
 
 struct LBoundaryAcc {
-  const float4 (*sb)[fa::BW];
-  const char4 (*sw)[fa::WW];
-  const float2 (*sv)[fa::VW];
+  const fa::Smem &sm;
   FusedAIn in;
   float4 w00;
   int X, Y, x, y, cx, cy;
-  __device__ __forceinline__ float4 base(int dx, int dy) const { return sb[cy + fa::HD + dy][cx + fa::HL + dx]; }
-  __device__ __forceinline__ char4 wall(int dx, int dy) const { return sw[cy + 2 + dy][cx + 2 + dx]; }
-  __device__ __forceinline__ float2 vort(int dx, int dy) const { return sv[cy + 1 + dy][cx + 1 + dx]; }
+  __device__ __forceinline__ float4 base(int dx, int dy) const { return sm.b.get(cy + fa::HD + dy, cx + fa::HL + dx); }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return sm.w[cy + 2 + dy][cx + 2 + dx]; }
+  __device__ __forceinline__ float2 vort(int dx, int dy) const { return make_float2(sm.vx[cy + 1 + dy][cx + 1 + dx], sm.vy[cy + 1 + dy][cx + 1 + dx]); }
   __device__ __forceinline__ float4 water(int dx, int dy) const
   {
     if (dx == 0 && dy == 0) return w00;
@@ -76,46 +101,49 @@ __global__ __launch_bounds__(NT) void k_fused_a(Geo g, Uni u, const float *__res
                                                 float4 *__restrict__ water_out, char4 *__restrict__ wall_out, float *__restrict__ curl_out)
 {
   using namespace fa;
-  __shared__ float4 sb[BH][BW];
-  __shared__ char4 sw[WH][WW];
-  __shared__ float sc[CH][CW];
-  __shared__ float2 sv[VH][VW];
+  __shared__ Smem sm;
   const int X = g.X, Y = g.Y;
   const int tid = threadIdx.x;
   const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  const bool small = (X < TX + 8) || (Y < TY + 8); // tiny grids: the tile + halo may wrap more than once
 
   // ---- stage 0: base_0 and wall_0 tiles with halo (REPEAT wrap on both axes) ----
   for (int i = tid; i < BW * BH; i += NT) {
     const int ly = i / BW, lx = i - ly * BW;
-    sb[ly][lx] = in.base[fidx(wrapmod(tx0 + lx - HL, X), wrapmod(ty0 + ly - HD, Y), X)];
+    const int gx = small ? wrapmod(tx0 + lx - HL, X) : wrapfast(tx0 + lx - HL, X);
+    const int gy = small ? wrapmod(ty0 + ly - HD, Y) : wrapfast(ty0 + ly - HD, Y);
+    sm.b.put(ly, lx, in.base[fidx(gx, gy, X)]);
   }
   for (int i = tid; i < WW * WH; i += NT) {
     const int ly = i / WW, lx = i - ly * WW;
-    sw[ly][lx] = in.wall[fidx(wrapmod(tx0 + lx - 2, X), wrapmod(ty0 + ly - 2, Y), X)];
+    const int gx = small ? wrapmod(tx0 + lx - 2, X) : wrapfast(tx0 + lx - 2, X);
+    const int gy = small ? wrapmod(ty0 + ly - 2, Y) : wrapfast(ty0 + ly - 2, Y);
+    sm.w[ly][lx] = in.wall[fidx(gx, gy, X)];
   }
   __syncthreads();
 
-  // ---- stage 1: velocity on [-2,+2]^2, in place (writes .xy, neighbours are only read for .z) ----
+  // ---- stage 1: velocity on [-2,+2]^2, in place (writes vx, vy; neighbours are only read for P) ----
   for (int i = tid; i < WW * WH; i += NT) {
     const int ly = i / WW, lx = i - ly * WW;
-    const float4 b = velocity_cell(u, sb[ly][lx], sb[ly][lx + 1].z, sb[ly + 1][lx].z, sw[ly][lx].y);
-    sb[ly][lx].x = b.x;
-    sb[ly][lx].y = b.y;
+    const float4 b = velocity_cell(u, sm.b.get(ly, lx), sm.b.z[ly][lx + 1], sm.b.z[ly + 1][lx], sm.w[ly][lx].y);
+    sm.b.x[ly][lx] = b.x;
+    sm.b.y[ly][lx] = b.y;
   }
   __syncthreads();
 
   // ---- stage 2: curl on [-2,+1]^2 ----
   for (int i = tid; i < CW * CH; i += NT) {
     const int ly = i / CW, lx = i - ly * CW;
-    const float4 c = sb[ly][lx];
-    sc[ly][lx] = curl_cell(c.x, c.y, sb[ly][lx + 1].y, sb[ly + 1][lx].x);
+    sm.c[ly][lx] = curl_cell(sm.b.x[ly][lx], sm.b.y[ly][lx], sm.b.y[ly][lx + 1], sm.b.x[ly + 1][lx]);
   }
   __syncthreads();
 
   // ---- stage 3: vortForce on [-1,0]^2 ----
   for (int i = tid; i < VW * VH; i += NT) {
     const int ly = i / VW, lx = i - ly * VW;
-    sv[ly][lx] = vorticity_cell(sc[ly + 1][lx + 1], sc[ly + 1][lx], sc[ly + 1][lx + 2], sc[ly][lx + 1], sc[ly + 2][lx + 1]);
+    const float2 v = vorticity_cell(sm.c[ly + 1][lx + 1], sm.c[ly + 1][lx], sm.c[ly + 1][lx + 2], sm.c[ly][lx + 1], sm.c[ly + 2][lx + 1]);
+    sm.vx[ly][lx] = v.x;
+    sm.vy[ly][lx] = v.y;
   }
   __syncthreads();
 
@@ -124,19 +152,19 @@ __global__ __launch_bounds__(NT) void k_fused_a(Geo g, Uni u, const float *__res
   const int x = tx0 + cx;
   if (x >= X) return;
 #pragma unroll
-  for (int k = 0; k < TY / (NT / TX); k++) {
+  for (int k = 0; k < RPT; k++) {
     const int cy = (tid / TX) + k * (NT / TX);
     const int y = ty0 + cy;
     if (y >= Y) break;
     const size_t gi = fidx(x, y, X);
-    LBoundaryAcc a{sb, sw, sv, in, in.water[gi], X, Y, x, y, cx, cy};
+    LBoundaryAcc a{sm, in, in.water[gi], X, Y, x, y, cx, cy};
     float4 b, w;
     char4 wl;
     boundary_cell(u, g, initial_T, x, y, a, b, w, wl);
     base_out[gi] = b;
     water_out[gi] = w;
     wall_out[gi] = wl;
-    curl_out[gi] = sc[cy + 2][cx + 2];
+    curl_out[gi] = sm.c[cy + 2][cx + 2];
   }
 }
 
@@ -145,95 +173,162 @@ __global__ __launch_bounds__(NT) void k_fused_a(Geo g, Uni u, const float *__res
 // ================================================================================================
 namespace fb_ {
 // advection is evaluated on x,y in [-1,0] (pressure needs the left and lower neighbour); its 7-point velocity
-// stencil reaches 1 further and the back-traced bilinear footprint (|v| < 1) one more: inputs on [-3,+2].
+// stencil reaches 1 further and the back-traced bilinear footprint up to 2 further (|v| < 2): inputs on [-3,+2].
 constexpr int HL = 3, HR = 2, HD = 3, HU = 2;
 constexpr int IW = TX + HL + HR, IH = TY + HD + HU; // 69 x 21
 constexpr int AW = TX + 1, AH = TY + 1;             // advection results on [-1,0]
+constexpr float VMAX = 1.9f;                        // back-traces shorter than this stay inside the staged tile
+struct SmemIn {
+  Planes4<IH, IW> b, q; // post-boundary base, water
+  char4 w[IH][IW + 1];
+};
+struct SmemOut { // advection output needed by neighbours (aliases SmemIn after a barrier)
+  float vx[AH][AW], vy[AH][AW], T[AH][AW];
+  char4 w[AH][AW + 1];
+};
 } // namespace fb_
 
+// LDS-only accessor: valid when every back-trace of the cell is shorter than VMAX
 struct LAdvectAcc {
-  const float4 (*sb)[fb_::IW];
-  const float4 (*sq)[fb_::IW];
-  const char4 (*sw)[fb_::IW];
-  FusedBIn in;
-  int X, Y, x, y, lx, ly; // lx, ly: position of the own cell inside the input tiles
-  __device__ __forceinline__ float4 base(int dx, int dy) const { return sb[ly + dy][lx + dx]; }
-  __device__ __forceinline__ char4 wall(int dx, int dy) const { return sw[ly + dy][lx + dx]; }
-  __device__ __forceinline__ bool inside(int dx, int dy) const
-  {
-    return (unsigned)(lx + dx) < (unsigned)fb_::IW && (unsigned)(ly + dy) < (unsigned)fb_::IH;
-  }
-  __device__ __forceinline__ size_t gat(int dx, int dy) const { return fidx(wrapmod(x + dx, X), wrapmod(y + dy, Y), X); }
-  // data-dependent footprint: LDS when it lies in the staged tile (|v| < 1 always does), global memory otherwise
-  __device__ __forceinline__ float4 base_off(int dx, int dy) const { return inside(dx, dy) ? sb[ly + dy][lx + dx] : in.base[gat(dx, dy)]; }
-  __device__ __forceinline__ float4 water_off(int dx, int dy) const { return inside(dx, dy) ? sq[ly + dy][lx + dx] : in.water[gat(dx, dy)]; }
-  __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return inside(dx, dy) ? sw[ly + dy][lx + dx] : in.wall[gat(dx, dy)]; }
+  const fb_::SmemIn &sm;
+  int lx, ly; // position of the own cell inside the input tiles
+  __device__ __forceinline__ float4 base(int dx, int dy) const { return sm.b.get(ly + dy, lx + dx); }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return sm.w[ly + dy][lx + dx]; }
+  __device__ __forceinline__ float4 base_off(int dx, int dy) const { return sm.b.get(ly + dy, lx + dx); }
+  __device__ __forceinline__ float4 water_off(int dx, int dy) const { return sm.q.get(ly + dy, lx + dx); }
+  __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return sm.w[ly + dy][lx + dx]; }
 };
 
+// global-memory accessor for the rare cells whose back-trace leaves the tile
+struct GAdvectAccB {
+  FusedBIn in;
+  int X, Y, x, y;
+  __device__ __forceinline__ size_t at_off(int dx, int dy) const { return fidx(wrapmod(x + dx, X), wrapmod(y + dy, Y), X); }
+  __device__ __forceinline__ float4 base(int dx, int dy) const { return in.base[at_off(dx, dy)]; }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return in.wall[at_off(dx, dy)]; }
+  __device__ __forceinline__ float4 base_off(int dx, int dy) const { return in.base[at_off(dx, dy)]; }
+  __device__ __forceinline__ float4 water_off(int dx, int dy) const { return in.water[at_off(dx, dy)]; }
+  __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return in.wall[at_off(dx, dy)]; }
+};
+
+// Context of the slow path, kept in device memory so that the out-of-line call passes pointers to global
+// memory instead of forcing the kernel arguments through scratch. (advection does not use iterNum.)
+struct SlowCtx {
+  Geo g;
+  Uni u;
+  const float *initial_T, *snd_T, *snd_W, *snd_Vel;
+  FusedBIn in;
+};
+struct AdvOut {
+  float4 b, w;
+  char4 wl;
+};
+
+__device__ __noinline__ AdvOut advection_cell_global(const SlowCtx *__restrict__ c, int x, int y)
+{
+  GAdvectAccB a{c->in, c->g.X, c->g.Y, x, y};
+  AdvOut o;
+  advection_cell(c->u, c->g, c->initial_T, c->snd_T, c->snd_W, c->snd_Vel, x, y, a, o.b, o.w, o.wl);
+  return o;
+}
+
+// one region cell of stage 1
+__device__ __forceinline__ void advect_tile_cell(const Uni &u, const Geo &g, const float *initial_T, const float *snd_T, const float *snd_W,
+                                                 const float *snd_Vel, const fb_::SmemIn &sm, const SlowCtx *ctx, int x, int y, int lx, int ly,
+                                                 float4 &b, float4 &w, char4 &wl)
+{
+  using namespace fb_;
+  // the three staggered back-trace velocities are combinations of these eight (advectionShader.frag:85-89)
+  const float m = fmaxf(fmaxf(fmaxf(fabsf(sm.b.x[ly][lx]), fabsf(sm.b.x[ly][lx - 1])), fmaxf(fabsf(sm.b.x[ly + 1][lx]), fabsf(sm.b.x[ly + 1][lx - 1]))),
+                        fmaxf(fmaxf(fabsf(sm.b.y[ly][lx]), fabsf(sm.b.y[ly - 1][lx])), fmaxf(fabsf(sm.b.y[ly][lx + 1]), fabsf(sm.b.y[ly - 1][lx + 1]))));
+  if (m < VMAX) {
+    LAdvectAcc a{sm, lx, ly};
+    advection_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, x, y, a, b, w, wl);
+  } else { // rare (|v| >= 1.9 cells/iteration, or NaN): back-trace may leave the staged tile
+    const AdvOut o = advection_cell_global(ctx, x, y);
+    b = o.b;
+    w = o.w;
+    wl = o.wl;
+  }
+}
+
 struct LLightAcc {
-  const float4 (*sa)[fb_::AW]; // advection output base on [-1,0]
+  const fb_::SmemOut &so;
   const float4 *light_;
   float4 water_;
   char4 wall_;
+  float T0;
   int X, x, cx, cy;
-  __device__ __forceinline__ float T(int dy) const { return sa[cy + 1 + dy][cx + 1].w; } // dy in {0,-1}
+  __device__ __forceinline__ float T(int dy) const { return dy == 0 ? T0 : so.T[cy][cx + 1]; } // dy in {0,-1}
   __device__ __forceinline__ float4 water() const { return water_; }
   __device__ __forceinline__ char4 wall() const { return wall_; }
-  __device__ __forceinline__ float4 light_at(int dx, int j) const { return light_[fidx(wrapmod(x + dx, X), j, X)]; }
+  __device__ __forceinline__ float4 light_at(int dx, int j) const { return light_[fidx(wrapfast(x + dx, X), j, X)]; }
 };
 
 template <bool WRITE_DISP>
 __global__ __launch_bounds__(NT) void k_fused_b(Geo g, Uni u, const float *__restrict__ initial_T, const float *__restrict__ snd_T,
                                                 const float *__restrict__ snd_W, const float *__restrict__ snd_Vel, FusedBIn in,
-                                                float4 *__restrict__ base_out, float4 *__restrict__ base_disp, float4 *__restrict__ water_out,
+                                                const SlowCtx *__restrict__ ctx, float4 *__restrict__ base_out, float4 *__restrict__ base_disp, float4 *__restrict__ water_out,
                                                 char4 *__restrict__ wall_out, float4 *__restrict__ light_out)
 {
   using namespace fb_;
-  __shared__ float4 sb[IH][IW];
-  __shared__ float4 sq[IH][IW];
-  __shared__ char4 sw[IH][IW];
-  __shared__ float4 sa[AH][AW]; // advection output: base
-  __shared__ char4 saw[AH][AW]; // advection output: wall
+  __shared__ union {
+    SmemIn in;
+    SmemOut out;
+  } sm;
   const int X = g.X, Y = g.Y;
   const int tid = threadIdx.x;
   const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  const bool small = (X < TX + 8) || (Y < TY + 8);
 
   // ---- stage 0: post-boundary base / water / wall tiles with halo ----
   for (int i = tid; i < IW * IH; i += NT) {
     const int ly = i / IW, lx = i - ly * IW;
-    const size_t gi = fidx(wrapmod(tx0 + lx - HL, X), wrapmod(ty0 + ly - HD, Y), X);
-    sb[ly][lx] = in.base[gi];
-    sq[ly][lx] = in.water[gi];
-    sw[ly][lx] = in.wall[gi];
+    const int gx = small ? wrapmod(tx0 + lx - HL, X) : wrapfast(tx0 + lx - HL, X);
+    const int gy = small ? wrapmod(ty0 + ly - HD, Y) : wrapfast(ty0 + ly - HD, Y);
+    const size_t gi = fidx(gx, gy, X);
+    sm.in.b.put(ly, lx, in.base[gi]);
+    sm.in.q.put(ly, lx, in.water[gi]);
+    sm.in.w[ly][lx] = in.wall[gi];
   }
   __syncthreads();
 
-  // ---- stage 1: advection on [-1,0]^2; own cells keep their water in registers ----
+  // ---- stage 1: advection on [-1,0]^2, results in registers ----
   const int cx = tid & (TX - 1);
-  constexpr int RPT = TY / (NT / TX); // rows per thread
-  float4 wreg[RPT];
+  float4 breg[RPT], wreg[RPT];
   char4 wlreg[RPT];
 #pragma unroll
   for (int k = 0; k < RPT; k++) {
     const int cy = (tid / TX) + k * (NT / TX);
-    const int x = wrapmod(tx0 + cx, X), y = wrapmod(ty0 + cy, Y);
-    LAdvectAcc a{sb, sq, sw, in, X, Y, x, y, cx + HL, cy + HD};
-    float4 b;
-    advection_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, x, y, a, b, wreg[k], wlreg[k]);
-    sa[cy + 1][cx + 1] = b;
-    saw[cy + 1][cx + 1] = wlreg[k];
+    const int x = small ? wrapmod(tx0 + cx, X) : wrapfast(tx0 + cx, X), y = small ? wrapmod(ty0 + cy, Y) : wrapfast(ty0 + cy, Y);
+    advect_tile_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, sm.in, ctx, x, y, cx + HL, cy + HD, breg[k], wreg[k], wlreg[k]);
   }
   // left column (cx = -1, cy = -1..TY-1) and bottom row (cy = -1, cx = 0..TX-1): TX + TY + 1 extra cells
-  if (tid < TX + TY + 1) {
-    const int ecx = (tid < TX) ? tid : -1;
-    const int ecy = (tid < TX) ? -1 : tid - TX - 1;
-    const int x = wrapmod(tx0 + ecx, X), y = wrapmod(ty0 + ecy, Y);
-    LAdvectAcc a{sb, sq, sw, in, X, Y, x, y, ecx + HL, ecy + HD};
-    float4 b, w;
-    char4 wl;
-    advection_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, x, y, a, b, w, wl);
-    sa[ecy + 1][ecx + 1] = b;
-    saw[ecy + 1][ecx + 1] = wl;
+  float4 eb = make_float4(0.f, 0.f, 0.f, 0.f);
+  char4 ewl = make_char4(0, 0, 0, 0);
+  const bool extra = tid < TX + TY + 1;
+  const int ecx = (tid < TX) ? tid : -1;
+  const int ecy = (tid < TX) ? -1 : tid - TX - 1;
+  if (extra) {
+    const int x = small ? wrapmod(tx0 + ecx, X) : wrapfast(tx0 + ecx, X), y = small ? wrapmod(ty0 + ecy, Y) : wrapfast(ty0 + ecy, Y);
+    float4 w;
+    advect_tile_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, sm.in, ctx, x, y, ecx + HL, ecy + HD, eb, w, ewl);
+  }
+  __syncthreads(); // every thread is done reading the input tiles: their LDS is reused for the outputs
+
+#pragma unroll
+  for (int k = 0; k < RPT; k++) {
+    const int cy = (tid / TX) + k * (NT / TX);
+    sm.out.vx[cy + 1][cx + 1] = breg[k].x;
+    sm.out.vy[cy + 1][cx + 1] = breg[k].y;
+    sm.out.T[cy + 1][cx + 1] = breg[k].w;
+    sm.out.w[cy + 1][cx + 1] = wlreg[k];
+  }
+  if (extra) {
+    sm.out.vx[ecy + 1][ecx + 1] = eb.x;
+    sm.out.vy[ecy + 1][ecx + 1] = eb.y;
+    sm.out.T[ecy + 1][ecx + 1] = eb.w;
+    sm.out.w[ecy + 1][ecx + 1] = ewl;
   }
   __syncthreads();
 
@@ -246,14 +341,13 @@ __global__ __launch_bounds__(NT) void k_fused_b(Geo g, Uni u, const float *__res
     const int y = ty0 + cy;
     if (y >= Y) break;
     const size_t gi = fidx(x, y, X);
-    const float4 b = sa[cy + 1][cx + 1];
-    const float4 bd = sa[cy][cx + 1];
-    const char4 wd = saw[cy][cx + 1];
-    base_out[gi] = pressure_cell(b, sa[cy + 1][cx].x, bd.y, bd.w, wd.x, wd.y);
+    const float4 b = breg[k];
+    const char4 wd = sm.out.w[cy][cx + 1];
+    base_out[gi] = pressure_cell(b, sm.out.vx[cy + 1][cx], sm.out.vy[cy][cx + 1], sm.out.T[cy][cx + 1], wd.x, wd.y);
     if (WRITE_DISP) base_disp[gi] = b;
     water_out[gi] = wreg[k];
     wall_out[gi] = wlreg[k];
-    LLightAcc la{sa, in.light, wreg[k], wlreg[k], X, x, cx, cy};
+    LLightAcc la{sm.out, in.light, wreg[k], wlreg[k], b.w, X, x, cx, cy};
     light_out[gi] = lighting_cell(u, g, x, y, la);
   }
 }
@@ -266,16 +360,16 @@ inline void launch_fused_a(const Geo &g, const Uni &u, const float *initial_T, c
 }
 
 inline void launch_fused_b(const Geo &g, const Uni &u, const float *initial_T, const float *snd_T, const float *snd_W, const float *snd_Vel,
-                           const FusedBIn &in, float4 *base_out, float4 *base_disp, float4 *water_out, char4 *wall_out, float4 *light_out,
-                           bool write_disp, hipStream_t stream)
+                           const FusedBIn &in, const SlowCtx *ctx, float4 *base_out, float4 *base_disp, float4 *water_out, char4 *wall_out,
+                           float4 *light_out, bool write_disp, hipStream_t stream)
 {
   const dim3 grid((g.X + TX - 1) / TX, (g.Y + TY - 1) / TY);
   if (write_disp)
-    hipLaunchKernelGGL(k_fused_b<true>, grid, dim3(NT), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, base_out, base_disp, water_out,
-                       wall_out, light_out);
+    hipLaunchKernelGGL(k_fused_b<true>, grid, dim3(NT), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp,
+                       water_out, wall_out, light_out);
   else
-    hipLaunchKernelGGL(k_fused_b<false>, grid, dim3(NT), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, base_out, base_disp, water_out,
-                       wall_out, light_out);
+    hipLaunchKernelGGL(k_fused_b<false>, grid, dim3(NT), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp,
+                       water_out, wall_out, light_out);
 }
 
 } // namespace wx

@@ -74,6 +74,7 @@ struct wx_sim {
   float *drops[2] = {nullptr, nullptr};
   float *initial_T = nullptr, *snd_T = nullptr, *snd_W = nullptr, *snd_Vel = nullptr;
   DevState *state = nullptr;
+  SlowCtx *slow_ctx = nullptr; // device copy of geometry/uniforms/pointers for the out-of-line advection path
   bool fb_dirty = false; // feedback/deposition hold non-zero data (particles ran last iteration)
   // profiling
   bool profiling = false;
@@ -225,6 +226,16 @@ void build_uni(wx_sim *s)
   u.cos_a = cosf(p.sunAngle);
   u.sin_a = sinf(p.sunAngle);
   u.sin_ma = sinf(-p.sunAngle);
+  // uniform-only sub-expressions of the shaders, evaluated once with the same fp32 operations
+  u.vel_keep = 1.0f - p.dragMultiplier * 0.0002f;
+  u.wind_add = p.wind * 0.000001f;
+  u.snd_dragk = 1.0f - map_rangeC(p.soundingForcing, 0.1f, 1.0f, 0.0f, 0.001f);
+  u.snd_velk = map_rangeC(p.soundingForcing, 0.9f, 1.0f, 0.0f, 0.001f);
+  u.a_texX = 1.0f / (float)s->Xg;
+  u.a_texY = 1.0f / (float)s->Y;
+  u.a_invTexY = 1.0f / u.a_texY;
+  u.a_aspect = u.a_texY / u.a_texX;
+  u.chc = 300.0f / (float)s->Y;
 }
 
 template <class T> int dalloc(wx_sim *s, T **p, size_t n)
@@ -333,8 +344,8 @@ int iterate_fused(wx_sim *s, bool write_disp)
   {
     FusedBIn in{s->base[1], s->water[0], s->wall[1], s->light[src]};
     ProfScope ps(s, K_FUSED_APL);
-    launch_fused_b(g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, s->base[0], s->base[2], s->water[1], s->wall[0], s->light[dst],
-                   write_disp, s->stream);
+    launch_fused_b(g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, s->slow_ctx, s->base[0], s->base[2], s->water[1], s->wall[0],
+                   s->light[dst], write_disp, s->stream);
   }
   return WX_OK;
 }
@@ -393,6 +404,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (rc == WX_OK) rc = dalloc(s, &s->snd_W, (size_t)Y + 8);
   if (rc == WX_OK) rc = dalloc(s, &s->snd_Vel, (size_t)Y + 8);
   if (rc == WX_OK) rc = dalloc(s, &s->state, 1);
+  if (rc == WX_OK) rc = dalloc(s, &s->slow_ctx, 1);
   if (rc != WX_OK) {
     g_create_error = s->err;
     wx_destroy(s);
@@ -433,6 +445,7 @@ void wx_destroy(wx_sim *s)
   hipFree(s->snd_W);
   hipFree(s->snd_Vel);
   hipFree(s->state);
+  hipFree(s->slow_ctx);
   delete s;
 }
 
@@ -476,6 +489,10 @@ int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const f
   if (sounding_T) HIPCHK(s, hipMemcpyAsync(s->snd_T, sounding_T, nb, hipMemcpyHostToDevice, s->stream));
   if (sounding_W) HIPCHK(s, hipMemcpyAsync(s->snd_W, sounding_W, nb, hipMemcpyHostToDevice, s->stream));
   if (sounding_Vel) HIPCHK(s, hipMemcpyAsync(s->snd_Vel, sounding_Vel, nb, hipMemcpyHostToDevice, s->stream));
+  {
+    SlowCtx c{s->geo, s->uni, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, FusedBIn{s->base[1], s->water[0], s->wall[1], nullptr}};
+    HIPCHK(s, hipMemcpyAsync(s->slow_ctx, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
+  }
   if (p->inactiveDroplets >= 0.0f)
     HIPCHK(s, hipMemcpyAsync(&s->state->inactiveDroplets, &p->inactiveDroplets, 4, hipMemcpyHostToDevice, s->stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
