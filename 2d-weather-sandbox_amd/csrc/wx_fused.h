@@ -24,8 +24,18 @@
 
 namespace wx {
 
-constexpr int TX = 64, TY = 16, NT = 256;
-constexpr int RPT = TY / (NT / TX); // tile rows per thread
+constexpr int TX = 64, TY = 16;
+#ifndef WX_NTA
+#define WX_NTA 1024
+#endif
+#ifndef WX_NTB
+#define WX_NTB 512
+#endif
+#ifndef WX_B_MINWAVES
+#define WX_B_MINWAVES 4
+#endif
+constexpr int NTA = WX_NTA; // kernel A: 47 VGPRs -> two 16-wave workgroups per CU = 8 waves/SIMD
+constexpr int NTB = WX_NTB; // kernel B: 8-wave workgroups
 constexpr bool kHaveFused = true;
 
 struct FusedAIn {
@@ -97,7 +107,7 @@ struct LBoundaryAcc {
   __device__ __forceinline__ float2 dep() const { return in.dep ? in.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
 };
 
-__global__ __launch_bounds__(NT) void k_fused_a(Geo g, Uni u, const float *__restrict__ initial_T, FusedAIn in, float4 *__restrict__ base_out,
+__global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__restrict__ initial_T, FusedAIn in, float4 *__restrict__ base_out,
                                                 float4 *__restrict__ water_out, char4 *__restrict__ wall_out, float *__restrict__ curl_out)
 {
   using namespace fa;
@@ -108,13 +118,13 @@ __global__ __launch_bounds__(NT) void k_fused_a(Geo g, Uni u, const float *__res
   const bool small = (X < TX + 8) || (Y < TY + 8); // tiny grids: the tile + halo may wrap more than once
 
   // ---- stage 0: base_0 and wall_0 tiles with halo (REPEAT wrap on both axes) ----
-  for (int i = tid; i < BW * BH; i += NT) {
+  for (int i = tid; i < BW * BH; i += NTA) {
     const int ly = i / BW, lx = i - ly * BW;
     const int gx = small ? wrapmod(tx0 + lx - HL, X) : wrapfast(tx0 + lx - HL, X);
     const int gy = small ? wrapmod(ty0 + ly - HD, Y) : wrapfast(ty0 + ly - HD, Y);
     sm.b.put(ly, lx, in.base[fidx(gx, gy, X)]);
   }
-  for (int i = tid; i < WW * WH; i += NT) {
+  for (int i = tid; i < WW * WH; i += NTA) {
     const int ly = i / WW, lx = i - ly * WW;
     const int gx = small ? wrapmod(tx0 + lx - 2, X) : wrapfast(tx0 + lx - 2, X);
     const int gy = small ? wrapmod(ty0 + ly - 2, Y) : wrapfast(ty0 + ly - 2, Y);
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(NT) void k_fused_a(Geo g, Uni u, const float *__res
   __syncthreads();
 
   // ---- stage 1: velocity on [-2,+2]^2, in place (writes vx, vy; neighbours are only read for P) ----
-  for (int i = tid; i < WW * WH; i += NT) {
+  for (int i = tid; i < WW * WH; i += NTA) {
     const int ly = i / WW, lx = i - ly * WW;
     const float4 b = velocity_cell(u, sm.b.get(ly, lx), sm.b.z[ly][lx + 1], sm.b.z[ly + 1][lx], sm.w[ly][lx].y);
     sm.b.x[ly][lx] = b.x;
@@ -132,14 +142,14 @@ __global__ __launch_bounds__(NT) void k_fused_a(Geo g, Uni u, const float *__res
   __syncthreads();
 
   // ---- stage 2: curl on [-2,+1]^2 ----
-  for (int i = tid; i < CW * CH; i += NT) {
+  for (int i = tid; i < CW * CH; i += NTA) {
     const int ly = i / CW, lx = i - ly * CW;
     sm.c[ly][lx] = curl_cell(sm.b.x[ly][lx], sm.b.y[ly][lx], sm.b.y[ly][lx + 1], sm.b.x[ly + 1][lx]);
   }
   __syncthreads();
 
   // ---- stage 3: vortForce on [-1,0]^2 ----
-  for (int i = tid; i < VW * VH; i += NT) {
+  for (int i = tid; i < VW * VH; i += NTA) {
     const int ly = i / VW, lx = i - ly * VW;
     const float2 v = vorticity_cell(sm.c[ly + 1][lx + 1], sm.c[ly + 1][lx], sm.c[ly + 1][lx + 2], sm.c[ly][lx + 1], sm.c[ly + 2][lx + 1]);
     sm.vx[ly][lx] = v.x;
@@ -152,8 +162,8 @@ __global__ __launch_bounds__(NT) void k_fused_a(Geo g, Uni u, const float *__res
   const int x = tx0 + cx;
   if (x >= X) return;
 #pragma unroll
-  for (int k = 0; k < RPT; k++) {
-    const int cy = (tid / TX) + k * (NT / TX);
+  for (int k = 0; k < TY / (NTA / TX); k++) {
+    const int cy = (tid / TX) + k * (NTA / TX);
     const int y = ty0 + cy;
     if (y >= Y) break;
     const size_t gi = fidx(x, y, X);
@@ -266,7 +276,7 @@ struct LLightAcc {
 };
 
 template <bool WRITE_DISP>
-__global__ __launch_bounds__(NT) void k_fused_b(Geo g, Uni u, const float *__restrict__ initial_T, const float *__restrict__ snd_T,
+__global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, const float *__restrict__ initial_T, const float *__restrict__ snd_T,
                                                 const float *__restrict__ snd_W, const float *__restrict__ snd_Vel, FusedBIn in,
                                                 const SlowCtx *__restrict__ ctx, float4 *__restrict__ base_out, float4 *__restrict__ base_disp, float4 *__restrict__ water_out,
                                                 char4 *__restrict__ wall_out, float4 *__restrict__ light_out)
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(NT) void k_fused_b(Geo g, Uni u, const float *__res
   const bool small = (X < TX + 8) || (Y < TY + 8);
 
   // ---- stage 0: post-boundary base / water / wall tiles with halo ----
-  for (int i = tid; i < IW * IH; i += NT) {
+  for (int i = tid; i < IW * IH; i += NTB) {
     const int ly = i / IW, lx = i - ly * IW;
     const int gx = small ? wrapmod(tx0 + lx - HL, X) : wrapfast(tx0 + lx - HL, X);
     const int gy = small ? wrapmod(ty0 + ly - HD, Y) : wrapfast(ty0 + ly - HD, Y);
@@ -295,11 +305,12 @@ __global__ __launch_bounds__(NT) void k_fused_b(Geo g, Uni u, const float *__res
 
   // ---- stage 1: advection on [-1,0]^2, results in registers ----
   const int cx = tid & (TX - 1);
+  constexpr int RPT = TY / (NTB / TX); // tile rows per thread
   float4 breg[RPT], wreg[RPT];
   char4 wlreg[RPT];
 #pragma unroll
   for (int k = 0; k < RPT; k++) {
-    const int cy = (tid / TX) + k * (NT / TX);
+    const int cy = (tid / TX) + k * (NTB / TX);
     const int x = small ? wrapmod(tx0 + cx, X) : wrapfast(tx0 + cx, X), y = small ? wrapmod(ty0 + cy, Y) : wrapfast(ty0 + cy, Y);
     advect_tile_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, sm.in, ctx, x, y, cx + HL, cy + HD, breg[k], wreg[k], wlreg[k]);
   }
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(NT) void k_fused_b(Geo g, Uni u, const float *__res
 
 #pragma unroll
   for (int k = 0; k < RPT; k++) {
-    const int cy = (tid / TX) + k * (NT / TX);
+    const int cy = (tid / TX) + k * (NTB / TX);
     sm.out.vx[cy + 1][cx + 1] = breg[k].x;
     sm.out.vy[cy + 1][cx + 1] = breg[k].y;
     sm.out.T[cy + 1][cx + 1] = breg[k].w;
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(NT) void k_fused_b(Geo g, Uni u, const float *__res
   if (x >= X) return;
 #pragma unroll
   for (int k = 0; k < RPT; k++) {
-    const int cy = (tid / TX) + k * (NT / TX);
+    const int cy = (tid / TX) + k * (NTB / TX);
     const int y = ty0 + cy;
     if (y >= Y) break;
     const size_t gi = fidx(x, y, X);
@@ -356,7 +367,7 @@ inline void launch_fused_a(const Geo &g, const Uni &u, const float *initial_T, c
                            char4 *wall_out, float *curl_out, hipStream_t stream)
 {
   const dim3 grid((g.X + TX - 1) / TX, (g.Y + TY - 1) / TY);
-  hipLaunchKernelGGL(k_fused_a, grid, dim3(NT), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out);
+  hipLaunchKernelGGL(k_fused_a, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out);
 }
 
 inline void launch_fused_b(const Geo &g, const Uni &u, const float *initial_T, const float *snd_T, const float *snd_W, const float *snd_Vel,
@@ -365,10 +376,10 @@ inline void launch_fused_b(const Geo &g, const Uni &u, const float *initial_T, c
 {
   const dim3 grid((g.X + TX - 1) / TX, (g.Y + TY - 1) / TY);
   if (write_disp)
-    hipLaunchKernelGGL(k_fused_b<true>, grid, dim3(NT), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp,
+    hipLaunchKernelGGL(k_fused_b<true>, grid, dim3(NTB), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp,
                        water_out, wall_out, light_out);
   else
-    hipLaunchKernelGGL(k_fused_b<false>, grid, dim3(NT), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp,
+    hipLaunchKernelGGL(k_fused_b<false>, grid, dim3(NTB), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp,
                        water_out, wall_out, light_out);
 }
 

@@ -16,7 +16,7 @@ from .params import WxParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libwxsim.so")
+LIB_PATH = os.environ.get("WXSIM_LIB") or os.path.join(CSRC, "libwxsim.so")  # WXSIM_LIB: tuning variants
 
 FIELD_IDS = {
     "BASE_CUR": 0, "BASE_DISP": 1, "WATER_0": 2, "WATER_CUR": 3, "WALL_CUR": 4, "WALL_DISP": 5,
