@@ -32,10 +32,10 @@ constexpr int TX = 64, TY = 16;
 #define WX_NTB 512
 #endif
 #ifndef WX_B_MINWAVES
-#define WX_B_MINWAVES 4
+#define WX_B_MINWAVES 6
 #endif
 constexpr int NTA = WX_NTA; // kernel A: 47 VGPRs -> two 16-wave workgroups per CU = 8 waves/SIMD
-constexpr int NTB = WX_NTB; // kernel B: 8-wave workgroups
+constexpr int NTB = WX_NTB; // kernel B: three 8-wave workgroups per CU (52 KB LDS each) = 6 waves/SIMD, <= 80 VGPRs
 constexpr bool kHaveFused = true;
 
 struct FusedAIn {
@@ -170,7 +170,14 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
     LBoundaryAcc a{sm, in, in.water[gi], X, Y, x, y, cx, cy};
     float4 b, w;
     char4 wl;
+#ifdef WX_ABL_NOBOUNDARY
+    b = a.base(0, 0);
+    w = a.w00;
+    wl = a.wall(0, 0);
+    b.x += a.vort(0, 0).x + a.vort(-1, 0).y + a.vort(0, -1).x;
+#else
     boundary_cell(u, g, initial_T, x, y, a, b, w, wl);
+#endif
     base_out[gi] = b;
     water_out[gi] = w;
     wall_out[gi] = wl;
@@ -251,6 +258,12 @@ __device__ __forceinline__ void advect_tile_cell(const Uni &u, const Geo &g, con
   // the three staggered back-trace velocities are combinations of these eight (advectionShader.frag:85-89)
   const float m = fmaxf(fmaxf(fmaxf(fabsf(sm.b.x[ly][lx]), fabsf(sm.b.x[ly][lx - 1])), fmaxf(fabsf(sm.b.x[ly + 1][lx]), fabsf(sm.b.x[ly + 1][lx - 1]))),
                         fmaxf(fmaxf(fabsf(sm.b.y[ly][lx]), fabsf(sm.b.y[ly - 1][lx])), fmaxf(fabsf(sm.b.y[ly][lx + 1]), fabsf(sm.b.y[ly - 1][lx + 1]))));
+#ifdef WX_ABL_NOADV
+  b = sm.b.get(ly, lx);
+  w = sm.q.get(ly, lx);
+  wl = sm.w[ly][lx];
+  return;
+#endif
   if (m < VMAX) {
     LAdvectAcc a{sm, lx, ly};
     advection_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, x, y, a, b, w, wl);
@@ -358,8 +371,12 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, co
     if (WRITE_DISP) base_disp[gi] = b;
     water_out[gi] = wreg[k];
     wall_out[gi] = wlreg[k];
+#ifdef WX_ABL_NOLIGHT
+    light_out[gi] = in.light[gi];
+#else
     LLightAcc la{sm.out, in.light, wreg[k], wlreg[k], b.w, X, x, cx, cy};
     light_out[gi] = lighting_cell(u, g, x, y, la);
+#endif
   }
 }
 
