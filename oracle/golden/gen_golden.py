@@ -276,7 +276,52 @@ def fx_precip64():
                        keep=("base_cur", "water_cur", "wall_cur", "light_0", "light_1"))
 
 
+BRUSH_CASES = [
+    # (name, userInputType, (x, y), intensity, iterations); wall-editing tools run ONE iteration: afterwards the
+    # circular edit is no longer quad aligned and SwiftShader's advection bug would corrupt the golden
+    ("temperature", 1, (0.30, 0.30), 0.5, 3), ("temperature_sea", 1, (0.02, 0.03), 0.5, 3), ("water", 2, (0.30, 0.45), 0.1, 3),
+    ("water_neg", 2, (0.30, 0.45), -0.1, 3), ("smoke", 3, (0.60, 0.30), 0.05, 3), ("wind", 4, (0.50, 0.50), 0.8, 3),
+    ("wholewidth_temp", 1, (-1.0, 0.40), 0.2, 3), ("wholewidth_wind", 4, (-1.0, 0.40), 0.8, 3),
+    ("wall_inert", 10, (0.70, 0.40), 0.01, 1), ("wall_land", 11, (0.30, 0.30), 0.01, 1), ("wall_sea", 12, (0.55, 0.20), 0.01, 1),
+    ("wall_remove", 10, (0.22, 0.10), -0.01, 1), ("fire", 13, (0.20, 0.13), 0.01, 1), ("fire_out", 13, (0.72, 0.05), -0.01, 1),
+    ("urban", 14, (0.20, 0.13), 0.01, 1), ("runway", 15, (0.50, 0.05), 0.01, 1), ("industrial", 16, (0.66, 0.10), 0.01, 1),
+    ("urban_remove", 14, (0.48, 0.03), -0.01, 1), ("moisture", 20, (0.20, 0.13), 0.5, 3), ("snow", 21, (0.20, 0.13), 0.5, 3),
+    ("snow_remove", 21, (0.22, 0.15), -0.5, 3), ("vegetation", 22, (0.20, 0.13), 0.01, 3), ("vegetation_remove", 22, (0.20, 0.13), -0.01, 3),
+]
+
+
+def fx_brush64():
+    """User-brush branch of advectionShader.frag:229-401: every tool once, on the synth64 terrain."""
+    rng = np.random.default_rng(1234)
+    X, Y = 64, 48
+    gui, u, base, water, wall = synth_terrain(X, Y, rng)
+    probe = run_harness({"X": X, "Y": Y, "probe": True, "n_drops": 0})
+    out = {"X": X, "Y": Y, "in_base": base, "in_water": water, "in_wall": wall, "initial_T": np.asarray(u["initial_T"], np.float32),
+           "varyings": _dec(probe["probe"], np.float32).reshape(Y, X, 4), "cases": json.dumps([c[0] for c in BRUSH_CASES])}
+    tmp = tempfile.mkdtemp(prefix="wxgold_")
+    base.tofile(os.path.join(tmp, "base.f32"))
+    water.tofile(os.path.join(tmp, "water.f32"))
+    wall.tofile(os.path.join(tmp, "wall.i8"))
+    for name, ut, (bx, by), inten, nit in BRUSH_CASES:
+        uu = dict(u, userInputType=ut, userInputValues=(bx, by, inten, 6.0), userInputMove=(0.004, -0.002))
+        job = {"X": X, "Y": Y, "n_drops": 0, "dir": "file://" + tmp + "/", "uniforms": js_uniforms(uu),
+               "initial_T": [float(v) for v in u["initial_T"]], "niter": nit, "dump_iters": [nit], "precip": False, "iter0": 0}
+        res = run_harness(job)
+        d = res["dumps"][str(nit)]
+        out[f"{name}_uniforms"] = json.dumps(js_uniforms(uu))
+        out[f"{name}_niter"] = nit
+        out[f"{name}_base"] = _dec(d["base_cur"], np.float32).reshape(Y, X, 4)
+        out[f"{name}_water"] = _dec(d["water_cur"], np.float32).reshape(Y, X, 4)
+        out[f"{name}_wall"] = _dec(d["wall_cur"], np.int8).reshape(Y, X, 4)
+        changed = int((out[f"{name}_wall"] != wall).any(-1).sum())
+        print(f"[brush64] {name}: type {ut}, {nit} it, err={res['err']}, wall cells changed vs input: {changed}")
+    path = os.path.join(OUT_DIR, "brush64.npz")
+    np.savez_compressed(path, **out)
+    print(f"[brush64] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 FIXTURES = {
+    "brush64": fx_brush64,
     "save100qa": lambda: fx_save100(False),
     "save100qa_precip": lambda: fx_save100(True),
     "synth64": fx_synth64,

@@ -281,3 +281,34 @@ def test_slab_handles_equal_whole_domain(pkg, E, fused, nslab, halo):
         ref = whole.read_rect(f)
         for r, h in enumerate(slabs):
             assert np.array_equal(h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]), (f, r)
+
+
+def test_brush_and_airplane_inputs_bit_exact(pkg, oracle, E, fused):
+    """Next-row (f1): user brush (every tool of advectionShader.frag:229-401) and airplane inputs (:415-457):
+    HIP == oracle bit for bit, on the inputs/uniforms of the reference goldens (tests/golden/brush64.npz)."""
+    import json, os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "brush64.npz"))
+    X, Y = int(g["X"]), int(g["Y"])
+    cases = json.loads(str(g["cases"]))
+    extra = {"airplane_dump": dict(airplaneValues=(0.4, 0.5, 0.7, -1.0)), "airplane_crash_air": dict(airplaneValues=(0.6, 0.6, 0.0, 1.0)),
+             "airplane_crash_ground": dict(airplaneValues=(0.2, 0.09, 0.0, 1.0)), "nowrap_brush": dict(userInputType=1, userInputValues=(0.98, 0.5, 0.3, 6.0), wrapHorizontally=0)}
+    for case in cases + list(extra):
+        if case in extra:
+            u = json.loads(str(g["temperature_uniforms"]))
+            u.update(userInputType=-1)
+            u.update(extra[case])
+            n = 2
+        else:
+            u = json.loads(str(g[f"{case}_uniforms"]))
+            n = int(g[f"{case}_niter"]) + 1  # one more iteration than the golden: the edited walls then feed back
+        for k in ("userInputValues", "userInputMove", "airplaneValues"):
+            u[k] = tuple(u[k])
+        u["initial_T"] = g["initial_T"]
+        u["enablePrecipitation"] = 0
+        u["quad_scale"] = 0
+        h, o = _make_pair(pkg, oracle, E, X, Y, g["in_base"], g["in_water"], g["in_wall"], u)
+        h.step(n)
+        o.step(n)
+        for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "WATER_0", "LIGHT_1"):
+            assert np.array_equal(h.read_rect(f), o.field(f)), (case, f)
+        h.close()

@@ -180,3 +180,42 @@ def test_hash_known_answers(oracle):
         expect = np.float32(r) - np.float32(1.0)
         assert L.wxo_random2d(sx, sy) == expect
         assert 0.0 <= expect < 1.0
+
+
+def _brush_cases():
+    import json as _json
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "brush64.npz"))
+    return _json.loads(str(g["cases"]))
+
+
+@pytest.mark.parametrize("case", _brush_cases())
+def test_brush_tools(oracle, case):
+    """User-brush branch of the advection pass (advectionShader.frag:229-401), every tool, vs the reference."""
+    import json, os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "brush64.npz"))
+    u = json.loads(str(g[f"{case}_uniforms"]))
+    for k in ("userInputValues", "userInputMove", "airplaneValues"):
+        u[k] = tuple(u[k])
+    u["initial_T"] = g["initial_T"]
+    u["varyings"] = g["varyings"]
+    u["enablePrecipitation"] = 0
+    X, Y, n = int(g["X"]), int(g["Y"]), int(g[f"{case}_niter"])
+    s = oracle.OracleSim(X, Y, 0)
+    s.upload(g["in_base"], g["in_water"], g["in_wall"])
+    s.set_params(u)
+    s.step(n)
+    assert np.array_equal(s.field("WALL_CUR"), g[f"{case}_wall"]), "wall edits must be bit-exact"
+    b, rb = s.field("BASE_CUR"), g[f"{case}_base"]
+    w, rw = s.field("WATER_CUR"), g[f"{case}_water"]
+    # the brush weight uses smoothstep()/length() whose rounding is implementation defined: 1e-6 relative
+    assert np.abs(b[..., :3] - rb[..., :3]).max() <= 5e-7
+    assert np.abs(b[..., 3] - rb[..., 3]).max() <= 4 * ULP_T
+    assert np.abs(w - rw).max() <= 5e-5
+    # and the tool did something (differs from the run without brush)
+    s0 = oracle.OracleSim(X, Y, 0)
+    s0.upload(g["in_base"], g["in_water"], g["in_wall"])
+    s0.set_params(dict(u, userInputType=-1))
+    s0.step(n)
+    changed = (not np.array_equal(s0.field("WALL_CUR"), s.field("WALL_CUR"))) or np.abs(s0.field("BASE_CUR") - b).max() > 0 \
+        or np.abs(s0.field("WATER_CUR") - w).max() > 0
+    assert changed
