@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--X", type=int, default=16384)
     ap.add_argument("--Y", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--particles", type=int, default=0, help="also run the particle pass with N droplets (BASELINE configs[4]; N=1 GPU only)")
     return ap.parse_args()
 
 
@@ -98,8 +99,15 @@ def main():
 
     if world == 1:
         base, water, wall = pkg.synth.terrain_grid(X, Y)
-        h = pkg.engine.Handle(X, Y, 0)
-        h.upload(base, water, wall)
+        h = pkg.engine.Handle(X, Y, a.particles)
+        if a.particles:
+            u["enablePrecipitation"] = 1
+            # a cloud deck so that droplets spawn, grow and fall during the run
+            yy = np.arange(Y)[:, None]
+            deck = (wall[..., 1] != 0) & (yy > Y // 4) & (yy < Y // 2)
+            water[..., 1] = np.where(deck, 1.5, water[..., 1]).astype(np.float32)
+            water[..., 0] = np.where(deck, water[..., 0] + 1.5, water[..., 0]).astype(np.float32)
+        h.upload(base, water, wall, pkg.synth.init_rain_drops(a.particles) if a.particles else None)
         del base, water, wall
         h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
         stepper = h
@@ -149,7 +157,7 @@ def main():
             "metric": "Mcell-steps/s", "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{X}x{Y} terrain grid, all six grid passes + lighting, particles off (BASELINE configs[2])",
+            "config": {"workload": f"{X}x{Y} terrain grid, all six grid passes + lighting, " + (f"{a.particles} precipitation particles (BASELINE configs[4] on one GPU)" if a.particles else "particles off (BASELINE configs[2])"),
                        "grid": [X, Y], "decomposition": "none" if world == 1 else f"{world} x-slabs, ring halo exchange every 2 iterations (RCCL send/recv)",
                        "iteration_algorithmic_bytes_per_cell": 72},
             "iteration_roofline_frac_A_wet": cells * a.steps * 72 / dt / 1e9 / (HBM_PEAK_GBS * world),
