@@ -6,6 +6,7 @@
 // WX_E_DEVICE otherwise.
 #include "../../include/wxsim.h"
 #include "wx_fused.h"
+#include "wx_full.h"
 #include "wx_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -14,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -37,11 +39,12 @@ enum KernelId {
   K_HALO,
   K_FUSED_VCVB, // velocity + curl + vorticity + boundary
   K_FUSED_APL,  // advection + pressure + lighting
+  K_FUSED_FULL, // the whole iteration in one kernel
   K_COUNT
 };
 const char *const kKernelNames[K_COUNT] = {"velocity", "curl", "vorticity", "boundary", "advection", "pressure", "lighting",
                                            "precipitation", "lightning", "copy", "halo", "fused_vel_curl_vort_boundary",
-                                           "fused_advect_pressure_light"};
+                                           "fused_advect_pressure_light", "fused_full_iteration"};
 
 struct ProfRec {
   hipEvent_t a, b;
@@ -58,14 +61,14 @@ struct wx_sim {
   int even = 1;          // app.js `even`
   int drop_cur = 0;      // particle buffer holding the latest state
   int64_t iter = 0;
-  int fused = 1;         // 1: fused LDS-tiled kernels (default); WX_FUSED=0 in the environment: one kernel per reference pass
+  int fused = 2;         // 2: whole iteration in one kernel (default); 1: two fused kernels; 0: one kernel per reference pass (env WX_FUSED)
   wx_params p{};
   Geo geo{};
   Uni uni{};
   hipStream_t stream = nullptr;
   // device storage
   float4 *base[3] = {nullptr, nullptr, nullptr}; // [2]: post-advection base of the fused path (= baseTexture_1)
-  float4 *water[2] = {nullptr, nullptr}, *light[2] = {nullptr, nullptr};
+  float4 *water[3] = {nullptr, nullptr, nullptr}, *light[3] = {nullptr, nullptr, nullptr}; // [2]: spare of the single-kernel ping-pong
   bool ran_fused = false; // the last iteration used the fused ping-pong (field mapping differs)
   char4 *wall[2] = {nullptr, nullptr};
   float *curl = nullptr;
@@ -75,6 +78,7 @@ struct wx_sim {
   float *initial_T = nullptr, *snd_T = nullptr, *snd_W = nullptr, *snd_Vel = nullptr;
   DevState *state = nullptr;
   SlowCtx *slow_ctx = nullptr; // device copy of geometry/uniforms/pointers for the out-of-line advection path
+  FullCtx *full_ctx = nullptr;
   bool fb_dirty = false; // feedback/deposition hold non-zero data (particles ran last iteration)
   // profiling
   bool profiling = false;
@@ -350,6 +354,30 @@ int iterate_fused(wx_sim *s, bool write_disp)
   return WX_OK;
 }
 
+// The whole iteration as ONE kernel (wx_full.h). Reads base[0], wall[0], water[1], light[0], light[src]; writes the
+// other buffer of each pair and swaps the pointers, so that afterwards the usual roles hold again
+// (base[0]/wall[0] = post-pressure state, water[1] = post-advection water, light[0]/light[1] as in the reference).
+int iterate_full(wx_sim *s, bool opt_out)
+{
+  const Geo g = s->geo;
+  Uni u = s->uni;
+  u.iterNum = (float)s->iter;
+  u.iterI = (int)u.iterNum;
+  const int src = s->even ? 0 : 1;
+  float4 *light_dst = s->even ? s->light[1] : s->light[2]; // never the light[0] that other tiles' boundary stage reads
+  FullIn in{s->base[0], s->wall[0], s->water[1], s->light[0], s->light[src], s->fb_dirty ? s->fb : nullptr, s->fb_dirty ? s->dep : nullptr};
+  FullOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], s->water[0], s->curl};
+  {
+    ProfScope ps(s, K_FUSED_FULL);
+    launch_fused_full(g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, s->full_ctx, out, opt_out, s->stream);
+  }
+  std::swap(s->base[0], s->base[1]);
+  std::swap(s->wall[0], s->wall[1]);
+  std::swap(s->water[1], s->water[2]);
+  if (!s->even) std::swap(s->light[0], s->light[2]);
+  return WX_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -405,6 +433,9 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (rc == WX_OK) rc = dalloc(s, &s->snd_Vel, (size_t)Y + 8);
   if (rc == WX_OK) rc = dalloc(s, &s->state, 1);
   if (rc == WX_OK) rc = dalloc(s, &s->slow_ctx, 1);
+  if (rc == WX_OK) rc = dalloc(s, &s->full_ctx, 1);
+  if (rc == WX_OK) rc = dalloc(s, &s->water[2], n);
+  if (rc == WX_OK) rc = dalloc(s, &s->light[2], n);
   if (rc != WX_OK) {
     g_create_error = s->err;
     wx_destroy(s);
@@ -446,6 +477,9 @@ void wx_destroy(wx_sim *s)
   hipFree(s->snd_Vel);
   hipFree(s->state);
   hipFree(s->slow_ctx);
+  hipFree(s->full_ctx);
+  hipFree(s->water[2]);
+  hipFree(s->light[2]);
   delete s;
 }
 
@@ -492,6 +526,8 @@ int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const f
   {
     SlowCtx c{s->geo, s->uni, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, FusedBIn{s->base[1], s->water[0], s->wall[1], nullptr}};
     HIPCHK(s, hipMemcpyAsync(s->slow_ctx, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
+    FullCtx fc{s->geo, s->uni, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel};
+    HIPCHK(s, hipMemcpyAsync(s->full_ctx, &fc, sizeof(fc), hipMemcpyHostToDevice, s->stream));
   }
   if (p->inactiveDroplets >= 0.0f)
     HIPCHK(s, hipMemcpyAsync(&s->state->inactiveDroplets, &p->inactiveDroplets, 4, hipMemcpyHostToDevice, s->stream));
@@ -511,7 +547,9 @@ int wx_step(wx_sim *s, int n_iter)
   // the fused kernels implement the full grid-pass set; any other pass_mask runs the per-pass kernels
   const bool fused = s->fused && (mask & 0x3Fu) == 0x3Fu;
   for (int it = 0; it < n_iter; it++) {
-    if (fused)
+    if (fused && s->fused >= 2)
+      iterate_full(s, precip || it == n_iter - 1);
+    else if (fused)
       iterate_fused(s, precip || it == n_iter - 1);
     else
       iterate_per_pass(s, mask, precip);

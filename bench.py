@@ -27,6 +27,8 @@ ALGO_BYTES = {
     # A: R base16 wall4 water16 light16, W base16 water16 wall4 curl4; B: R base16 water16 wall4 light16,
     # W base16 water16 wall4 light16 (+16 for the post-advection base on the last iteration of a wx_step call only)
     "fused_vel_curl_vort_boundary": 52 + 40, "fused_advect_pressure_light": 52 + 52,
+    # single-kernel iteration: R base16 wall4 water16 light_0 16 light_src 16, W base16 wall4 water16 light16
+    "fused_full_iteration": 68 + 52,
 }
 
 

@@ -21,7 +21,7 @@ def E(pkg):
     return engine
 
 
-@pytest.fixture(params=[1, 0], ids=["fused", "perpass"])
+@pytest.fixture(params=[2, 1, 0], ids=["full", "fused", "perpass"])
 def fused(request):
     """Both kernel sets go through every parity test: WX_FUSED is read by wx_create."""
     import os
@@ -203,17 +203,18 @@ def test_full_size_invariants(pkg, E):
         return out
 
     n = 12
-    r_f = run(base, water, wall, n, 1)
-    r_p = run(base, water, wall, n, 0)
-    for f in fields:
-        assert np.array_equal(r_f[f], r_p[f]), f"fused and per-pass kernels differ in {f}"
-    del r_p
+    r_f = run(base, water, wall, n, 2)
+    for mode in (1, 0):
+        r_p = run(base, water, wall, n, mode)
+        for f in fields:
+            assert np.array_equal(r_f[f], r_p[f]), f"single-kernel iteration and kernel set {mode} differ in {f}"
+        del r_p
     b0, w0, wl0 = r_f["BASE_CUR"], r_f["WATER_CUR"], r_f["WALL_CUR"]
     assert np.isfinite(b0).all() and np.isfinite(w0).all() and np.isfinite(r_f["LIGHT_0"]).all()
     assert (w0[..., 0] >= 0).all() and (w0[..., 1] >= 0).all()
     assert np.abs(b0[..., :2]).max() > 1e-3  # the flow developed
     # determinism
-    r_2 = run(base, water, wall, n, 1)
+    r_2 = run(base, water, wall, n, 2)
     assert all(np.array_equal(r_f[f], r_2[f]) for f in fields)
     del r_2
     # periodic in x: shifting the input by a multiple of 80 columns (industrial stacks use x % 80) shifts the
@@ -221,7 +222,7 @@ def test_full_size_invariants(pkg, E):
     # absolute x like in the reference, so its rounding depends on x (ulp(16384.5) = 1e-3 cell): velocity,
     # pressure and temperature are equivariant to rounding noise (99 % of the values bit-equal), not bit for bit.
     k = 80 * 37
-    r_s = run(np.roll(base, k, 1), np.roll(water, k, 1), np.roll(wall, k, 1), n, 1)
+    r_s = run(np.roll(base, k, 1), np.roll(water, k, 1), np.roll(wall, k, 1), n, 2)
     assert np.array_equal(np.roll(wl0, k, 1), r_s["WALL_CUR"])
     assert np.abs(np.roll(w0, k, 1) - r_s["WATER_CUR"]).max() <= 1e-5
     d = np.abs(np.roll(b0, k, 1) - r_s["BASE_CUR"])
