@@ -30,13 +30,17 @@ namespace wx {
 constexpr int NTF = WX_NTF;
 
 namespace ff {
-constexpr int R = 5;                                // halo of base_0 on the low side
-// a region [lo,+hi] spans cells lo .. T-1+hi: T - lo + hi cells per axis
-constexpr int B0W = TX + 10, B0H = TY + 10;         // base_0 on [-5,+5]
-constexpr int W0W = TX + 9, W0H = TY + 9;           // wall_0 on [-5,+4]
-constexpr int CW = TX + 8, CH = TY + 8;             // curl on [-5,+3]
-constexpr int VW = TX + 6, VH = TY + 6;             // vortForce on [-4,+2]
-constexpr int BW = TX + 5, BH = TY + 5;             // boundary output on [-3,+2]  (== fb_::IW x fb_::IH)
+// a region [lo,+hi] spans cells lo .. T-1+hi: T - lo + hi cells per axis. With Q = fb_::REACH (2 below):
+constexpr int Q = fb_::REACH;
+constexpr int BL = 1 + Q;                           // boundary output on [-(1+Q), +Q]   ([-3,+2])  == advection input tile
+constexpr int VL = 2 + Q;                           // vortForce on [-(2+Q), +Q]         ([-4,+2])
+constexpr int R = 3 + Q;                            // curl on [-(3+Q), +(Q+1)]          ([-5,+3]); velocity / wall_0 on
+                                                    // [-(3+Q), +(Q+2)] ([-5,+4]); base_0 on [-(3+Q), +(Q+3)] ([-5,+5])
+constexpr int B0W = TX + 2 * Q + 6, B0H = TY + 2 * Q + 6;
+constexpr int W0W = TX + 2 * Q + 5, W0H = TY + 2 * Q + 5;
+constexpr int CW = TX + 2 * Q + 4, CH = TY + 2 * Q + 4;
+constexpr int VW = TX + 2 * Q + 2, VH = TY + 2 * Q + 2;
+constexpr int BW = TX + 2 * Q + 1, BH = TY + 2 * Q + 1;
 constexpr int NB = (BW * BH + NTF - 1) / NTF;       // boundary cells per thread
 constexpr int RPT = TY / (NTF / TX);                // tile rows per thread
 static_assert(BW == fb_::IW && BH == fb_::IH, "advection input tile");
@@ -67,7 +71,7 @@ struct FullOut {
   float *curl;       // optional
 };
 
-// ---- boundary accessor on the phase-1 tiles; (cx,cy) in [-3, TX+2) x [-3, TY+2) ----
+// ---- boundary accessor on the phase-1 tiles; (cx,cy) in [-BL, TX+Q) x [-BL, TY+Q) ----
 struct FBoundaryAcc {
   const ff::Phase1 &sm;
   const FullIn &in;
@@ -75,7 +79,7 @@ struct FBoundaryAcc {
   int X, Y, x, y, cx, cy;
   __device__ __forceinline__ float4 base(int dx, int dy) const { return sm.b.get(cy + ff::R + dy, cx + ff::R + dx); }
   __device__ __forceinline__ char4 wall(int dx, int dy) const { return sm.w[cy + ff::R + dy][cx + ff::R + dx]; }
-  __device__ __forceinline__ float2 vort(int dx, int dy) const { return make_float2(sm.vx[cy + 4 + dy][cx + 4 + dx], sm.vy[cy + 4 + dy][cx + 4 + dx]); }
+  __device__ __forceinline__ float2 vort(int dx, int dy) const { return make_float2(sm.vx[cy + ff::VL + dy][cx + ff::VL + dx], sm.vy[cy + ff::VL + dy][cx + ff::VL + dx]); }
   __device__ __forceinline__ float4 water(int dx, int dy) const
   {
     if (dx == 0 && dy == 0) return w00;
@@ -194,10 +198,16 @@ __device__ __forceinline__ void advect_full_cell(const Uni &u, const Geo &g, con
   }
 }
 
+// Uniforms and geometry are NOT kernel arguments here: 60+ scalar uniforms kept live across seven stages overflow
+// the SGPR file (the first version spilled ~1600 SGPRs through v_readlane). They live in device memory (FullCtx)
+// and every stage re-reads the few it needs after its barrier.
+#define WX_STAGE_UNI()                 \
+  Uni u = ctx->u;                      \
+  u.iterNum = iterNum;                 \
+  u.iterI = (int)iterNum;
+
 template <bool OPT_OUT>
-__global__ __launch_bounds__(NTF, WX_F_MINWAVES) void k_fused_full(Geo g, Uni u, const float *__restrict__ initial_T, const float *__restrict__ snd_T,
-                                                                    const float *__restrict__ snd_W, const float *__restrict__ snd_Vel, FullIn in,
-                                                                    const FullCtx *__restrict__ ctx, FullOut out)
+__global__ __launch_bounds__(NTF, WX_F_MINWAVES) void k_fused_full(const FullCtx *ctx, float iterNum, FullIn in, FullOut out)
 {
   using namespace ff;
   __shared__ union {
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(NTF, WX_F_MINWAVES) void k_fused_full(Geo g, Uni u,
     fb_::SmemIn p2;   // post-boundary base / water / wall on [-3,+2]
     fb_::SmemOut p3;  // advection output on [-1,0]
   } sm;
-  const int X = g.X, Y = g.Y;
+  const int X = ctx->g.X, Y = ctx->g.Y;
   const int tid = threadIdx.x;
   const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
   const bool small = (X < TX + 16) || (Y < TY + 16);
@@ -228,17 +238,22 @@ __global__ __launch_bounds__(NTF, WX_F_MINWAVES) void k_fused_full(Geo g, Uni u,
     const int i = tid + k * NTF;
     if (i < BW * BH) {
       const int ry = i / BW, rx = i - ry * BW;
-      bw00[k] = in.water[fidx(WX_WRAPX(tx0 + rx - 3), WX_WRAPY(ty0 + ry - 3), X)];
+      bw00[k] = in.water[fidx(WX_WRAPX(tx0 + rx - BL), WX_WRAPY(ty0 + ry - BL), X)];
     }
   }
   __syncthreads();
 
   // ---- stage 1: velocity on [-5,+4]^2 in place ----
-  for (int i = tid; i < W0W * W0H; i += NTF) {
-    const int ly = i / W0W, lx = i - ly * W0W;
-    const float4 b = velocity_cell(u, sm.p1.b.get(ly, lx), sm.p1.b.z[ly][lx + 1], sm.p1.b.z[ly + 1][lx], sm.p1.w[ly][lx].y);
-    sm.p1.b.x[ly][lx] = b.x;
-    sm.p1.b.y[ly][lx] = b.y;
+  {
+    Uni u;
+    u.vel_keep = ctx->u.vel_keep;
+    u.wind_add = ctx->u.wind_add;
+    for (int i = tid; i < W0W * W0H; i += NTF) {
+      const int ly = i / W0W, lx = i - ly * W0W;
+      const float4 b = velocity_cell(u, sm.p1.b.get(ly, lx), sm.p1.b.z[ly][lx + 1], sm.p1.b.z[ly + 1][lx], sm.p1.w[ly][lx].y);
+      sm.p1.b.x[ly][lx] = b.x;
+      sm.p1.b.y[ly][lx] = b.y;
+    }
   }
   __syncthreads();
 
@@ -261,20 +276,25 @@ __global__ __launch_bounds__(NTF, WX_F_MINWAVES) void k_fused_full(Geo g, Uni u,
   // ---- stage 4: boundary on [-3,+2]^2, results in registers (the phase-1 tiles are still being read) ----
   float4 bb[NB], bq[NB];
   char4 bwl[NB];
+  {
+    WX_STAGE_UNI();
+    const Geo g = ctx->g;
+    const float *initial_T = ctx->initial_T;
 #pragma unroll
-  for (int k = 0; k < NB; k++) {
-    const int i = tid + k * NTF;
-    if (i < BW * BH) {
-      const int ry = i / BW, rx = i - ry * BW;
-      const int cx = rx - 3, cy = ry - 3;
-      const int x = WX_WRAPX(tx0 + cx), y = WX_WRAPY(ty0 + cy);
-      FBoundaryAcc a{sm.p1, in, bw00[k], X, Y, x, y, cx, cy};
-      boundary_cell(u, g, initial_T, x, y, a, bb[k], bq[k], bwl[k]);
-      if (OPT_OUT) {
-        if (cx >= 0 && cx < TX && cy >= 0 && cy < TY && tx0 + cx < X && ty0 + cy < Y) {
-          const size_t gi = fidx(tx0 + cx, ty0 + cy, X);
-          out.water0[gi] = bq[k];
-          out.curl[gi] = sm.p1.c[cy + R][cx + R];
+    for (int k = 0; k < NB; k++) {
+      const int i = tid + k * NTF;
+      if (i < BW * BH) {
+        const int ry = i / BW, rx = i - ry * BW;
+        const int cx = rx - BL, cy = ry - BL;
+        const int x = WX_WRAPX(tx0 + cx), y = WX_WRAPY(ty0 + cy);
+        FBoundaryAcc a{sm.p1, in, bw00[k], X, Y, x, y, cx, cy};
+        boundary_cell(u, g, initial_T, x, y, a, bb[k], bq[k], bwl[k]);
+        if (OPT_OUT) {
+          if (cx >= 0 && cx < TX && cy >= 0 && cy < TY && tx0 + cx < X && ty0 + cy < Y) {
+            const size_t gi = fidx(tx0 + cx, ty0 + cy, X);
+            out.water0[gi] = bq[k];
+            out.curl[gi] = sm.p1.c[cy + R][cx + R];
+          }
         }
       }
     }
@@ -296,21 +316,26 @@ __global__ __launch_bounds__(NTF, WX_F_MINWAVES) void k_fused_full(Geo g, Uni u,
   const int cx = tid & (TX - 1);
   float4 breg[RPT], wreg[RPT];
   char4 wlreg[RPT];
-#pragma unroll
-  for (int k = 0; k < RPT; k++) {
-    const int cy = (tid / TX) + k * (NTF / TX);
-    advect_full_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, sm.p2, ctx, in, WX_WRAPX(tx0 + cx), WX_WRAPY(ty0 + cy), cx + fb_::HL, cy + fb_::HD,
-                     breg[k], wreg[k], wlreg[k]);
-  }
   float4 eb = make_float4(0.f, 0.f, 0.f, 0.f);
   char4 ewl = make_char4(0, 0, 0, 0);
   const bool extra = tid < TX + TY + 1;
   const int ecx = (tid < TX) ? tid : -1;
   const int ecy = (tid < TX) ? -1 : tid - TX - 1;
-  if (extra) {
-    float4 w;
-    advect_full_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, sm.p2, ctx, in, WX_WRAPX(tx0 + ecx), WX_WRAPY(ty0 + ecy), ecx + fb_::HL, ecy + fb_::HD,
-                     eb, w, ewl);
+  {
+    WX_STAGE_UNI();
+    const Geo g = ctx->g;
+    const float *initial_T = ctx->initial_T, *snd_T = ctx->snd_T, *snd_W = ctx->snd_W, *snd_Vel = ctx->snd_Vel;
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int cy = (tid / TX) + k * (NTF / TX);
+      advect_full_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, sm.p2, ctx, in, WX_WRAPX(tx0 + cx), WX_WRAPY(ty0 + cy), cx + fb_::HL, cy + fb_::HD,
+                       breg[k], wreg[k], wlreg[k]);
+    }
+    if (extra) {
+      float4 w;
+      advect_full_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, sm.p2, ctx, in, WX_WRAPX(tx0 + ecx), WX_WRAPY(ty0 + ecy), ecx + fb_::HL, ecy + fb_::HD,
+                       eb, w, ewl);
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -332,33 +357,37 @@ __global__ __launch_bounds__(NTF, WX_F_MINWAVES) void k_fused_full(Geo g, Uni u,
   // ---- stage 6: pressure + lighting on the tile ----
   const int x = tx0 + cx;
   if (x >= X) return;
+  {
+    WX_STAGE_UNI();
+    const Geo g = ctx->g;
 #pragma unroll
-  for (int k = 0; k < RPT; k++) {
-    const int cy = (tid / TX) + k * (NTF / TX);
-    const int y = ty0 + cy;
-    if (y >= Y) break;
-    const size_t gi = fidx(x, y, X);
-    const float4 b = breg[k];
-    const char4 wd = sm.p3.w[cy][cx + 1];
-    out.base[gi] = pressure_cell(b, sm.p3.vx[cy + 1][cx], sm.p3.vy[cy][cx + 1], sm.p3.T[cy][cx + 1], wd.x, wd.y);
-    if (OPT_OUT) out.base_disp[gi] = b;
-    out.water[gi] = wreg[k];
-    out.wall[gi] = wlreg[k];
-    LLightAcc la{sm.p3, in.light_src, wreg[k], wlreg[k], b.w, X, x, cx, cy};
-    out.light[gi] = lighting_cell(u, g, x, y, la);
+    for (int k = 0; k < RPT; k++) {
+      const int cy = (tid / TX) + k * (NTF / TX);
+      const int y = ty0 + cy;
+      if (y >= Y) break;
+      const size_t gi = fidx(x, y, X);
+      const float4 b = breg[k];
+      const char4 wd = sm.p3.w[cy][cx + 1];
+      out.base[gi] = pressure_cell(b, sm.p3.vx[cy + 1][cx], sm.p3.vy[cy][cx + 1], sm.p3.T[cy][cx + 1], wd.x, wd.y);
+      if (OPT_OUT) out.base_disp[gi] = b;
+      out.water[gi] = wreg[k];
+      out.wall[gi] = wlreg[k];
+      LLightAcc la{sm.p3, in.light_src, wreg[k], wlreg[k], b.w, X, x, cx, cy};
+      out.light[gi] = lighting_cell(u, g, x, y, la);
+    }
   }
 #undef WX_WRAPX
 #undef WX_WRAPY
 }
 
-inline void launch_fused_full(const Geo &g, const Uni &u, const float *initial_T, const float *snd_T, const float *snd_W, const float *snd_Vel,
-                              const FullIn &in, const FullCtx *ctx, const FullOut &out, bool opt_out, hipStream_t stream)
+inline void launch_fused_full(const Geo &g, float iterNum, const FullIn &in, const FullCtx *ctx, const FullOut &out, bool opt_out,
+                              hipStream_t stream)
 {
   const dim3 grid((g.X + TX - 1) / TX, (g.Y + TY - 1) / TY);
   if (opt_out)
-    hipLaunchKernelGGL(k_fused_full<true>, grid, dim3(NTF), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, out);
+    hipLaunchKernelGGL(k_fused_full<true>, grid, dim3(NTF), 0, stream, ctx, iterNum, in, out);
   else
-    hipLaunchKernelGGL(k_fused_full<false>, grid, dim3(NTF), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, out);
+    hipLaunchKernelGGL(k_fused_full<false>, grid, dim3(NTF), 0, stream, ctx, iterNum, in, out);
 }
 
 } // namespace wx

@@ -188,13 +188,19 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
 // ================================================================================================
 // kernel B
 // ================================================================================================
+#ifndef WX_REACH
+#define WX_REACH 1
+#endif
 namespace fb_ {
 // advection is evaluated on x,y in [-1,0] (pressure needs the left and lower neighbour); its 7-point velocity
-// stencil reaches 1 further and the back-traced bilinear footprint up to 2 further (|v| < 2): inputs on [-3,+2].
-constexpr int HL = 3, HR = 2, HD = 3, HU = 2;
-constexpr int IW = TX + HL + HR, IH = TY + HD + HU; // 69 x 21
+// stencil reaches 1 further, and so does the back-traced bilinear footprint as long as |v| < 1 cell/iteration
+// (REACH = 1; the shaders document velocities as "-1.0 to 1.0", common.glsl:40-41): inputs on [-2,+1].
+// Cells with a longer back-trace take the exact out-of-line path. REACH = 2 stages [-3,+2] and covers |v| < 2.
+constexpr int REACH = WX_REACH;
+constexpr int HL = 1 + REACH, HR = REACH, HD = 1 + REACH, HU = REACH;
+constexpr int IW = TX + HL + HR, IH = TY + HD + HU;
 constexpr int AW = TX + 1, AH = TY + 1;             // advection results on [-1,0]
-constexpr float VMAX = 1.9f;                        // back-traces shorter than this stay inside the staged tile
+constexpr float VMAX = REACH == 1 ? 0.9f : 1.9f;    // back-traces shorter than this stay inside the staged tile
 struct SmemIn {
   Planes4<IH, IW> b, q; // post-boundary base, water
   char4 w[IH][IW + 1];

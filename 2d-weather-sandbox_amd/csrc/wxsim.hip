@@ -369,7 +369,7 @@ int iterate_full(wx_sim *s, bool opt_out)
   FullOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], s->water[0], s->curl};
   {
     ProfScope ps(s, K_FUSED_FULL);
-    launch_fused_full(g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, s->full_ctx, out, opt_out, s->stream);
+    launch_fused_full(g, u.iterNum, in, s->full_ctx, out, opt_out, s->stream);
   }
   std::swap(s->base[0], s->base[1]);
   std::swap(s->wall[0], s->wall[1]);
