@@ -61,7 +61,8 @@ struct wx_sim {
   int even = 1;          // app.js `even`
   int drop_cur = 0;      // particle buffer holding the latest state
   int64_t iter = 0;
-  int fused = 2;         // 2: whole iteration in one kernel (default); 1: two fused kernels; 0: one kernel per reference pass (env WX_FUSED)
+  int fused = 1;         // 1: two fused LDS-tiled kernels (default, fastest measured); 2: whole iteration in one kernel; 0: one kernel
+                         // per reference pass (env WX_FUSED)
   wx_params p{};
   Geo geo{};
   Uni uni{};
