@@ -174,7 +174,23 @@ __global__ void k_copy4(const char4 *__restrict__ src, char4 *__restrict__ dst, 
 struct DevState {
   float inactiveDroplets; // the `inactiveDroplets` uniform, refreshed on the device every 600 iterations
   float lightning[4];     // lightningDataTexture (1x1 RGBA32F)
+  float px_count;         // this iteration's 1-px blends into texel (0,0): +1 per still-inactive droplet
+  float px_light[4];      // this iteration's 1-px blends into texel (1,0): lightning requests
 };
+
+// Splat accumulation: a 12x12 point sprite anchored at pixel (i0,j0) adds the same value to pixels
+// i0..i0+11 x j0..j0+11. Instead of 144 x 5 atomics per droplet the value is added ONCE at the anchor of a padded
+// accumulation grid and a 12x12 box sum (k_splat_box) produces the feedback / deposition textures.
+// Anchor range: i0 = ceil(xw - 6.5) in [-6, X-6]  ->  column q = i0 + 6 in [0, X]; rows likewise.
+struct SplatGrid {
+  float4 *acc4;  // (mass, heat, vapor, -) deposits, pitch AP
+  float2 *acc2;  // (rain, snow) deposits
+  unsigned char *dirty;   // per 64x16 tile of the accumulation grid: holds deposits
+  unsigned char *fb_zero; // per 64x16 tile of the feedback texture: known to be all zero
+  int AP, AH;    // pitch (>= X+1) and rows (>= Y+1) of the accumulation grid
+  int TXn, TYn;  // tiles per row / column
+};
+constexpr int STX = 64, STY = 16; // splat tile
 
 // common.glsl:103-111
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x)
@@ -219,7 +235,7 @@ __device__ __forceinline__ void atomic_add_f(float *p, float v)
 
 __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops, const float *__restrict__ drops_in,
                                                         const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
-                                                        const DevState *__restrict__ st, float *__restrict__ drops_out, float4 *fb, float2 *dep)
+                                                        DevState *__restrict__ st, float *__restrict__ drops_out, SplatGrid sg)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n_drops;
@@ -383,45 +399,161 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
     const unsigned long long m = __ballot(count_inactive);
     if (m != 0ull) {
       const int lane = threadIdx.x & 63;
-      if (lane == __ffsll((long long)m) - 1) unsafeAtomicAdd(&fb[0].x, (float)__popcll(m));
+      if (lane == __ffsll((long long)m) - 1) unsafeAtomicAdd(&st->px_count, (float)__popcll(m));
     }
   }
   if (!live || count_inactive) return;
 
-  // point sprite: clip test on the centre, then every pixel whose centre lies in [w - size/2, w + size/2)
+  // point sprite: clip test on the centre (precipitationShader.vert gl_Position / gl_PointSize)
   if (!(gposx >= -1.0f && gposx <= 1.0f && gposy >= -1.0f && gposy <= 1.0f)) return;
   const float xw = (gposx + 1.0f) * 0.5f * resX, yw = (gposy + 1.0f) * 0.5f * resY;
-  int i0, i1, j0, j1;
   if (size <= 1.0f) {
-    i0 = i1 = (int)floorf(xw);
-    j0 = j1 = (int)floorf(yw);
-  } else {
-    const float h = size * 0.5f;
-    i0 = (int)ceilf(xw - h - 0.5f);
-    i1 = i0 + (int)size - 1;
-    j0 = (int)ceilf(yw - h - 0.5f);
-    j1 = j0 + (int)size - 1;
+    // the only 1-px sprite that reaches this point is a lightning request, drawn at pixel (1,0)
+    // (precipitationShader.vert:135-139)
+    atomic_add_f(&st->px_light[0], feedback[0]);
+    atomic_add_f(&st->px_light[1], feedback[1]);
+    atomic_add_f(&st->px_light[2], feedback[2]);
+    atomic_add_f(&st->px_light[3], feedback[3]);
+    return;
   }
-  for (int j = j0; j <= j1; j++) {
-    if (j < 0 || j >= Y) continue;
-    for (int ii = i0; ii <= i1; ii++) {
-      if (ii < 0 || ii >= X) continue;
-      float *f = reinterpret_cast<float *>(fb + cidx(ii, j, X));
-      atomic_add_f(f + 0, feedback[0]);
-      atomic_add_f(f + 1, feedback[1]);
-      atomic_add_f(f + 2, feedback[2]);
-      atomic_add_f(f + 3, feedback[3]);
-      float *d = reinterpret_cast<float *>(dep + cidx(ii, j, X));
-      atomic_add_f(d + 0, deposition[0]);
-      atomic_add_f(d + 1, deposition[1]);
+  // 12x12 sprite: every pixel whose centre lies in [w - 6, w + 6); one deposit at the anchor pixel
+  const int q = (int)ceilf(xw - 6.0f - 0.5f) + 6, r = (int)ceilf(yw - 6.0f - 0.5f) + 6;
+  const size_t ai = (size_t)r * sg.AP + q;
+  float *f = reinterpret_cast<float *>(sg.acc4 + ai);
+  atomic_add_f(f + 0, feedback[0]);
+  atomic_add_f(f + 1, feedback[1]);
+  atomic_add_f(f + 2, feedback[2]);
+  float *d = reinterpret_cast<float *>(sg.acc2 + ai);
+  atomic_add_f(d + 0, deposition[0]);
+  atomic_add_f(d + 1, deposition[1]);
+  sg.dirty[(r / STY) * sg.TXn + (q / STX)] = 1;
+}
+
+// 12x12 box sum of the deposits -> precipitationFeedbackTexture (RGBA32F) + precipitationDepositionTexture (RG32F).
+// out(i,j) = sum of acc(q,r) for q in [i-5, i+6], r in [j-5, j+6] (anchor q = i0+6 covers pixels i0..i0+11).
+// One workgroup per 64x16 output tile; tiles whose 3x3 neighbourhood holds no deposits only (re)write zeros, and
+// not even that when the texture tile is already known to be zero. Replaces the per-iteration clear of both
+// textures (app.js:5933-5934) and the blend-unit splats.
+__global__ __launch_bounds__(256) void k_splat_box(int X, int Y, SplatGrid sg, const DevState *__restrict__ st, float4 *__restrict__ fb,
+                                                   float2 *__restrict__ dep)
+{
+  constexpr int WW = STX + 11, WH = STY + 11;
+  __shared__ float pl[5][WH][WW + 1];
+  __shared__ float hs[WH][STX + 1];
+  __shared__ int any_dirty;
+  const int tid = threadIdx.x;
+  const int tbx = blockIdx.x, tby = blockIdx.y;
+  const int x0 = tbx * STX, y0 = tby * STY;
+  if (tid == 0) {
+    int a = 0;
+    // deposits that reach this tile sit in accumulation tiles tbx-1..tbx+1 (window q in [x0-5, x0+69])
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        const int ax = tbx + dx, ay = tby + dy;
+        if (ax >= 0 && ay >= 0 && ax < sg.TXn && ay < sg.TYn) a |= sg.dirty[ay * sg.TXn + ax];
+      }
+    any_dirty = a;
+  }
+  __syncthreads();
+  const int cx = tid & 63, cyg = tid >> 6;
+  const bool corner = (tbx == 0 && tby == 0);
+  const int tile = tby * sg.TXn + tbx;
+  if (!any_dirty) {
+    if (sg.fb_zero[tile] && !corner) return; // texture tile still zero from an earlier iteration
+    for (int k = 0; k < STY / 4; k++) {
+      const int x = x0 + cx, y = y0 + cyg + 4 * k;
+      if (x < X && y < Y) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (corner && y == 0 && x == 0) v.x = st->px_count;
+        if (corner && y == 0 && x == 1) v = make_float4(st->px_light[0], st->px_light[1], st->px_light[2], st->px_light[3]);
+        fb[(size_t)y * X + x] = v;
+        dep[(size_t)y * X + x] = make_float2(0.f, 0.f);
+      }
+    }
+    if (tid == 0) sg.fb_zero[tile] = corner ? 0 : 1;
+    return;
+  }
+  // stage the deposit window (zero outside the accumulation grid)
+  for (int i = tid; i < WW * WH; i += 256) {
+    const int ly = i / WW, lx = i - ly * WW;
+    const int q = x0 - 5 + lx, r = y0 - 5 + ly;
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 a2 = make_float2(0.f, 0.f);
+    if (q >= 0 && r >= 0 && q <= X && r <= Y) {
+      a4 = sg.acc4[(size_t)r * sg.AP + q];
+      a2 = sg.acc2[(size_t)r * sg.AP + q];
+    }
+    pl[0][ly][lx] = a4.x;
+    pl[1][ly][lx] = a4.y;
+    pl[2][ly][lx] = a4.z;
+    pl[3][ly][lx] = a2.x;
+    pl[4][ly][lx] = a2.y;
+  }
+  __syncthreads();
+  float res[5][STY / 4];
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    // horizontal 12-sums for every window row, then vertical 12-sums (fixed summation order)
+    for (int i = tid; i < WH * STX; i += 256) {
+      const int ly = i >> 6, lx = i & 63;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; k++) s += pl[c][ly][lx + k];
+      hs[ly][lx] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < STY / 4; k++) {
+      const int ly = cyg + 4 * k;
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < 12; m++) s += hs[ly + m][cx];
+      res[c][k] = s;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < STY / 4; k++) {
+    const int x = x0 + cx, y = y0 + cyg + 4 * k;
+    if (x < X && y < Y) {
+      float4 v = make_float4(res[0][k], res[1][k], res[2][k], 0.f);
+      if (corner && y == 0 && x == 0) v.x += st->px_count;
+      if (corner && y == 0 && x == 1) {
+        v.x += st->px_light[0];
+        v.y += st->px_light[1];
+        v.z += st->px_light[2];
+        v.w += st->px_light[3];
+      }
+      fb[(size_t)y * X + x] = v;
+      dep[(size_t)y * X + x] = make_float2(res[3][k], res[4][k]);
     }
   }
+  if (tid == 0) sg.fb_zero[tile] = 0;
+}
+
+// zero the accumulation tiles that hold deposits (after k_splat_box consumed them)
+__global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg)
+{
+  const int tile = blockIdx.y * sg.TXn + blockIdx.x;
+  if (!sg.dirty[tile]) return;
+  const int x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
+  for (int i = threadIdx.x; i < STX * STY; i += 256) {
+    const int q = x0 + (i & 63), r = y0 + (i >> 6);
+    if (q < sg.AP && r < sg.AH) {
+      sg.acc4[(size_t)r * sg.AP + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      sg.acc2[(size_t)r * sg.AP + q] = make_float2(0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) sg.dirty[tile] = 0;
 }
 
 // lightningLocationShader.frag:24-38 + the 600-iteration inactive count (app.js:5957-5966), one thread
 __global__ void k_lightning(float iterNum, int refresh_inactive, const float4 *__restrict__ fb, DevState *st)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->px_count = 0.f; // consumed by k_splat_box
+  st->px_light[0] = st->px_light[1] = st->px_light[2] = st->px_light[3] = 0.f;
   if (refresh_inactive) st->inactiveDroplets = fb[0].x;
   const float4 n = fb[1]; // texel (1,0)
   if (n.z < fmaxf(iterNum - 1.0f, 1.0f) || n.z > iterNum) return; // discard

@@ -35,6 +35,7 @@ enum KernelId {
   K_LIGHTING,
   K_PRECIP,
   K_LIGHTNING,
+  K_SPLAT, // box filter of the particle deposits + accumulation clear
   K_COPY,
   K_HALO,
   K_FUSED_VCVB, // velocity + curl + vorticity + boundary
@@ -43,7 +44,7 @@ enum KernelId {
   K_COUNT
 };
 const char *const kKernelNames[K_COUNT] = {"velocity", "curl", "vorticity", "boundary", "advection", "pressure", "lighting",
-                                           "precipitation", "lightning", "copy", "halo", "fused_vel_curl_vort_boundary",
+                                           "precipitation", "lightning", "splat_box", "copy", "halo", "fused_vel_curl_vort_boundary",
                                            "fused_advect_pressure_light", "fused_full_iteration"};
 
 struct ProfRec {
@@ -80,6 +81,7 @@ struct wx_sim {
   DevState *state = nullptr;
   SlowCtx *slow_ctx = nullptr; // device copy of geometry/uniforms/pointers for the out-of-line advection path
   FullCtx *full_ctx = nullptr;
+  SplatGrid sg{};              // particle splat accumulation (allocated when the handle has droplets)
   bool fb_dirty = false; // feedback/deposition hold non-zero data (particles ran last iteration)
   // profiling
   bool profiling = false;
@@ -437,6 +439,17 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (rc == WX_OK) rc = dalloc(s, &s->full_ctx, 1);
   if (rc == WX_OK) rc = dalloc(s, &s->water[2], n);
   if (rc == WX_OK) rc = dalloc(s, &s->light[2], n);
+  if (rc == WX_OK && n_droplets > 0) {
+    SplatGrid &sg = s->sg;
+    sg.AP = s->X + 8;
+    sg.AH = Y + 8;
+    sg.TXn = (s->X + 1 + STX - 1) / STX;
+    sg.TYn = (Y + 1 + STY - 1) / STY;
+    rc = dalloc(s, &sg.acc4, (size_t)sg.AP * sg.AH);
+    if (rc == WX_OK) rc = dalloc(s, &sg.acc2, (size_t)sg.AP * sg.AH);
+    if (rc == WX_OK) rc = dalloc(s, &sg.dirty, (size_t)sg.TXn * sg.TYn);
+    if (rc == WX_OK) rc = dalloc(s, &sg.fb_zero, (size_t)sg.TXn * sg.TYn);
+  }
   if (rc != WX_OK) {
     g_create_error = s->err;
     wx_destroy(s);
@@ -481,6 +494,10 @@ void wx_destroy(wx_sim *s)
   hipFree(s->full_ctx);
   hipFree(s->water[2]);
   hipFree(s->light[2]);
+  hipFree(s->sg.acc4);
+  hipFree(s->sg.acc2);
+  hipFree(s->sg.dirty);
+  hipFree(s->sg.fb_zero);
   delete s;
 }
 
@@ -502,6 +519,13 @@ int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wa
   HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 16, s->stream));
   HIPCHK(s, hipMemsetAsync(s->dep, 0, n * 8, s->stream));
   HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
+  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 20, s->stream));
+  if (s->sg.acc4) {
+    HIPCHK(s, hipMemsetAsync(s->sg.acc4, 0, (size_t)s->sg.AP * s->sg.AH * 16, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->sg.acc2, 0, (size_t)s->sg.AP * s->sg.AH * 8, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->sg.dirty, 0, (size_t)s->sg.TXn * s->sg.TYn, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->sg.fb_zero, 1, (size_t)s->sg.TXn * s->sg.TYn, s->stream));
+  }
   HIPCHK(s, hipStreamSynchronize(s->stream)); // the caller keeps ownership of the host arrays
   s->fb_dirty = false;
   s->ran_fused = false;
@@ -557,13 +581,8 @@ int wx_step(wx_sim *s, int n_iter)
     s->ran_fused = fused;
     const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
     s->even = !s->even;
-    // 8 clear feedback + deposition (app.js:5933-5934); skipped while they are known to be zero
-    if (s->fb_dirty || precip) {
-      hipMemsetAsync(s->fb, 0, n * 16, s->stream);
-      hipMemsetAsync(s->dep, 0, n * 8, s->stream);
-      s->fb_dirty = false;
-    }
-    // 9, 10 precipitation + lightning location (app.js:5936-5983)
+    // 8-10 clear feedback/deposition, precipitation, lightning location (app.js:5933-5983). The clear and the
+    // blend-unit splats are replaced by: deposit at the sprite anchors -> 12x12 box sum that (re)writes both textures.
     if (precip) {
       Uni u = s->uni;
       u.iterNum = (float)s->iter;
@@ -571,14 +590,28 @@ int wx_step(wx_sim *s, int n_iter)
       {
         ProfScope ps(s, K_PRECIP);
         hipLaunchKernelGGL(k_precipitation, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, u, s->n_drops, s->drops[src],
-                           fused ? s->base[2] : s->base[1], s->water[1], s->state, s->drops[dst], s->fb, s->dep);
+                           fused ? s->base[2] : s->base[1], s->water[1], s->state, s->drops[dst], s->sg);
+      }
+      {
+        ProfScope ps(s, K_SPLAT);
+        hipLaunchKernelGGL(k_splat_box, dim3((s->X + STX - 1) / STX, (s->Y + STY - 1) / STY), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->state,
+                           s->fb, s->dep);
       }
       {
         ProfScope ps(s, K_LIGHTNING);
         hipLaunchKernelGGL(k_lightning, dim3(1), dim3(64), 0, s->stream, u.iterNum, (int)(s->iter % 600 == 0), s->fb, s->state);
       }
+      {
+        ProfScope ps(s, K_SPLAT);
+        hipLaunchKernelGGL(k_splat_clear, dim3(s->sg.TXn, s->sg.TYn), dim3(256), 0, s->stream, s->X, s->Y, s->sg);
+      }
       s->drop_cur = dst;
       s->fb_dirty = true;
+    } else if (s->fb_dirty) { // particles were switched off: the reference's clear leaves both textures zero
+      hipMemsetAsync(s->fb, 0, n * 16, s->stream);
+      hipMemsetAsync(s->dep, 0, n * 8, s->stream);
+      if (s->sg.fb_zero) hipMemsetAsync(s->sg.fb_zero, 1, (size_t)s->sg.TXn * s->sg.TYn, s->stream);
+      s->fb_dirty = false;
     }
     s->iter++;
   }
