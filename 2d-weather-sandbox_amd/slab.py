@@ -24,7 +24,7 @@ from . import params
 from .engine import Handle
 
 CONE_PER_ITERATION = 6  # columns per side, see module docstring
-DEFAULT_HALO = 12       # two iterations per exchange
+DEFAULT_HALO = 48       # eight iterations per exchange: amortises the ~0.1 ms P2P round trip, 4.7 % redundant columns at 2048/GPU
 
 
 def slab_columns(X: int, rank: int, world: int):

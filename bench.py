@@ -160,7 +160,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{X}x{Y} terrain grid, all six grid passes + lighting, " + (f"{a.particles} precipitation particles (BASELINE configs[4] on one GPU)" if a.particles else "particles off (BASELINE configs[2])"),
-                       "grid": [X, Y], "decomposition": "none" if world == 1 else f"{world} x-slabs, ring halo exchange every 2 iterations (RCCL send/recv)",
+                       "grid": [X, Y], "decomposition": "none" if world == 1 else f"{world} x-slabs, 48 ghost columns, ring halo exchange every 8 iterations (RCCL send/recv)",
                        "iteration_algorithmic_bytes_per_cell": 72},
             "iteration_roofline_frac_A_wet": cells * a.steps * 72 / dt / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roof,
