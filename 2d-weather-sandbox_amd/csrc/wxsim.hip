@@ -7,6 +7,7 @@
 #include "../../include/wxsim.h"
 #include "wx_fused.h"
 #include "wx_full.h"
+#include "wx_dry.h"
 #include "wx_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -41,11 +42,12 @@ enum KernelId {
   K_FUSED_VCVB, // velocity + curl + vorticity + boundary
   K_FUSED_APL,  // advection + pressure + lighting
   K_FUSED_FULL, // the whole iteration in one kernel
+  K_FUSED_DRY,  // velocity + advection + pressure (pass_mask WX_PASS_DRY)
   K_COUNT
 };
 const char *const kKernelNames[K_COUNT] = {"velocity", "curl", "vorticity", "boundary", "advection", "pressure", "lighting",
                                            "precipitation", "lightning", "splat_box", "copy", "halo", "fused_vel_curl_vort_boundary",
-                                           "fused_advect_pressure_light", "fused_full_iteration"};
+                                           "fused_advect_pressure_light", "fused_full_iteration", "fused_dry_vel_advect_pressure"};
 
 struct ProfRec {
   hipEvent_t a, b;
@@ -83,6 +85,7 @@ struct wx_sim {
   FullCtx *full_ctx = nullptr;
   SplatGrid sg{};              // particle splat accumulation (allocated when the handle has droplets)
   bool fb_dirty = false; // feedback/deposition hold non-zero data (particles ran last iteration)
+  bool water_trivial = false; // uploaded water texture: 0 in air cells, only the wall marker in wall cells
   // profiling
   bool profiling = false;
   std::vector<ProfRec> prof;
@@ -381,6 +384,27 @@ int iterate_full(wx_sim *s, bool opt_out)
   return WX_OK;
 }
 
+// BASELINE configs[1] (pass_mask == WX_PASS_DRY): velocity + advection + pressure in one kernel (wx_dry.h).
+// The masked-off boundary pass makes water_0 a copy of water_1, so advection's water input is water[1].
+int iterate_dry(wx_sim *s, bool write_disp)
+{
+  const bool water = !(s->water_trivial && s->p.userInputType < 0 && s->p.airplaneValues[3] == 0.0f);
+  DryIn in{s->base[0], s->wall[0], s->water[1]};
+  DryOut out{s->base[1], s->wall[1], s->water[2], s->base[2]};
+  {
+    ProfScope ps(s, K_FUSED_DRY);
+    launch_fused_dry(s->geo, s->uni, s->full_ctx, in, out, water, write_disp, s->stream);
+  }
+  std::swap(s->base[0], s->base[1]);
+  std::swap(s->wall[0], s->wall[1]);
+  if (water) {
+    // reference ping-pong with the boundary pass masked off: water_0 = previous water_1, water_1 = advected water
+    std::swap(s->water[0], s->water[1]);
+    std::swap(s->water[1], s->water[2]);
+  }
+  return WX_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -506,6 +530,16 @@ int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wa
   if (!s) return WX_E_INVALID;
   if (!base || !water || !wall) return fail(s, WX_E_INVALID, "wx_upload: NULL grid array");
   const size_t n = ncell(s);
+  {
+    bool trivial = true;
+    for (size_t i = 0; i < n && trivial; i++) {
+      const float *w = water + 4 * i;
+      const int8_t *wl = wall + 4 * i;
+      const float x_expected = wl[1] == 0 ? (wl[0] == 2 ? 1002.0f : 1001.0f) : 0.0f;
+      trivial = (w[0] == x_expected) && w[1] == 0.0f && w[2] == 0.0f && w[3] == 0.0f && wl[3] >= 0;
+    }
+    s->water_trivial = trivial;
+  }
   for (int i = 0; i < 2; i++) {
     HIPCHK(s, hipMemcpyAsync(s->base[i], base, n * 16, hipMemcpyHostToDevice, s->stream));
     HIPCHK(s, hipMemcpyAsync(s->water[i], water, n * 16, hipMemcpyHostToDevice, s->stream));
@@ -571,14 +605,17 @@ int wx_step(wx_sim *s, int n_iter)
   const size_t n = ncell(s);
   // the fused kernels implement the full grid-pass set; any other pass_mask runs the per-pass kernels
   const bool fused = s->fused && (mask & 0x3Fu) == 0x3Fu;
+  const bool dry = s->fused && (mask & 0x3Fu) == WX_PASS_DRY;
   for (int it = 0; it < n_iter; it++) {
-    if (fused && s->fused >= 2)
+    if (dry)
+      iterate_dry(s, precip || it == n_iter - 1);
+    else if (fused && s->fused >= 2)
       iterate_full(s, precip || it == n_iter - 1);
     else if (fused)
       iterate_fused(s, precip || it == n_iter - 1);
     else
       iterate_per_pass(s, mask, precip);
-    s->ran_fused = fused;
+    s->ran_fused = fused || dry;
     const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
     s->even = !s->even;
     // 8-10 clear feedback/deposition, precipitation, lightning location (app.js:5933-5983). The clear and the
@@ -590,7 +627,7 @@ int wx_step(wx_sim *s, int n_iter)
       {
         ProfScope ps(s, K_PRECIP);
         hipLaunchKernelGGL(k_precipitation, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, u, s->n_drops, s->drops[src],
-                           fused ? s->base[2] : s->base[1], s->water[1], s->state, s->drops[dst], s->sg);
+                           (fused || dry) ? s->base[2] : s->base[1], s->water[1], s->state, s->drops[dst], s->sg);
       }
       {
         ProfScope ps(s, K_SPLAT);

@@ -29,6 +29,8 @@ ALGO_BYTES = {
     "fused_vel_curl_vort_boundary": 52 + 40, "fused_advect_pressure_light": 52 + 52,
     # single-kernel iteration: R base16 wall4 water16 light_0 16 light_src 16, W base16 wall4 water16 light16
     "fused_full_iteration": 68 + 52,
+    # dry config: A_dry = base 16 R + 16 W + wall 4 R; the kernel also passes the wall texel through (+4 W)
+    "fused_dry_vel_advect_pressure": 36,
 }
 
 
@@ -40,6 +42,8 @@ def parse():
     ap.add_argument("--X", type=int, default=16384)
     ap.add_argument("--Y", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["wet", "dry"], default="wet",
+                    help="wet: BASELINE configs[2] (default, the metric's config); dry: configs[1] pressure+velocity+advection only")
     ap.add_argument("--particles", type=int, default=0, help="also run the particle pass with N droplets (BASELINE configs[4]; N=1 GPU only)")
     return ap.parse_args()
 
@@ -99,8 +103,15 @@ def main():
     u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
     u["enablePrecipitation"] = 0
 
+    if a.workload == "dry":
+        assert world == 1 and not a.particles
+        u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, pass_mask=pkg.params.PASS_DRY)
+        u["enablePrecipitation"] = 0
     if world == 1:
-        base, water, wall = pkg.synth.terrain_grid(X, Y)
+        if a.workload == "dry":
+            base, water, wall = pkg.synth.dry_grid(X, Y)
+        else:
+            base, water, wall = pkg.synth.terrain_grid(X, Y)
         h = pkg.engine.Handle(X, Y, a.particles)
         if a.particles:
             u["enablePrecipitation"] = 1
@@ -159,10 +170,10 @@ def main():
             "metric": "Mcell-steps/s", "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{X}x{Y} terrain grid, all six grid passes + lighting, " + (f"{a.particles} precipitation particles (BASELINE configs[4] on one GPU)" if a.particles else "particles off (BASELINE configs[2])"),
+            "config": {"workload": (f"{X}x{Y} dry-air grid, pressure+velocity+advection only (BASELINE configs[1])" if a.workload == "dry" else f"{X}x{Y} terrain grid, all six grid passes + lighting, ") if a.workload == "dry" else f"{X}x{Y} terrain grid, all six grid passes + lighting, " + (f"{a.particles} precipitation particles (BASELINE configs[4] on one GPU)" if a.particles else "particles off (BASELINE configs[2])"),
                        "grid": [X, Y], "decomposition": "none" if world == 1 else f"{world} x-slabs, 48 ghost columns, ring halo exchange every 8 iterations (RCCL send/recv)",
-                       "iteration_algorithmic_bytes_per_cell": 72},
-            "iteration_roofline_frac_A_wet": cells * a.steps * 72 / dt / 1e9 / (HBM_PEAK_GBS * world),
+                       "iteration_algorithmic_bytes_per_cell": 36 if a.workload == "dry" else 72},
+            "iteration_roofline_frac_A_wet": cells * a.steps * (36 if a.workload == "dry" else 72) / dt / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -113,17 +113,26 @@ def test_bit_exact_terrain_grid(pkg, oracle, E, X, Y, fused):
         _assert_grid_equal(h, o)
 
 
-def test_dry_config_pass_mask(pkg, oracle, E):
-    """BASELINE config 2: pressure + velocity + advection only."""
-    X, Y = 256, 128
+@pytest.mark.parametrize("moist", [False, True], ids=["dry", "moist"])
+@pytest.mark.parametrize("X,Y", [(256, 128), (130, 50)])
+def test_dry_config_pass_mask(pkg, oracle, E, fused, X, Y, moist):
+    """BASELINE config 1 (pass_mask = velocity|advection|pressure): the single fused dry kernel (with and without a
+    water texture to carry) and the per-pass kernels, bit-exact vs the oracle; fast velocities exercise the
+    out-of-tile back-trace path."""
     base, water, wall = pkg.synth.dry_grid(X, Y)
-    base[40:60, 100:140, 3] += 3.0  # a warm bubble so something moves
-    base[..., 2] += np.random.default_rng(3).normal(0, 1e-3, (Y, X)).astype(np.float32)
+    base[Y // 3:Y // 2, X // 3:X // 2, 3] += 3.0  # a warm bubble so something moves
+    rng = np.random.default_rng(3)
+    base[..., 2] += rng.normal(0, 1e-3, (Y, X)).astype(np.float32)
+    base[1:, :, 0] += rng.normal(0, 0.35, (Y - 1, X)).astype(np.float32)  # some |v| > 0.9
+    if moist:
+        water[1:, :, 0] = 3.0 + rng.random((Y - 1, X)).astype(np.float32)
+        water[1:, :, 3] = 0.1
     u = pkg.params.uniforms_from_gui(pkg.params.merge_settings(None), Y, pass_mask=pkg.params.PASS_DRY)
     h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
-    h.step(25)
-    o.step(25)
-    _assert_grid_equal(h, o, ["BASE_CUR", "BASE_DISP", "WATER_CUR", "WALL_CUR"])
+    for _ in range(3):
+        h.step(7)
+        o.step(7)
+        _assert_grid_equal(h, o, ["BASE_CUR", "BASE_DISP", "WATER_CUR", "WATER_0", "WALL_CUR"])
     assert np.abs(h.read_rect("BASE_CUR")[..., 0]).max() > 1e-4
 
 
