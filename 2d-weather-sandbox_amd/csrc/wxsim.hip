@@ -545,6 +545,7 @@ int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wa
     HIPCHK(s, hipMemcpyAsync(s->water[i], water, n * 16, hipMemcpyHostToDevice, s->stream));
     HIPCHK(s, hipMemcpyAsync(s->wall[i], wall, n * 4, hipMemcpyHostToDevice, s->stream));
     HIPCHK(s, hipMemsetAsync(s->light[i], 0, n * 16, s->stream));
+    if (i == 0) HIPCHK(s, hipMemsetAsync(s->light[2], 0, n * 16, s->stream));
     if (drops && s->n_drops > 0)
       HIPCHK(s, hipMemcpyAsync(s->drops[i], drops, (size_t)s->n_drops * 20, hipMemcpyHostToDevice, s->stream));
   }
