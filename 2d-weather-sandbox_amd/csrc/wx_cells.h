@@ -233,21 +233,27 @@ __device__ __forceinline__ void boundary_cell(const Uni &u, const Geo &g, const 
 
   if (wl[DISTANCE] != 0) { // fluid
     const float4 light = a.light(0);
+    const bool has_fb = a.has_fb(); // wave-uniform: false while no particle has ever written feedback
     const float4 fb = a.fb();
     wl[TYPE] = wD.x;
     if (wl[TYPE] != WALLTYPE_WATER) b.w += light.y; // NET_HEATING
-    b.w += fb.y;                                     // HEAT
+    if (has_fb) {
+      b.w += fb.y; // HEAT
 
-    const float precipCoalescence = fmaxf(-fb.z, 0.0f);
-    w.y -= precipCoalescence;
-    w.x -= precipCoalescence;
-    const float precipEvaporation = fmaxf(fb.z, 0.0f);
-    w.x += precipEvaporation;
+      const float precipCoalescence = fmaxf(-fb.z, 0.0f);
+      w.y -= precipCoalescence;
+      w.x -= precipCoalescence;
+      const float precipEvaporation = fmaxf(fb.z, 0.0f);
+      w.x += precipEvaporation;
 
-    w.z = fmaxf(w.z * 0.997f - 0.00001f + fb.x * 0.005f, 0.0f);
+      w.z = fmaxf(w.z * 0.997f - 0.00001f + fb.x * 0.005f, 0.0f);
 
-    w.w /= 1.0f + fmaxf(-fb.z * 0.1f, 0.0f) + fb.x * 0.000f;
-    w.w -= fb.x * 0.0001f;
+      w.w /= 1.0f + fmaxf(-fb.z * 0.1f, 0.0f) + fb.x * 0.000f;
+      w.w -= fb.x * 0.0001f;
+    } else {
+      // feedback == 0: every term above is x +- 0 or x / 1 -- the same values without the arithmetic
+      w.z = fmaxf(w.z * 0.997f - 0.00001f, 0.0f);
+    }
     w.w -= fmaxf((w.w - 4.0f) * 0.01f, 0.0f);
     w.w = fmaxf(w.w, 0.0f);
     if (w.w > 4.0f) w.w -= w.z * 0.02f;
@@ -257,7 +263,7 @@ __device__ __forceinline__ void boundary_cell(const Uni &u, const Geo &g, const 
     const int iy = (int)cc.fy;
     float gravityForce = ((b.w + bU.w) * 0.5f - (initial_T[iy] + initial_T[iy + 1]) * 0.5f) * gravMult;
     gravityForce -= w.y * gravMult * u.waterWeight;
-    gravityForce -= fb.x * gravMult * u.waterWeight;
+    if (has_fb) gravityForce -= fb.x * gravMult * u.waterWeight;
     b.y += gravityForce;
 
     float snowCover = 0.0f, soilMoisture = 0.0f;
@@ -635,23 +641,28 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
     w.y += condensation;
 
     if (tcy > u.globalEffectsStartAlt && tcy < u.globalEffectsEndAlt) { // :154-181
-      w.x -= clampf(u.globalDrying, 0.0f, fmaxf(w.x - maxWater(fmaxf(realTemp - 20.0f, CtoK(-80.0f))), 0.0f));
+      // clamp(0, 0, hi >= 0) == 0: nothing to evaluate while the slider is at its default 0 (uniform branch)
+      if (u.globalDrying != 0.0f) w.x -= clampf(u.globalDrying, 0.0f, fmaxf(w.x - maxWater(fmaxf(realTemp - 20.0f, CtoK(-80.0f))), 0.0f));
       b.w += u.globalHeating;
 
-      const int si = (int)(tcy * u.a_invTexY);
-      const int si1 = si - 1 < 0 ? 0 : si - 1; // index -1 is undefined in the reference -> clamp
-      const float sT = (snd_T[si] + snd_T[si1]) / 2.0f;
-      const float sW = (snd_W[si] + snd_W[si1]) / 2.0f;
-      const float sV = (snd_Vel[si] + snd_Vel[si1]) / 2.0f;
+      // real-sounding forcing: with soundingForcing == 0 every update is x -= d * 0 and x *= 1 (uniform branch;
+      // identical values for finite fields)
+      if (u.soundingForcing != 0.0f) {
+        const int si = (int)(tcy * u.a_invTexY);
+        const int si1 = si - 1 < 0 ? 0 : si - 1; // index -1 is undefined in the reference -> clamp
+        const float sT = (snd_T[si] + snd_T[si1]) / 2.0f;
+        const float sW = (snd_W[si] + snd_W[si1]) / 2.0f;
+        const float sV = (snd_Vel[si] + snd_Vel[si1]) / 2.0f;
 
-      const float Tdiff = b.w - sT;
-      b.w -= Tdiff * 0.001f * u.soundingForcing;
-      const float Wdiff = w.x - sW;
-      w.x -= Wdiff * 0.001f * u.soundingForcing;
-      b.x *= u.snd_dragk;
-      b.y *= u.snd_dragk;
-      const float velDiff = b.x - sV;
-      b.x -= velDiff * u.snd_velk;
+        const float Tdiff = b.w - sT;
+        b.w -= Tdiff * 0.001f * u.soundingForcing;
+        const float Wdiff = w.x - sW;
+        w.x -= Wdiff * 0.001f * u.soundingForcing;
+        b.x *= u.snd_dragk;
+        b.y *= u.snd_dragk;
+        const float velDiff = b.x - sV;
+        b.x -= velDiff * u.snd_velk;
+      }
     }
     w.x = fmaxf(w.x, 0.0f);
   } else { // wall :189-227

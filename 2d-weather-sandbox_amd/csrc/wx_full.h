@@ -91,6 +91,7 @@ struct FBoundaryAcc {
     yy = yy < 0 ? 0 : (yy > Y - 1 ? Y - 1 : yy);
     return in.light0[fidx(x, yy, X)];
   }
+  __device__ __forceinline__ bool has_fb() const { return in.fb != nullptr; }
   __device__ __forceinline__ float4 fb() const { return in.fb ? in.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ __forceinline__ float2 dep() const { return in.dep ? in.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
 };
@@ -141,6 +142,7 @@ struct GRecomputeAcc {
     yy = yy < 0 ? 0 : (yy > Y - 1 ? Y - 1 : yy);
     return in_.light0[fidx(x, yy, X)];
   }
+  __device__ __forceinline__ bool has_fb() const { return in_.fb != nullptr; }
   __device__ __forceinline__ float4 fb() const { return in_.fb ? in_.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ __forceinline__ float2 dep() const { return in_.dep ? in_.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
 };

@@ -103,6 +103,7 @@ struct LBoundaryAcc {
     yy = yy < 0 ? 0 : (yy > Y - 1 ? Y - 1 : yy);
     return in.light[fidx(x, yy, X)];
   }
+  __device__ __forceinline__ bool has_fb() const { return in.fb != nullptr; }
   __device__ __forceinline__ float4 fb() const { return in.fb ? in.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ __forceinline__ float2 dep() const { return in.dep ? in.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
 };

@@ -72,6 +72,7 @@ struct GBoundaryAcc {
     yy = yy < 0 ? 0 : (yy > Y - 1 ? Y - 1 : yy);
     return p.light[cidx(x, yy, X)];
   }
+  __device__ __forceinline__ bool has_fb() const { return p.fb != nullptr; }
   __device__ __forceinline__ float4 fb() const { return p.fb ? p.fb[cidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ __forceinline__ float2 dep() const { return p.dep ? p.dep[cidx(x, y, X)] : make_float2(0.f, 0.f); }
 };
