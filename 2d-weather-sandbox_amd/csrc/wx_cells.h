@@ -544,7 +544,10 @@ __device__ __forceinline__ float smoothstepf(float e0, float e1, float x)
   return t * t * (3.0f - 2.0f * t);
 }
 
-template <class A>
+// NO_WATER: the water texture is identically zero in air cells (BASELINE config 1, checked by the host) and no
+// sounding forcing is active: the water interpolation and the phase-change block then provably leave base unchanged
+// (condensation = max(negative * 0.2, -0) = -0, dT = -0) and water zero, so they are not evaluated.
+template <bool NO_WATER = false, class A>
 __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const float *__restrict__ initial_T,
                                                const float *__restrict__ snd_T, const float *__restrict__ snd_W,
                                                const float *__restrict__ snd_Vel, int x, int y, const A &a, float4 &base_out,
@@ -597,12 +600,18 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
       const float4 bc = a.base_off(t.dx0, t.dy0 + 1), bd = a.base_off(t.dx0 + 1, t.dy0 + 1);
       b.z = bilerp4(ba.z, bb.z, bc.z, bd.z, mAB, mCD, mY);
       b.w = bilerp4(ba.w, bb.w, bc.w, bd.w, mAB, mCD, mY);
-      const float4 qa = a.water_off(t.dx0, t.dy0), qb = a.water_off(t.dx0 + 1, t.dy0);
-      const float4 qc = a.water_off(t.dx0, t.dy0 + 1), qd = a.water_off(t.dx0 + 1, t.dy0 + 1);
-      w.x = bilerp4(qa.x, qb.x, qc.x, qd.x, mAB, mCD, mY);
-      w.y = bilerp4(qa.y, qb.y, qc.y, qd.y, mAB, mCD, mY);
-      w.w = bilerp4(qa.w, qb.w, qc.w, qd.w, mAB, mCD, mY);
+      if (!NO_WATER) {
+        const float4 qa = a.water_off(t.dx0, t.dy0), qb = a.water_off(t.dx0 + 1, t.dy0);
+        const float4 qc = a.water_off(t.dx0, t.dy0 + 1), qd = a.water_off(t.dx0 + 1, t.dy0 + 1);
+        w.x = bilerp4(qa.x, qb.x, qc.x, qd.x, mAB, mCD, mY);
+        w.y = bilerp4(qa.y, qb.y, qc.y, qd.y, mAB, mCD, mY);
+        w.w = bilerp4(qa.w, qb.w, qc.w, qd.w, mAB, mCD, mY);
+      }
     }
+    if (NO_WATER) {
+      w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (tcy > u.globalEffectsStartAlt && tcy < u.globalEffectsEndAlt) b.w += u.globalHeating;
+    } else {
     {
       // precipitation visualisation channel, +0.05 in y (:103)
       const Taps t = mktaps(cc, y, fx - velAtP_x + 0.0f, fy - velAtP_y + 0.05f);
@@ -665,6 +674,7 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
       }
     }
     w.x = fmaxf(w.x, 0.0f);
+    } // !NO_WATER
   } else { // wall :189-227
     b = a.base(0, 0);
     w = a.water_off(0, 0);

@@ -104,7 +104,7 @@ __device__ __forceinline__ void advect_dry_cell(const Uni &u, const Geo &g, cons
                         fmaxf(fmaxf(fabsf(sm.b.y[ly][lx]), fabsf(sm.b.y[ly - 1][lx])), fmaxf(fabsf(sm.b.y[ly][lx + 1]), fabsf(sm.b.y[ly - 1][lx + 1]))));
   if (m < fb_::VMAX) {
     LDryAcc<WATER> a{sm, lx, ly};
-    advection_cell(u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, x, y, a, b, w, wl);
+    advection_cell<!WATER>(u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, x, y, a, b, w, wl);
   } else {
     const AdvOut o = advection_cell_dry_global(ctx, in, WATER, x, y);
     b = o.b;

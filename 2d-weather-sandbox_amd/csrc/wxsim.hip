@@ -388,7 +388,7 @@ int iterate_full(wx_sim *s, bool opt_out)
 // The masked-off boundary pass makes water_0 a copy of water_1, so advection's water input is water[1].
 int iterate_dry(wx_sim *s, bool write_disp)
 {
-  const bool water = !(s->water_trivial && s->p.userInputType < 0 && s->p.airplaneValues[3] == 0.0f);
+  const bool water = !(s->water_trivial && s->p.userInputType < 0 && s->p.airplaneValues[3] == 0.0f && s->p.soundingForcing == 0.0f);
   DryIn in{s->base[0], s->wall[0], s->water[1]};
   DryOut out{s->base[1], s->wall[1], s->water[2], s->base[2]};
   {
