@@ -102,6 +102,12 @@ __device__ __forceinline__ void advect_dry_cell(const Uni &u, const Geo &g, cons
 {
   const float m = fmaxf(fmaxf(fmaxf(fabsf(sm.b.x[ly][lx]), fabsf(sm.b.x[ly][lx - 1])), fmaxf(fabsf(sm.b.x[ly + 1][lx]), fabsf(sm.b.x[ly + 1][lx - 1]))),
                         fmaxf(fmaxf(fabsf(sm.b.y[ly][lx]), fabsf(sm.b.y[ly - 1][lx])), fmaxf(fabsf(sm.b.y[ly][lx + 1]), fabsf(sm.b.y[ly - 1][lx + 1]))));
+#ifdef WX_ABL_NOADV
+  b = sm.b.get(ly, lx);
+  w = make_float4(0.f, 0.f, 0.f, 0.f);
+  wl = sm.w[ly][lx];
+  return;
+#endif
   if (m < fb_::VMAX) {
     LDryAcc<WATER> a{sm, lx, ly};
     advection_cell<!WATER>(u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, x, y, a, b, w, wl);

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--X", type=int, default=16384)
     ap.add_argument("--Y", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two short rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--workload", choices=["wet", "dry"], default="wet",
                     help="wet: BASELINE configs[2] (default, the metric's config); dry: configs[1] pressure+velocity+advection only")
     ap.add_argument("--particles", type=int, default=0, help="also run the particle pass with N droplets (BASELINE configs[4]; N=1 GPU only)")
@@ -72,6 +73,50 @@ def cpu_baseline(pkg, budget_s=12.0):
     dt = time.perf_counter() - t0
     return {"value": X * Y * n / dt / 1e6, "unit": "Mcell-steps/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"CPU oracle (C/OpenMP restatement, not the reference itself), {X}x{Y} terrain grid, {n} iterations, {dt:.1f} s"}
+
+
+KERNEL_SYMBOL = {  # profile name -> substring of the kernel symbol rocprofv3 reports
+    "fused_vel_curl_vort_boundary": "k_fused_a", "fused_advect_pressure_light": "k_fused_b", "fused_full_iteration": "k_fused_full",
+    "fused_dry_vel_advect_pressure": "k_fused_dry", "advection": "k_advection", "boundary": "k_boundary", "lighting": "k_lighting",
+    "velocity": "k_velocity", "pressure": "k_pressure", "curl": "k_curl", "vorticity": "k_vorticity", "precipitation": "k_precipitation",
+}
+
+
+def pmc_traffic(a, kernel):
+    """HBM bytes per launch of `kernel` from the PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE
+    in SEPARATE rocprofv3 --pmc passes (kernel-trace only), units of KiB, FETCH_SIZE doubled (on gfx950 it reports half of a
+    wide coalesced read stream). Re-runs this script for a few steps under rocprofv3; returns None on any problem."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    sym = KERNEL_SYMBOL.get(kernel)
+    if not exe or not sym:
+        return None
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="wxpmc_", dir="/tmp")
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2",
+                   "--X", str(a.X), "--Y", str(a.Y), "--workload", a.workload, "--no-cpu-baseline", "--no-pmc"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            c = sqlite3.connect(dbs[0])
+            rows = c.execute("select k.kernel_name, d.event_id, d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol k "
+                             "on d.kernel_id = k.id order by d.start").fetchall()
+            ev = [e for n, e, _ in rows if sym in n][2:]  # skip the warm-up launches
+            per = []
+            for e in ev:
+                v = c.execute("select sum(value) from rocpd_pmc_event where event_id = ?", (e,)).fetchone()[0]
+                if v is not None:
+                    per.append(v)
+            vals[counter] = sum(per) / len(per)
+            shutil.rmtree(d, ignore_errors=True)
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
 
 
 def main():
@@ -162,8 +207,10 @@ def main():
             name, (ms, cnt) = dom
             avg_ms = ms / cnt
             achieved = ALGO_BYTES.get(name, 0) * local_cells / (avg_ms * 1e-3) / 1e9
+            traffic = None if (a.no_pmc or world > 1) else pmc_traffic(a, name)
             roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": cnt,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, KiB counters)",
+                    "algorithmic_bytes_per_launch": ALGO_BYTES.get(name, 0) * local_cells, "avg_launch_ms": avg_ms, "launches": cnt,
                     "algo_bytes_per_cell": ALGO_BYTES.get(name, 0),
                     "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()}}
         out = {
