@@ -63,14 +63,15 @@ def cpu_baseline(pkg, budget_s=12.0):
     o = wx_oracle.OracleSim(X, Y, 0)
     o.upload(base, water, wall)
     o.set_params(u)
-    o.step(1)
+    o.step(2)  # warm-up (page faults, OpenMP team start)
+    n, chunk = 0, 4
     t0 = time.perf_counter()
-    o.step(2)
-    per = (time.perf_counter() - t0) / 2
-    n = max(3, min(400, int(budget_s / max(per, 1e-6))))
-    t0 = time.perf_counter()
-    o.step(n)
-    dt = time.perf_counter() - t0
+    while True:  # bounded sample: whole chunks until the time budget is used
+        o.step(chunk)
+        n += chunk
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 2000:
+            break
     return {"value": X * Y * n / dt / 1e6, "unit": "Mcell-steps/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"CPU oracle (C/OpenMP restatement, not the reference itself), {X}x{Y} terrain grid, {n} iterations, {dt:.1f} s"}
 
