@@ -6,8 +6,9 @@
 // Each workgroup (256 threads = 4 wavefronts) owns a TX x TY = 64 x 16 tile. The chained stencils are
 // evaluated on shrinking halo regions held in LDS, so intermediate textures (velocity output, curl,
 // vortForce, advection output) never travel to HBM:
-//   HBM traffic / cell-iteration:  A: 52 R + 40 W   B: 52 R + 52 W (+16 W when the post-advection base is
-//   requested)  ~= 196 B vs ~380 B for the reference's pass structure.
+//   HBM traffic / cell-iteration:  A: 52 R + 36 W   B: 52 R + 52 W (+4 W curl, +16 W post-advection base only when
+//   a consumer can see them: last iteration of a wx_step call / particles)  = 192 B vs ~380 B for the reference's
+//   pass structure.
 // The per-cell arithmetic is the same wx_cells.h code as the per-pass kernels: results are bit-identical.
 //
 // LDS layout: one fp32 PLANE per channel (structure of arrays, odd row stride). A wavefront reading one
@@ -108,6 +109,9 @@ struct LBoundaryAcc {
   __device__ __forceinline__ float2 dep() const { return in.dep ? in.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
 };
 
+// WRITE_CURL: the curl texture has only display-side consumers (app.js:6081-6219), so it is stored only by the last
+// iteration of a wx_step call.
+template <bool WRITE_CURL>
 __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__restrict__ initial_T, FusedAIn in, float4 *__restrict__ base_out,
                                                 float4 *__restrict__ water_out, char4 *__restrict__ wall_out, float *__restrict__ curl_out)
 {
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
     base_out[gi] = b;
     water_out[gi] = w;
     wall_out[gi] = wl;
-    curl_out[gi] = sm.c[cy + 2][cx + 2];
+    if (WRITE_CURL) curl_out[gi] = sm.c[cy + 2][cx + 2];
   }
 }
 
@@ -388,10 +392,13 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, co
 }
 
 inline void launch_fused_a(const Geo &g, const Uni &u, const float *initial_T, const FusedAIn &in, float4 *base_out, float4 *water_out,
-                           char4 *wall_out, float *curl_out, hipStream_t stream)
+                           char4 *wall_out, float *curl_out, bool write_curl, hipStream_t stream)
 {
   const dim3 grid((g.X + TX - 1) / TX, (g.Y + TY - 1) / TY);
-  hipLaunchKernelGGL(k_fused_a, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out);
+  if (write_curl)
+    hipLaunchKernelGGL(k_fused_a<true>, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out);
+  else
+    hipLaunchKernelGGL(k_fused_a<false>, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out);
 }
 
 inline void launch_fused_b(const Geo &g, const Uni &u, const float *initial_T, const float *snd_T, const float *snd_W, const float *snd_Vel,

@@ -269,7 +269,7 @@ int copy_wall(wx_sim *s, const char4 *src, char4 *dst)
 }
 
 // One iteration with the reference's pass structure (one kernel per draw call).
-int iterate_per_pass(wx_sim *s, unsigned mask, bool precip)
+int iterate_per_pass(wx_sim *s, unsigned mask)
 {
   const dim3 grid = grid2d(s), block(BX, BY);
   const Geo g = s->geo;
@@ -332,7 +332,6 @@ int iterate_per_pass(wx_sim *s, unsigned mask, bool precip)
     ProfScope ps(s, K_LIGHTING);
     hipLaunchKernelGGL(k_lighting, grid, block, 0, s->stream, g, u, s->base[1], s->water[1], s->wall[1], s->light[src], s->light[dst]);
   }
-  (void)precip;
   return WX_OK;
 }
 
@@ -349,7 +348,7 @@ int iterate_fused(wx_sim *s, bool write_disp)
   {
     FusedAIn in{s->base[0], s->wall[0], s->water[1], s->light[0], s->fb_dirty ? s->fb : nullptr, s->fb_dirty ? s->dep : nullptr};
     ProfScope ps(s, K_FUSED_VCVB);
-    launch_fused_a(g, u, s->initial_T, in, s->base[1], s->water[0], s->wall[1], s->curl, s->stream);
+    launch_fused_a(g, u, s->initial_T, in, s->base[1], s->water[0], s->wall[1], s->curl, write_disp, s->stream);
   }
   {
     FusedBIn in{s->base[1], s->water[0], s->wall[1], s->light[src]};
@@ -615,7 +614,7 @@ int wx_step(wx_sim *s, int n_iter)
     else if (fused)
       iterate_fused(s, precip || it == n_iter - 1);
     else
-      iterate_per_pass(s, mask, precip);
+      iterate_per_pass(s, mask);
     s->ran_fused = fused || dry;
     const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
     s->even = !s->even;

@@ -24,9 +24,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 ALGO_BYTES = {
     "velocity": 20 + 20, "curl": 16 + 4, "vorticity": 4 + 8, "boundary": 60 + 36, "advection": 36 + 36,
     "pressure": 20 + 20, "lighting": 52 + 16,
-    # A: R base16 wall4 water16 light16, W base16 water16 wall4 curl4; B: R base16 water16 wall4 light16,
+    # A: R base16 wall4 water16 light16, W base16 water16 wall4 (+curl4 on the last iteration of a wx_step call); B: R base16 water16 wall4 light16,
     # W base16 water16 wall4 light16 (+16 for the post-advection base on the last iteration of a wx_step call only)
-    "fused_vel_curl_vort_boundary": 52 + 40, "fused_advect_pressure_light": 52 + 52,
+    "fused_vel_curl_vort_boundary": 52 + 36, "fused_advect_pressure_light": 52 + 52,
     # single-kernel iteration: R base16 wall4 water16 light_0 16 light_src 16, W base16 wall4 water16 light16
     "fused_full_iteration": 68 + 52,
     # dry config: A_dry = base 16 R + 16 W + wall 4 R; the kernel also passes the wall texel through (+4 W)

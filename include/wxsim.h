@@ -85,7 +85,7 @@ enum {
   WX_FIELD_LIGHT_0 = 6,    /* lightTexture_0 (the one boundaryShader samples, app.js:5868-5869) */
   WX_FIELD_LIGHT_1 = 7,
   WX_FIELD_CURL = 8,       /* R32F */
-  WX_FIELD_VORT = 9,       /* RG32F vortForce */
+  WX_FIELD_VORT = 9,       /* RG32F vortForce (an intermediate: only the per-pass kernel set, WX_FUSED=0, stores it) */
   WX_FIELD_PRECIP_FB = 10, /* RGBA32F precipitationFeedbackTexture */
   WX_FIELD_PRECIP_DEP = 11,/* RG32F precipitationDepositionTexture */
   WX_FIELD_LIGHTNING = 12, /* 1x1 RGBA32F lightningDataTexture */
