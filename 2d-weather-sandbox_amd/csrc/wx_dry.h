@@ -129,7 +129,9 @@ __global__ __launch_bounds__(NTD, WX_D_MINWAVES) void k_fused_dry(Geo g, Uni u, 
   } sm;
   const int X = g.X, Y = g.Y;
   const int tid = threadIdx.x;
-  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  int tbx, tby;
+  tile_of_block(tiles_x(X), tbx, tby);
+  const int tx0 = tbx * TX, ty0 = tby * TY;
   const bool small = (X < TX + 8) || (Y < TY + 8);
 #define WX_WRAPX(v) (small ? wrapmod((v), X) : wrapfast((v), X))
 #define WX_WRAPY(v) (small ? wrapmod((v), Y) : wrapfast((v), Y))
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(NTD, WX_D_MINWAVES) void k_fused_dry(Geo g, Uni u, 
 
 inline void launch_fused_dry(const Geo &g, const Uni &u, const FullCtx *ctx, const DryIn &in, const DryOut &out, bool water, bool write_disp, hipStream_t stream)
 {
-  const dim3 grid((g.X + TX - 1) / TX, (g.Y + TY - 1) / TY);
+  const dim3 grid(((g.X + TX - 1) / TX) * ((g.Y + TY - 1) / TY));
   if (water) {
     if (write_disp)
       hipLaunchKernelGGL((k_fused_dry<true, true>), grid, dim3(NTD), 0, stream, g, u, ctx, in, out);

@@ -219,7 +219,9 @@ __global__ __launch_bounds__(NTF, WX_F_MINWAVES) void k_fused_full(const FullCtx
   } sm;
   const int X = ctx->g.X, Y = ctx->g.Y;
   const int tid = threadIdx.x;
-  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  int tbx, tby;
+  tile_of_block(tiles_x(X), tbx, tby);
+  const int tx0 = tbx * TX, ty0 = tby * TY;
   const bool small = (X < TX + 16) || (Y < TY + 16);
 #define WX_WRAPX(v) (small ? wrapmod((v), X) : wrapfast((v), X))
 #define WX_WRAPY(v) (small ? wrapmod((v), Y) : wrapfast((v), Y))
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(NTF, WX_F_MINWAVES) void k_fused_full(const FullCtx
 inline void launch_fused_full(const Geo &g, float iterNum, const FullIn &in, const FullCtx *ctx, const FullOut &out, bool opt_out,
                               hipStream_t stream)
 {
-  const dim3 grid((g.X + TX - 1) / TX, (g.Y + TY - 1) / TY);
+  const dim3 grid(((g.X + TX - 1) / TX) * ((g.Y + TY - 1) / TY));
   if (opt_out)
     hipLaunchKernelGGL(k_fused_full<true>, grid, dim3(NTF), 0, stream, ctx, iterNum, in, out);
   else

@@ -55,6 +55,25 @@ __device__ __forceinline__ size_t fidx(int x, int y, int X) { return (size_t)y *
 // wrap for i in [-n, 2n): tile halos of grids at least as large as the halo
 __device__ __forceinline__ int wrapfast(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
 
+// XCD-aware tile order. The dispatcher places workgroup `id` on XCD id % 8 (observed, MI355X_MICROARCH.md); every XCD has
+// its own L2. With the natural order horizontally adjacent tiles land on different XCDs and the 128-byte lines of
+// their shared halo columns are fetched once per XCD. Here XCD k walks the column block [k*GX/8, (k+1)*GX/8) row band by
+// row band, so that left/right (and, one band later, upper/lower) neighbours hit the same L2. Placement only affects
+// speed, never results.
+__device__ __forceinline__ void tile_of_block(int GX, int &bx, int &by)
+{
+  const int id = blockIdx.x;
+  if ((GX & 7) == 0) {
+    const int k = id & 7, j = id >> 3, w = GX >> 3;
+    by = j / w;
+    bx = k * w + (j - by * w);
+  } else {
+    by = id / GX;
+    bx = id - by * GX;
+  }
+}
+__device__ __forceinline__ int tiles_x(int X) { return (X + 63) / 64; }
+
 // fp32 plane set of a float4 field
 template <int H, int W> struct Planes4 {
   float x[H][W], y[H][W], z[H][W], w[H][W];
@@ -119,7 +138,9 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
   __shared__ Smem sm;
   const int X = g.X, Y = g.Y;
   const int tid = threadIdx.x;
-  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  int tbx, tby;
+  tile_of_block(tiles_x(X), tbx, tby);
+  const int tx0 = tbx * TX, ty0 = tby * TY;
   const bool small = (X < TX + 8) || (Y < TY + 8); // tiny grids: the tile + halo may wrap more than once
 
   // ---- stage 0: base_0 and wall_0 tiles with halo (REPEAT wrap on both axes) ----
@@ -312,7 +333,9 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, co
   } sm;
   const int X = g.X, Y = g.Y;
   const int tid = threadIdx.x;
-  const int tx0 = blockIdx.x * TX, ty0 = blockIdx.y * TY;
+  int tbx, tby;
+  tile_of_block(tiles_x(X), tbx, tby);
+  const int tx0 = tbx * TX, ty0 = tby * TY;
   const bool small = (X < TX + 8) || (Y < TY + 8);
 
   // ---- stage 0: post-boundary base / water / wall tiles with halo ----
@@ -394,7 +417,7 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, co
 inline void launch_fused_a(const Geo &g, const Uni &u, const float *initial_T, const FusedAIn &in, float4 *base_out, float4 *water_out,
                            char4 *wall_out, float *curl_out, bool write_curl, hipStream_t stream)
 {
-  const dim3 grid((g.X + TX - 1) / TX, (g.Y + TY - 1) / TY);
+  const dim3 grid(((g.X + TX - 1) / TX) * ((g.Y + TY - 1) / TY));
   if (write_curl)
     hipLaunchKernelGGL(k_fused_a<true>, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out);
   else
@@ -405,7 +428,7 @@ inline void launch_fused_b(const Geo &g, const Uni &u, const float *initial_T, c
                            const FusedBIn &in, const SlowCtx *ctx, float4 *base_out, float4 *base_disp, float4 *water_out, char4 *wall_out,
                            float4 *light_out, bool write_disp, hipStream_t stream)
 {
-  const dim3 grid((g.X + TX - 1) / TX, (g.Y + TY - 1) / TY);
+  const dim3 grid(((g.X + TX - 1) / TX) * ((g.Y + TY - 1) / TY));
   if (write_disp)
     hipLaunchKernelGGL(k_fused_b<true>, grid, dim3(NTB), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp,
                        water_out, wall_out, light_out);
