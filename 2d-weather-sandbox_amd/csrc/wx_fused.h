@@ -59,11 +59,16 @@ __device__ __forceinline__ int wrapfast(int i, int n) { return i < 0 ? i + n : (
 // its own L2. With the natural order horizontally adjacent tiles land on different XCDs and the 128-byte lines of
 // their shared halo columns are fetched once per XCD. Here XCD k walks the column block [k*GX/8, (k+1)*GX/8) row band by
 // row band, so that left/right (and, one band later, upper/lower) neighbours hit the same L2. Placement only affects
-// speed, never results.
+// speed, never results. MEASURED (16384x2048): FETCH_SIZE of kernel B drops from 1.18x to 1.05x of the algorithmic
+// bytes, but the kernel gets 2 % SLOWER (the re-fetched halo lines were served by the Infinity Cache, and the
+// column-block order concentrates each XCD on fewer HBM channels), so the natural order stays the default.
+#ifndef WX_XCD_TILES
+#define WX_XCD_TILES 0
+#endif
 __device__ __forceinline__ void tile_of_block(int GX, int &bx, int &by)
 {
   const int id = blockIdx.x;
-  if ((GX & 7) == 0) {
+  if (WX_XCD_TILES && (GX & 7) == 0) {
     const int k = id & 7, j = id >> 3, w = GX >> 3;
     by = j / w;
     bx = k * w + (j - by * w);
