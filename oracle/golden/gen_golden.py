@@ -320,7 +320,42 @@ def fx_brush64():
     print(f"[brush64] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def fx_randwalls64():
+    """Random 2x2-aligned wall blocks of every type: floating islands, overhangs, caves, one-block-wide gaps, sea next to
+    air (dyke rule), walls in the top rows (y wrap) -- the wall-geometry branches of boundaryShader.frag:155-196,
+    :245-269 and :373-388 that smooth terrain never reaches. One iteration at iterNum = 100 (soil / snow smoothing, vegetation, fire spread branches)."""
+    rng = np.random.default_rng(4242)
+    X, Y = 64, 48
+    gui, u, base, water, wall = synth_terrain(X, Y, rng)
+    nb = 70
+    for _ in range(nb):
+        bx, by = int(rng.integers(0, X // 2)) * 2, int(rng.integers(1, Y // 2)) * 2
+        w, h = int(rng.integers(1, 4)) * 2, int(rng.integers(1, 3)) * 2
+        t = int(rng.integers(0, 7))
+        ys, xs = slice(by, min(by + h, Y)), slice(bx, min(bx + w, X))
+        wall[ys, xs, 0] = t
+        wall[ys, xs, 1] = 0
+        wall[ys, xs, 2] = 0
+        wall[ys, xs, 3] = int(rng.integers(0, 120))
+        base[ys, xs, 0:2] = 0.0
+        base[ys, xs, 3] = 298.15 if t == 2 else 1000.0
+        water[ys, xs, 0] = 1002.0 if t == 2 else 1001.0
+        water[ys, xs, 1] = 0.0
+        water[ys, xs, 2] = float(rng.integers(0, 60))
+        water[ys, xs, 3] = float(rng.integers(0, 3)) * 6.0
+    # Only the per-pass dumps up to the boundary pass are usable: the boundary pass grows walls by one row (fill rules),
+    # after which they are no longer quad aligned and SwiftShader's advection output is garbage (SURVEY Appendix C).
+    out = run_fixture("randwalls64", X, Y, base, water, wall, None, u, niter=1, dump_iters=[], perpass_iter=0, precip=False,
+                      iter0=100, keep=())
+    path = os.path.join(OUT_DIR, "randwalls64.npz")
+    keep = {k: v for k, v in out.items() if not k.startswith("pp_") or k.split("_")[1] in ("velocity", "curl", "vort", "boundary")}
+    np.savez_compressed(path, **keep)
+    print(f"[randwalls64] trimmed to the passes before advection: {os.path.getsize(path) / 1024:.0f} KiB")
+    return keep
+
+
 FIXTURES = {
+    "randwalls64": fx_randwalls64,
     "brush64": fx_brush64,
     "save100qa": lambda: fx_save100(False),
     "save100qa_precip": lambda: fx_save100(True),

@@ -54,7 +54,7 @@ def _assert_grid_equal(h, o, fields=GRID_FIELDS):
         assert np.array_equal(a, b), f"{f}: {np.count_nonzero(a != b)} of {a.size} values differ, max |d| = {np.abs(a.astype(np.float64) - b).max()}"
 
 
-@pytest.mark.parametrize("name", ["save100qa", "synth64"])
+@pytest.mark.parametrize("name", ["save100qa", "synth64", "randwalls64"])
 @pytest.mark.parametrize("quad_scale", [0, 1])
 def test_bit_exact_vs_oracle_on_golden_inputs(pkg, oracle, golden, E, name, quad_scale, fused):
     g, u = golden(name)
@@ -92,7 +92,7 @@ def test_vs_swiftshader_goldens(pkg, golden, E, fused):
         assert np.abs(h.read_rect("WATER_CUR") - g[f"it{it}_water_cur"]).max() <= tw
 
 
-@pytest.mark.parametrize("X,Y", [(512, 128), (192, 96), (130, 50)])
+@pytest.mark.parametrize("X,Y", [(512, 128), (192, 96), (130, 50), (4100, 20)])
 def test_bit_exact_terrain_grid(pkg, oracle, E, X, Y, fused):
     """setupShader-style terrain with default settings, all grid passes + lighting; ragged sizes included."""
     S = pkg.synth

@@ -219,3 +219,30 @@ def test_brush_tools(oracle, case):
     changed = (not np.array_equal(s0.field("WALL_CUR"), s.field("WALL_CUR"))) or np.abs(s0.field("BASE_CUR") - b).max() > 0 \
         or np.abs(s0.field("WATER_CUR") - w).max() > 0
     assert changed
+
+
+def test_boundary_on_random_wall_geometry(oracle, golden):
+    """Floating islands, overhangs, caves, gaps, sea next to air, walls in the top rows: the wall-geometry branches of
+    boundaryShader.frag:155-196, 245-269, 373-388 at iterNum = 100. velocity / curl / vorticity / boundary vs the reference."""
+    g, u = golden("randwalls64")
+    u, p = _params(oracle, g, u)
+    L = oracle.lib()
+    X, Y = int(g["X"]), int(g["Y"])
+    bo, wo = _z((Y, X, 4)), _z((Y, X, 4), np.int8)
+    L.wxo_velocity(p, g["in_base"].ravel(), g["in_wall"].ravel(), bo.ravel(), wo.ravel())
+    assert np.array_equal(bo, g["pp_velocity_base"]) and np.array_equal(wo, g["pp_velocity_wall"])
+    cu = _z((Y, X))
+    L.wxo_curl(p, bo.ravel(), cu.ravel())
+    assert np.array_equal(cu, g["pp_curl"])
+    vo = _z((Y, X, 2))
+    L.wxo_vorticity(p, cu.ravel(), vo.ravel())
+    assert np.array_equal(vo, g["pp_vort"])
+    b2, wa, wl = _z((Y, X, 4)), _z((Y, X, 4)), _z((Y, X, 4), np.int8)
+    L.wxo_boundary(p, u["initial_T"], float(g["iter0"]), bo.ravel(), g["in_water"].ravel(), vo.ravel(), wo.ravel(), _z(Y * X * 4), _z(Y * X * 4),
+                   _z(Y * X * 2), b2.ravel(), wa.ravel(), wl.ravel())
+    assert np.array_equal(wl, g["pp_boundary_wall"])
+    assert (wl != g["in_wall"]).any(-1).sum() > 300  # the geometry rules did fire
+    assert np.array_equal(b2[..., :3], g["pp_boundary_base"][..., :3])
+    assert np.abs(b2[..., 3] - g["pp_boundary_base"][..., 3]).max() <= ULP_T
+    assert np.abs(wa - g["pp_boundary_water"]).max() <= 2e-6
+    assert (wa == g["pp_boundary_water"]).mean() > 0.999
