@@ -533,6 +533,18 @@ __device__ __forceinline__ Taps mktaps(const CellCoord &cc, int y, float posx, f
   t.dy0 = (int)fly - y;
   return t;
 }
+// The four texels (dx0 + i, dy0 + j), i, j in {0, 1}, of a bilinear footprint. Generic form: through the accessor's
+// arbitrary-offset reads; an accessor whose storage makes the four taps constant offsets from one address provides
+// its own make_fp overload (wx_march.h).
+template <class A> struct FpGeneric {
+  const A &a;
+  int dx0, dy0;
+  __device__ __forceinline__ float4 base(int i, int j) const { return a.base_off(dx0 + i, dy0 + j); }
+  __device__ __forceinline__ float4 water(int i, int j) const { return a.water_off(dx0 + i, dy0 + j); }
+  __device__ __forceinline__ char4 wall(int i, int j) const { return a.wall_off(dx0 + i, dy0 + j); }
+};
+template <class A> __device__ __forceinline__ FpGeneric<A> make_fp(const A &a, int dx0, int dy0) { return FpGeneric<A>{a, dx0, dy0}; }
+
 __device__ __forceinline__ float bilerp4(float a, float b, float c, float d, float mAB, float mCD, float mY)
 {
   return mixf(mixf(a, b, mAB), mixf(c, d, mCD), mY);
@@ -570,19 +582,20 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
 
     {
       const Taps t = mktaps(cc, y, fx - velAtVx_x, fy - velAtVx_y);
-      b.x = bilerp4(a.base_off(t.dx0, t.dy0).x, a.base_off(t.dx0 + 1, t.dy0).x, a.base_off(t.dx0, t.dy0 + 1).x,
-                    a.base_off(t.dx0 + 1, t.dy0 + 1).x, t.fx, t.fx, t.fy);
+      const auto f = make_fp(a, t.dx0, t.dy0);
+      b.x = bilerp4(f.base(0, 0).x, f.base(1, 0).x, f.base(0, 1).x, f.base(1, 1).x, t.fx, t.fx, t.fy);
     }
     {
       const Taps t = mktaps(cc, y, fx - velAtVy_x, fy - velAtVy_y);
-      b.y = bilerp4(a.base_off(t.dx0, t.dy0).y, a.base_off(t.dx0 + 1, t.dy0).y, a.base_off(t.dx0, t.dy0 + 1).y,
-                    a.base_off(t.dx0 + 1, t.dy0 + 1).y, t.fx, t.fx, t.fy);
+      const auto f = make_fp(a, t.dx0, t.dy0);
+      b.y = bilerp4(f.base(0, 0).y, f.base(1, 0).y, f.base(0, 1).y, f.base(1, 1).y, t.fx, t.fx, t.fy);
     }
     {
       // bilerpWall at velAtP (common.glsl:216-254): P, T and water.xyw share one footprint
       const Taps t = mktaps(cc, y, fx - velAtP_x, fy - velAtP_y);
-      const int wa = a.wall_off(t.dx0, t.dy0).y, wb = a.wall_off(t.dx0 + 1, t.dy0).y;
-      const int wc = a.wall_off(t.dx0, t.dy0 + 1).y, wd = a.wall_off(t.dx0 + 1, t.dy0 + 1).y;
+      const auto f = make_fp(a, t.dx0, t.dy0);
+      const int wa = f.wall(0, 0).y, wb = f.wall(1, 0).y;
+      const int wc = f.wall(0, 1).y, wd = f.wall(1, 1).y;
       float mAB = t.fx, mCD = t.fx, mY = t.fy;
       if (wa == 0)
         mAB = 1.0f;
@@ -596,13 +609,13 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
         mY = 1.0f;
       else if (wc == 0 && wd == 0)
         mY = 0.0f;
-      const float4 ba = a.base_off(t.dx0, t.dy0), bb = a.base_off(t.dx0 + 1, t.dy0);
-      const float4 bc = a.base_off(t.dx0, t.dy0 + 1), bd = a.base_off(t.dx0 + 1, t.dy0 + 1);
+      const float4 ba = f.base(0, 0), bb = f.base(1, 0);
+      const float4 bc = f.base(0, 1), bd = f.base(1, 1);
       b.z = bilerp4(ba.z, bb.z, bc.z, bd.z, mAB, mCD, mY);
       b.w = bilerp4(ba.w, bb.w, bc.w, bd.w, mAB, mCD, mY);
       if (!NO_WATER) {
-        const float4 qa = a.water_off(t.dx0, t.dy0), qb = a.water_off(t.dx0 + 1, t.dy0);
-        const float4 qc = a.water_off(t.dx0, t.dy0 + 1), qd = a.water_off(t.dx0 + 1, t.dy0 + 1);
+        const float4 qa = f.water(0, 0), qb = f.water(1, 0);
+        const float4 qc = f.water(0, 1), qd = f.water(1, 1);
         w.x = bilerp4(qa.x, qb.x, qc.x, qd.x, mAB, mCD, mY);
         w.y = bilerp4(qa.y, qb.y, qc.y, qd.y, mAB, mCD, mY);
         w.w = bilerp4(qa.w, qb.w, qc.w, qd.w, mAB, mCD, mY);
@@ -615,8 +628,9 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
     {
       // precipitation visualisation channel, +0.05 in y (:103)
       const Taps t = mktaps(cc, y, fx - velAtP_x + 0.0f, fy - velAtP_y + 0.05f);
-      const int wa = a.wall_off(t.dx0, t.dy0).y, wb = a.wall_off(t.dx0 + 1, t.dy0).y;
-      const int wc = a.wall_off(t.dx0, t.dy0 + 1).y, wd = a.wall_off(t.dx0 + 1, t.dy0 + 1).y;
+      const auto f = make_fp(a, t.dx0, t.dy0);
+      const int wa = f.wall(0, 0).y, wb = f.wall(1, 0).y;
+      const int wc = f.wall(0, 1).y, wd = f.wall(1, 1).y;
       float mAB = t.fx, mCD = t.fx, mY = t.fy;
       if (wa == 0)
         mAB = 1.0f;
@@ -630,8 +644,7 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
         mY = 1.0f;
       else if (wc == 0 && wd == 0)
         mY = 0.0f;
-      w.z = bilerp4(a.water_off(t.dx0, t.dy0).z, a.water_off(t.dx0 + 1, t.dy0).z, a.water_off(t.dx0, t.dy0 + 1).z,
-                    a.water_off(t.dx0 + 1, t.dy0 + 1).z, mAB, mCD, mY);
+      w.z = bilerp4(f.water(0, 0).z, f.water(1, 0).z, f.water(0, 1).z, f.water(1, 1).z, mAB, mCD, mY);
     }
 
     float realTemp = b.w - tcy * u.dryLapse;

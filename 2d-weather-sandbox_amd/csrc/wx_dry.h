@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NTD, WX_D_MINWAVES) void k_fused_dry(Geo g, Uni u, 
 
 inline void launch_fused_dry(const Geo &g, const Uni &u, const FullCtx *ctx, const DryIn &in, const DryOut &out, bool water, bool write_disp, hipStream_t stream)
 {
-  const dim3 grid(((g.X + TX - 1) / TX) * ((g.Y + TY - 1) / TY));
+  const dim3 grid = tile_grid(g.X, g.Y);
   if (water) {
     if (write_disp)
       hipLaunchKernelGGL((k_fused_dry<true, true>), grid, dim3(NTD), 0, stream, g, u, ctx, in, out);

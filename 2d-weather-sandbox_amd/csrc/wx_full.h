@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NTF, WX_F_MINWAVES) void k_fused_full(const FullCtx
 inline void launch_fused_full(const Geo &g, float iterNum, const FullIn &in, const FullCtx *ctx, const FullOut &out, bool opt_out,
                               hipStream_t stream)
 {
-  const dim3 grid(((g.X + TX - 1) / TX) * ((g.Y + TY - 1) / TY));
+  const dim3 grid = tile_grid(g.X, g.Y);
   if (opt_out)
     hipLaunchKernelGGL(k_fused_full<true>, grid, dim3(NTF), 0, stream, ctx, iterNum, in, out);
   else

@@ -65,8 +65,15 @@ __device__ __forceinline__ int wrapfast(int i, int n) { return i < 0 ? i + n : (
 #ifndef WX_XCD_TILES
 #define WX_XCD_TILES 0
 #endif
+#ifndef WX_GRID2D
+#define WX_GRID2D 1
+#endif
 __device__ __forceinline__ void tile_of_block(int GX, int &bx, int &by)
 {
+#if WX_GRID2D
+  bx = blockIdx.x;
+  by = blockIdx.y;
+#else
   const int id = blockIdx.x;
   if (WX_XCD_TILES && (GX & 7) == 0) {
     const int k = id & 7, j = id >> 3, w = GX >> 3;
@@ -76,6 +83,15 @@ __device__ __forceinline__ void tile_of_block(int GX, int &bx, int &by)
     by = id / GX;
     bx = id - by * GX;
   }
+#endif
+}
+inline dim3 tile_grid(int X, int Y)
+{
+#if WX_GRID2D
+  return dim3((X + 63) / 64, (Y + 15) / 16);
+#else
+  return dim3(((X + 63) / 64) * ((Y + 15) / 16));
+#endif
 }
 __device__ __forceinline__ int tiles_x(int X) { return (X + 63) / 64; }
 
@@ -422,7 +438,7 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, co
 inline void launch_fused_a(const Geo &g, const Uni &u, const float *initial_T, const FusedAIn &in, float4 *base_out, float4 *water_out,
                            char4 *wall_out, float *curl_out, bool write_curl, hipStream_t stream)
 {
-  const dim3 grid(((g.X + TX - 1) / TX) * ((g.Y + TY - 1) / TY));
+  const dim3 grid = tile_grid(g.X, g.Y);
   if (write_curl)
     hipLaunchKernelGGL(k_fused_a<true>, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out);
   else
@@ -433,7 +449,7 @@ inline void launch_fused_b(const Geo &g, const Uni &u, const float *initial_T, c
                            const FusedBIn &in, const SlowCtx *ctx, float4 *base_out, float4 *base_disp, float4 *water_out, char4 *wall_out,
                            float4 *light_out, bool write_disp, hipStream_t stream)
 {
-  const dim3 grid(((g.X + TX - 1) / TX) * ((g.Y + TY - 1) / TY));
+  const dim3 grid = tile_grid(g.X, g.Y);
   if (write_disp)
     hipLaunchKernelGGL(k_fused_b<true>, grid, dim3(NTB), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp,
                        water_out, wall_out, light_out);

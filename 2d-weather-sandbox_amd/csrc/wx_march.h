@@ -1,0 +1,229 @@
+// wx_march.h -- the dry-air iteration (velocity -> advection -> pressure, BASELINE configs[1]) as a row-MARCHING
+// kernel: one wavefront owns a 64-column strip and walks up the rows of its segment.
+//
+//   lane l <-> column c0 - 2 + l;  step r (new input row r):  load row r+1 (prefetch)  |  velocity(r-1)  |
+//   advection(r-2)  |  pressure(r-2) -> store row r-2
+//
+// * vertical neighbours are the wave's own previous rows: kept in registers (pressure) or in a 4-row LDS ring that
+//   is PRIVATE to the wave (advection's data-dependent taps) -- no vertical halo is ever re-loaded or re-computed;
+// * horizontal neighbours come from the ring (lane +- 1) or a wavefront shuffle (pressure's left neighbour);
+// * of the 64 lanes 60 produce output (velocity needs lane+1, advection lane+-1, pressure lane-1): 6.7 % redundancy
+//   instead of 33 % (tile + halo) in wx_dry.h, and no workgroup barriers: the only synchronisation is the wave's own
+//   in-order LDS queue;
+// * the next row's global loads are issued before the current row's arithmetic (software prefetch).
+// HBM traffic: base 16 R + 16 W, wall 4 R + 4 W per cell. Same per-cell arithmetic (wx_cells.h): bit-identical results.
+// Only the water-free state (NO_WATER, see wx_dry.h) marches; anything else uses the tiled kernel.
+#pragma once
+#include "wx_cells.h"
+#include "wx_dry.h"
+
+namespace wx {
+
+#ifndef WX_MARCH_MAXSEG
+#define WX_MARCH_MAXSEG 128 // upper bound of the rows one wave marches (3 warm-up rows per segment are redundant work)
+#endif
+#ifndef WX_MARCH_XCD
+#define WX_MARCH_XCD 1
+#endif
+#ifndef WX_MARCH_MINWAVES
+#define WX_MARCH_MINWAVES 6
+#endif
+constexpr int MOUT = 60;           // output columns per wave (lanes 2..61)
+
+// Ring of the last four rows. Slot 4 mirrors slot 0, so the two rows of a bilinear footprint (slots s, s+1 with
+// s = row & 3) are always adjacent in memory: a footprint costs one address computation, its taps are constant offsets
+// from it. The two edge lanes (never output lanes) READ as if they were lanes 1 / 62, so lane +- 1 needs no clamp.
+// 5 x 64 x 20 B = 6400 B = five 1280-byte LDS granules: 25 waves per CU fit, the register budget allows 24.
+constexpr int MRW = 64;
+struct MarchRing {
+  float vx[5][MRW], vy[5][MRW], P[5][MRW], T[5][MRW];
+  char4 w[5][MRW];
+  template <typename A, typename V> __device__ __forceinline__ static void put(A &plane, int slot, int lane, V v)
+  {
+    plane[slot][lane] = v;
+    if (slot == 0) plane[4][lane] = v;
+  }
+};
+
+struct MDryAcc {
+  const MarchRing &rg;
+  int lane1, yc; // lane1 = the lane this one reads as (edge lanes: 1 / 62); yc: unwrapped row counter of the own cell (ring slot = row & 3)
+  __device__ __forceinline__ float4 base(int dx, int dy) const
+  {
+    const int s = (yc + dy) & 3, l = lane1 + dx;
+    return make_float4(rg.vx[s][l], rg.vy[s][l], rg.P[s][l], rg.T[s][l]);
+  }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return rg.w[(yc + dy) & 3][lane1 + dx]; }
+  __device__ __forceinline__ float4 base_off(int dx, int dy) const { return base(dx, dy); }
+  __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return wall(dx, dy); }
+  __device__ __forceinline__ float4 water_off(int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+
+// bilinear footprint in the ring: one address, four constant-offset taps (the upper row of slot 3 is the mirror row 4)
+struct MDryFp {
+  const MarchRing &rg;
+  int s, l;
+  __device__ __forceinline__ float4 base(int i, int j) const { return make_float4(rg.vx[s + j][l + i], rg.vy[s + j][l + i], rg.P[s + j][l + i], rg.T[s + j][l + i]); }
+  __device__ __forceinline__ char4 wall(int i, int j) const { return rg.w[s + j][l + i]; }
+  __device__ __forceinline__ float4 water(int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+__device__ __forceinline__ MDryFp make_fp(const MDryAcc &a, int dx0, int dy0) { return MDryFp{a.rg, (a.yc + dy0) & 3, a.lane1 + dx0}; }
+
+template <bool WRITE_DISP>
+__global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows)
+{
+  __shared__ MarchRing rg;
+  const int X = g.X, Y = g.Y;
+  const int lane = threadIdx.x;
+#if WX_MARCH_XCD
+  // XCD-aware placement: workgroup id lands on XCD id % 8 (MI355X_MICROARCH.md). The (segment, strip) items are numbered
+  // segment-major and XCD k takes the contiguous range [k*T/8, (k+1)*T/8): neighbouring strips run on the same XCD, so the
+  // 128-byte lines they share (2 halo columns each side; 60-column strips are not line aligned) are fetched into ONE L2
+  // instead of two. Measured FETCH_SIZE: 1.22x -> 1.00x of the bytes the strips need; 32768x4096: 1.39 -> 1.11 ms.
+  const int total = n_strips * ((Y + seg_rows - 1) / seg_rows), k = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int first = (int)(((long long)k * total) >> 3), count = (int)(((long long)(k + 1) * total) >> 3) - first;
+  if (j >= count) return;
+  const int item = first + j, seg = item / n_strips, strip = item - seg * n_strips;
+#else
+  const int strip = blockIdx.x % n_strips, seg = blockIdx.x / n_strips;
+#endif
+  const int c_out = strip * MOUT + lane - 2;         // output column of this lane (may be >= X in the last strip)
+  const int col = wrapmod(c_out, X);                 // column this lane loads / computes
+  const bool lane_out = lane >= 2 && lane <= 61 && c_out < X;
+  const int y_lo = seg * seg_rows, y_hi = min(y_lo + seg_rows, Y);
+
+  const int lr = lane < 1 ? 1 : (lane > 62 ? 62 : lane); // ring column the advection of this lane reads around
+  const int lright = lane < 63 ? lane + 1 : 63;          // right neighbour for the velocity stage
+  // registers: newest two input rows, last advection row
+  float4 b_new, b_prev = make_float4(0.f, 0.f, 0.f, 0.f);
+  int w_new; // the wall texel stays one raw dword until it is used (unpacking it next to the load would wait for the load)
+  char4 w_prev = make_char4(0, 0, 0, 0);
+  const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
+  float adv_vy_prev = 0.f, adv_T_prev = 0.f;
+  char4 adv_w_prev = make_char4(0, 0, 0, 0);
+  int big1 = 0, big2 = 0, big3 = 0; // "some |v| >= 0.9" of velocity rows r-1, r-2, r-3
+
+  // prefetch of the first row
+  int r = y_lo - 2;
+  {
+    const size_t gi = fidx(col, wrapmod(r, Y), X);
+    b_new = in.base[gi];
+    w_new = wall_raw[gi];
+  }
+  for (; r <= y_hi + 1; r++) {
+    const int rc = r + 8; // non-negative ring counter
+    const float4 b_cur = b_new;
+    int w_raw = w_new;
+    asm volatile("" : "+v"(w_raw)); // keeps the byte unpacking on this side of the prefetch
+    const char4 w_cur = make_char4((signed char)(w_raw & 0xff), (signed char)((w_raw >> 8) & 0xff), (signed char)((w_raw >> 16) & 0xff), (signed char)(w_raw >> 24));
+    // software prefetch: next row's loads are in flight while this row is processed
+    if (r < y_hi + 1) {
+      const size_t gi = fidx(col, wrapmod(r + 1, Y), X);
+      b_new = in.base[gi];
+      w_new = wall_raw[gi];
+    }
+    // row r: P, T and wall enter the ring (velocity leaves them unchanged)
+    MarchRing::put(rg.P, rc & 3, lane, b_cur.z);
+    MarchRing::put(rg.T, rc & 3, lane, b_cur.w);
+    MarchRing::put(rg.w, rc & 3, lane, w_cur);
+    __syncthreads(); // one wave per workgroup: orders the wave's LDS traffic, no cross-wave wait
+
+    if (r >= y_lo - 1) { // velocity of row r-1: P of the right neighbour from the ring, P above = this row
+      const int s1 = (rc - 1) & 3;
+      const float Pr = rg.P[s1][lright];
+      float4 v = velocity_cell(u, b_prev, Pr, b_cur.z, w_prev.y);
+      if (lane == 63) v.x = v.y = 0.0f; // has no right neighbour in the ring; no output lane ever reads this velocity
+      MarchRing::put(rg.vx, s1, lane, v.x);
+      MarchRing::put(rg.vy, s1, lane, v.y);
+      big1 = __any(fmaxf(fabsf(v.x), fabsf(v.y)) >= 0.9f); // any back-trace of this row that may leave the 3x3 cells?
+    }
+    __syncthreads();
+
+    if (r >= y_lo + 1) { // advection of row y = r-2 (velocity rows r-3 .. r-1 are in the ring)
+      const int y = wrapmod(r - 2, Y);
+      float4 ab, aw;
+      char4 awl;
+      {
+        const int yc = rc - 2, l1 = lr;
+        bool fast = true;
+        if (big1 | big2 | big3) { // wave-uniform: some velocity of rows y-1 .. y+1 is large -> per-lane test
+          const float m = fmaxf(fmaxf(fmaxf(fabsf(rg.vx[yc & 3][l1]), fabsf(rg.vx[yc & 3][l1 - 1])),
+                                      fmaxf(fabsf(rg.vx[(yc + 1) & 3][l1]), fabsf(rg.vx[(yc + 1) & 3][l1 - 1]))),
+                                fmaxf(fmaxf(fabsf(rg.vy[yc & 3][l1]), fabsf(rg.vy[(yc - 1) & 3][l1])),
+                                      fmaxf(fabsf(rg.vy[yc & 3][l1 + 1]), fabsf(rg.vy[(yc - 1) & 3][l1 + 1]))));
+          fast = m < 0.9f;
+        }
+        if (fast) {
+          MDryAcc a{rg, l1, yc};
+          advection_cell<true>(u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, col, y, a, ab, aw, awl);
+        } else { // exact out-of-line path (velocity recomputed from global memory)
+          const AdvOut o = advection_cell_dry_global(ctx, in, false, col, y);
+          ab = o.b;
+          aw = o.w;
+          awl = o.wl;
+        }
+      }
+      if (r >= y_lo + 2) { // pressure of row y: left neighbour by wavefront shuffle, row below from registers
+        const float vx_l = __shfl_up(ab.x, 1);
+        const float4 p = pressure_cell(ab, vx_l, adv_vy_prev, adv_T_prev, adv_w_prev.x, adv_w_prev.y);
+        if (lane_out) {
+          const size_t gi = fidx(c_out, y, X);
+          out.base[gi] = p;
+          out.wall[gi] = awl;
+          if (WRITE_DISP) out.base_disp[gi] = ab;
+        }
+      }
+      adv_vy_prev = ab.y;
+      adv_T_prev = ab.w;
+      adv_w_prev = awl;
+    }
+    b_prev = b_cur;
+    w_prev = w_cur;
+    big3 = big2;
+    big2 = big1;
+  }
+}
+
+// Segment height: the grid is cut so that the number of waves is just under a whole multiple of what the device holds
+// at once (CUs x resident waves), i.e. every "round" of waves is full and the last one ends together.
+inline int march_seg_rows(int n_strips, int Y)
+{
+  static int capacity = 0;
+  if (!capacity) {
+    int dev = 0, ncu = 0, nb = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_dry<false>, 64, 0) != hipSuccess || ncu <= 0 || nb <= 0)
+      capacity = 256 * 4 * WX_MARCH_MINWAVES;
+    else
+      capacity = ncu * nb;
+    if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_march] CUs=%d blocks/CU=%d capacity=%d\n", ncu, nb, capacity);
+  }
+  if (const char *e = getenv("WX_MARCH_SEG")) return atoi(e) < Y ? atoi(e) : Y;
+  int maxseg = WX_MARCH_MAXSEG;
+  if (const char *e = getenv("WX_MARCH_MAXSEG")) maxseg = atoi(e) > 0 ? atoi(e) : maxseg;
+  for (int k = 1; k < 64; k++) {
+    const int nseg = (int)((long long)k * capacity / n_strips);
+    if (nseg < 1) continue;
+    const int rows = (Y + nseg - 1) / nseg;
+    if (rows <= maxseg) return rows < 8 ? (Y < 8 ? Y : 8) : rows;
+  }
+  return maxseg < Y ? maxseg : Y;
+}
+
+inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, const DryIn &in, const DryOut &out, bool write_disp, hipStream_t stream)
+{
+  const int n_strips = (g.X + MOUT - 1) / MOUT;
+  const int seg_rows = march_seg_rows(n_strips, g.Y), n_seg = (g.Y + seg_rows - 1) / seg_rows;
+  const dim3 grid(WX_MARCH_XCD ? 8 * ((n_strips * n_seg + 7) / 8) : n_strips * n_seg);
+  static bool dbg = getenv("WX_MARCH_DEBUG") != nullptr;
+  if (dbg) {
+    fprintf(stderr, "[wx_march] strips=%d seg_rows=%d segs=%d waves=%d\n", n_strips, seg_rows, n_seg, n_strips * n_seg);
+    dbg = false;
+  }
+  if (write_disp)
+    hipLaunchKernelGGL(k_march_dry<true>, grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows);
+  else
+    hipLaunchKernelGGL(k_march_dry<false>, grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows);
+}
+
+} // namespace wx

@@ -8,6 +8,7 @@
 #include "wx_fused.h"
 #include "wx_full.h"
 #include "wx_dry.h"
+#include "wx_march.h"
 #include "wx_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -43,11 +44,12 @@ enum KernelId {
   K_FUSED_APL,  // advection + pressure + lighting
   K_FUSED_FULL, // the whole iteration in one kernel
   K_FUSED_DRY,  // velocity + advection + pressure (pass_mask WX_PASS_DRY)
+  K_MARCH_DRY,  // the same as a row-marching wavefront kernel (wx_march.h)
   K_COUNT
 };
 const char *const kKernelNames[K_COUNT] = {"velocity", "curl", "vorticity", "boundary", "advection", "pressure", "lighting",
                                            "precipitation", "lightning", "splat_box", "copy", "halo", "fused_vel_curl_vort_boundary",
-                                           "fused_advect_pressure_light", "fused_full_iteration", "fused_dry_vel_advect_pressure"};
+                                           "fused_advect_pressure_light", "fused_full_iteration", "fused_dry_vel_advect_pressure", "march_dry_vel_advect_pressure"};
 
 struct ProfRec {
   hipEvent_t a, b;
@@ -64,6 +66,8 @@ struct wx_sim {
   int even = 1;          // app.js `even`
   int drop_cur = 0;      // particle buffer holding the latest state
   int64_t iter = 0;
+  int dry_march = 1;     // water-free dry iteration: 1 = row-marching wavefront kernel (wx_march.h, default: 0.32 vs 0.38 ms at
+                         // 16384x2048), 0 = LDS-tiled kernel (wx_dry.h); env WX_DRY_MARCH
   int fused = 1;         // 1: two fused LDS-tiled kernels (default, fastest measured); 2: whole iteration in one kernel; 0: one kernel
                          // per reference pass (env WX_FUSED)
   wx_params p{};
@@ -390,7 +394,10 @@ int iterate_dry(wx_sim *s, bool write_disp)
   const bool water = !(s->water_trivial && s->p.userInputType < 0 && s->p.airplaneValues[3] == 0.0f && s->p.soundingForcing == 0.0f);
   DryIn in{s->base[0], s->wall[0], s->water[1]};
   DryOut out{s->base[1], s->wall[1], s->water[2], s->base[2]};
-  {
+  if (!water && s->dry_march && s->X >= 64) {
+    ProfScope ps(s, K_MARCH_DRY);
+    launch_march_dry(s->geo, s->uni, s->full_ctx, in, out, write_disp, s->stream);
+  } else {
     ProfScope ps(s, K_FUSED_DRY);
     launch_fused_dry(s->geo, s->uni, s->full_ctx, in, out, water, write_disp, s->stream);
   }
@@ -438,6 +445,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   s->halo = halo;
   s->n_drops = n_droplets;
   if (const char *f = getenv("WX_FUSED")) s->fused = atoi(f);
+  if (const char *f = getenv("WX_DRY_MARCH")) s->dry_march = atoi(f);
   if (!kHaveFused) s->fused = 0;
   const size_t n = ncell(s);
   int rc = WX_OK;

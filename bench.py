@@ -31,6 +31,7 @@ ALGO_BYTES = {
     "fused_full_iteration": 68 + 52,
     # dry config: A_dry = base 16 R + 16 W + wall 4 R; the kernel also passes the wall texel through (+4 W)
     "fused_dry_vel_advect_pressure": 36,
+    "march_dry_vel_advect_pressure": 36,
 }
 
 
@@ -78,7 +79,7 @@ def cpu_baseline(pkg, budget_s=12.0):
 
 KERNEL_SYMBOL = {  # profile name -> substring of the kernel symbol rocprofv3 reports
     "fused_vel_curl_vort_boundary": "k_fused_a", "fused_advect_pressure_light": "k_fused_b", "fused_full_iteration": "k_fused_full",
-    "fused_dry_vel_advect_pressure": "k_fused_dry", "advection": "k_advection", "boundary": "k_boundary", "lighting": "k_lighting",
+    "fused_dry_vel_advect_pressure": "k_fused_dry", "march_dry_vel_advect_pressure": "k_march_dry", "advection": "k_advection", "boundary": "k_boundary", "lighting": "k_lighting",
     "velocity": "k_velocity", "pressure": "k_pressure", "curl": "k_curl", "vorticity": "k_vorticity", "precipitation": "k_precipitation",
 }
 
@@ -94,10 +95,10 @@ def pmc_traffic(a, kernel):
     exe = shutil.which("rocprofv3")
     sym = KERNEL_SYMBOL.get(kernel)
     if not exe or not sym:
-        return None
+        return None, None
     vals = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             d = tempfile.mkdtemp(prefix="wxpmc_", dir="/tmp")
             cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2",
                    "--X", str(a.X), "--Y", str(a.Y), "--workload", a.workload, "--no-cpu-baseline", "--no-pmc"]
@@ -115,9 +116,9 @@ def pmc_traffic(a, kernel):
                     per.append(v)
             vals[counter] = sum(per) / len(per)
             shutil.rmtree(d, ignore_errors=True)
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, vals["SQ_INSTS_VALU"]
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -208,12 +209,16 @@ def main():
             name, (ms, cnt) = dom
             avg_ms = ms / cnt
             achieved = ALGO_BYTES.get(name, 0) * local_cells / (avg_ms * 1e-3) / 1e9
-            traffic = None if (a.no_pmc or world > 1) else pmc_traffic(a, name)
+            traffic, valu = (None, None) if (a.no_pmc or world > 1) else pmc_traffic(a, name)
             roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, KiB counters)",
                     "algorithmic_bytes_per_launch": ALGO_BYTES.get(name, 0) * local_cells, "avg_launch_ms": avg_ms, "launches": cnt,
                     "algo_bytes_per_cell": ALGO_BYTES.get(name, 0),
                     "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()}}
+            if valu:
+                # the second limiter: a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
+                roof["valu"] = {"wave_insts_per_launch": valu, "busy_frac": valu * 4.0 / (1024 * 2.4e9 * avg_ms * 1e-3),
+                                "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time)"}
         out = {
             "metric": "Mcell-steps/s", "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,

@@ -136,6 +136,28 @@ def test_dry_config_pass_mask(pkg, oracle, E, fused, X, Y, moist):
     assert np.abs(h.read_rect("BASE_CUR")[..., 0]).max() > 1e-4
 
 
+@pytest.mark.parametrize("X,Y", [(256, 128), (130, 50), (64, 8), (1000, 70), (4100, 20)])
+def test_dry_marching_kernel(pkg, oracle, E, X, Y, monkeypatch):
+    """The row-marching wavefront kernel (wx_march.h, WX_DRY_MARCH=1) on the water-free dry state: bit-exact vs the
+    oracle, strips and row segments that do not divide the grid, |v| > 0.9 through the out-of-line path."""
+    monkeypatch.setenv("WX_DRY_MARCH", "1")
+    monkeypatch.setenv("WX_FUSED", "1")
+    base, water, wall = pkg.synth.dry_grid(X, Y)
+    base[Y // 3:Y // 2, X // 3:X // 2, 3] += 3.0
+    rng = np.random.default_rng(11)
+    base[..., 2] += rng.normal(0, 1e-3, (Y, X)).astype(np.float32)
+    base[1:, :, 0] += rng.normal(0, 0.35, (Y - 1, X)).astype(np.float32)
+    u = pkg.params.uniforms_from_gui(pkg.params.merge_settings(None), Y, pass_mask=pkg.params.PASS_DRY)
+    h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
+    h.profile(True)
+    for _ in range(3):
+        h.step(7)
+        o.step(7)
+        _assert_grid_equal(h, o, ["BASE_CUR", "BASE_DISP", "WATER_CUR", "WATER_0", "WALL_CUR"])
+    prof = h.profile_read()
+    assert prof["march_dry_vel_advect_pressure"][1] == 21, prof  # the marching kernel is what ran
+
+
 def test_particles_vs_oracle(pkg, oracle, golden, E, fused):
     g, u = golden("precip64")
     u = dict(u, quad_scale=0, enablePrecipitation=1)
