@@ -215,6 +215,19 @@ def main():
                     "algorithmic_bytes_per_launch": ALGO_BYTES.get(name, 0) * local_cells, "avg_launch_ms": avg_ms, "launches": cnt,
                     "algo_bytes_per_cell": ALGO_BYTES.get(name, 0),
                     "kernels_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()}}
+            if world == 1:
+                # practical ceiling: a plain device-to-device copy of 1 GiB, read + write bytes counted
+                src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+                dst = torch.empty_like(src)
+                dst.copy_(src)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    dst.copy_(src)
+                e1.record()
+                torch.cuda.synchronize()
+                roof["measured_copy_GBps"] = 2.0 * (1 << 30) * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+                del src, dst
             if valu:
                 # the second limiter: a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
                 roof["valu"] = {"wave_insts_per_launch": valu, "busy_frac": valu * 4.0 / (1024 * 2.4e9 * avg_ms * 1e-3),

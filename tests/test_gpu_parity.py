@@ -261,6 +261,58 @@ def test_full_size_invariants(pkg, E):
     assert (d == 0).mean() > 0.99
 
 
+def test_full_size_dry_marching_equals_tiled(pkg, E, monkeypatch):
+    """BASELINE configs[1] at 16384 x 2048: the row-marching kernel and the LDS-tiled kernel (independent data paths:
+    wave-private row ring + shuffles vs 64x16 tiles) agree bit for bit after 25 iterations."""
+    X, Y = 16384, 2048
+    base, water, wall = pkg.synth.dry_grid(X, Y)
+    rng = np.random.default_rng(17)
+    base[1:, :, 0] += rng.normal(0, 0.2, (Y - 1, X)).astype(np.float32)  # includes |v| > 0.9 cells (exact out-of-line path)
+    base[1:, :, 2] += rng.normal(0, 1e-3, (Y - 1, X)).astype(np.float32)
+    u = pkg.params.uniforms_from_gui(pkg.params.merge_settings(None), Y, pass_mask=pkg.params.PASS_DRY)
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    out = {}
+    for march in (1, 0):
+        monkeypatch.setenv("WX_DRY_MARCH", str(march))
+        h = E.Handle(X, Y, 0)
+        h.upload(base, water, wall)
+        h.set_params(p, u["initial_T"])
+        h.profile(True)
+        h.step(25)
+        out[march] = {f: h.read_rect(f) for f in ("BASE_CUR", "BASE_DISP", "WALL_CUR")}
+        assert ("march_dry_vel_advect_pressure" in h.profile_read()) == bool(march)
+        h.close()
+    for f in out[1]:
+        assert np.array_equal(out[1][f], out[0][f]), f
+    assert np.isfinite(out[1]["BASE_CUR"]).all() and np.abs(out[1]["BASE_CUR"][..., 1]).max() > 1e-4
+
+
+def test_full_size_long_run_stays_physical(pkg, E):
+    """600 iterations of the full wet iteration at 16384 x 2048 (day side, default sliders): no NaN/Inf, water
+    non-negative, velocities inside the shaders' documented -1..1 cell/iteration range, air temperature physical,
+    wall masks unchanged where nothing can build or erode them."""
+    X, Y = 16384, 2048
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 50.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+    h = E.Handle(X, Y, 0)
+    h.upload(base, water, wall)
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    h.step(600)
+    b, w, wl = h.read_rect("BASE_CUR"), h.read_rect("WATER_CUR"), h.read_rect("WALL_CUR")
+    assert h.iter == 600
+    assert np.isfinite(b).all() and np.isfinite(w).all() and np.isfinite(h.read_rect("LIGHT_0")).all()
+    air = wl[..., 1] != 0
+    assert (w[..., 0][air] >= 0).all() and (w[..., 1][air] >= 0).all()
+    assert np.abs(b[..., :2]).max() < 1.0
+    realT = b[..., 3] - ((np.arange(Y, dtype=np.float32)[:, None] + 0.5) / Y) * np.float32(u["dryLapse"])
+    assert realT[air].min() > 150.0 and realT[air].max() < 400.0
+    assert np.array_equal(wl[..., 0], wall[..., 0])  # wall types: no brush, no fire -> unchanged
+    h.close()
+
+
 @pytest.mark.parametrize("nslab,halo", [(2, 12), (4, 6)])
 def test_slab_handles_equal_whole_domain(pkg, E, fused, nslab, halo):
     """wx_create_slab + wx_halo_pack/unpack: N slab handles on one GPU, halos copied device-to-device in ring
