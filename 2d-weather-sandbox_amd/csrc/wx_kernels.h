@@ -170,8 +170,24 @@ __global__ void k_copy4(const char4 *__restrict__ src, char4 *__restrict__ dst, 
 // ------------------------------------------------------------------------------------------------
 // Particles: precipitationShader.vert:66-293 + point rasterisation with ONE,ONE blending
 // (app.js:5940-5953). One thread per droplet; splats are fp32 atomic adds (order-nondeterministic,
-// exactly like the reference's blend unit). Whole-domain handles only.
+// exactly like the reference's blend unit).
+//
+// Column slabs (no reference counterpart): every rank holds the WHOLE droplet pool. In iteration j of an exchange
+// period a rank processes the droplets whose sample column lies where its grid is still valid (owned columns +
+// halo - 6j ghost columns) -- droplets in the overlap are processed redundantly, and identically, by both neighbours,
+// exactly like ghost cells -- and leaves the others untouched. A droplet processed inside the OWNED columns gets the
+// key (j+1)*2048 + (active after the step ? 1024 : 0) + (1023 - rank); at the end of the period an all-reduce(MAX) of the keys names, per droplet, the rank
+// that tracked it last, whose copy every rank adopts (slab.py). Sprites never wrap around the domain edge (the
+// reference clips them at the framebuffer): if the edge ("seam") runs through the local array, anchors right of it are
+// stored one column further right and the box sum never crosses it.
 // ------------------------------------------------------------------------------------------------
+struct SlabP {
+  int lo, hi;         // local columns [lo, hi): sample positions this rank processes in this iteration
+  int own_lo, own_hi; // owned local columns
+  int seam;           // local column of global column 0 if it lies strictly inside the local array, else 0
+  int keyval;         // claim key of this iteration; 0 = whole-domain handle (no keys)
+  int *keys;
+};
 struct DevState {
   float inactiveDroplets; // the `inactiveDroplets` uniform, refreshed on the device every 600 iterations
   float lightning[4];     // lightningDataTexture (1x1 RGBA32F)
@@ -222,11 +238,17 @@ __device__ __forceinline__ float det_cbrt(float x)
   return y;
 }
 
-__device__ __forceinline__ size_t texel(int X, int Y, float u_, float v_)
+// texel of the LOCAL array that holds global texture coordinate (u, v); the column may lie outside the local array
+// (>= g.X) on slab handles -- callers check local_col() first
+__device__ __forceinline__ int local_col(const Geo &g, float u_)
 {
-  const int ix = wrapmod((int)floorf(u_ * (float)X), X);
-  const int iy = wrapmod((int)floorf(v_ * (float)Y), Y);
-  return cidx(ix, iy, X);
+  int lc = wrapmod((int)floorf(u_ * (float)g.Xg), g.Xg) - g.xoff;
+  return lc < 0 ? lc + g.Xg : lc;
+}
+__device__ __forceinline__ size_t texel(const Geo &g, float u_, float v_)
+{
+  const int iy = wrapmod((int)floorf(v_ * (float)g.Y), g.Y);
+  return cidx(local_col(g, u_), iy, g.X);
 }
 
 __device__ __forceinline__ void atomic_add_f(float *p, float v)
@@ -236,17 +258,30 @@ __device__ __forceinline__ void atomic_add_f(float *p, float v)
 
 __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops, const float *__restrict__ drops_in,
                                                         const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
-                                                        DevState *__restrict__ st, float *__restrict__ drops_out, SplatGrid sg)
+                                                        DevState *__restrict__ st, float *__restrict__ drops_out, SplatGrid sg, SlabP sp)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n_drops;
-  const int X = g.X, Y = g.Y;
-  const float resX = (float)X, resY = (float)Y;
+  bool live = i < n_drops;
+  const int Y = g.Y;
+  const float resX = (float)g.Xg, resY = (float)Y;
   const float initalMass = 0.15f;
-  bool count_inactive = false;
+  bool count_inactive = false, claim = false;
 
   float feedback[4] = {0.f, 0.f, 0.f, 0.f}, deposition[2] = {0.f, 0.f};
   float size = 1.0f, gposx = -2.0f, gposy = -2.0f; // default: clipped
+
+  if (live && sp.keyval) { // slab handle: is the sample position (spawn probe / own position) in my valid columns?
+    const float dpx = drops_in[5 * (size_t)i], dpy = drops_in[5 * (size_t)i + 1], m0 = drops_in[5 * (size_t)i + 2];
+    (void)dpy;
+    const float tcx = m0 < 0.0f ? random2d(m0, dpx + u.iterNum * 0.3754f) : dpx / 2.0f + 0.5f;
+    const int lc = local_col(g, tcx);
+    if (lc < sp.lo || lc >= sp.hi) { // no: another rank tracks this droplet
+      for (int c = 0; c < 5; c++) drops_out[5 * (size_t)i + c] = drops_in[5 * (size_t)i + c];
+      live = false;
+    } else {
+      claim = lc >= sp.own_lo && lc < sp.own_hi;
+    }
+  }
 
   if (live) {
     const float dpx = drops_in[5 * (size_t)i], dpy = drops_in[5 * (size_t)i + 1];
@@ -260,7 +295,7 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
     if (m0 < 0.0f) { // inactive :72-162
       tcx = random2d(m0, dpx + u.iterNum * 0.3754f);
       tcy = random2d(m1, dpx + u.iterNum * 0.073162f);
-      const size_t t = texel(X, Y, tcx, tcy);
+      const size_t t = texel(g, tcx, tcy);
       base = base_in[t];
       water = water_in[t];
       realTemp = base.w - tcy * u.dryLapse;
@@ -316,7 +351,7 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
       if (!spawned) {
         tcx = dpx / 2.0f + 0.5f;
         tcy = dpy / 2.0f + 0.5f;
-        const size_t t = texel(X, Y, tcx, tcy);
+        const size_t t = texel(g, tcx, tcy);
         water = water_in[t];
         base = base_in[t];
         realTemp = base.w - tcy * u.dryLapse;
@@ -328,7 +363,7 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
         newM0 = -2.0f - dpx;
         newM1 = dpy;
       } else if (newPosy < -1.0f || water.x > 1000.0f) {
-        if (base_in[texel(X, Y, tcx, tcy + g.texY)].w > 500.0f) newPosy += g.texY * 1.0f;
+        if (base_in[texel(g, tcx, tcy + g.texY)].w > 500.0f) newPosy += g.texY * 1.0f;
         deposition[0] = newM0;
         deposition[1] = newM1;
         newM0 = -2.0f - dpx;
@@ -392,6 +427,9 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
     drops_out[5 * (size_t)i + 2] = newM0;
     drops_out[5 * (size_t)i + 3] = newM1;
     drops_out[5 * (size_t)i + 4] = fmaxf(newDensity, 0.0f);
+    // claim key: later iteration > earlier; at equal iteration a copy that is (still / newly) ACTIVE beats a rank that
+    // merely evaluated the spawn probe of its stale inactive copy; then the lower rank
+    if (claim) sp.keys[i] = sp.keyval + (newM0 >= 0.0f ? 1024 : 0);
   }
 
   // inactive-droplet count: the reference blends +1 into texel (0,0) per droplet
@@ -418,7 +456,14 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
     return;
   }
   // 12x12 sprite: every pixel whose centre lies in [w - 6, w + 6); one deposit at the anchor pixel
-  const int q = (int)ceilf(xw - 6.0f - 0.5f) + 6, r = (int)ceilf(yw - 6.0f - 0.5f) + 6;
+  int q = (int)ceilf(xw - 6.0f - 0.5f) + 6;
+  const int r = (int)ceilf(yw - 6.0f - 0.5f) + 6;
+  // global anchor column -> local accumulation column (see SlabP::seam)
+  if (sp.seam > 0 && xw < (float)g.xoff)
+    q += sp.seam + 1; // low-x side of the domain edge: right of the seam, stored one column further right
+  else
+    q -= g.xoff;
+  if (q < 0 || q >= sg.AP) return; // the sprite lies outside this slab
   const size_t ai = (size_t)r * sg.AP + q;
   float *f = reinterpret_cast<float *>(sg.acc4 + ai);
   atomic_add_f(f + 0, feedback[0]);
@@ -435,8 +480,10 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
 // One workgroup per 64x16 output tile; tiles whose 3x3 neighbourhood holds no deposits only (re)write zeros, and
 // not even that when the texture tile is already known to be zero. Replaces the per-iteration clear of both
 // textures (app.js:5933-5934) and the blend-unit splats.
+// seam > 0 (slab handle whose local array contains the domain edge at a tile boundary): sums never cross it, anchors
+// right of it sit one column further right; then the (0,0) / (1,0) mailbox texels are not injected either.
 __global__ __launch_bounds__(256) void k_splat_box(int X, int Y, SplatGrid sg, const DevState *__restrict__ st, float4 *__restrict__ fb,
-                                                   float2 *__restrict__ dep)
+                                                   float2 *__restrict__ dep, int seam, int mailbox)
 {
   constexpr int WW = STX + 11, WH = STY + 11;
   __shared__ float pl[5][WH][WW + 1];
@@ -457,8 +504,10 @@ __global__ __launch_bounds__(256) void k_splat_box(int X, int Y, SplatGrid sg, c
   }
   __syncthreads();
   const int cx = tid & 63, cyg = tid >> 6;
-  const bool corner = (tbx == 0 && tby == 0);
+  const bool corner = mailbox && (tbx == 0 && tby == 0);
   const int tile = tby * sg.TXn + tbx;
+  const bool right = seam > 0 && x0 >= seam;
+  const int qmin = right ? seam : 0, qmax = (seam > 0 && !right) ? seam : X, qshift = right ? 1 : 0;
   if (!any_dirty) {
     if (sg.fb_zero[tile] && !corner) return; // texture tile still zero from an earlier iteration
     for (int k = 0; k < STY / 4; k++) {
@@ -480,9 +529,9 @@ __global__ __launch_bounds__(256) void k_splat_box(int X, int Y, SplatGrid sg, c
     const int q = x0 - 5 + lx, r = y0 - 5 + ly;
     float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 a2 = make_float2(0.f, 0.f);
-    if (q >= 0 && r >= 0 && q <= X && r <= Y) {
-      a4 = sg.acc4[(size_t)r * sg.AP + q];
-      a2 = sg.acc2[(size_t)r * sg.AP + q];
+    if (q >= qmin && r >= 0 && q <= qmax && r <= Y) {
+      a4 = sg.acc4[(size_t)r * sg.AP + q + qshift];
+      a2 = sg.acc2[(size_t)r * sg.AP + q + qshift];
     }
     pl[0][ly][lx] = a4.x;
     pl[1][ly][lx] = a4.y;
@@ -550,18 +599,51 @@ __global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg)
 }
 
 // lightningLocationShader.frag:24-38 + the 600-iteration inactive count (app.js:5957-5966), one thread
-__global__ void k_lightning(float iterNum, int refresh_inactive, const float4 *__restrict__ fb, DevState *st)
+// (slab handles: the mailbox texels are not part of the local feedback texture -- the request is taken from the
+// accumulator directly, the inactive count is refreshed by wx_particles_adopt)
+__global__ void k_lightning(float iterNum, int refresh_inactive, const float4 *__restrict__ fb, DevState *st, int mailbox)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float4 n = mailbox ? fb[1] : make_float4(st->px_light[0], st->px_light[1], st->px_light[2], st->px_light[3]); // texel (1,0)
   st->px_count = 0.f; // consumed by k_splat_box
   st->px_light[0] = st->px_light[1] = st->px_light[2] = st->px_light[3] = 0.f;
-  if (refresh_inactive) st->inactiveDroplets = fb[0].x;
-  const float4 n = fb[1]; // texel (1,0)
+  if (refresh_inactive && mailbox) st->inactiveDroplets = fb[0].x;
   if (n.z < fmaxf(iterNum - 1.0f, 1.0f) || n.z > iterNum) return; // discard
   st->lightning[0] = n.x;
   st->lightning[1] = n.y;
   st->lightning[2] = n.z;
   st->lightning[3] = n.w;
+}
+
+// ---- slab particle reconciliation (see SlabP) ----
+__global__ void k_drops_contribute(int n, const int *__restrict__ keys, const int *__restrict__ win, const float *__restrict__ drops,
+                                   float *__restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool mine = win[i] > 0 && keys[i] == win[i];
+  for (int c = 0; c < 5; c++) out[5 * (size_t)i + c] = mine ? drops[5 * (size_t)i + c] : 0.0f;
+}
+__global__ void k_drops_adopt(int n, int *__restrict__ keys, const int *__restrict__ win, const float *__restrict__ state,
+                              float *__restrict__ drops, DevState *st, int count_inactive)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool inactive = false;
+  if (i < n) {
+    if (win[i] > 0)
+      for (int c = 0; c < 5; c++) drops[5 * (size_t)i + c] = state[5 * (size_t)i + c];
+    keys[i] = 0;
+    inactive = drops[5 * (size_t)i + 2] < 0.0f;
+  }
+  if (count_inactive) { // the 600-iteration refresh of the `inactiveDroplets` uniform (app.js:5957-5966); st->px_count was zeroed by the host
+    const unsigned long long m = __ballot(inactive);
+    if (m != 0ull && (threadIdx.x & 63) == __ffsll((long long)m) - 1) unsafeAtomicAdd(&st->px_count, (float)__popcll(m));
+  }
+}
+__global__ void k_inactive_from_count(DevState *st)
+{
+  st->inactiveDroplets = st->px_count;
+  st->px_count = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -571,8 +653,10 @@ __global__ void k_lightning(float iterNum, int refresh_inactive, const float4 *_
 struct HaloPtrs {
   float4 *base, *water, *light0, *light1;
   char4 *wall;
+  float4 *fb;  // particle feedback / deposition textures: exchanged only on handles that carry particles
+  float2 *dep; // buffer layout then: [4 x h*Y float4][fb h*Y float4][dep h*Y float2][wall h*Y char4]
 };
-__global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, int x_start, float4 *buf16, char4 *buf4)
+__global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, int x_start, float4 *buf16, float2 *buf8, char4 *buf4)
 {
   const int n = h * Y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -583,9 +667,13 @@ __global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, int x_start, float4
     buf16[2 * n + i] = f.light0[s];
     buf16[3 * n + i] = f.light1[s];
     buf4[i] = f.wall[s];
+    if (f.fb) {
+      buf16[4 * n + i] = f.fb[s];
+      buf8[i] = f.dep[s];
+    }
   }
 }
-__global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, int x_start, const float4 *buf16, const char4 *buf4)
+__global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, int x_start, const float4 *buf16, const float2 *buf8, const char4 *buf4)
 {
   const int n = h * Y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -596,6 +684,10 @@ __global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, int x_start, cons
     f.light0[s] = buf16[2 * n + i];
     f.light1[s] = buf16[3 * n + i];
     f.wall[s] = buf4[i];
+    if (f.fb) {
+      f.fb[s] = buf16[4 * n + i];
+      f.dep[s] = buf8[i];
+    }
   }
 }
 

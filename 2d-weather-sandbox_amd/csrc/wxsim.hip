@@ -65,6 +65,11 @@ struct wx_sim {
   bool uploaded = false, have_params = false;
   int even = 1;          // app.js `even`
   int drop_cur = 0;      // particle buffer holding the latest state
+  // slab handles with particles (see SlabP in wx_kernels.h)
+  int *keys = nullptr;   // per-droplet claim key of the current exchange period
+  int period_j = 0;      // iterations since wx_slab_period_begin: halo - 6*j ghost columns are still valid
+  int rank = 0;          // tie-break of the claim keys (wx_slab_set_rank)
+  int seam = 0;          // local column of global column 0 if strictly inside the local array
   int64_t iter = 0;
   int dry_march = 1;     // water-free dry iteration: 1 = row-marching wavefront kernel (wx_march.h, default: 0.32 vs 0.38 ms at
                          // 16384x2048), 0 = LDS-tiled kernel (wx_dry.h); env WX_DRY_MARCH
@@ -432,7 +437,10 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (halo > 0 && X_owned < halo) return fail(nullptr, WX_E_INVALID, "wx_create_slab: X_owned (%d) < halo (%d)", X_owned, halo);
   if (halo == 0 && X_owned != X_global)
     return fail(nullptr, WX_E_INVALID, "wx_create_slab: a slab narrower than the domain needs halo > 0");
-  if (n_droplets > 0 && X_owned != X_global) return fail(nullptr, WX_E_INVALID, "particles are only supported on whole-domain handles");
+  if (n_droplets > 0 && halo > 0 && (halo % 64 || X_owned % 64 || X_owned + 2 * halo > X_global))
+    return fail(nullptr, WX_E_INVALID,
+                "wx_create_slab: particles on a slab need halo and X_owned to be multiples of 64 (the sprite clip at the domain edge must fall "
+                "on a splat tile boundary) and X_owned + 2*halo <= X_global; got halo=%d X_owned=%d X_global=%d", halo, X_owned, X_global);
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0)
@@ -474,12 +482,19 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
     SplatGrid &sg = s->sg;
     sg.AP = s->X + 8;
     sg.AH = Y + 8;
-    sg.TXn = (s->X + 1 + STX - 1) / STX;
+    sg.TXn = (s->X + 2 + STX - 1) / STX; // anchors 0 .. X (+1 right of a seam)
     sg.TYn = (Y + 1 + STY - 1) / STY;
     rc = dalloc(s, &sg.acc4, (size_t)sg.AP * sg.AH);
     if (rc == WX_OK) rc = dalloc(s, &sg.acc2, (size_t)sg.AP * sg.AH);
     if (rc == WX_OK) rc = dalloc(s, &sg.dirty, (size_t)sg.TXn * sg.TYn);
     if (rc == WX_OK) rc = dalloc(s, &sg.fb_zero, (size_t)sg.TXn * sg.TYn);
+    if (rc == WX_OK && halo > 0) rc = dalloc(s, &s->keys, (size_t)n_droplets);
+    if (rc == WX_OK && halo > 0) {
+      if (hipMemset(s->keys, 0, (size_t)n_droplets * 4) != hipSuccess) rc = WX_E_DEVICE;
+      int xoff = (x0 - halo) % X_global;
+      if (xoff < 0) xoff += X_global;
+      s->seam = (xoff > 0 && xoff + s->X > X_global) ? X_global - xoff : 0;
+    }
   }
   if (rc != WX_OK) {
     g_create_error = s->err;
@@ -521,6 +536,7 @@ void wx_destroy(wx_sim *s)
   hipFree(s->snd_W);
   hipFree(s->snd_Vel);
   hipFree(s->state);
+  hipFree(s->keys);
   hipFree(s->slow_ctx);
   hipFree(s->full_ctx);
   hipFree(s->water[2]);
@@ -634,17 +650,27 @@ int wx_step(wx_sim *s, int n_iter)
       u.iterI = (int)u.iterNum;
       {
         ProfScope ps(s, K_PRECIP);
+        SlabP sp{0, s->X, 0, s->X, 0, 0, nullptr};
+        if (s->keys) { // slab: the grid of this iteration is valid on the owned columns + (halo - 6*(j+1)) ghost columns; the
+          // feedback texture is exact where every droplet within a sprite radius (6 px) was processed, so the owned columns
+          // need 6 valid ghost columns even in the last iteration of a period
+          const int margin = s->halo - WX_SLAB_CONE * (s->period_j + 1);
+          if (margin < 6)
+            return fail(s, WX_E_STATE, "wx_step: %d iterations since the last halo exchange, %d ghost columns allow %d with particles",
+                        s->period_j + 1, s->halo, (s->halo - 6) / WX_SLAB_CONE);
+          sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, (s->period_j + 1) * 2048 + (1023 - s->rank), s->keys};
+        }
         hipLaunchKernelGGL(k_precipitation, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, u, s->n_drops, s->drops[src],
-                           (fused || dry) ? s->base[2] : s->base[1], s->water[1], s->state, s->drops[dst], s->sg);
+                           (fused || dry) ? s->base[2] : s->base[1], s->water[1], s->state, s->drops[dst], s->sg, sp);
       }
       {
         ProfScope ps(s, K_SPLAT);
         hipLaunchKernelGGL(k_splat_box, dim3((s->X + STX - 1) / STX, (s->Y + STY - 1) / STY), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->state,
-                           s->fb, s->dep);
+                           s->fb, s->dep, s->seam, s->keys ? 0 : 1);
       }
       {
         ProfScope ps(s, K_LIGHTNING);
-        hipLaunchKernelGGL(k_lightning, dim3(1), dim3(64), 0, s->stream, u.iterNum, (int)(s->iter % 600 == 0), s->fb, s->state);
+        hipLaunchKernelGGL(k_lightning, dim3(1), dim3(64), 0, s->stream, u.iterNum, (int)(s->iter % 600 == 0), s->fb, s->state, s->keys ? 0 : 1);
       }
       {
         ProfScope ps(s, K_SPLAT);
@@ -652,6 +678,7 @@ int wx_step(wx_sim *s, int n_iter)
       }
       s->drop_cur = dst;
       s->fb_dirty = true;
+      if (s->keys) s->period_j++;
     } else if (s->fb_dirty) { // particles were switched off: the reference's clear leaves both textures zero
       hipMemsetAsync(s->fb, 0, n * 16, s->stream);
       hipMemsetAsync(s->dep, 0, n * 8, s->stream);
@@ -761,7 +788,9 @@ void *wx_device_ptr(wx_sim *s, int field)
 
 int wx_local_width(const wx_sim *s) { return s ? s->X : 0; }
 
-size_t wx_halo_bytes(const wx_sim *s) { return s ? (size_t)s->halo * s->Y * (4 * 16 + 4) : 0; }
+// base_0, water_1, light_0, light_1 (float4), wall_0 (char4); handles that carry particles also exchange the feedback
+// (float4) and deposition (float2) textures, which the boundary pass of the next iteration reads
+size_t wx_halo_bytes(const wx_sim *s) { return s ? (size_t)s->halo * s->Y * (4 * 16 + 4 + (s->keys ? 16 + 8 : 0)) : 0; }
 
 static int halo_xstart(const wx_sim *s, int side, bool pack)
 {
@@ -774,10 +803,11 @@ int wx_halo_pack(wx_sim *s, int side, void *dev_buf)
   if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
   if (s->halo == 0) return fail(s, WX_E_STATE, "handle has no halo");
   const int n = s->halo * s->Y;
-  HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->wall[0]};
+  HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->wall[0], s->keys ? s->fb : nullptr, s->keys ? s->dep : nullptr};
+  const size_t o8 = (size_t)n * (s->keys ? 80 : 64), o4 = o8 + (s->keys ? (size_t)n * 8 : 0);
   ProfScope ps(s, K_HALO);
   hipLaunchKernelGGL(k_halo_pack, dim3((n + 255) / 256), dim3(256), 0, s->stream, f, s->X, s->Y, s->halo, halo_xstart(s, side, true),
-                     (float4 *)dev_buf, (char4 *)((char *)dev_buf + (size_t)n * 64));
+                     (float4 *)dev_buf, (float2 *)((char *)dev_buf + o8), (char4 *)((char *)dev_buf + o4));
   HIPCHK(s, hipGetLastError());
   return WX_OK;
 }
@@ -787,11 +817,77 @@ int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
   if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
   if (s->halo == 0) return fail(s, WX_E_STATE, "handle has no halo");
   const int n = s->halo * s->Y;
-  HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->wall[0]};
+  HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->wall[0], s->keys ? s->fb : nullptr, s->keys ? s->dep : nullptr};
+  const size_t o8 = (size_t)n * (s->keys ? 80 : 64), o4 = o8 + (s->keys ? (size_t)n * 8 : 0);
   ProfScope ps(s, K_HALO);
   hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256), dim3(256), 0, s->stream, f, s->X, s->Y, s->halo, halo_xstart(s, side, false),
-                     (const float4 *)dev_buf, (const char4 *)((const char *)dev_buf + (size_t)n * 64));
+                     (const float4 *)dev_buf, (const float2 *)((const char *)dev_buf + o8), (const char4 *)((const char *)dev_buf + o4));
+  if (s->keys) { // the ghost tiles of the feedback texture now hold a neighbour's values: nothing is "known zero" any more
+    hipMemsetAsync(s->sg.fb_zero, 0, (size_t)s->sg.TXn * s->sg.TYn, s->stream);
+    s->fb_dirty = true;
+  }
   HIPCHK(s, hipGetLastError());
+  return WX_OK;
+}
+
+// ---- particles on slabs: reconciliation of the replicated droplet pool (protocol in slab.py / SlabP) ----
+int wx_slab_set_rank(wx_sim *s, int rank)
+{
+  if (!s || rank < 0 || rank > 1023) return WX_E_INVALID;
+  s->rank = rank;
+  return WX_OK;
+}
+
+int wx_slab_period_begin(wx_sim *s)
+{
+  if (!s) return WX_E_INVALID;
+  s->period_j = 0;
+  return WX_OK;
+}
+
+int wx_particles_keys(wx_sim *s, int32_t *dev_keys_out)
+{
+  if (!s || !dev_keys_out) return WX_E_INVALID;
+  if (!s->keys) return fail(s, WX_E_STATE, "wx_particles_keys: not a slab handle with particles");
+  HIPCHK(s, hipMemcpyAsync(dev_keys_out, s->keys, (size_t)s->n_drops * 4, hipMemcpyDeviceToDevice, s->stream));
+  return WX_OK;
+}
+
+int wx_particles_contribute(wx_sim *s, const int32_t *dev_winner_keys, float *dev_state_out)
+{
+  if (!s || !dev_winner_keys || !dev_state_out) return WX_E_INVALID;
+  if (!s->keys) return fail(s, WX_E_STATE, "wx_particles_contribute: not a slab handle with particles");
+  hipLaunchKernelGGL(k_drops_contribute, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->keys, dev_winner_keys,
+                     s->drops[s->drop_cur], dev_state_out);
+  HIPCHK(s, hipGetLastError());
+  return WX_OK;
+}
+
+int wx_particles_adopt(wx_sim *s, const int32_t *dev_winner_keys, const float *dev_state, int refresh_inactive)
+{
+  if (!s || !dev_winner_keys || !dev_state) return WX_E_INVALID;
+  if (!s->keys) return fail(s, WX_E_STATE, "wx_particles_adopt: not a slab handle with particles");
+  if (refresh_inactive) HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 4, s->stream));
+  hipLaunchKernelGGL(k_drops_adopt, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->keys, dev_winner_keys, dev_state,
+                     s->drops[s->drop_cur], s->state, refresh_inactive);
+  if (refresh_inactive) hipLaunchKernelGGL(k_inactive_from_count, dim3(1), dim3(1), 0, s->stream, s->state);
+  HIPCHK(s, hipGetLastError());
+  return WX_OK;
+}
+
+int wx_lightning_get(wx_sim *s, float out[4])
+{
+  if (!s || !out) return WX_E_INVALID;
+  HIPCHK(s, hipMemcpyAsync(out, s->state->lightning, 16, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(s, hipStreamSynchronize(s->stream));
+  return WX_OK;
+}
+
+int wx_lightning_set(wx_sim *s, const float in[4])
+{
+  if (!s || !in) return WX_E_INVALID;
+  HIPCHK(s, hipMemcpyAsync(s->state->lightning, in, 16, hipMemcpyHostToDevice, s->stream));
+  HIPCHK(s, hipStreamSynchronize(s->stream));
   return WX_OK;
 }
 

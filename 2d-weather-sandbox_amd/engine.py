@@ -30,7 +30,8 @@ EXPORTS = [
     "wx_create", "wx_create_slab", "wx_destroy", "wx_last_error", "wx_abi_version", "wx_upload", "wx_set_params",
     "wx_step", "wx_sync", "wx_get_iter", "wx_set_iter", "wx_read_rect", "wx_read_particles", "wx_set_stream",
     "wx_device_ptr", "wx_local_width", "wx_halo_bytes", "wx_halo_pack", "wx_halo_unpack", "wx_profile",
-    "wx_profile_read", "wx_kernel_count", "wx_kernel_name",
+    "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_particles_keys",
+    "wx_particles_contribute", "wx_particles_adopt", "wx_lightning_get", "wx_lightning_set",
 ]
 
 
@@ -93,6 +94,13 @@ def lib() -> C.CDLL:
     L.wx_kernel_count.restype = i32
     L.wx_kernel_name.argtypes = [i32]
     L.wx_kernel_name.restype = C.c_char_p
+    L.wx_slab_set_rank.argtypes = [vp, i32]
+    L.wx_slab_period_begin.argtypes = [vp]
+    L.wx_particles_keys.argtypes = [vp, vp]
+    L.wx_particles_contribute.argtypes = [vp, vp, vp]
+    L.wx_particles_adopt.argtypes = [vp, vp, vp, i32]
+    L.wx_lightning_get.argtypes = [vp, vp]
+    L.wx_lightning_set.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -216,6 +224,31 @@ class Handle:
 
     def halo_unpack(self, side: int, dev_ptr: int):
         self._chk(lib().wx_halo_unpack(self._h, side, C.c_void_p(dev_ptr)))
+
+    # ---- particles on slabs (device pointers; see include/wxsim.h) ----
+    def slab_set_rank(self, rank: int):
+        self._chk(lib().wx_slab_set_rank(self._h, rank))
+
+    def slab_period_begin(self):
+        self._chk(lib().wx_slab_period_begin(self._h))
+
+    def particles_keys(self, dev_ptr: int):
+        self._chk(lib().wx_particles_keys(self._h, C.c_void_p(dev_ptr)))
+
+    def particles_contribute(self, dev_winner: int, dev_state_out: int):
+        self._chk(lib().wx_particles_contribute(self._h, C.c_void_p(dev_winner), C.c_void_p(dev_state_out)))
+
+    def particles_adopt(self, dev_winner: int, dev_state: int, refresh_inactive: bool = False):
+        self._chk(lib().wx_particles_adopt(self._h, C.c_void_p(dev_winner), C.c_void_p(dev_state), 1 if refresh_inactive else 0))
+
+    def lightning(self) -> np.ndarray:
+        out = np.zeros(4, np.float32)
+        self._chk(lib().wx_lightning_get(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_lightning(self, v):
+        v = np.ascontiguousarray(v, np.float32)
+        self._chk(lib().wx_lightning_set(self._h, v.ctypes.data_as(C.c_void_p)))
 
     def profile(self, enable: bool):
         self._chk(lib().wx_profile(self._h, 1 if enable else 0))

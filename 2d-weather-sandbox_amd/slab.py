@@ -9,6 +9,12 @@ owned columns of the carried state (base_0, wall_0, water_1, both light textures
 ring neighbours with point-to-point send/recv (RCCL over xGMI on GPUs, gloo in the CPU tests) and unpacked
 into their ghost columns. There is no collective on the data path.
 
+Particles (``n_droplets > 0``): every rank holds the whole droplet pool and processes, redundantly in the ghost
+zones, the droplets whose sample position lies where its grid is still valid (csrc/wx_kernels.h, ``SlabP``). At every
+halo exchange (which then also carries the feedback / deposition textures) the pool is reconciled: all-reduce(MAX)
+of the per-droplet claim keys, all-reduce(SUM) of the winners' states (the 4-float lightning state rides along) --
+the only collectives of the path, ``20 B x n_droplets`` every ``(halo - 6) // 6`` iterations.
+
 ``SlabSim`` is written against a small engine interface so that the identical exchange logic runs on the HIP
 engine (``HipSlabEngine``, device tensors + NCCL) and on a checker engine in the CPU tests (gloo).
 """
@@ -37,16 +43,43 @@ def slab_columns(X: int, rank: int, world: int):
 class HipSlabEngine:
     """One slab on one GPU through the C ABI (wx_create_slab / wx_halo_pack / wx_halo_unpack)."""
 
-    def __init__(self, X_global: int, Y: int, x0: int, X_owned: int, halo: int, device: torch.device):
+    def __init__(self, X_global: int, Y: int, x0: int, X_owned: int, halo: int, device: torch.device, n_droplets: int = 0,
+                 rank: int = 0):
         self.device = device
         torch.cuda.set_device(device)
-        self.h = Handle(X_owned, Y, 0, X_global=X_global, x0=x0, halo=halo)
+        self.n_droplets = n_droplets
+        self.h = Handle(X_owned, Y, n_droplets, X_global=X_global, x0=x0, halo=halo)
+        self.h.slab_set_rank(rank)
         # run the kernels on torch's current stream so that they are ordered with the NCCL send/recv ops
         self.h.set_stream(torch.cuda.current_stream(device).cuda_stream)
         self.nbytes = self.h.halo_bytes()
 
-    def upload(self, base, water, wall):
-        self.h.upload(base, water, wall)
+    def upload(self, base, water, wall, drops=None):
+        self.h.upload(base, water, wall, drops)
+
+    # particle pool reconciliation (device tensors in, device tensors out)
+    def new_particle_buffers(self):
+        """(claim keys, droplet states): one extra int / five extra floats at the end carry the lightning state."""
+        return (torch.zeros(self.n_droplets + 1, dtype=torch.int32, device=self.device),
+                torch.zeros(self.n_droplets * 5 + 5, dtype=torch.float32, device=self.device))
+
+    def particle_keys(self, keys: torch.Tensor):
+        self.h.particles_keys(keys.data_ptr())
+
+    def particle_contribute(self, winner: torch.Tensor, state: torch.Tensor):
+        self.h.particles_contribute(winner.data_ptr(), state.data_ptr())
+
+    def particle_adopt(self, winner: torch.Tensor, state: torch.Tensor, refresh_inactive: bool):
+        self.h.particles_adopt(winner.data_ptr(), state.data_ptr(), refresh_inactive)
+
+    def lightning(self):
+        return self.h.lightning()
+
+    def set_lightning(self, v):
+        self.h.set_lightning(v)
+
+    def period_begin(self):
+        self.h.slab_period_begin()
 
     def set_params(self, u: Dict[str, Any]):
         self.h.set_params(params.fill_struct(params.WxParams(), u), u["initial_T"], u.get("sounding_T"), u.get("sounding_W"),
@@ -75,12 +108,22 @@ class SlabSim:
         if world > 1 and halo < CONE_PER_ITERATION:
             raise ValueError(f"halo must be >= {CONE_PER_ITERATION}")
         self.engine, self.rank, self.world, self.halo = engine, rank, world, halo
-        self.iters_per_exchange = max(1, halo // CONE_PER_ITERATION)
+        self.particles = getattr(engine, "n_droplets", 0) > 0
+        # with particles the owned columns need a sprite radius (6 px) of valid ghost columns in the last iteration too
+        self.iters_per_exchange = max(1, (halo - 6 if self.particles else halo) // CONE_PER_ITERATION)
         self.left, self.right = (rank - 1) % world, (rank + 1) % world
         self._since_exchange = 0
+        self._iters = 0
         if world > 1:
             self.send = [engine.new_buffer(), engine.new_buffer()]  # [to left, to right]
             self.recv = [engine.new_buffer(), engine.new_buffer()]  # [from left, from right]
+            if self.particles:
+                self.keys, self.state = engine.new_particle_buffers()
+            # gloo has no device-tensor send/recv (it is the CPU-test / single-GPU plumbing transport): stage through the host
+            self._stage = dist.get_backend() == "gloo" and self.send[0].is_cuda
+            if self._stage:
+                self._hsend = [torch.empty_like(b, device="cpu") for b in self.send]
+                self._hrecv = [torch.empty_like(b, device="cpu") for b in self.recv]
 
     @property
     def handle(self):
@@ -93,18 +136,50 @@ class SlabSim:
         e = self.engine
         e.pack(0, self.send[0])
         e.pack(1, self.send[1])
+        send, recv = self.send, self.recv
+        if self._stage:
+            e.sync()
+            for hb, b in zip(self._hsend, self.send):
+                hb.copy_(b)
+            send, recv = self._hsend, self._hrecv
         if self.world == 2:
             # both neighbours are the same rank: order the two messages identically on both sides
-            ops = [dist.P2POp(dist.isend, self.send[0], self.left), dist.P2POp(dist.isend, self.send[1], self.right),
-                   dist.P2POp(dist.irecv, self.recv[1], self.right), dist.P2POp(dist.irecv, self.recv[0], self.left)]
+            ops = [dist.P2POp(dist.isend, send[0], self.left), dist.P2POp(dist.isend, send[1], self.right),
+                   dist.P2POp(dist.irecv, recv[1], self.right), dist.P2POp(dist.irecv, recv[0], self.left)]
         else:
-            ops = [dist.P2POp(dist.isend, self.send[0], self.left), dist.P2POp(dist.irecv, self.recv[1], self.right),
-                   dist.P2POp(dist.isend, self.send[1], self.right), dist.P2POp(dist.irecv, self.recv[0], self.left)]
+            ops = [dist.P2POp(dist.isend, send[0], self.left), dist.P2POp(dist.irecv, recv[1], self.right),
+                   dist.P2POp(dist.isend, send[1], self.right), dist.P2POp(dist.irecv, recv[0], self.left)]
         for r in dist.batch_isend_irecv(ops):
             r.wait()
+        if self._stage:
+            for hb, b in zip(self._hrecv, self.recv):
+                b.copy_(hb)
         e.unpack(0, self.recv[0])  # left ghosts  <- left neighbour's right edge
         e.unpack(1, self.recv[1])  # right ghosts <- right neighbour's left edge
+        if self.particles:
+            self.reconcile_particles()
         self._since_exchange = 0
+
+    def reconcile_particles(self):
+        """Make every rank's copy of the droplet pool the copy of the rank that tracked each droplet last, and every
+        rank's lightning state the latest strike any rank registered. Two all-reduces: MAX over the claim keys (+ the
+        strike iteration), SUM over the winners' states (+ the winning strike)."""
+        e, n = self.engine, self.engine.n_droplets
+        e.particle_keys(self.keys)
+        strike = np.asarray(e.lightning(), np.float32)  # (x, y, iteration, intensity), lightningLocationShader.frag:24-38
+        self.keys[n] = int(strike[2])
+        dist.all_reduce(self.keys, op=dist.ReduceOp.MAX)
+        e.particle_contribute(self.keys, self.state)
+        mine = strike[2] > 0 and int(strike[2]) == int(self.keys[n])
+        self.state[5 * n:] = torch.tensor([1.0, *strike] if mine else [0.0] * 5, dtype=torch.float32)
+        dist.all_reduce(self.state, op=dist.ReduceOp.SUM)
+        # the reference refreshes the `inactiveDroplets` uniform every 600 iterations (app.js:5957-5966)
+        refresh = (self._iters // 600) != ((self._iters - self._since_exchange) // 600)
+        e.particle_adopt(self.keys, self.state, refresh)
+        tail = self.state[5 * n:].cpu().numpy()
+        if tail[0] > 0:
+            e.set_lightning(tail[1:] / tail[0])  # identical copies from the ranks that share the strike
+        e.period_begin()
 
     def step(self, n: int):
         done = 0
@@ -113,6 +188,7 @@ class SlabSim:
             self.engine.step(k)
             done += k
             self._since_exchange += k
+            self._iters += k
             if self._since_exchange >= self.iters_per_exchange:
                 self.exchange()
 
@@ -122,23 +198,26 @@ class SlabSim:
     # ---- construction on the HIP engine ----
     @classmethod
     def from_generator(cls, pkg, X: int, Y: int, u: Dict[str, Any], rank: int, world: int, device: torch.device,
-                       halo: int = DEFAULT_HALO) -> "SlabSim":
-        """Each rank generates only its own slab (plus ghost columns) of the synthetic terrain grid."""
+                       halo: int = DEFAULT_HALO, drops=None, cloud_deck: bool = False) -> "SlabSim":
+        """Each rank generates only its own slab (plus ghost columns) of the synthetic terrain grid; ``drops`` is the
+        WHOLE droplet pool (identical on every rank)."""
         x0, xo = slab_columns(X, rank, world)
-        eng = HipSlabEngine(X, Y, x0, xo, halo, device)
+        eng = HipSlabEngine(X, Y, x0, xo, halo, device, 0 if drops is None else len(drops), rank)
         base, water, wall = pkg.synth.terrain_grid(X, Y, cols=(x0 - halo, xo + 2 * halo))
-        eng.upload(base, water, wall)
+        if cloud_deck:
+            pkg.synth.add_cloud_deck(water, wall)
+        eng.upload(base, water, wall, drops)
         eng.set_params(u)
         return cls(eng, rank, world, halo)
 
     @classmethod
     def from_arrays(cls, X: int, Y: int, base, water, wall, u: Dict[str, Any], rank: int, world: int, device: torch.device,
-                    halo: int = DEFAULT_HALO) -> "SlabSim":
-        """Cut this rank's slab out of whole-domain arrays (Y, X, 4)."""
+                    halo: int = DEFAULT_HALO, drops=None) -> "SlabSim":
+        """Cut this rank's slab out of whole-domain arrays (Y, X, 4); ``drops`` is the whole droplet pool."""
         x0, xo = slab_columns(X, rank, world)
         idx = (x0 - halo + np.arange(xo + 2 * halo)) % X
-        eng = HipSlabEngine(X, Y, x0, xo, halo, device)
-        eng.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]))
+        eng = HipSlabEngine(X, Y, x0, xo, halo, device, 0 if drops is None else len(drops), rank)
+        eng.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]), drops)
         eng.set_params(u)
         return cls(eng, rank, world, halo)
 

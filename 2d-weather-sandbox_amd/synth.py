@@ -136,3 +136,13 @@ def init_rain_drops(n: int, seed: int = 7) -> np.ndarray:
     d = rng.random((n, 5)).astype(np.float32)
     d[:, 2] = -10.0 + d[:, 2]
     return d
+
+
+def add_cloud_deck(water: np.ndarray, wall: np.ndarray) -> None:
+    """In place: a cloud layer between Y/4 and Y/2 (cloud water 1.5, total water raised accordingly) so that droplets
+    spawn, grow and fall during a benchmark run (BASELINE configs[4]). Works on whole grids and on column slabs."""
+    Y = wall.shape[0]
+    yy = np.arange(Y)[:, None]
+    deck = (wall[..., 1] != 0) & (yy > Y // 4) & (yy < Y // 2)
+    water[..., 1] = np.where(deck, 1.5, water[..., 1]).astype(np.float32)
+    water[..., 0] = np.where(deck, water[..., 0] + 1.5, water[..., 0]).astype(np.float32)

@@ -162,11 +162,7 @@ def main():
         h = pkg.engine.Handle(X, Y, a.particles)
         if a.particles:
             u["enablePrecipitation"] = 1
-            # a cloud deck so that droplets spawn, grow and fall during the run
-            yy = np.arange(Y)[:, None]
-            deck = (wall[..., 1] != 0) & (yy > Y // 4) & (yy < Y // 2)
-            water[..., 1] = np.where(deck, 1.5, water[..., 1]).astype(np.float32)
-            water[..., 0] = np.where(deck, water[..., 0] + 1.5, water[..., 0]).astype(np.float32)
+            pkg.synth.add_cloud_deck(water, wall)  # so that droplets spawn, grow and fall during the run
         h.upload(base, water, wall, pkg.synth.init_rain_drops(a.particles) if a.particles else None)
         del base, water, wall
         h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
@@ -176,7 +172,12 @@ def main():
         barrier = lambda: None
     else:
         from weather_sandbox_amd import slab
-        drv = slab.SlabSim.from_generator(pkg, X, Y, u, rank, world, torch.device("cuda", local_rank))
+        if a.particles:  # the whole droplet pool on every rank; halo 64: sprite clipping needs tile-aligned slab edges
+            u["enablePrecipitation"] = 1
+            drv = slab.SlabSim.from_generator(pkg, X, Y, u, rank, world, torch.device("cuda", local_rank), halo=64,
+                                              drops=pkg.synth.init_rain_drops(a.particles), cloud_deck=True)
+        else:
+            drv = slab.SlabSim.from_generator(pkg, X, Y, u, rank, world, torch.device("cuda", local_rank))
         stepper = drv.handle
         step = drv.step
         sync = lambda: (drv.sync(), torch.cuda.synchronize())
@@ -237,7 +238,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{X}x{Y} dry-air grid, pressure+velocity+advection only (BASELINE configs[1])" if a.workload == "dry" else f"{X}x{Y} terrain grid, all six grid passes + lighting, ") if a.workload == "dry" else f"{X}x{Y} terrain grid, all six grid passes + lighting, " + (f"{a.particles} precipitation particles (BASELINE configs[4] on one GPU)" if a.particles else "particles off (BASELINE configs[2])"),
-                       "grid": [X, Y], "decomposition": "none" if world == 1 else f"{world} x-slabs, 48 ghost columns, ring halo exchange every 8 iterations (RCCL send/recv)",
+                       "grid": [X, Y], "decomposition": "none" if world == 1 else (f"{world} x-slabs, 64 ghost columns, ring halo exchange + droplet-pool reconciliation (2 all-reduces) every 9 iterations" if a.particles else f"{world} x-slabs, 48 ghost columns, ring halo exchange every 8 iterations (RCCL send/recv)"),
                        "iteration_algorithmic_bytes_per_cell": 36 if a.workload == "dry" else 72},
             "iteration_roofline_frac_A_wet": cells * a.steps * (36 if a.workload == "dry" else 72) / dt / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roof,

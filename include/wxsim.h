@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WX_ABI_VERSION 1
+#define WX_ABI_VERSION 2
 
 /* error codes */
 #define WX_OK 0
@@ -105,6 +105,10 @@ int wx_create(int X, int Y, int n_droplets, wx_sim **out);
  * [x0, x0 + X_owned) of a periodic domain X_global wide and stores `halo` ghost columns on each side
  * (local width X_owned + 2*halo; local column i is global column (x0 - halo + i) mod X_global). */
 int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_droplets, wx_sim **out);
+/* Dependency cone of one iteration, columns per side: `halo` ghost columns stay exact for halo / WX_SLAB_CONE
+ * iterations ((halo - 6) / WX_SLAB_CONE with particles: the feedback texture needs every droplet within a sprite radius),
+ * then the halo must be exchanged (wx_halo_pack / wx_halo_unpack). */
+#define WX_SLAB_CONE 6
 
 void wx_destroy(wx_sim *s);
 const char *wx_last_error(const wx_sim *s); /* also valid with s == NULL for create failures */
@@ -146,12 +150,32 @@ int wx_read_particles(wx_sim *s, int first, int count, float *dst);
 int wx_set_stream(wx_sim *s, void *hip_stream);     /* NULL = legacy default stream */
 void *wx_device_ptr(wx_sim *s, int field);          /* device address of a field's current storage */
 int wx_local_width(const wx_sim *s);                /* X_owned + 2*halo */
-/* Halo exchange of the state carried across iterations (base_0, wall_0, water_1, both light textures):
+/* Halo exchange of the state carried across iterations (base_0, wall_0, water_1, both light textures; with particles also
+ * the feedback and deposition textures):
  * pack the `halo` outermost OWNED columns of one side into a contiguous device buffer / unpack a
  * neighbour's buffer into this handle's ghost columns. side: 0 = left (low x), 1 = right. */
 size_t wx_halo_bytes(const wx_sim *s);
 int wx_halo_pack(wx_sim *s, int side, void *dev_buf);
 int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf);
+
+/* Particles on slabs (n_droplets > 0 with halo > 0; halo and X_owned multiples of 64). Every rank holds the WHOLE droplet
+ * pool (same wx_upload drops array on every rank) and, in each iteration, processes the droplets whose sample position
+ * (precipitationShader.vert:82-84 spawn probe, or own position) lies in the columns where its grid is still valid; a
+ * droplet processed inside the OWNED columns in iteration j of the exchange period gets the claim key
+ * (j+1)*2048 + (still active ? 1024 : 0) + (1023 - rank). At the end of a period (when the halo is exchanged; the halo buffers then also carry the
+ * feedback / deposition textures) the ranks reconcile the pool:
+ *   wx_particles_keys -> all-reduce(MAX) -> wx_particles_contribute -> all-reduce(SUM) -> wx_particles_adopt,
+ *   lightning state: wx_lightning_get -> pick the latest strike -> wx_lightning_set;  then wx_slab_period_begin.
+ * All buffers are DEVICE pointers (n_droplets int32 keys, 5*n_droplets floats); calls are enqueued on the handle's stream.
+ * refresh_inactive != 0 also refreshes the `inactiveDroplets` uniform from the reconciled pool (the reference does that
+ * every 600 iterations, app.js:5957-5966). */
+int wx_slab_set_rank(wx_sim *s, int rank);
+int wx_slab_period_begin(wx_sim *s);
+int wx_particles_keys(wx_sim *s, int32_t *dev_keys_out);
+int wx_particles_contribute(wx_sim *s, const int32_t *dev_winner_keys, float *dev_state_out);
+int wx_particles_adopt(wx_sim *s, const int32_t *dev_winner_keys, const float *dev_state, int refresh_inactive);
+int wx_lightning_get(wx_sim *s, float out[4]);
+int wx_lightning_set(wx_sim *s, const float in[4]);
 
 /* Per-kernel device time from HIP events recorded on the handle's stream around every launch.
  * wx_profile(s, 1) starts collecting, wx_profile_read returns accumulated milliseconds and launch counts

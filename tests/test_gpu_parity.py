@@ -367,6 +367,117 @@ def test_slab_handles_equal_whole_domain(pkg, E, fused, nslab, halo):
             assert np.array_equal(h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]), (f, r)
 
 
+@pytest.mark.parametrize("nslab", [2, 4])
+def test_slab_particles_equal_whole_domain(pkg, E, nslab):
+    """Particles on column slabs (replicated droplet pool, ghost-zone processing, claim-key reconciliation): N slab
+    handles on one GPU, the collectives of slab.py emulated with torch ops, against the undecomposed handle. Droplets
+    sit on slab edges, in ghost zones and within a sprite radius of the domain edge (sprites are clipped there, never
+    wrapped). Droplet arithmetic is order independent; the splat sums are fp32 atomics, so fields agree to summation
+    order."""
+    import torch
+    X, Y, halo, n_iter, N = 512, 128, 64, 25, 6000
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    pkg.synth.add_cloud_deck(water, wall)
+    rng = np.random.default_rng(4)
+    air = wall[..., 1] != 0
+    base[..., 0] += np.where(air, rng.normal(0, 0.3, (Y, X)), 0).astype(np.float32)  # droplets drift across slab edges
+    drops = pkg.synth.init_rain_drops(N)
+    na = 2500  # active droplets: everywhere, plus clusters on the slab edges and on the domain edge
+    px = rng.uniform(-1, 1, na)
+    xo = X // nslab
+    for k, e in enumerate(np.arange(nslab) * xo):
+        px[k * 200:(k + 1) * 200] = (e + rng.uniform(-8, 8, 200)) / X * 2 - 1
+    px[1000:1200] = np.where(rng.random(200) < 0.5, -1 + rng.uniform(0, 7, 200) * 2 / X, 1 - rng.uniform(0, 7, 200) * 2 / X)
+    drops[:na, 0] = ((px + 1) % 2 - 1).astype(np.float32)
+    drops[:na, 1] = rng.uniform(-0.6, 0.2, na).astype(np.float32)
+    drops[:na, 2] = rng.uniform(0.1, 1.0, na).astype(np.float32)
+    drops[:na, 3] = np.where(rng.random(na) < 0.3, rng.uniform(0.1, 0.5, na), 0).astype(np.float32)
+    drops[:na, 4] = 1.0
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 35.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 1
+    u["inactiveDroplets"] = float(N - na)
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    whole = E.Handle(X, Y, N)
+    whole.upload(base, water, wall, drops)
+    whole.set_params(p, u["initial_T"])
+    slabs, bufs = [], []
+    for r in range(nslab):
+        h = E.Handle(xo, Y, N, X_global=X, x0=r * xo, halo=halo)
+        h.slab_set_rank(r)
+        idx = (r * xo - halo + np.arange(xo + 2 * halo)) % X
+        h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]), drops)
+        h.set_params(p, u["initial_T"])
+        assert h.halo_bytes() == halo * Y * 92  # + feedback 16 + deposition 8
+        slabs.append(h)
+        bufs.append([torch.empty(h.halo_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2)])
+    keys = [torch.zeros(N, dtype=torch.int32, device="cuda") for _ in range(nslab)]
+    state = [torch.zeros(5 * N, dtype=torch.float32, device="cuda") for _ in range(nslab)]
+    per = (halo - 6) // 6  # a sprite radius of valid ghost columns must remain in the last iteration
+    with pytest.raises(E.WxError):  # more iterations than the ghost columns allow
+        slabs[0].step(per + 1)
+    for h in slabs:  # ... the failed call did run `per` iterations on slab 0: start over
+        h.close()
+    slabs = []
+    for r in range(nslab):
+        h = E.Handle(xo, Y, N, X_global=X, x0=r * xo, halo=halo)
+        h.slab_set_rank(r)
+        idx = (r * xo - halo + np.arange(xo + 2 * halo)) % X
+        h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]), drops)
+        h.set_params(p, u["initial_T"])
+        slabs.append(h)
+    done = 0
+    while done < n_iter:
+        k = min(per, n_iter - done)
+        for h in slabs:
+            h.step(k)
+        done += k
+        for r, h in enumerate(slabs):
+            h.halo_pack(0, bufs[r][0].data_ptr())
+            h.halo_pack(1, bufs[r][1].data_ptr())
+        for h in slabs:
+            h.sync()
+        for r, h in enumerate(slabs):
+            h.halo_unpack(0, bufs[(r - 1) % nslab][1].data_ptr())
+            h.halo_unpack(1, bufs[(r + 1) % nslab][0].data_ptr())
+        # reconcile_particles() of slab.py with the all-reduces spelled out
+        for r, h in enumerate(slabs):
+            h.particles_keys(keys[r].data_ptr())
+            h.sync()
+        win = torch.stack(keys).max(0).values.contiguous()
+        assert int((win > 0).sum()) == N  # every droplet was tracked inside somebody's owned columns
+        for r, h in enumerate(slabs):
+            h.particles_contribute(win.data_ptr(), state[r].data_ptr())
+            h.sync()
+        total = torch.stack(state).sum(0).contiguous()
+        best = max((h.lightning() for h in slabs), key=lambda v: float(v[2]))
+        for h in slabs:
+            h.particles_adopt(win.data_ptr(), total.data_ptr(), False)
+            h.set_lightning(best)
+            h.slab_period_begin()
+            h.sync()
+    whole.step(n_iter)
+    d_ref = whole.read_particles()
+    assert (d_ref[:, 2] >= 0).sum() > 500 and (d_ref[:, 2] < 0).sum() > 500
+    for h in slabs:
+        d = h.read_particles()
+        assert np.array_equal(d[:, 2] >= 0, d_ref[:, 2] >= 0), "same droplets active"
+        assert np.abs(d - d_ref).max() <= 1e-6
+    tol = {"PRECIP_FB": 1e-6, "PRECIP_DEP": 1e-6, "BASE_CUR": 1e-6, "WATER_CUR": 1e-6}
+    for f, t in tol.items():
+        ref = whole.read_rect(f)
+        for r, h in enumerate(slabs):
+            a, b = h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]
+            if f == "PRECIP_FB" and r == 0:  # texels (0,0) / (1,0) are the reference's mailboxes, not kept on slabs
+                a, b = a.copy(), b.copy()
+                a[0, :2], b[0, :2] = 0, 0
+            assert np.abs(a - b).max() <= t * max(1.0, np.abs(b).max()), (f, r, np.abs(a - b).max())
+    assert np.abs(whole.read_rect("PRECIP_FB")).max() > 0
+    for r, h in enumerate(slabs):
+        assert np.array_equal(h.read_rect("WALL_CUR", halo, 0, xo, Y), whole.read_rect("WALL_CUR")[:, r * xo:(r + 1) * xo])
+
+
 def test_brush_and_airplane_inputs_bit_exact(pkg, oracle, E, fused):
     """Next-row (f1): user brush (every tool of advectionShader.frag:229-401) and airplane inputs (:415-457):
     HIP == oracle bit for bit, on the inputs/uniforms of the reference goldens (tests/golden/brush64.npz)."""

@@ -135,3 +135,102 @@ def test_slab_geometry(pkg):
         slab.slab_columns(100, 0, 3)
     with pytest.raises(ValueError):
         slab.SlabSim(object(), 0, 2, 4)
+
+
+class MockParticleEngine:
+    """The particle side of the slab-engine interface with scripted claim keys: checks SlabSim.reconcile_particles()
+    (two all-reduces; the lightning state rides along) without any physics."""
+
+    def __init__(self, rank, world, n):
+        self.rank, self.world, self.n_droplets = rank, world, n
+        rng = np.random.default_rng(100 + rank)
+        self.pool = rng.random((n, 5)).astype(np.float32) + rank  # this rank's (possibly stale) copy
+        self.my_keys = np.zeros(n, np.int32)
+        self.strike = np.zeros(4, np.float32)
+        self.adopted_refresh = None
+        self.periods = 0
+
+    # grid side: nothing to exchange
+    def new_buffer(self):
+        return torch.zeros(8, dtype=torch.uint8)
+
+    def pack(self, side, buf):
+        pass
+
+    def unpack(self, side, buf):
+        pass
+
+    def step(self, n):
+        pass
+
+    def sync(self):
+        pass
+
+    def new_particle_buffers(self):
+        return torch.zeros(self.n_droplets + 1, dtype=torch.int32), torch.zeros(5 * self.n_droplets + 5, dtype=torch.float32)
+
+    def particle_keys(self, keys):
+        keys[:self.n_droplets] = torch.from_numpy(self.my_keys)
+
+    def particle_contribute(self, winner, state):
+        w = winner[:self.n_droplets].numpy()
+        mine = (w > 0) & (w == self.my_keys)
+        state[:5 * self.n_droplets] = torch.from_numpy(np.where(mine[:, None], self.pool, 0).astype(np.float32).reshape(-1))
+
+    def particle_adopt(self, winner, state, refresh):
+        w = winner[:self.n_droplets].numpy()
+        st = state[:5 * self.n_droplets].numpy().reshape(-1, 5)
+        self.pool = np.where((w > 0)[:, None], st, self.pool).astype(np.float32)
+        self.my_keys[:] = 0
+        self.adopted_refresh = refresh
+
+    def lightning(self):
+        return self.strike
+
+    def set_lightning(self, v):
+        self.strike = np.asarray(v, np.float32).copy()
+
+    def period_begin(self):
+        self.periods += 1
+
+
+def _particle_worker(rank, world, port, n, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import wxpkg
+    wxpkg.load_package()
+    from weather_sandbox_amd import slab
+    eng = MockParticleEngine(rank, world, n)
+    drv = slab.SlabSim(eng, rank, world, 64)
+    assert drv.particles and drv.iters_per_exchange == (64 - 6) // 6
+    rng = np.random.default_rng(5)  # the same script on every rank
+    owner = rng.integers(-1, world, n)  # -1: nobody processed the droplet in its owned columns
+    it = rng.integers(1, 10, n)
+    eng.my_keys = np.where(owner == rank, it * 2048 + 1024 + (1023 - rank), 0).astype(np.int32)
+    # a stale inactive copy on rank 0 that evaluated a probe in the SAME (last) iteration must lose against the active copy
+    eng.my_keys[0] = 9 * 2048 + (1024 if rank == world - 1 else 0) + (1023 - rank) if rank in (0, world - 1) else 0
+    owner[0] = world - 1
+    eng.strike = np.array([0.1 * rank, 0.2, 40.0 + rank, 1.5], np.float32) if rank > 0 else np.zeros(4, np.float32)
+    before = eng.pool.copy()
+    drv.step(drv.iters_per_exchange)  # one full period -> exchange() -> reconcile_particles()
+    np.savez(os.path.join(out_dir, f"p{rank}.npz"), before=before, after=eng.pool, owner=owner, strike=eng.strike, periods=eng.periods,
+             refresh=bool(eng.adopted_refresh))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_particle_pool_reconciliation(tmp_path, world):
+    """slab.SlabSim.reconcile_particles over gloo: every rank ends with the winner's copy of every droplet, unclaimed
+    droplets keep the local copy, the latest lightning strike reaches everybody."""
+    n = 500
+    mp.spawn(_particle_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), f"p{r}.npz")) for r in range(world)]
+    owner = res[0]["owner"]
+    for r in range(world):
+        for i in range(n):
+            want = res[r]["before"][i] if owner[i] < 0 else res[owner[i]]["before"][i]
+            assert np.array_equal(res[r]["after"][i], want), (r, i, owner[i])
+        assert np.allclose(res[r]["strike"], [0.1 * (world - 1), 0.2, 40.0 + world - 1, 1.5])
+        assert int(res[r]["periods"]) == 1 and not bool(res[r]["refresh"])
