@@ -45,11 +45,23 @@ struct FusedAIn {
   const float4 *water, *light, *fb;
   const float2 *dep;
 };
+// Copy-on-write of kernel A's water / wall outputs: away from terrain and without particle feedback the boundary pass
+// returns both bit-identical to its inputs. Kernel A then leaves the 64x16 tile unwritten and sets clean[tile] = 1, and
+// kernel B reads such tiles from A's INPUT buffers (water_alt / wall_alt). 20 of kernel A's 88 B/cell disappear for
+// every clean tile; results are unchanged by construction (the skipped stores would have written the same bits).
 struct FusedBIn {
   const float4 *base, *water;
   const char4 *wall;
   const float4 *light;
+  const float4 *water_alt; // what kernel A read: valid wherever clean[tile] != 0
+  const char4 *wall_alt;
+  const unsigned char *clean; // per tile, row pitch txn; nullptr = every tile was written
+  int txn;
+  __device__ __forceinline__ bool is_clean(int gx, int gy) const { return clean && clean[(gy >> 4) * txn + (gx >> 6)]; }
+  __device__ __forceinline__ float4 water_at(int gx, int gy, size_t gi) const { return (is_clean(gx, gy) ? water_alt : water)[gi]; }
+  __device__ __forceinline__ char4 wall_at(int gx, int gy, size_t gi) const { return (is_clean(gx, gy) ? wall_alt : wall)[gi]; }
 };
+static_assert(TX == 64 && TY == 16, "is_clean() hard-codes the tile shape");
 
 __device__ __forceinline__ size_t fidx(int x, int y, int X) { return (size_t)y * X + x; }
 // wrap for i in [-n, 2n): tile halos of grids at least as large as the halo
@@ -153,7 +165,8 @@ struct LBoundaryAcc {
 // iteration of a wx_step call.
 template <bool WRITE_CURL>
 __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__restrict__ initial_T, FusedAIn in, float4 *__restrict__ base_out,
-                                                float4 *__restrict__ water_out, char4 *__restrict__ wall_out, float *__restrict__ curl_out)
+                                                float4 *__restrict__ water_out, char4 *__restrict__ wall_out, float *__restrict__ curl_out,
+                                                unsigned char *__restrict__ clean_out)
 {
   using namespace fa;
   __shared__ Smem sm;
@@ -207,12 +220,15 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
   // ---- stage 4: boundary on the tile ----
   const int cx = tid & (TX - 1);
   const int x = tx0 + cx;
-  if (x >= X) return;
+  constexpr int RPT = TY / (NTA / TX);
+  float4 wv[RPT];
+  char4 wlv[RPT];
+  bool same = true; // water and wall outputs of this thread's cells are bit-identical to the inputs
 #pragma unroll
-  for (int k = 0; k < TY / (NTA / TX); k++) {
+  for (int k = 0; k < RPT; k++) {
     const int cy = (tid / TX) + k * (NTA / TX);
     const int y = ty0 + cy;
-    if (y >= Y) break;
+    if (x >= X || y >= Y) continue;
     const size_t gi = fidx(x, y, X);
     LBoundaryAcc a{sm, in, in.water[gi], X, Y, x, y, cx, cy};
     float4 b, w;
@@ -226,10 +242,25 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
     boundary_cell(u, g, initial_T, x, y, a, b, w, wl);
 #endif
     base_out[gi] = b;
-    water_out[gi] = w;
-    wall_out[gi] = wl;
     if (WRITE_CURL) curl_out[gi] = sm.c[cy + 2][cx + 2];
+    wv[k] = w;
+    wlv[k] = wl;
+    const char4 w0 = a.wall(0, 0);
+    same = same && __float_as_int(w.x) == __float_as_int(a.w00.x) && __float_as_int(w.y) == __float_as_int(a.w00.y) &&
+           __float_as_int(w.z) == __float_as_int(a.w00.z) && __float_as_int(w.w) == __float_as_int(a.w00.w) && wl.x == w0.x && wl.y == w0.y &&
+           wl.z == w0.z && wl.w == w0.w;
   }
+  const int tile_clean = clean_out ? __syncthreads_and(same) : 0;
+  if (!tile_clean) {
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int y = ty0 + (tid / TX) + k * (NTA / TX);
+      if (x >= X || y >= Y) continue;
+      water_out[fidx(x, y, X)] = wv[k];
+      wall_out[fidx(x, y, X)] = wlv[k];
+    }
+  }
+  if (clean_out && tid == 0) clean_out[tby * tiles_x(X) + tbx] = (unsigned char)tile_clean;
 }
 
 // ================================================================================================
@@ -275,10 +306,18 @@ struct GAdvectAccB {
   int X, Y, x, y;
   __device__ __forceinline__ size_t at_off(int dx, int dy) const { return fidx(wrapmod(x + dx, X), wrapmod(y + dy, Y), X); }
   __device__ __forceinline__ float4 base(int dx, int dy) const { return in.base[at_off(dx, dy)]; }
-  __device__ __forceinline__ char4 wall(int dx, int dy) const { return in.wall[at_off(dx, dy)]; }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return wall_off(dx, dy); }
   __device__ __forceinline__ float4 base_off(int dx, int dy) const { return in.base[at_off(dx, dy)]; }
-  __device__ __forceinline__ float4 water_off(int dx, int dy) const { return in.water[at_off(dx, dy)]; }
-  __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return in.wall[at_off(dx, dy)]; }
+  __device__ __forceinline__ float4 water_off(int dx, int dy) const
+  {
+    const int gx = wrapmod(x + dx, X), gy = wrapmod(y + dy, Y);
+    return in.water_at(gx, gy, fidx(gx, gy, X));
+  }
+  __device__ __forceinline__ char4 wall_off(int dx, int dy) const
+  {
+    const int gx = wrapmod(x + dx, X), gy = wrapmod(y + dy, Y);
+    return in.wall_at(gx, gy, fidx(gx, gy, X));
+  }
 };
 
 // Context of the slow path, kept in device memory so that the out-of-line call passes pointers to global
@@ -358,6 +397,17 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, co
   tile_of_block(tiles_x(X), tbx, tby);
   const int tx0 = tbx * TX, ty0 = tby * TY;
   const bool small = (X < TX + 8) || (Y < TY + 8);
+  __shared__ unsigned char cflag[9];
+  if (tid < 9) {
+    const int gtx = tiles_x(X), gty = (Y + TY - 1) / TY;
+    const int nx = wrapfast(tbx + tid % 3 - 1, gtx), ny = wrapfast(tby + tid / 3 - 1, gty);
+    cflag[tid] = in.clean ? in.clean[ny * in.txn + nx] : 0;
+  }
+  __syncthreads();
+  int nclean = 0;
+#pragma unroll
+  for (int t = 0; t < 9; t++) nclean += cflag[t] != 0;
+  const bool mixed = (nclean != 0 && nclean != 9) || (small && in.clean != nullptr);
 
   // ---- stage 0: post-boundary base / water / wall tiles with halo ----
   for (int i = tid; i < IW * IH; i += NTB) {
@@ -366,8 +416,12 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, co
     const int gy = small ? wrapmod(ty0 + ly - HD, Y) : wrapfast(ty0 + ly - HD, Y);
     const size_t gi = fidx(gx, gy, X);
     sm.in.b.put(ly, lx, in.base[gi]);
-    sm.in.q.put(ly, lx, in.water[gi]);
-    sm.in.w[ly][lx] = in.wall[gi];
+    // tiles kernel A left unwritten are read from A's inputs; the 3x3 tile flags were staged in LDS. Almost always the
+    // nine flags agree (97 % of the tiles are clean away from terrain): then the choice is wave-uniform.
+    bool cl = nclean == 9;
+    if (mixed) cl = small ? in.is_clean(gx, gy) : (cflag[((ly >= HD) + (ly >= HD + TY)) * 3 + (lx >= HL) + (lx >= HL + TX)] != 0);
+    sm.in.q.put(ly, lx, (cl ? in.water_alt : in.water)[gi]);
+    sm.in.w[ly][lx] = (cl ? in.wall_alt : in.wall)[gi];
   }
   __syncthreads();
 
@@ -435,14 +489,27 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, co
   }
 }
 
+// fills the tiles of `dst` that kernel A left unwritten (clean != 0) from A's input buffer
+__global__ __launch_bounds__(256) void k_cow_resolve(int X, int Y, const unsigned char *__restrict__ clean, const float4 *__restrict__ src,
+                                                     float4 *__restrict__ dst)
+{
+  if (!clean[blockIdx.y * gridDim.x + blockIdx.x]) return;
+  const int x = blockIdx.x * TX + (threadIdx.x & 63);
+  if (x >= X) return;
+  for (int cy = threadIdx.x >> 6; cy < TY; cy += 4) {
+    const int y = blockIdx.y * TY + cy;
+    if (y < Y) dst[fidx(x, y, X)] = src[fidx(x, y, X)];
+  }
+}
+
 inline void launch_fused_a(const Geo &g, const Uni &u, const float *initial_T, const FusedAIn &in, float4 *base_out, float4 *water_out,
-                           char4 *wall_out, float *curl_out, bool write_curl, hipStream_t stream)
+                           char4 *wall_out, float *curl_out, bool write_curl, unsigned char *clean_out, hipStream_t stream)
 {
   const dim3 grid = tile_grid(g.X, g.Y);
   if (write_curl)
-    hipLaunchKernelGGL(k_fused_a<true>, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out);
+    hipLaunchKernelGGL(k_fused_a<true>, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out, clean_out);
   else
-    hipLaunchKernelGGL(k_fused_a<false>, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out);
+    hipLaunchKernelGGL(k_fused_a<false>, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out, clean_out);
 }
 
 inline void launch_fused_b(const Geo &g, const Uni &u, const float *initial_T, const float *snd_T, const float *snd_W, const float *snd_Vel,

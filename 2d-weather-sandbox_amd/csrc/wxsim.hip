@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstring>
 #include <utility>
 #include <string>
 #include <vector>
@@ -83,14 +84,23 @@ struct wx_sim {
   float4 *base[3] = {nullptr, nullptr, nullptr}; // [2]: post-advection base of the fused path (= baseTexture_1)
   float4 *water[3] = {nullptr, nullptr, nullptr}, *light[3] = {nullptr, nullptr, nullptr}; // [2]: spare of the single-kernel ping-pong
   bool ran_fused = false; // the last iteration used the fused ping-pong (field mapping differs)
-  char4 *wall[2] = {nullptr, nullptr};
+  char4 *wall[3] = {nullptr, nullptr, nullptr}; // [2]: third buffer of the copy-on-write scheme (wx_fused.h, FusedBIn)
   float *curl = nullptr;
   float2 *vort = nullptr, *dep = nullptr;
   float4 *fb = nullptr;
   float *drops[2] = {nullptr, nullptr};
   float *initial_T = nullptr, *snd_T = nullptr, *snd_W = nullptr, *snd_Vel = nullptr;
   DevState *state = nullptr;
-  SlowCtx *slow_ctx = nullptr; // device copy of geometry/uniforms/pointers for the out-of-line advection path
+  // device copies of geometry/uniforms/pointers for the out-of-line advection path. The buffer roles of kernel B
+  // alternate between two configurations (pointer rotation), so two contexts are cached and matched by content.
+  SlowCtx *slow_ctx = nullptr;
+  SlowCtx slow_host[2];
+  bool slow_valid[2] = {false, false};
+  int slow_next = 0;
+  // copy-on-write of kernel A's water / wall outputs
+  int cow = 1;                         // env WX_COW=0 disables it
+  unsigned char *cow_clean = nullptr;  // per 64x16 tile: kernel A left water[0] / wall[1] unwritten
+  bool cow_pending = false;            // water[0] has unwritten tiles whose values live in water[2]
   FullCtx *full_ctx = nullptr;
   SplatGrid sg{};              // particle splat accumulation (allocated when the handle has droplets)
   bool fb_dirty = false; // feedback/deposition hold non-zero data (particles ran last iteration)
@@ -347,6 +357,40 @@ int iterate_per_pass(wx_sim *s, unsigned mask)
 // The same iteration as two fused kernels (wx_fused.h); results are bit-identical to iterate_per_pass.
 // write_disp: also store the post-advection base (the reference's baseTexture_1, read by the particle pass and
 // by display-side consumers) -- needed only for the last iteration of a wx_step call or when particles run.
+// device-side SlowCtx matching kernel B's inputs of this iteration (two cached configurations)
+static const SlowCtx *slow_ctx_for(wx_sim *s, const FusedBIn &in)
+{
+  SlowCtx c;
+  memset(&c, 0, sizeof(c)); // padding bytes take part in the comparison
+  c.g = s->geo;
+  c.u = s->uni;
+  c.initial_T = s->initial_T;
+  c.snd_T = s->snd_T;
+  c.snd_W = s->snd_W;
+  c.snd_Vel = s->snd_Vel;
+  c.in = in;
+  c.in.light = nullptr;
+  for (int i = 0; i < 2; i++)
+    if (s->slow_valid[i] && memcmp(&s->slow_host[i], &c, sizeof(c)) == 0) return s->slow_ctx + i;
+  const int i = s->slow_next;
+  s->slow_next ^= 1;
+  // an earlier launch may still read this slot: the (rare) rebuild waits for the stream
+  hipStreamSynchronize(s->stream);
+  memcpy(&s->slow_host[i], &c, sizeof(c));
+  hipMemcpy(s->slow_ctx + i, &s->slow_host[i], sizeof(c), hipMemcpyHostToDevice);
+  s->slow_valid[i] = true;
+  return s->slow_ctx + i;
+}
+
+// Before anything outside kernel B reads water[0] (waterTexture_0): fill the tiles kernel A left unwritten.
+static void cow_resolve(wx_sim *s)
+{
+  if (!s->cow_pending) return;
+  const dim3 grid((s->X + 63) / 64, (s->Y + 15) / 16);
+  hipLaunchKernelGGL(k_cow_resolve, grid, dim3(256), 0, s->stream, s->X, s->Y, s->cow_clean, s->water[2], s->water[0]);
+  s->cow_pending = false;
+}
+
 int iterate_fused(wx_sim *s, bool write_disp)
 {
   const Geo g = s->geo;
@@ -354,17 +398,24 @@ int iterate_fused(wx_sim *s, bool write_disp)
   u.iterNum = (float)s->iter;
   u.iterI = (int)u.iterNum;
   const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
+  unsigned char *clean = s->cow ? s->cow_clean : nullptr;
   {
     FusedAIn in{s->base[0], s->wall[0], s->water[1], s->light[0], s->fb_dirty ? s->fb : nullptr, s->fb_dirty ? s->dep : nullptr};
     ProfScope ps(s, K_FUSED_VCVB);
-    launch_fused_a(g, u, s->initial_T, in, s->base[1], s->water[0], s->wall[1], s->curl, write_disp, s->stream);
+    launch_fused_a(g, u, s->initial_T, in, s->base[1], s->water[0], s->wall[1], s->curl, write_disp, clean, s->stream);
   }
   {
-    FusedBIn in{s->base[1], s->water[0], s->wall[1], s->light[src]};
+    // B reads A's outputs (water[0], wall[1]) -- or, for tiles A left unwritten, A's inputs (water[1], wall[0]) -- and
+    // writes the third buffer of each; afterwards the pointers rotate back into their usual roles
+    FusedBIn in{s->base[1], s->water[0], s->wall[1], s->light[src], s->water[1], s->wall[0], clean, (s->X + 63) / 64};
+    const SlowCtx *ctx = slow_ctx_for(s, in);
     ProfScope ps(s, K_FUSED_APL);
-    launch_fused_b(g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, s->slow_ctx, s->base[0], s->base[2], s->water[1], s->wall[0],
-                   s->light[dst], write_disp, s->stream);
+    launch_fused_b(g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, ctx, s->base[0], s->base[2], s->water[2], s->wall[2], s->light[dst],
+                   write_disp, s->stream);
   }
+  std::swap(s->water[1], s->water[2]); // water[1] = post-advection water, water[2] = what A read (source of the clean tiles)
+  std::swap(s->wall[0], s->wall[2]);
+  s->cow_pending = clean != nullptr;
   return WX_OK;
 }
 
@@ -454,6 +505,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   s->n_drops = n_droplets;
   if (const char *f = getenv("WX_FUSED")) s->fused = atoi(f);
   if (const char *f = getenv("WX_DRY_MARCH")) s->dry_march = atoi(f);
+  if (const char *f = getenv("WX_COW")) s->cow = atoi(f);
   if (!kHaveFused) s->fused = 0;
   const size_t n = ncell(s);
   int rc = WX_OK;
@@ -474,7 +526,9 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (rc == WX_OK) rc = dalloc(s, &s->snd_W, (size_t)Y + 8);
   if (rc == WX_OK) rc = dalloc(s, &s->snd_Vel, (size_t)Y + 8);
   if (rc == WX_OK) rc = dalloc(s, &s->state, 1);
-  if (rc == WX_OK) rc = dalloc(s, &s->slow_ctx, 1);
+  if (rc == WX_OK) rc = dalloc(s, &s->slow_ctx, 2);
+  if (rc == WX_OK) rc = dalloc(s, &s->wall[2], n);
+  if (rc == WX_OK) rc = dalloc(s, &s->cow_clean, (size_t)((s->X + 63) / 64) * ((Y + 15) / 16));
   if (rc == WX_OK) rc = dalloc(s, &s->full_ctx, 1);
   if (rc == WX_OK) rc = dalloc(s, &s->water[2], n);
   if (rc == WX_OK) rc = dalloc(s, &s->light[2], n);
@@ -538,6 +592,8 @@ void wx_destroy(wx_sim *s)
   hipFree(s->state);
   hipFree(s->keys);
   hipFree(s->slow_ctx);
+  hipFree(s->wall[2]);
+  hipFree(s->cow_clean);
   hipFree(s->full_ctx);
   hipFree(s->water[2]);
   hipFree(s->light[2]);
@@ -586,6 +642,8 @@ int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wa
   }
   HIPCHK(s, hipStreamSynchronize(s->stream)); // the caller keeps ownership of the host arrays
   s->fb_dirty = false;
+  s->cow_pending = false;
+  s->period_j = 0;
   s->ran_fused = false;
   s->even = 1;
   s->drop_cur = 0;
@@ -607,8 +665,7 @@ int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const f
   if (sounding_W) HIPCHK(s, hipMemcpyAsync(s->snd_W, sounding_W, nb, hipMemcpyHostToDevice, s->stream));
   if (sounding_Vel) HIPCHK(s, hipMemcpyAsync(s->snd_Vel, sounding_Vel, nb, hipMemcpyHostToDevice, s->stream));
   {
-    SlowCtx c{s->geo, s->uni, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, FusedBIn{s->base[1], s->water[0], s->wall[1], nullptr}};
-    HIPCHK(s, hipMemcpyAsync(s->slow_ctx, &c, sizeof(c), hipMemcpyHostToDevice, s->stream));
+    s->slow_valid[0] = s->slow_valid[1] = false; // uniforms changed: the contexts are rebuilt on the next fused iteration
     FullCtx fc{s->geo, s->uni, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel};
     HIPCHK(s, hipMemcpyAsync(s->full_ctx, &fc, sizeof(fc), hipMemcpyHostToDevice, s->stream));
   }
@@ -630,6 +687,7 @@ int wx_step(wx_sim *s, int n_iter)
   // the fused kernels implement the full grid-pass set; any other pass_mask runs the per-pass kernels
   const bool fused = s->fused && (mask & 0x3Fu) == 0x3Fu;
   const bool dry = s->fused && (mask & 0x3Fu) == WX_PASS_DRY;
+  if (!(fused && s->fused == 1)) cow_resolve(s); // the other kernel sets take water[0] as a fully written buffer
   for (int it = 0; it < n_iter; it++) {
     if (dry)
       iterate_dry(s, precip || it == n_iter - 1);
@@ -687,6 +745,15 @@ int wx_step(wx_sim *s, int n_iter)
     }
     s->iter++;
   }
+  if (s->cow_pending && getenv("WX_COW_DEBUG")) {
+    const size_t nt = (size_t)((s->X + 63) / 64) * ((s->Y + 15) / 16);
+    std::vector<unsigned char> f(nt);
+    hipStreamSynchronize(s->stream);
+    hipMemcpy(f.data(), s->cow_clean, nt, hipMemcpyDeviceToHost);
+    size_t c = 0;
+    for (unsigned char v : f) c += v != 0;
+    fprintf(stderr, "[wx_cow] iter %lld: %zu of %zu tiles clean\n", (long long)s->iter, c, nt);
+  }
   HIPCHK(s, hipGetLastError());
   return WX_OK;
 }
@@ -711,7 +778,7 @@ static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int
   switch (field) {
   case WX_FIELD_BASE_CUR: *ptr = s->base[0]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_BASE_DISP: *ptr = s->ran_fused ? s->base[2] : s->base[1]; *channels = 4; *elem = 4; return 0;
-  case WX_FIELD_WATER_0: *ptr = s->water[0]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_WATER_0: cow_resolve(s); *ptr = s->water[0]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_WATER_CUR: *ptr = s->water[1]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_WALL_CUR: *ptr = s->wall[0]; *channels = 4; *elem = 1; return 0;
   // wallTexture_1 (post-advection) == wallTexture_0 after the pressure pass-through; the fused path keeps one copy

@@ -24,7 +24,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 ALGO_BYTES = {
     "velocity": 20 + 20, "curl": 16 + 4, "vorticity": 4 + 8, "boundary": 60 + 36, "advection": 36 + 36,
     "pressure": 20 + 20, "lighting": 52 + 16,
-    # A: R base16 wall4 water16 light16, W base16 water16 wall4 (+curl4 on the last iteration of a wx_step call); B: R base16 water16 wall4 light16,
+    # A: R base16 wall4 water16 light16, W base16 water16 wall4 (+curl4 on the last iteration of a wx_step call; the water16 + wall4
+    # stores are skipped for tiles the boundary pass leaves unchanged -- still counted here, the pass semantically produces them);
+    # B: R base16 water16 wall4 light16,
     # W base16 water16 wall4 light16 (+16 for the post-advection base on the last iteration of a wx_step call only)
     "fused_vel_curl_vort_boundary": 52 + 36, "fused_advect_pressure_light": 52 + 52,
     # single-kernel iteration: R base16 wall4 water16 light_0 16 light_src 16, W base16 wall4 water16 light16

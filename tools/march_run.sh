@@ -1,3 +1,7 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "full_size" 2>&1 | tail -15
-timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline'].get('measured_copy_GBps'), d['roofline'].get('valu'))"
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+for i in 1 2; do
+for c in 0 1; do
+WX_COW=$c timeout 300 python bench.py --no-cpu-baseline --no-pmc --steps 200 --warmup 20 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('cow=$c', d['value'], d['ms_per_step'], d['roofline']['kernels_ms_per_step'])"
+done
+done
