@@ -27,7 +27,7 @@ namespace wx {
 
 constexpr int TX = 64, TY = 16;
 #ifndef WX_NTA
-#define WX_NTA 1024
+#define WX_NTA 512
 #endif
 #ifndef WX_NTB
 #define WX_NTB 512
@@ -55,7 +55,7 @@ struct FusedBIn {
   const float4 *light;
   const float4 *water_alt; // what kernel A read: valid wherever clean[tile] != 0
   const char4 *wall_alt;
-  const unsigned char *clean; // per tile, row pitch txn; nullptr = every tile was written
+  const unsigned int *clean; // per tile (one dword: read with scalar loads), row pitch txn; nullptr = every tile was written
   int txn;
   __device__ __forceinline__ bool is_clean(int gx, int gy) const { return clean && clean[(gy >> 4) * txn + (gx >> 6)]; }
   __device__ __forceinline__ float4 water_at(int gx, int gy, size_t gi) const { return (is_clean(gx, gy) ? water_alt : water)[gi]; }
@@ -163,10 +163,12 @@ struct LBoundaryAcc {
 
 // WRITE_CURL: the curl texture has only display-side consumers (app.js:6081-6219), so it is stored only by the last
 // iteration of a wx_step call.
-template <bool WRITE_CURL>
+// SMALL: tiny grids whose tile + halo may wrap more than once (general modulo instead of one compare; a template
+// parameter because a uniform branch inside the fill loops keeps the loads of successive elements from overlapping).
+template <bool WRITE_CURL, bool SMALL>
 __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__restrict__ initial_T, FusedAIn in, float4 *__restrict__ base_out,
                                                 float4 *__restrict__ water_out, char4 *__restrict__ wall_out, float *__restrict__ curl_out,
-                                                unsigned char *__restrict__ clean_out)
+                                                unsigned int *__restrict__ clean_out)
 {
   using namespace fa;
   __shared__ Smem sm;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
   int tbx, tby;
   tile_of_block(tiles_x(X), tbx, tby);
   const int tx0 = tbx * TX, ty0 = tby * TY;
-  const bool small = (X < TX + 8) || (Y < TY + 8); // tiny grids: the tile + halo may wrap more than once
+  constexpr bool small = SMALL;
 
   // ---- stage 0: base_0 and wall_0 tiles with halo (REPEAT wrap on both axes) ----
   for (int i = tid; i < BW * BH; i += NTA) {
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
       wall_out[fidx(x, y, X)] = wlv[k];
     }
   }
-  if (clean_out && tid == 0) clean_out[tby * tiles_x(X) + tbx] = (unsigned char)tile_clean;
+  if (clean_out && tid == 0) clean_out[tby * tiles_x(X) + tbx] = (unsigned int)tile_clean;
 }
 
 // ================================================================================================
@@ -380,7 +382,7 @@ struct LLightAcc {
   __device__ __forceinline__ float4 light_at(int dx, int j) const { return light_[fidx(wrapfast(x + dx, X), j, X)]; }
 };
 
-template <bool WRITE_DISP>
+template <bool WRITE_DISP, bool SMALL>
 __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, const float *__restrict__ initial_T, const float *__restrict__ snd_T,
                                                 const float *__restrict__ snd_W, const float *__restrict__ snd_Vel, FusedBIn in,
                                                 const SlowCtx *__restrict__ ctx, float4 *__restrict__ base_out, float4 *__restrict__ base_disp, float4 *__restrict__ water_out,
@@ -396,18 +398,19 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, co
   int tbx, tby;
   tile_of_block(tiles_x(X), tbx, tby);
   const int tx0 = tbx * TX, ty0 = tby * TY;
-  const bool small = (X < TX + 8) || (Y < TY + 8);
-  __shared__ unsigned char cflag[9];
-  if (tid < 9) {
+  constexpr bool small = SMALL;
+  // copy-on-write flags of the 3x3 tiles this workgroup reads from: wave-uniform addresses -> scalar loads. (The host
+  // passes clean == nullptr for grids so small that the halo wraps more than once.)
+  unsigned int cflag = 0; // bit t: tile (t % 3 - 1, t / 3 - 1) was left unwritten by kernel A
+  if (in.clean) {
     const int gtx = tiles_x(X), gty = (Y + TY - 1) / TY;
-    const int nx = wrapfast(tbx + tid % 3 - 1, gtx), ny = wrapfast(tby + tid / 3 - 1, gty);
-    cflag[tid] = in.clean ? in.clean[ny * in.txn + nx] : 0;
-  }
-  __syncthreads();
-  int nclean = 0;
 #pragma unroll
-  for (int t = 0; t < 9; t++) nclean += cflag[t] != 0;
-  const bool mixed = (nclean != 0 && nclean != 9) || (small && in.clean != nullptr);
+    for (int t = 0; t < 9; t++) {
+      const int nx = wrapfast(tbx + t % 3 - 1, gtx), ny = wrapfast(tby + t / 3 - 1, gty);
+      cflag |= (in.clean[ny * in.txn + nx] != 0u ? 1u : 0u) << t;
+    }
+  }
+
 
   // ---- stage 0: post-boundary base / water / wall tiles with halo ----
   for (int i = tid; i < IW * IH; i += NTB) {
@@ -416,10 +419,9 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, co
     const int gy = small ? wrapmod(ty0 + ly - HD, Y) : wrapfast(ty0 + ly - HD, Y);
     const size_t gi = fidx(gx, gy, X);
     sm.in.b.put(ly, lx, in.base[gi]);
-    // tiles kernel A left unwritten are read from A's inputs; the 3x3 tile flags were staged in LDS. Almost always the
-    // nine flags agree (97 % of the tiles are clean away from terrain): then the choice is wave-uniform.
-    bool cl = nclean == 9;
-    if (mixed) cl = small ? in.is_clean(gx, gy) : (cflag[((ly >= HD) + (ly >= HD + TY)) * 3 + (lx >= HL) + (lx >= HL + TX)] != 0);
+    // tiles kernel A left unwritten are read from A's inputs (straight-line code: the fill loop must stay branch-free
+    // for the loads of several elements to overlap)
+    const bool cl = ((cflag >> (((ly >= HD) + (ly >= HD + TY)) * 3 + (lx >= HL) + (lx >= HL + TX))) & 1u) != 0u;
     sm.in.q.put(ly, lx, (cl ? in.water_alt : in.water)[gi]);
     sm.in.w[ly][lx] = (cl ? in.wall_alt : in.wall)[gi];
   }
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u, co
 }
 
 // fills the tiles of `dst` that kernel A left unwritten (clean != 0) from A's input buffer
-__global__ __launch_bounds__(256) void k_cow_resolve(int X, int Y, const unsigned char *__restrict__ clean, const float4 *__restrict__ src,
+__global__ __launch_bounds__(256) void k_cow_resolve(int X, int Y, const unsigned int *__restrict__ clean, const float4 *__restrict__ src,
                                                      float4 *__restrict__ dst)
 {
   if (!clean[blockIdx.y * gridDim.x + blockIdx.x]) return;
@@ -503,13 +505,17 @@ __global__ __launch_bounds__(256) void k_cow_resolve(int X, int Y, const unsigne
 }
 
 inline void launch_fused_a(const Geo &g, const Uni &u, const float *initial_T, const FusedAIn &in, float4 *base_out, float4 *water_out,
-                           char4 *wall_out, float *curl_out, bool write_curl, unsigned char *clean_out, hipStream_t stream)
+                           char4 *wall_out, float *curl_out, bool write_curl, unsigned int *clean_out, hipStream_t stream)
 {
   const dim3 grid = tile_grid(g.X, g.Y);
-  if (write_curl)
-    hipLaunchKernelGGL(k_fused_a<true>, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out, clean_out);
-  else
-    hipLaunchKernelGGL(k_fused_a<false>, grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out, clean_out);
+  const bool small = (g.X < TX + 8) || (g.Y < TY + 8);
+#define WX_LAUNCH_A(C, S) hipLaunchKernelGGL((k_fused_a<C, S>), grid, dim3(NTA), 0, stream, g, u, initial_T, in, base_out, water_out, wall_out, curl_out, clean_out)
+  if (write_curl) {
+    if (small) WX_LAUNCH_A(true, true); else WX_LAUNCH_A(true, false);
+  } else {
+    if (small) WX_LAUNCH_A(false, true); else WX_LAUNCH_A(false, false);
+  }
+#undef WX_LAUNCH_A
 }
 
 inline void launch_fused_b(const Geo &g, const Uni &u, const float *initial_T, const float *snd_T, const float *snd_W, const float *snd_Vel,
@@ -517,12 +523,16 @@ inline void launch_fused_b(const Geo &g, const Uni &u, const float *initial_T, c
                            float4 *light_out, bool write_disp, hipStream_t stream)
 {
   const dim3 grid = tile_grid(g.X, g.Y);
-  if (write_disp)
-    hipLaunchKernelGGL(k_fused_b<true>, grid, dim3(NTB), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp,
-                       water_out, wall_out, light_out);
-  else
-    hipLaunchKernelGGL(k_fused_b<false>, grid, dim3(NTB), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp,
-                       water_out, wall_out, light_out);
+  const bool small = (g.X < TX + 8) || (g.Y < TY + 8);
+#define WX_LAUNCH_B(D, S)                                                                                                                  \
+  hipLaunchKernelGGL((k_fused_b<D, S>), grid, dim3(NTB), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp, \
+                     water_out, wall_out, light_out)
+  if (write_disp) {
+    if (small) WX_LAUNCH_B(true, true); else WX_LAUNCH_B(true, false);
+  } else {
+    if (small) WX_LAUNCH_B(false, true); else WX_LAUNCH_B(false, false);
+  }
+#undef WX_LAUNCH_B
 }
 
 } // namespace wx

@@ -99,7 +99,7 @@ struct wx_sim {
   int slow_next = 0;
   // copy-on-write of kernel A's water / wall outputs
   int cow = 1;                         // env WX_COW=0 disables it
-  unsigned char *cow_clean = nullptr;  // per 64x16 tile: kernel A left water[0] / wall[1] unwritten
+  unsigned int *cow_clean = nullptr;   // per 64x16 tile: kernel A left water[0] / wall[1] unwritten
   bool cow_pending = false;            // water[0] has unwritten tiles whose values live in water[2]
   FullCtx *full_ctx = nullptr;
   SplatGrid sg{};              // particle splat accumulation (allocated when the handle has droplets)
@@ -398,7 +398,7 @@ int iterate_fused(wx_sim *s, bool write_disp)
   u.iterNum = (float)s->iter;
   u.iterI = (int)u.iterNum;
   const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
-  unsigned char *clean = s->cow ? s->cow_clean : nullptr;
+  unsigned int *clean = (s->cow && s->X >= 72 && s->Y >= 24) ? s->cow_clean : nullptr; // not for grids whose tile halo wraps twice
   {
     FusedAIn in{s->base[0], s->wall[0], s->water[1], s->light[0], s->fb_dirty ? s->fb : nullptr, s->fb_dirty ? s->dep : nullptr};
     ProfScope ps(s, K_FUSED_VCVB);
@@ -747,11 +747,11 @@ int wx_step(wx_sim *s, int n_iter)
   }
   if (s->cow_pending && getenv("WX_COW_DEBUG")) {
     const size_t nt = (size_t)((s->X + 63) / 64) * ((s->Y + 15) / 16);
-    std::vector<unsigned char> f(nt);
+    std::vector<unsigned int> f(nt);
     hipStreamSynchronize(s->stream);
-    hipMemcpy(f.data(), s->cow_clean, nt, hipMemcpyDeviceToHost);
+    hipMemcpy(f.data(), s->cow_clean, nt * 4, hipMemcpyDeviceToHost);
     size_t c = 0;
-    for (unsigned char v : f) c += v != 0;
+    for (unsigned int v : f) c += v != 0;
     fprintf(stderr, "[wx_cow] iter %lld: %zu of %zu tiles clean\n", (long long)s->iter, c, nt);
   }
   HIPCHK(s, hipGetLastError());
