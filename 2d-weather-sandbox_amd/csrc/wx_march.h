@@ -22,6 +22,9 @@ namespace wx {
 #ifndef WX_MARCH_MAXSEG
 #define WX_MARCH_MAXSEG 128 // upper bound of the rows one wave marches (3 warm-up rows per segment are redundant work)
 #endif
+#ifndef WX_MARCH_UNI_MEM
+#define WX_MARCH_UNI_MEM 1 // measured: SGPR spills 12 -> 0, 0.31 -> 0.29 ms at 16384x2048
+#endif
 #ifndef WX_MARCH_XCD
 #define WX_MARCH_XCD 1
 #endif
@@ -70,9 +73,14 @@ struct MDryFp {
 __device__ __forceinline__ MDryFp make_fp(const MDryAcc &a, int dx0, int dy0) { return MDryFp{a.rg, (a.yc + dy0) & 3, a.lane1 + dx0}; }
 
 template <bool WRITE_DISP>
-__global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows)
+__global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u_arg, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows)
 {
   __shared__ MarchRing rg;
+#if WX_MARCH_UNI_MEM
+  const Uni &u = ctx->u; // (the dry passes do not use iterNum)
+#else
+  const Uni &u = u_arg;
+#endif
   const int X = g.X, Y = g.Y;
   const int lane = threadIdx.x;
 #if WX_MARCH_XCD
