@@ -107,6 +107,35 @@ inline dim3 tile_grid(int X, int Y)
 }
 __device__ __forceinline__ int tiles_x(int X) { return (X + 63) / 64; }
 
+// Row-wise tile fill: wave w takes the rows w, w + NT/64, ... of a W x H region whose lower-left cell is (x_lo, y_lo);
+// lane l takes the columns l and l + 64. The wrapped global column is computed once per lane and the row part of every
+// address is wave-uniform (scalar), so an element costs ~4 vector instructions instead of ~18 for the flat
+// "i -> (i / W, i % W) -> wrap -> address" form; the row loop is straight-line code (see the copy-on-write note).
+template <int NT, int W, int H, bool SMALL, class F>
+__device__ __forceinline__ void fill_rows(int tid, int x_lo, int y_lo, int X, int Y, F &&f) // f(ly, lx, global index)
+{
+  static_assert(W > 64 && W <= 128, "one full 64-column chunk plus a narrow remainder");
+  constexpr int NW = NT / 64, ROUNDS = (H + NW - 1) / NW, E = W - 64;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int gx = SMALL ? wrapmod(x_lo + lane, X) : wrapfast(x_lo + lane, X);
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++) {
+    // constant trip count and no branch: rows past the end are clamped (a few waves re-load row H-1 and store the same
+    // values again), so that all loads of a thread are issued back to back
+    const int ly = min(wave + r * NW, H - 1);
+    const int gy = SMALL ? wrapmod(y_lo + ly, Y) : wrapfast(y_lo + ly, Y);
+    f(ly, lane, fidx(gx, gy, X));
+  }
+  // the E remaining columns: one element per thread
+  static_assert(E * H <= NT, "remainder fits one pass");
+  if (tid < E * H) {
+    const int ly = tid / E, lx = 64 + tid - ly * E;
+    const int ex = SMALL ? wrapmod(x_lo + lx, X) : wrapfast(x_lo + lx, X);
+    const int ey = SMALL ? wrapmod(y_lo + ly, Y) : wrapfast(y_lo + ly, Y);
+    f(ly, lx, fidx(ex, ey, X));
+  }
+}
+
 // fp32 plane set of a float4 field
 template <int H, int W> struct Planes4 {
   float x[H][W], y[H][W], z[H][W], w[H][W];
@@ -177,21 +206,10 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
   int tbx, tby;
   tile_of_block(tiles_x(X), tbx, tby);
   const int tx0 = tbx * TX, ty0 = tby * TY;
-  constexpr bool small = SMALL;
 
   // ---- stage 0: base_0 and wall_0 tiles with halo (REPEAT wrap on both axes) ----
-  for (int i = tid; i < BW * BH; i += NTA) {
-    const int ly = i / BW, lx = i - ly * BW;
-    const int gx = small ? wrapmod(tx0 + lx - HL, X) : wrapfast(tx0 + lx - HL, X);
-    const int gy = small ? wrapmod(ty0 + ly - HD, Y) : wrapfast(ty0 + ly - HD, Y);
-    sm.b.put(ly, lx, in.base[fidx(gx, gy, X)]);
-  }
-  for (int i = tid; i < WW * WH; i += NTA) {
-    const int ly = i / WW, lx = i - ly * WW;
-    const int gx = small ? wrapmod(tx0 + lx - 2, X) : wrapfast(tx0 + lx - 2, X);
-    const int gy = small ? wrapmod(ty0 + ly - 2, Y) : wrapfast(ty0 + ly - 2, Y);
-    sm.w[ly][lx] = in.wall[fidx(gx, gy, X)];
-  }
+  fill_rows<NTA, BW, BH, SMALL>(tid, tx0 - HL, ty0 - HD, X, Y, [&](int ly, int lx, size_t gi) { sm.b.put(ly, lx, in.base[gi]); });
+  fill_rows<NTA, WW, WH, SMALL>(tid, tx0 - 2, ty0 - 2, X, Y, [&](int ly, int lx, size_t gi) { sm.w[ly][lx] = in.wall[gi]; });
   __syncthreads();
 
   // ---- stage 1: velocity on [-2,+2]^2, in place (writes vx, vy; neighbours are only read for P) ----
@@ -421,14 +439,15 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u_arg
 
 
   // ---- stage 0: post-boundary base / water / wall tiles with halo ----
+  // (flat index form: with three arrays per element the row-wise fill_rows() of kernel A measured 4 % slower here)
   for (int i = tid; i < IW * IH; i += NTB) {
     const int ly = i / IW, lx = i - ly * IW;
-    const int gx = small ? wrapmod(tx0 + lx - HL, X) : wrapfast(tx0 + lx - HL, X);
-    const int gy = small ? wrapmod(ty0 + ly - HD, Y) : wrapfast(ty0 + ly - HD, Y);
+    const int gx = SMALL ? wrapmod(tx0 + lx - HL, X) : wrapfast(tx0 + lx - HL, X);
+    const int gy = SMALL ? wrapmod(ty0 + ly - HD, Y) : wrapfast(ty0 + ly - HD, Y);
     const size_t gi = fidx(gx, gy, X);
     sm.in.b.put(ly, lx, in.base[gi]);
-    // tiles kernel A left unwritten are read from A's inputs (straight-line code: the fill loop must stay branch-free
-    // for the loads of several elements to overlap)
+    // tiles kernel A left unwritten are read from A's inputs (pure arithmetic on the 9-bit mask: the fill loop must stay
+    // branch-free for the loads of several elements to overlap)
     const bool cl = ((cflag >> (((ly >= HD) + (ly >= HD + TY)) * 3 + (lx >= HL) + (lx >= HL + TX))) & 1u) != 0u;
     sm.in.q.put(ly, lx, (cl ? in.water_alt : in.water)[gi]);
     sm.in.w[ly][lx] = (cl ? in.wall_alt : in.wall)[gi];
