@@ -136,6 +136,23 @@ __device__ __forceinline__ void fill_rows(int tid, int x_lo, int y_lo, int X, in
   }
 }
 
+// The same decomposition for an in-LDS stage over a W x H region: f(ly, lx), every element exactly once (the velocity
+// stage updates in place).
+template <int NT, int W, int H, class F> __device__ __forceinline__ void for_rows(int tid, F &&f)
+{
+  static_assert(W > 64 && W <= 128, "one full 64-column chunk plus a narrow remainder");
+  constexpr int NW = NT / 64, ROUNDS = (H + NW - 1) / NW, E = W - 64;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#pragma unroll
+  for (int r = 0; r < ROUNDS; r++)
+    if (wave + r * NW < H) f(wave + r * NW, lane); // wave-uniform condition
+  static_assert(E * H <= NT, "remainder fits one pass");
+  if (tid < E * H) {
+    const int ly = tid / E;
+    f(ly, 64 + tid - ly * E);
+  }
+}
+
 // fp32 plane set of a float4 field
 template <int H, int W> struct Planes4 {
   float x[H][W], y[H][W], z[H][W], w[H][W];
@@ -213,28 +230,23 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
   __syncthreads();
 
   // ---- stage 1: velocity on [-2,+2]^2, in place (writes vx, vy; neighbours are only read for P) ----
-  for (int i = tid; i < WW * WH; i += NTA) {
-    const int ly = i / WW, lx = i - ly * WW;
+  for_rows<NTA, WW, WH>(tid, [&](int ly, int lx) {
     const float4 b = velocity_cell(u, sm.b.get(ly, lx), sm.b.z[ly][lx + 1], sm.b.z[ly + 1][lx], sm.w[ly][lx].y);
     sm.b.x[ly][lx] = b.x;
     sm.b.y[ly][lx] = b.y;
-  }
+  });
   __syncthreads();
 
   // ---- stage 2: curl on [-2,+1]^2 ----
-  for (int i = tid; i < CW * CH; i += NTA) {
-    const int ly = i / CW, lx = i - ly * CW;
-    sm.c[ly][lx] = curl_cell(sm.b.x[ly][lx], sm.b.y[ly][lx], sm.b.y[ly][lx + 1], sm.b.x[ly + 1][lx]);
-  }
+  for_rows<NTA, CW, CH>(tid, [&](int ly, int lx) { sm.c[ly][lx] = curl_cell(sm.b.x[ly][lx], sm.b.y[ly][lx], sm.b.y[ly][lx + 1], sm.b.x[ly + 1][lx]); });
   __syncthreads();
 
   // ---- stage 3: vortForce on [-1,0]^2 ----
-  for (int i = tid; i < VW * VH; i += NTA) {
-    const int ly = i / VW, lx = i - ly * VW;
+  for_rows<NTA, VW, VH>(tid, [&](int ly, int lx) {
     const float2 v = vorticity_cell(sm.c[ly + 1][lx + 1], sm.c[ly + 1][lx], sm.c[ly + 1][lx + 2], sm.c[ly][lx + 1], sm.c[ly + 2][lx + 1]);
     sm.vx[ly][lx] = v.x;
     sm.vy[ly][lx] = v.y;
-  }
+  });
   __syncthreads();
 
   // ---- stage 4: boundary on the tile ----
