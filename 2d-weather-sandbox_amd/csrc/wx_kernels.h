@@ -157,6 +157,34 @@ __global__ __launch_bounds__(BX *BY) void k_lighting(Geo g, Uni u, const float4 
   light_out[cidx(x, y, g.X)] = lighting_cell(u, g, x, y, a);
 }
 
+// ---- device-side initialiser (wx_setup_columns): the 2-D part of setupShader.frag:63-89 ----
+// Column x is wall below row wall_rows[x] (sea if sea[x], else land), air above; per-row sounding for the air cells.
+__global__ __launch_bounds__(BX *BY) void k_setup_columns(int X, int Y, const int *__restrict__ wall_rows, const unsigned int *__restrict__ sea,
+                                                           const double *__restrict__ veg_noise, const float *__restrict__ snow,
+                                                           const float *__restrict__ T_air, const float *__restrict__ tot,
+                                                           const float *__restrict__ cloud, float4 *__restrict__ base, float4 *__restrict__ water,
+                                                           char4 *__restrict__ wall)
+{
+  const int x = blockIdx.x * BX + threadIdx.x, y = blockIdx.y * BY + threadIdx.y;
+  if (x >= X || y >= Y) return;
+  const int nrows = wall_rows[x];
+  const bool is_wall = y < nrows, is_sea = is_wall && sea[x] != 0u, is_land = is_wall && !is_sea;
+  float4 b = make_float4(0.f, 0.f, 0.f, is_wall ? (is_sea ? 25.0f + 273.15f : 1000.0f) : T_air[y]);
+  float4 w = make_float4(is_wall ? (is_sea ? 1002.0f : 1001.0f) : tot[y], is_wall ? 0.0f : cloud[y], is_land ? 25.0f : (is_sea ? 100.0f : 0.0f),
+                         is_land ? snow[x] : 0.0f);
+  int veg = 0;
+  if (is_land) { // setupShader.frag:72: 110 - fragCoord.y * 2 + noise * 150, evaluated in double like the host generator
+    const double v = 110.0 - ((double)y + 0.5) * 2.0 + veg_noise[x];
+    veg = (int)fmin(fmax(trunc(v), 0.0), 127.0);
+  }
+  const int vdist = y - nrows + 1;
+  const int wdist = is_wall ? 0 : min(max(vdist, 1), 127);
+  const size_t i = cidx(x, y, X);
+  base[i] = b;
+  water[i] = w;
+  wall[i] = make_char4((signed char)(sea[x] != 0u ? 2 : 1), (signed char)wdist, (signed char)min(max(vdist, -127), 127), (signed char)veg);
+}
+
 // ---- pass-through copies for masked-off passes (pass_mask) ----
 __global__ void k_copy16(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
 {

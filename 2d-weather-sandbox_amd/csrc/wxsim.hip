@@ -604,6 +604,8 @@ void wx_destroy(wx_sim *s)
   delete s;
 }
 
+static int reset_after_upload(wx_sim *s, const float *drops);
+
 int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wall, const float *drops)
 {
   if (!s) return WX_E_INVALID;
@@ -623,6 +625,15 @@ int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wa
     HIPCHK(s, hipMemcpyAsync(s->base[i], base, n * 16, hipMemcpyHostToDevice, s->stream));
     HIPCHK(s, hipMemcpyAsync(s->water[i], water, n * 16, hipMemcpyHostToDevice, s->stream));
     HIPCHK(s, hipMemcpyAsync(s->wall[i], wall, n * 4, hipMemcpyHostToDevice, s->stream));
+  }
+  return reset_after_upload(s, drops);
+}
+
+// everything wx_upload resets besides the three grids (shared with wx_setup_columns)
+static int reset_after_upload(wx_sim *s, const float *drops)
+{
+  const size_t n = ncell(s);
+  for (int i = 0; i < 2; i++) {
     HIPCHK(s, hipMemsetAsync(s->light[i], 0, n * 16, s->stream));
     if (i == 0) HIPCHK(s, hipMemsetAsync(s->light[2], 0, n * 16, s->stream));
     if (drops && s->n_drops > 0)
@@ -649,6 +660,49 @@ int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wa
   s->drop_cur = 0;
   s->uploaded = true;
   return WX_OK;
+}
+
+// Device-side initialiser of a new simulation: what the reference's setup pass draws (setupShader.frag:36-92), filled
+// from the per-column terrain description and the per-row sounding instead of uploading three X*Y textures.
+int wx_setup_columns(wx_sim *s, const int32_t *wall_rows, const uint8_t *sea_column, const double *veg_noise, const float *snow,
+                     const float *T_air, const float *total_water, const float *cloud_water, const float *drops)
+{
+  if (!s) return WX_E_INVALID;
+  if (!wall_rows || !sea_column || !veg_noise || !snow || !T_air || !total_water || !cloud_water)
+    return fail(s, WX_E_INVALID, "wx_setup_columns: NULL descriptor array");
+  const int X = s->X, Y = s->Y;
+  for (int x = 0; x < X; x++)
+    if (wall_rows[x] < 0 || wall_rows[x] > Y) return fail(s, WX_E_RANGE, "wx_setup_columns: wall_rows[%d] = %d outside 0..%d", x, wall_rows[x], Y);
+  // descriptors live in device scratch for the duration of the fill: reuse the (not yet meaningful) curl / vort planes
+  static_assert(sizeof(double) == 8, "");
+  char *scratch = nullptr;
+  const size_t bytes = (size_t)X * (4 + 8 + 4 + 4) + (size_t)Y * 12;
+  if (hipMalloc(&scratch, bytes) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_setup_columns: %zu bytes of device scratch", bytes);
+  double *d_veg = (double *)scratch;
+  int32_t *d_rows = (int32_t *)(d_veg + X);
+  float *d_snow = (float *)(d_rows + X);
+  float *d_T = d_snow + X, *d_tot = d_T + Y, *d_cloud = d_tot + Y;
+  unsigned int *d_sea = (unsigned int *)(d_cloud + Y);
+  std::vector<unsigned int> sea32(X);
+  for (int x = 0; x < X; x++) sea32[x] = sea_column[x] ? 1u : 0u;
+  hipMemcpyAsync(d_veg, veg_noise, (size_t)X * 8, hipMemcpyHostToDevice, s->stream);
+  hipMemcpyAsync(d_rows, wall_rows, (size_t)X * 4, hipMemcpyHostToDevice, s->stream);
+  hipMemcpyAsync(d_snow, snow, (size_t)X * 4, hipMemcpyHostToDevice, s->stream);
+  hipMemcpyAsync(d_T, T_air, (size_t)Y * 4, hipMemcpyHostToDevice, s->stream);
+  hipMemcpyAsync(d_tot, total_water, (size_t)Y * 4, hipMemcpyHostToDevice, s->stream);
+  hipMemcpyAsync(d_cloud, cloud_water, (size_t)Y * 4, hipMemcpyHostToDevice, s->stream);
+  hipMemcpyAsync(d_sea, sea32.data(), (size_t)X * 4, hipMemcpyHostToDevice, s->stream);
+  hipLaunchKernelGGL(k_setup_columns, grid2d(s), dim3(BX, BY), 0, s->stream, X, Y, d_rows, d_sea, d_veg, d_snow, d_T, d_tot, d_cloud, s->base[0],
+                     s->water[0], s->wall[0]);
+  const size_t n = ncell(s);
+  hipMemcpyAsync(s->base[1], s->base[0], n * 16, hipMemcpyDeviceToDevice, s->stream);
+  hipMemcpyAsync(s->water[1], s->water[0], n * 16, hipMemcpyDeviceToDevice, s->stream);
+  hipMemcpyAsync(s->wall[1], s->wall[0], n * 4, hipMemcpyDeviceToDevice, s->stream);
+  hipError_t e = hipStreamSynchronize(s->stream); // sea32 and the caller's arrays may go away now
+  hipFree(scratch);
+  if (e != hipSuccess) return fail(s, WX_E_DEVICE, "wx_setup_columns: %s", hipGetErrorString(e));
+  s->water_trivial = false;
+  return reset_after_upload(s, drops);
 }
 
 int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const float *sounding_T, const float *sounding_W,

@@ -31,7 +31,7 @@ EXPORTS = [
     "wx_step", "wx_sync", "wx_get_iter", "wx_set_iter", "wx_read_rect", "wx_read_particles", "wx_set_stream",
     "wx_device_ptr", "wx_local_width", "wx_halo_bytes", "wx_halo_pack", "wx_halo_unpack", "wx_profile",
     "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_particles_keys",
-    "wx_particles_contribute", "wx_particles_adopt", "wx_lightning_get", "wx_lightning_set",
+    "wx_particles_contribute", "wx_particles_adopt", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns",
 ]
 
 
@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
     L.wx_particles_adopt.argtypes = [vp, vp, vp, i32]
     L.wx_lightning_get.argtypes = [vp, vp]
     L.wx_lightning_set.argtypes = [vp, vp]
+    L.wx_setup_columns.argtypes = [vp] + [vp] * 8
     _lib = L
     return L
 
@@ -224,6 +225,24 @@ class Handle:
 
     def halo_unpack(self, side: int, dev_ptr: int):
         self._chk(lib().wx_halo_unpack(self._h, side, C.c_void_p(dev_ptr)))
+
+    def setup_columns(self, desc, drops=None):
+        """Device-side initialiser from the 1-D descriptors of ``synth.terrain_columns`` (wx_setup_columns)."""
+        want = {"wall_rows": (np.int32, self.X), "sea": (np.uint8, self.X), "veg_noise": (np.float64, self.X), "snow": (np.float32, self.X),
+                "T_air": (np.float32, self.Y), "total_water": (np.float32, self.Y), "cloud_water": (np.float32, self.Y)}
+        arrs = []
+        for k, (dt, n) in want.items():
+            a = np.ascontiguousarray(desc[k], dt)
+            if a.shape != (n,):
+                raise ValueError(f"setup_columns: {k} has shape {a.shape}, expected ({n},)")
+            arrs.append(a)
+        dp = None
+        if drops is not None:
+            drops = np.ascontiguousarray(drops, np.float32)
+            if drops.shape != (self.n_droplets, 5):
+                raise ValueError("setup_columns: drops must be (n_droplets, 5) float32")
+            dp = drops.ctypes.data_as(C.c_void_p)
+        self._chk(lib().wx_setup_columns(self._h, *[a.ctypes.data_as(C.c_void_p) for a in arrs], dp))
 
     # ---- particles on slabs (device pointers; see include/wxsim.h) ----
     def slab_set_rank(self, rank: int):

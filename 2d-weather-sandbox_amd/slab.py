@@ -199,14 +199,11 @@ class SlabSim:
     @classmethod
     def from_generator(cls, pkg, X: int, Y: int, u: Dict[str, Any], rank: int, world: int, device: torch.device,
                        halo: int = DEFAULT_HALO, drops=None, cloud_deck: bool = False) -> "SlabSim":
-        """Each rank generates only its own slab (plus ghost columns) of the synthetic terrain grid; ``drops`` is the
-        WHOLE droplet pool (identical on every rank)."""
+        """Each rank fills only its own slab (plus ghost columns) of the synthetic terrain grid, on the device
+        (wx_setup_columns); ``drops`` is the WHOLE droplet pool (identical on every rank)."""
         x0, xo = slab_columns(X, rank, world)
         eng = HipSlabEngine(X, Y, x0, xo, halo, device, 0 if drops is None else len(drops), rank)
-        base, water, wall = pkg.synth.terrain_grid(X, Y, cols=(x0 - halo, xo + 2 * halo))
-        if cloud_deck:
-            pkg.synth.add_cloud_deck(water, wall)
-        eng.upload(base, water, wall, drops)
+        eng.h.setup_columns(pkg.synth.terrain_columns(X, Y, cols=(x0 - halo, xo + 2 * halo), cloud_deck=cloud_deck), drops)
         eng.set_params(u)
         return cls(eng, rank, world, halo)
 

@@ -46,11 +46,11 @@ def terrain_height(X: int, seed: float = 0.5, height_mult: float = 0.3) -> np.nd
     return h * height_mult
 
 
-def terrain_grid(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: float = 0.3, snap: int = 2, cols=None):
-    """(base, water, wall) of a new simulation (setupShader.frag:36-92), terrain snapped to ``snap`` cells.
-
-    ``cols=(start, count)`` returns only the columns ``(start + i) mod X`` (a slab with its ghost columns) of the
-    X-wide domain; every quantity is a function of the global column, so slabs tile the whole-domain result."""
+def terrain_columns(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: float = 0.3, snap: int = 2, cols=None, cloud_deck: bool = False):
+    """The 1-D part of the setup pass (setupShader.frag:36-92): per column the number of wall rows, sea / land, the
+    vegetation noise term and the snow height; per row the air temperature, total and cloud water of the initial
+    sounding. ``terrain_grid`` expands these descriptors on the host, ``Handle.setup_columns`` (wx_setup_columns) on the
+    device. ``cols=(start, count)`` selects the columns ``(start + i) mod X`` (a slab with its ghost columns)."""
     gui = params.merge_settings(None) if gui is None else gui
     sim_h = float(gui["simHeight"])
     dry_lapse = sim_h * float(gui["dryLapseRate"]) / 1000.0
@@ -68,43 +68,62 @@ def terrain_grid(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: float
     if cols is not None:
         gcol = (cols[0] + np.arange(cols[1])) % X
         h, nrows = h[gcol], nrows[gcol]
-        X = int(cols[1])
+    fx = gcol.astype(np.float64) + 0.5
+    # air: initial sounding (setupShader.frag:78-89)
+    yy = np.arange(Y)
+    tcy = (yy + 0.5) / Y
+    T_air = T0[:Y].astype(np.float64)
+    realT = T_air - tcy * dry_lapse
+    dew = np.where(tcy < 0.20, realT - 2.0, realT - 20.0)
+    tot = (dew / 250.0) ** 17
+    cloud = np.maximum(tot - (realT / 250.0) ** 17, 0.0)
+    T_air, tot, cloud = T_air.astype(np.float32), tot.astype(np.float32), cloud.astype(np.float32)
+    if cloud_deck:  # a cloud layer so that droplets spawn, grow and fall during a benchmark run (see add_cloud_deck)
+        deck = (yy > Y // 4) & (yy < Y // 2)
+        cloud = np.where(deck, np.float32(1.5), cloud).astype(np.float32)
+        tot = np.where(deck, tot + np.float32(1.5), tot).astype(np.float32)
+    return {
+        "wall_rows": nrows.astype(np.int32), "sea": (h < texY).astype(np.uint8),
+        "veg_noise": (_noise(fx * 0.01 + _rand(seed) * 10.0) * 150.0).astype(np.float64),
+        "snow": np.clip((h * sim_h - 2000.0) * 100.0 / 3000.0, 0.0, 100.0).astype(np.float32),
+        "T_air": T_air, "total_water": tot, "cloud_water": cloud,
+    }
+
+
+def terrain_grid(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: float = 0.3, snap: int = 2, cols=None):
+    """(base, water, wall) of a new simulation (setupShader.frag:36-92), terrain snapped to ``snap`` cells.
+
+    ``cols=(start, count)`` returns only the columns ``(start + i) mod X`` (a slab with its ghost columns) of the
+    X-wide domain; every quantity is a function of the global column, so slabs tile the whole-domain result."""
+    d = terrain_columns(X, Y, gui, seed, height_mult, snap, cols)
+    nrows, sea_col = d["wall_rows"].astype(np.int64), d["sea"].astype(bool)
+    X = len(nrows)
     yy = np.arange(Y)[:, None]
     is_wall = yy < nrows[None, :]
-    is_sea = (h < texY)[None, :] & is_wall
+    is_sea = sea_col[None, :] & is_wall
     is_land = is_wall & ~is_sea
 
     base = np.zeros((Y, X, 4), np.float32)
     water = np.zeros((Y, X, 4), np.float32)
     wall = np.zeros((Y, X, 4), np.int8)
 
-    # air: initial sounding (setupShader.frag:78-89)
-    tcy = (yy + 0.5) / Y
-    T_air = T0[:Y][:, None].astype(np.float64)
-    realT = T_air - tcy * dry_lapse
-    dew = np.where(tcy < 0.20, realT - 2.0, realT - 20.0)
-    tot = (dew / 250.0) ** 17
-    cloud = np.maximum(tot - (realT / 250.0) ** 17, 0.0)
     air = ~is_wall
-    base[..., 3] = np.where(air, T_air, 0.0)
-    water[..., 0] = np.where(air, tot, 0.0)
-    water[..., 1] = np.where(air, cloud, 0.0)
+    base[..., 3] = np.where(air, d["T_air"][:, None], np.float32(0.0))
+    water[..., 0] = np.where(air, d["total_water"][:, None], np.float32(0.0))
+    water[..., 1] = np.where(air, d["cloud_water"][:, None], np.float32(0.0))
 
     # walls (setupShader.frag:63-77)
-    base[..., 3] = np.where(is_sea, 25.0 + 273.15, base[..., 3])
+    base[..., 3] = np.where(is_sea, np.float32(25.0) + np.float32(273.15), base[..., 3])
     base[..., 3] = np.where(is_land, 1000.0, base[..., 3])
     water[..., 0] = np.where(is_sea, 1002.0, water[..., 0])
     water[..., 0] = np.where(is_land, 1001.0, water[..., 0])
     water[..., 2] = np.where(is_land, 25.0, water[..., 2])
     water[..., 2] = np.where(is_sea, 100.0, water[..., 2])
-    fx = gcol.astype(np.float64) + 0.5
-    veg = 110.0 - (yy + 0.5) * 2.0 + (_noise(fx * 0.01 + _rand(seed) * 10.0) * 150.0)[None, :]
+    veg = 110.0 - (yy + 0.5) * 2.0 + d["veg_noise"][None, :]
     wall[..., 3] = np.where(is_land, np.clip(np.trunc(veg), 0, 127), 0).astype(np.int8)
-    height_m = h * sim_h
-    snow = np.clip((height_m - 2000.0) * 100.0 / 3000.0, 0.0, 100.0)
-    water[..., 3] = np.where(is_land, snow[None, :], water[..., 3])
+    water[..., 3] = np.where(is_land, d["snow"][None, :], water[..., 3])
 
-    wall[..., 0] = np.where((h < texY)[None, :], 2, 1).astype(np.int8)  # type, extended upward like the boundary pass does
+    wall[..., 0] = np.where(sea_col[None, :], 2, 1).astype(np.int8)  # type, extended upward like the boundary pass does
     vdist = yy - nrows[None, :] + 1  # 1 for the first air row, 0 for the top wall row, negative below
     wall[..., 2] = np.clip(vdist, -127, 127).astype(np.int8)
     wall[..., 1] = np.where(is_wall, 0, np.clip(vdist, 1, 127)).astype(np.int8)

@@ -157,16 +157,16 @@ def main():
         u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, pass_mask=pkg.params.PASS_DRY)
         u["enablePrecipitation"] = 0
     if world == 1:
+        h = pkg.engine.Handle(X, Y, a.particles)
         if a.workload == "dry":
             base, water, wall = pkg.synth.dry_grid(X, Y)
-        else:
-            base, water, wall = pkg.synth.terrain_grid(X, Y)
-        h = pkg.engine.Handle(X, Y, a.particles)
-        if a.particles:
-            u["enablePrecipitation"] = 1
-            pkg.synth.add_cloud_deck(water, wall)  # so that droplets spawn, grow and fall during the run
-        h.upload(base, water, wall, pkg.synth.init_rain_drops(a.particles) if a.particles else None)
-        del base, water, wall
+            h.upload(base, water, wall)
+            del base, water, wall
+        else:  # device-side initialiser: 1-D terrain / sounding descriptors instead of 1.2 GB of host arrays
+            if a.particles:
+                u["enablePrecipitation"] = 1  # + a cloud deck so that droplets spawn, grow and fall during the run
+            h.setup_columns(pkg.synth.terrain_columns(X, Y, cloud_deck=bool(a.particles)),
+                            pkg.synth.init_rain_drops(a.particles) if a.particles else None)
         h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
         stepper = h
         step = lambda n: h.step(n)

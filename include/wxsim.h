@@ -120,6 +120,16 @@ int wx_abi_version(void);
  * it across KeyL reloads, app.js:4628-4640). Arrays cover the handle's LOCAL width. drops may be NULL. */
 int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wall, const float *drops);
 
+/* Device-side initialiser of a new simulation: replaces the setup draw (shaders/fragment/setupShader.frag:36-92,
+ * app.js `setupTextures` path for a new simulation) WITHOUT three X*Y host arrays. The caller passes the 1-D part of the
+ * generator -- per local column: number of wall rows (0..Y), sea (1) / land (0), the vegetation noise term
+ * `noise(x*0.01 + rand(seed)*10) * 150` (double) and the snow height; per row: air temperature, total and cloud water of
+ * the initial sounding (setupShader.frag:78-89) -- and the textures are filled on the device. Equivalent to wx_upload of
+ * the arrays that weather_sandbox_amd.synth.terrain_grid builds from the same descriptors (tested bit for bit); resets
+ * the same state as wx_upload. */
+int wx_setup_columns(wx_sim *s, const int32_t *wall_rows, const uint8_t *sea_column, const double *veg_noise, const float *snow,
+                     const float *T_air, const float *total_water, const float *cloud_water, const float *drops);
+
 /* Replaces the uniform pushes (see wx_params) plus the `initial_Tv` / realWorldSounding_* arrays
  * (app.js:5444-5474, 5485-5537). initial_T has Y+1 entries; sounding arrays Y+1 entries or NULL (= 0).
  * Takes effect at the next wx_step. */

@@ -478,6 +478,41 @@ def test_slab_particles_equal_whole_domain(pkg, E, nslab):
         assert np.array_equal(h.read_rect("WALL_CUR", halo, 0, xo, Y), whole.read_rect("WALL_CUR")[:, r * xo:(r + 1) * xo])
 
 
+@pytest.mark.parametrize("X,Y,cols", [(512, 128, None), (130, 50, None), (4096, 256, (4000, 300))])
+def test_device_side_setup_equals_uploaded_grid(pkg, E, X, Y, cols):
+    """wx_setup_columns: the textures filled on the device from the 1-D descriptors are bit-identical
+    to the arrays synth.terrain_grid builds from the same descriptors and uploads; so is the run that follows."""
+    S = pkg.synth
+    desc = S.terrain_columns(X, Y, cols=cols, cloud_deck=True)
+    base, water, wall = S.terrain_grid(X, Y, cols=cols)
+    S.add_cloud_deck(water, wall)
+    Xl = X if cols is None else cols[1]
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 40.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    kw = {} if cols is None else dict(X_global=X, x0=cols[0] + 12, halo=12)
+    a = E.Handle(Xl if cols is None else Xl - 24, Y, 0, **kw)
+    b = E.Handle(Xl if cols is None else Xl - 24, Y, 0, **kw)
+    a.upload(base, water, wall)
+    b.setup_columns(desc)
+    for h in (a, b):
+        h.set_params(p, u["initial_T"])
+    for f in ("BASE_CUR", "WATER_CUR", "WATER_0", "WALL_CUR", "LIGHT_0"):
+        assert np.array_equal(a.read_rect(f), b.read_rect(f)), f
+    a.step(6)
+    b.step(6)
+    for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1"):
+        assert np.array_equal(a.read_rect(f), b.read_rect(f)), f
+    bad = dict(desc, wall_rows=desc["wall_rows"].copy())
+    bad["wall_rows"][3] = Y + 1
+    with pytest.raises(E.WxError):
+        b.setup_columns(bad)
+    with pytest.raises(ValueError):
+        b.setup_columns(dict(desc, snow=desc["snow"][:-1]))
+
+
 def test_brush_and_airplane_inputs_bit_exact(pkg, oracle, E, fused):
     """Next-row (f1): user brush (every tool of advectionShader.frag:229-401) and airplane inputs (:415-457):
     HIP == oracle bit for bit, on the inputs/uniforms of the reference goldens (tests/golden/brush64.npz)."""
