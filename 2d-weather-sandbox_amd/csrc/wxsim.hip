@@ -80,6 +80,10 @@ struct wx_sim {
   Geo geo{};
   Uni uni{};
   hipStream_t stream = nullptr;
+  // display streaming (wx_stream_frame): copies run on their own stream, fenced against the compute stream by events
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_fields_ready = nullptr, ev_copy_done = nullptr;
+  bool copy_in_flight = false;
   // device storage
   float4 *base[3] = {nullptr, nullptr, nullptr}; // [2]: post-advection base of the fused path (= baseTexture_1)
   float4 *water[3] = {nullptr, nullptr, nullptr}, *light[3] = {nullptr, nullptr, nullptr}; // [2]: spare of the single-kernel ping-pong
@@ -589,6 +593,12 @@ void wx_destroy(wx_sim *s)
   hipFree(s->snd_T);
   hipFree(s->snd_W);
   hipFree(s->snd_Vel);
+  if (s->copy_stream) {
+    hipStreamSynchronize(s->copy_stream);
+    hipEventDestroy(s->ev_fields_ready);
+    hipEventDestroy(s->ev_copy_done);
+    hipStreamDestroy(s->copy_stream);
+  }
   hipFree(s->state);
   hipFree(s->keys);
   hipFree(s->slow_ctx);
@@ -741,6 +751,10 @@ int wx_step(wx_sim *s, int n_iter)
   // the fused kernels implement the full grid-pass set; any other pass_mask runs the per-pass kernels
   const bool fused = s->fused && (mask & 0x3Fu) == 0x3Fu;
   const bool dry = s->fused && (mask & 0x3Fu) == WX_PASS_DRY;
+  if (s->copy_in_flight) { // a streamed frame still reads the display fields: order this step after it (device-side wait)
+    HIPCHK(s, hipStreamWaitEvent(s->stream, s->ev_copy_done, 0));
+    s->copy_in_flight = false;
+  }
   if (!(fused && s->fused == 1)) cow_resolve(s); // the other kernel sets take water[0] as a fully written buffer
   for (int it = 0; it < n_iter; it++) {
     if (dry)
@@ -886,6 +900,61 @@ int wx_read_particles(wx_sim *s, int first, int count, float *dst)
   if (count == 0) return WX_OK;
   HIPCHK(s, hipMemcpyAsync(dst, s->drops[s->drop_cur] + 5 * (size_t)first, (size_t)count * 20, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
+  return WX_OK;
+}
+
+// ---- field streaming for display consumers ----
+namespace {
+const int kStreamFields[6] = {WX_FIELD_BASE_DISP, WX_FIELD_WATER_CUR, WX_FIELD_WALL_DISP, WX_FIELD_LIGHT_0, WX_FIELD_CURL, WX_FIELD_PRECIP_FB};
+}
+
+size_t wx_stream_bytes(int w, int h) { return (w > 0 && h > 0) ? (size_t)w * h * (16 + 16 + 4 + 16 + 4 + 16) : 0; }
+
+void *wx_host_alloc(size_t bytes)
+{
+  void *p = nullptr;
+  return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void wx_host_free(void *p)
+{
+  if (p) hipHostFree(p);
+}
+
+int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst)
+{
+  if (!s || !host_dst) return WX_E_INVALID;
+  if (!s->uploaded) return fail(s, WX_E_STATE, "wx_stream_frame before wx_upload");
+  if (w <= 0 || h <= 0 || x < 0 || y < 0 || x + w > s->X || y + h > s->Y)
+    return fail(s, WX_E_RANGE, "wx_stream_frame: rect (%d,%d %dx%d) outside %dx%d (no wrap)", x, y, w, h, s->X, s->Y);
+  if (!s->copy_stream) {
+    HIPCHK(s, hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    HIPCHK(s, hipEventCreateWithFlags(&s->ev_fields_ready, hipEventDisableTiming));
+    HIPCHK(s, hipEventCreateWithFlags(&s->ev_copy_done, hipEventDisableTiming));
+  }
+  // the copies start when everything enqueued so far on the compute stream has produced the fields ...
+  HIPCHK(s, hipEventRecord(s->ev_fields_ready, s->stream));
+  HIPCHK(s, hipStreamWaitEvent(s->copy_stream, s->ev_fields_ready, 0));
+  char *dst = (char *)host_dst;
+  for (int f = 0; f < 6; f++) {
+    const void *ptr;
+    int ch, el;
+    if (field_info(s, kStreamFields[f], &ptr, &ch, &el)) return fail(s, WX_E_INVALID, "wx_stream_frame: field %d", kStreamFields[f]);
+    const size_t texel = (size_t)ch * el;
+    HIPCHK(s, hipMemcpy2DAsync(dst, (size_t)w * texel, (const char *)ptr + ((size_t)y * s->X + x) * texel, (size_t)s->X * texel, (size_t)w * texel, h,
+                               hipMemcpyDeviceToHost, s->copy_stream));
+    dst += (size_t)w * h * texel;
+  }
+  // ... and the next wx_step (which overwrites them) waits for the copies on the device, not on the host
+  HIPCHK(s, hipEventRecord(s->ev_copy_done, s->copy_stream));
+  s->copy_in_flight = true;
+  return WX_OK;
+}
+
+int wx_stream_wait(wx_sim *s)
+{
+  if (!s) return WX_E_INVALID;
+  if (s->copy_stream) HIPCHK(s, hipStreamSynchronize(s->copy_stream));
   return WX_OK;
 }
 

@@ -32,6 +32,7 @@ EXPORTS = [
     "wx_device_ptr", "wx_local_width", "wx_halo_bytes", "wx_halo_pack", "wx_halo_unpack", "wx_profile",
     "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_particles_keys",
     "wx_particles_contribute", "wx_particles_adopt", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns",
+    "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait",
 ]
 
 
@@ -102,6 +103,14 @@ def lib() -> C.CDLL:
     L.wx_lightning_get.argtypes = [vp, vp]
     L.wx_lightning_set.argtypes = [vp, vp]
     L.wx_setup_columns.argtypes = [vp] + [vp] * 8
+    L.wx_stream_bytes.argtypes = [i32, i32]
+    L.wx_stream_bytes.restype = C.c_size_t
+    L.wx_host_alloc.argtypes = [C.c_size_t]
+    L.wx_host_alloc.restype = vp
+    L.wx_host_free.argtypes = [vp]
+    L.wx_host_free.restype = None
+    L.wx_stream_frame.argtypes = [vp, i32, i32, i32, i32, vp]
+    L.wx_stream_wait.argtypes = [vp]
     _lib = L
     return L
 
@@ -134,8 +143,11 @@ class Handle:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().wx_destroy(self._h)
+            lib().wx_destroy(self._h)  # (waits for a streamed frame in flight)
             self._h = None
+            if getattr(self, "_pin", None) is not None:
+                lib().wx_host_free(self._pin[0])
+                self._pin = None
 
     def __del__(self):
         try:
@@ -225,6 +237,38 @@ class Handle:
 
     def halo_unpack(self, side: int, dev_ptr: int):
         self._chk(lib().wx_halo_unpack(self._h, side, C.c_void_p(dev_ptr)))
+
+    # ---- display streaming (wx_stream_frame): one pinned buffer per Handle, re-used while the viewport size is unchanged
+    STREAM_FIELDS = (("BASE_DISP", np.float32, 4), ("WATER_CUR", np.float32, 4), ("WALL_DISP", np.int8, 4), ("LIGHT_0", np.float32, 4),
+                     ("CURL", np.float32, 1), ("PRECIP_FB", np.float32, 4))
+
+    def stream_frame(self, x: int = 0, y: int = 0, w: Optional[int] = None, h: Optional[int] = None):
+        """Start the asynchronous copy of the display fields of a viewport; returns immediately."""
+        w = self.X - x if w is None else w
+        h = self.Y - y if h is None else h
+        L = lib()
+        nbytes = L.wx_stream_bytes(w, h)
+        if getattr(self, "_pin", None) is None or self._pin[1] != nbytes:
+            if getattr(self, "_pin", None) is not None:
+                L.wx_host_free(self._pin[0])
+            p = L.wx_host_alloc(nbytes)
+            if not p:
+                raise MemoryError(f"wx_host_alloc({nbytes})")
+            self._pin = (p, nbytes)
+        self._chk(L.wx_stream_frame(self._h, x, y, w, h, C.c_void_p(self._pin[0])))
+        self._frame = (w, h)
+
+    def stream_wait(self):
+        """Wait for the frame started by stream_frame(); returns {field: array} views of the pinned buffer."""
+        self._chk(lib().wx_stream_wait(self._h))
+        w, h = self._frame
+        raw = (C.c_char * self._pin[1]).from_address(self._pin[0])
+        out, off = {}, 0
+        for name, dt, ch in self.STREAM_FIELDS:
+            n = w * h * ch
+            out[name] = np.frombuffer(raw, dtype=dt, count=n, offset=off).reshape(h, w, ch)
+            off += n * np.dtype(dt).itemsize
+        return out
 
     def setup_columns(self, desc, drops=None):
         """Device-side initialiser from the 1-D descriptors of ``synth.terrain_columns`` (wx_setup_columns)."""

@@ -156,6 +156,18 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
  * 5 floats per droplet (pos.xy, mass.xy, density) from the destination buffer of the last step. */
 int wx_read_particles(wx_sim *s, int first, int count, float *dst);
 
+/* Field streaming for a display consumer: what the reference's renderer binds every frame (app.js:6081-6219)
+ * -- BASE_DISP, WATER_CUR, WALL_DISP (int8), LIGHT_0, CURL, PRECIP_FB of the viewport rect, in this order, each field
+ * contiguous (w*h texels, rows bottom-up, no wrap) -- copied asynchronously into ONE host buffer of wx_stream_bytes(w, h)
+ * bytes, ideally pinned (wx_host_alloc). wx_stream_frame returns at once: the copies run on the handle's own copy
+ * stream after everything enqueued so far; later wx_step calls are ordered after them on the device, so the host never
+ * blocks; wx_stream_wait blocks until the frame is complete in host memory. One frame in flight per handle. */
+size_t wx_stream_bytes(int w, int h);
+void *wx_host_alloc(size_t bytes); /* pinned host memory; NULL on failure */
+void wx_host_free(void *p);
+int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst);
+int wx_stream_wait(wx_sim *s);
+
 /* ---- plumbing for hosts that own device memory / streams (PyTorch, multi-GPU halo exchange) ---- */
 int wx_set_stream(wx_sim *s, void *hip_stream);     /* NULL = legacy default stream */
 void *wx_device_ptr(wx_sim *s, int field);          /* device address of a field's current storage */

@@ -513,6 +513,42 @@ def test_device_side_setup_equals_uploaded_grid(pkg, E, X, Y, cols):
         b.setup_columns(dict(desc, snow=desc["snow"][:-1]))
 
 
+def test_display_field_streaming(pkg, golden, E):
+    """wx_stream_frame: the six display fields of a viewport arrive in one pinned buffer, hold the state
+    at the time of the call even though more iterations are enqueued right behind it, and do not disturb the run."""
+    g, u = golden("precip64")
+    u = dict(u, quad_scale=0, enablePrecipitation=1)
+    X, Y = int(g["X"]), int(g["Y"])
+
+    def make():
+        h = E.Handle(X, Y, len(g["in_drops"]))
+        h.upload(g["in_base"], g["in_water"], g["in_wall"], g["in_drops"])
+        h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+        return h
+
+    h, ref = make(), make()
+    rect = (8, 4, 40, 30)
+    h.step(5)
+    ref.step(5)
+    want = {name: ref.read_rect(name, *rect) for name, _, _ in E.Handle.STREAM_FIELDS}
+    h.stream_frame(*rect)
+    h.step(3)  # enqueued behind the copies: must not leak into the frame
+    frame = h.stream_wait()
+    for name, _, ch in E.Handle.STREAM_FIELDS:
+        assert frame[name].shape == (rect[3], rect[2], ch)
+        assert np.array_equal(frame[name].reshape(want[name].shape), want[name]), name
+    assert np.abs(frame["PRECIP_FB"]).max() > 0
+    ref.step(3)
+    assert np.array_equal(h.read_rect("WALL_CUR"), ref.read_rect("WALL_CUR"))
+    for f in ("BASE_CUR", "WATER_CUR"):  # two runs with particle feedback agree to the order of the splat atomics
+        assert np.abs(h.read_rect(f) - ref.read_rect(f)).max() <= 1e-5, f
+    h.stream_frame()  # whole grid, buffer re-allocated for the new size
+    full = h.stream_wait()
+    assert np.array_equal(full["WATER_CUR"], h.read_rect("WATER_CUR"))
+    with pytest.raises(E.WxError):
+        h.stream_frame(X - 4, 0, 8, 8)  # no wrap
+
+
 def test_brush_and_airplane_inputs_bit_exact(pkg, oracle, E, fused):
     """Next-row (f1): user brush (every tool of advectionShader.frag:229-401) and airplane inputs (:415-457):
     HIP == oracle bit for bit, on the inputs/uniforms of the reference goldens (tests/golden/brush64.npz)."""
