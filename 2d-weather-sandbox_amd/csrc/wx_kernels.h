@@ -216,6 +216,9 @@ struct SlabP {
   int keyval;         // claim key of this iteration; 0 = whole-domain handle (no keys)
   int *keys;
 };
+#ifndef WX_PRECIP_COUNT_MODE
+#define WX_PRECIP_COUNT_MODE 1
+#endif
 struct DevState {
   float inactiveDroplets; // the `inactiveDroplets` uniform, refreshed on the device every 600 iterations
   float lightning[4];     // lightningDataTexture (1x1 RGBA32F)
@@ -462,6 +465,7 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
 
   // inactive-droplet count: the reference blends +1 into texel (0,0) per droplet
   // (precipitationShader.vert:158-159); here one atomic per wavefront carries the lane count
+#if WX_PRECIP_COUNT_MODE == 0
   {
     const unsigned long long m = __ballot(count_inactive);
     if (m != 0ull) {
@@ -469,6 +473,12 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
       if (lane == __ffsll((long long)m) - 1) unsafeAtomicAdd(&st->px_count, (float)__popcll(m));
     }
   }
+#elif WX_PRECIP_COUNT_MODE == 1
+  { // one atomic per 256-thread block: 16 384 same-address atomics per launch were serialising in L2
+    const int c = __syncthreads_count(count_inactive);
+    if (threadIdx.x == 0 && c) unsafeAtomicAdd(&st->px_count, (float)c);
+  }
+#endif
   if (!live || count_inactive) return;
 
   // point sprite: clip test on the centre (precipitationShader.vert gl_Position / gl_PointSize)
