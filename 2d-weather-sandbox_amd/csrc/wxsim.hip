@@ -683,7 +683,7 @@ int wx_setup_columns(wx_sim *s, const int32_t *wall_rows, const uint8_t *sea_col
   const int X = s->X, Y = s->Y;
   for (int x = 0; x < X; x++)
     if (wall_rows[x] < 0 || wall_rows[x] > Y) return fail(s, WX_E_RANGE, "wx_setup_columns: wall_rows[%d] = %d outside 0..%d", x, wall_rows[x], Y);
-  // descriptors live in device scratch for the duration of the fill: reuse the (not yet meaningful) curl / vort planes
+  // the descriptors live in a device scratch allocation for the duration of the fill
   static_assert(sizeof(double) == 8, "");
   char *scratch = nullptr;
   const size_t bytes = (size_t)X * (4 + 8 + 4 + 4) + (size_t)Y * 12;
