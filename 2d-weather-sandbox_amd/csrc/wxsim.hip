@@ -372,8 +372,15 @@ static const SlowCtx *slow_ctx_for(wx_sim *s, const FusedBIn &in)
   c.snd_T = s->snd_T;
   c.snd_W = s->snd_W;
   c.snd_Vel = s->snd_Vel;
-  c.in = in;
-  c.in.light = nullptr;
+  // field by field: a struct assignment would also copy the caller's (indeterminate) padding bytes into the key
+  c.in.base = in.base;
+  c.in.water = in.water;
+  c.in.wall = in.wall;
+  c.in.light = nullptr; // alternates with the even / odd parity and is not used by the out-of-line path
+  c.in.water_alt = in.water_alt;
+  c.in.wall_alt = in.wall_alt;
+  c.in.clean = in.clean;
+  c.in.txn = in.txn;
   for (int i = 0; i < 2; i++)
     if (s->slow_valid[i] && memcmp(&s->slow_host[i], &c, sizeof(c)) == 0) return s->slow_ctx + i;
   const int i = s->slow_next;
