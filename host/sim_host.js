@@ -117,6 +117,55 @@ function initialTemperatureProfile(Y, simHeight, dryLapse)
   }
   return T;
 }
+// ---- new simulation: the 1-D part of the setup pass (setupShader.frag:26-92), expanded on the device by wx_setup_columns ----
+function fract(x) { return x - Math.floor(x); }
+function srand(n) { return fract(Math.sin(n) * 43758.5453123); }                      // setupShader.frag:26
+function snoise(p) { const fl = Math.floor(p), fc = p - fl; return srand(fl) * (1.0 - fc) + srand(fl + 1.0) * fc - 0.5; } // :28-33
+function terrainColumns(X, Y, gui, opts)
+{
+  opts = opts || {};
+  const seed = opts.seed != null ? opts.seed : 0.5, heightMult = opts.heightMult != null ? opts.heightMult : 0.3;
+  const snap = opts.snap != null ? opts.snap : 2; // even x / y steps (see SURVEY Appendix C); 1 = the reference's raw terrain
+  const simH = gui.simHeight, dryLapse = simH * gui.dryLapseRate / 1000.0, texY = 1.0 / Y;
+  const h = new Float64Array(X);
+  for (let x = 0; x < X; x++) { // :44-61
+    if (heightMult < 0.05) { h[x] = 0.0; continue; }
+    if (heightMult < 0.10) { h[x] = 0.005; continue; }
+    const v = (x + 0.5) * 0.001;
+    let acc = 0.0;
+    for (let i = 2.0; i < 1000.0; i *= 1.5) acc += snoise(v * i + srand(seed + i) * 10.0) * 0.5 / i;
+    h[x] = acc * heightMult;
+  }
+  if (snap > 1) for (let x = 0; x < X; x++) h[x] = h[x - x % snap];
+  const d = {wallRows: new Int32Array(X), sea: new Uint8Array(X), vegNoise: new Float64Array(X), snow: new Float32Array(X),
+             T_air: new Float32Array(Y), totalWater: new Float32Array(Y), cloudWater: new Float32Array(Y)};
+  for (let x = 0; x < X; x++) {
+    let rows = Math.max(1, Math.ceil(h[x] * Y - 0.5)); // wall: texCoord.y < texelSize.y or texCoord.y < height (:63-64)
+    if (snap > 1) rows = Math.floor((rows + snap - 1) / snap) * snap;
+    d.wallRows[x] = Math.min(rows, Y - 8);
+    d.sea[x] = h[x] < texY ? 1 : 0;
+    d.vegNoise[x] = snoise((x + 0.5) * 0.01 + srand(seed) * 10.0) * 150.0;         // :72
+    d.snow[x] = Math.min(Math.max((h[x] * simH - 2000.0) * 100.0 / 3000.0, 0.0), 100.0);
+  }
+  const T0 = initialTemperatureProfile(Y, simH, dryLapse);
+  for (let y = 0; y < Y; y++) { // initial sounding :78-89
+    const tcy = (y + 0.5) / Y, realT = T0[y] - tcy * dryLapse, dew = tcy < 0.20 ? realT - 2.0 : realT - 20.0;
+    const tot = Math.pow(dew / 250.0, 17);
+    d.T_air[y] = T0[y];
+    d.totalWater[y] = tot;
+    d.cloudWater[y] = Math.max(tot - Math.pow(realT / 250.0, 17), 0.0);
+  }
+  return d;
+}
+function initRainDrops(n, rng)
+{ // initRainDrops(), app.js:4901-4913: inactive droplets whose fields are random seeds
+  rng = rng || Math.random;
+  const d = new Float32Array(5 * n);
+  for (let i = 0; i < n; i++) {
+    d[5 * i] = rng(); d[5 * i + 1] = rng(); d[5 * i + 2] = -10.0 + rng(); d[5 * i + 3] = rng(); d[5 * i + 4] = rng();
+  }
+  return d;
+}
 function sunFromAngle(sunAngleDeg, sunIntensityGui)
 { // app.js:6538-6550
   return {
@@ -168,7 +217,12 @@ function WeatherSim(sf, opts)
   this.opts = opts;
   this.manualSun = opts.sunFixed ? this.gui.sunAngle : null; // updateSunlight('MANUAL_ANGLE')
   this.h = this.addon.create(this.X, this.Y, this.nDroplets);
-  this.addon.upload(this.h, sf.base, sf.water, sf.wall, this.nDroplets ? sf.droplets : null);
+  if (sf.columns) { // new simulation: textures filled on the device from the 1-D descriptors (setupShader.frag)
+    const c = sf.columns;
+    this.addon.setupColumns(this.h, c.wallRows, c.sea, c.vegNoise, c.snow, c.T_air, c.totalWater, c.cloudWater, this.nDroplets ? sf.droplets : null);
+  } else {
+    this.addon.upload(this.h, sf.base, sf.water, sf.wall, this.nDroplets ? sf.droplets : null);
+  }
   // startSimulation(): clock from month / timeOfDay (app.js:3902)
   const m = this.gui.month;
   this.simDateTime = new Date(2000, Math.floor(m) - 1, (m % 1) * 30.417);
@@ -230,11 +284,36 @@ WeatherSim.prototype.toSave = function() { // prepareDownload(): FB0 = base_0, w
   return {X: this.X, Y: this.Y, base: this.readRect('BASE_CUR', 0, 0, this.X, this.Y), water: this.readRect('WATER_0', 0, 0, this.X, this.Y),
           wall: this.readRect('WALL_CUR', 0, 0, this.X, this.Y), droplets: this.readParticles(), stations: [], settings: this.gui};
 };
+// display fields of a viewport, copied asynchronously into pinned memory (what the renderer binds, app.js:6081-6219):
+// returns {wait()} whose result holds typed-array views BASE_DISP, WATER_CUR, WALL_DISP, LIGHT_0, CURL, PRECIP_FB
+WeatherSim.prototype.streamFrame = function(x, y, w, h) {
+  const self = this, ab = this.addon.streamFrame(this.h, x, y, w, h), n = w * h;
+  return {wait: function() {
+    self.addon.streamWait(self.h);
+    let off = 0;
+    const f32 = function(ch) { const v = new Float32Array(ab, off, n * ch); off += 4 * n * ch; return v; };
+    const out = {BASE_DISP: f32(4), WATER_CUR: f32(4)};
+    out.WALL_DISP = new Int8Array(ab, off, 4 * n);
+    off += 4 * n;
+    out.LIGHT_0 = f32(4);
+    out.CURL = f32(1);
+    out.PRECIP_FB = f32(4);
+    return out;
+  }};
+};
 WeatherSim.prototype.destroy = function() { this.addon.destroy(this.h); };
+// startup without a save file: what mainScript() does for a new simulation (setup pass + initRainDrops)
+WeatherSim.newSimulation = function(X, Y, opts) {
+  opts = opts || {};
+  const gui = mergeSettings(opts.settings || null);
+  const nDrops = opts.nDroplets != null ? opts.nDroplets : Math.floor(X * Y / 25); // app.js: one droplet per 25 cells
+  return new WeatherSim({X: X, Y: Y, settings: gui, columns: terrainColumns(X, Y, gui, opts), droplets: nDrops ? initRainDrops(nDrops, opts.rng) : null}, opts);
+};
 
 module.exports = {WeatherSim: WeatherSim, loadSave: loadSave, decodeSave: decodeSave, encodeSave: encodeSave, mergeSettings: mergeSettings,
                   uniformsFromGui: uniformsFromGui, initialTemperatureProfile: initialTemperatureProfile, sunFromAngle: sunFromAngle,
-                  sunAngleFromTime: sunAngleFromTime, GUI_DEFAULTS: GUI_DEFAULTS, FIELD: FIELD};
+                  sunAngleFromTime: sunAngleFromTime, terrainColumns: terrainColumns, initRainDrops: initRainDrops, GUI_DEFAULTS: GUI_DEFAULTS,
+                  FIELD: FIELD};
 
 if (require.main === module) {
   const args = process.argv.slice(2);

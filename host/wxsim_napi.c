@@ -30,6 +30,13 @@ static struct {
   int (*set_iter)(wx_sim *, int64_t);
   int (*read_rect)(wx_sim *, int, int, int, int, int, void *, int);
   int (*read_particles)(wx_sim *, int, int, float *);
+  int (*setup_columns)(wx_sim *, const int32_t *, const uint8_t *, const double *, const float *, const float *, const float *, const float *,
+                       const float *);
+  size_t (*stream_bytes)(int, int);
+  void *(*host_alloc)(size_t);
+  void (*host_free)(void *);
+  int (*stream_frame)(wx_sim *, int, int, int, int, void *);
+  int (*stream_wait)(wx_sim *);
 } L;
 
 #define NAPI_CALL(env, call)                                                        \
@@ -300,6 +307,73 @@ static napi_value ReadParticles(napi_env env, napi_callback_info info)
   return a[3];
 }
 
+/* setupColumns(h, Int32Array wallRows, Uint8Array sea, Float64Array vegNoise, Float32Array snow, Float32Array T_air,
+ *              Float32Array totalWater, Float32Array cloudWater, Float32Array drops|null)
+ * [the setup draw of a new simulation, setupShader.frag:36-92, filled on the device from the 1-D descriptors] */
+static napi_value SetupColumns(napi_env env, napi_callback_info info)
+{
+  napi_value a[9];
+  if (get_args(env, info, 9, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  size_t n;
+  const int32_t *rows = (const int32_t *)typed_data(env, a[1], napi_int32_array, &n);
+  const uint8_t *sea = (const uint8_t *)typed_data(env, a[2], napi_uint8_array, &n);
+  const double *veg = (const double *)typed_data(env, a[3], napi_float64_array, &n);
+  const float *snow = (const float *)typed_data(env, a[4], napi_float32_array, &n);
+  const float *T = (const float *)typed_data(env, a[5], napi_float32_array, &n);
+  const float *tot = (const float *)typed_data(env, a[6], napi_float32_array, &n);
+  const float *cloud = (const float *)typed_data(env, a[7], napi_float32_array, &n);
+  const float *drops = (const float *)typed_data(env, a[8], napi_float32_array, &n);
+  if (!rows || !sea || !veg || !snow || !T || !tot || !cloud) {
+    napi_throw_type_error(env, NULL, "setupColumns: Int32Array, Uint8Array, Float64Array, then four Float32Array expected");
+    return NULL;
+  }
+  int rc = L.setup_columns(s, rows, sea, veg, snow, T, tot, cloud, drops);
+  if (rc) return throw_wx(env, s, rc, "wx_setup_columns");
+  return NULL;
+}
+
+static void finalize_pinned(napi_env env, void *data, void *hint) { L.host_free(data); }
+
+/* streamFrame(h, x, y, w, h) -> ArrayBuffer over pinned host memory that the copies fill asynchronously; streamWait(h)
+ * blocks until it is complete. Layout: BASE_DISP f32x4, WATER_CUR f32x4, WALL_DISP i8x4, LIGHT_0 f32x4, CURL f32, PRECIP_FB f32x4
+ * [what the renderer binds per frame, app.js:6081-6219] */
+static napi_value StreamFrame(napi_env env, napi_callback_info info)
+{
+  napi_value a[5];
+  if (get_args(env, info, 5, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  int32_t r[4];
+  for (int i = 0; i < 4; i++) NAPI_CALL(env, napi_get_value_int32(env, a[1 + i], &r[i]));
+  const size_t bytes = L.stream_bytes(r[2], r[3]);
+  void *buf = bytes ? L.host_alloc(bytes) : NULL;
+  if (!buf) {
+    napi_throw_error(env, NULL, "streamFrame: empty rectangle or wx_host_alloc failed");
+    return NULL;
+  }
+  int rc = L.stream_frame(s, r[0], r[1], r[2], r[3], buf);
+  if (rc) {
+    L.host_free(buf);
+    return throw_wx(env, s, rc, "wx_stream_frame");
+  }
+  napi_value ab;
+  NAPI_CALL(env, napi_create_external_arraybuffer(env, buf, bytes, finalize_pinned, NULL, &ab));
+  return ab;
+}
+
+static napi_value StreamWait(napi_env env, napi_callback_info info)
+{
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  int rc = L.stream_wait(s);
+  if (rc) return throw_wx(env, s, rc, "wx_stream_wait");
+  return NULL;
+}
+
 static napi_value AbiVersion(napi_env env, napi_callback_info info)
 {
   napi_value r;
@@ -337,6 +411,8 @@ static int load_lib(napi_env env)
   SYM(create, "wx_create") SYM(destroy, "wx_destroy") SYM(last_error, "wx_last_error") SYM(abi_version, "wx_abi_version")
   SYM(upload, "wx_upload") SYM(set_params, "wx_set_params") SYM(step, "wx_step") SYM(sync, "wx_sync") SYM(get_iter, "wx_get_iter")
   SYM(set_iter, "wx_set_iter") SYM(read_rect, "wx_read_rect") SYM(read_particles, "wx_read_particles")
+  SYM(setup_columns, "wx_setup_columns") SYM(stream_bytes, "wx_stream_bytes") SYM(host_alloc, "wx_host_alloc") SYM(host_free, "wx_host_free")
+  SYM(stream_frame, "wx_stream_frame") SYM(stream_wait, "wx_stream_wait")
 #undef SYM
   return 0;
 }
@@ -350,7 +426,8 @@ static napi_value Init(napi_env env, napi_value exports)
     {"step", 0, Step, 0, 0, 0, napi_default, 0},           {"sync", 0, Sync, 0, 0, 0, napi_default, 0},
     {"getIter", 0, GetIter, 0, 0, 0, napi_default, 0},     {"setIter", 0, SetIter, 0, 0, 0, napi_default, 0},
     {"readRect", 0, ReadRect, 0, 0, 0, napi_default, 0},   {"readParticles", 0, ReadParticles, 0, 0, 0, napi_default, 0},
-    {"abiVersion", 0, AbiVersion, 0, 0, 0, napi_default, 0},
+    {"abiVersion", 0, AbiVersion, 0, 0, 0, napi_default, 0}, {"setupColumns", 0, SetupColumns, 0, 0, 0, napi_default, 0},
+    {"streamFrame", 0, StreamFrame, 0, 0, 0, napi_default, 0}, {"streamWait", 0, StreamWait, 0, 0, 0, napi_default, 0},
   };
   NAPI_CALL(env, napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d));
   return exports;

@@ -67,3 +67,51 @@ def test_node_host_end_to_end_equals_python_host(pkg, golden, tmp_path):
     assert np.array_equal(got.base, ref.base) and np.array_equal(got.water, ref.water)
     assert got.droplets.shape == ref.droplets.shape
     assert got.settings["vorticity"] == 0.007
+
+
+@needs_node
+@pytest.mark.parametrize("X,Y", [(256, 96), (1000, 200)])
+def test_js_terrain_columns_match_python(pkg, X, Y):
+    """terrainColumns() of host/sim_host.js (new-simulation path) against synth.terrain_columns: same float64 math."""
+    js = ("const H=require('%s'); const d=H.terrainColumns(%d,%d,H.mergeSettings(null));"
+          "console.log(JSON.stringify({rows:Array.from(d.wallRows),sea:Array.from(d.sea),veg:Array.from(d.vegNoise),snow:Array.from(d.snow),"
+          "T:Array.from(d.T_air),tot:Array.from(d.totalWater),cloud:Array.from(d.cloudWater)}))" % (os.path.join(ROOT, "host", "sim_host.js"), X, Y))
+    d = json.loads(subprocess.check_output([NODE, "-e", js]))
+    ref = pkg.synth.terrain_columns(X, Y)
+    assert np.array_equal(np.asarray(d["rows"]), ref["wall_rows"]) and np.array_equal(np.asarray(d["sea"]), ref["sea"])
+    assert np.allclose(d["veg"], ref["veg_noise"], rtol=0, atol=1e-6)  # V8 vs libm sin(): last-ulp differences x 43758 x 150
+    for k, r in (("snow", "snow"), ("T", "T_air"), ("tot", "total_water"), ("cloud", "cloud_water")):
+        assert np.array_equal(np.asarray(d[k], np.float32), ref[r]), k
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_new_simulation_and_streaming(pkg, tmp_path):
+    """WeatherSim.newSimulation (setupColumns on the device) + streamFrame through JS/N-API == the Python host."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    X, Y, n = 256, 96, 30
+    out_file = str(tmp_path / "new.weathersandbox")
+    js = ("const H=require('%s'), fs=require('fs');"
+          "const sim=H.WeatherSim.newSimulation(%d,%d,{sunFixed:true,settings:{enablePrecipitation:false}});"
+          "sim.frame(%d); const fr=sim.streamFrame(8,4,64,32); sim.frame(5); const v=fr.wait();"
+          "let s=0; for (const x of v.WATER_CUR) s+=x; let t=0; for (const x of v.BASE_DISP) t+=x;"
+          "console.log(JSON.stringify({iter:sim.iterNum(), water:s, base:t, wall0:v.WALL_DISP[0], n:v.CURL.length}));"
+          "fs.writeFileSync('%s', H.encodeSave(sim.toSave())); sim.destroy();" % (os.path.join(ROOT, "host", "sim_host.js"), X, Y, n, out_file))
+    info = json.loads(subprocess.check_output([NODE, "-e", js]).decode().strip().split("\n")[-1])
+    assert info["iter"] == n + 5 and info["n"] == 64 * 32
+    E = pkg.engine
+    gui = pkg.params.merge_settings({"enablePrecipitation": False})  # droplets exist (the save format needs X*Y/25) but stay inert
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)  # the hosts' default (sim.py / sim_host.js)
+    h = E.Handle(X, Y, 0)
+    h.setup_columns(pkg.synth.terrain_columns(X, Y))
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    h.step(n)
+    fr = {f: h.read_rect(f, 8, 4, 64, 32) for f in ("WATER_CUR", "BASE_DISP", "WALL_DISP")}
+    assert np.isclose(info["water"], float(fr["WATER_CUR"].astype(np.float64).sum()), rtol=1e-12)
+    assert np.isclose(info["base"], float(fr["BASE_DISP"].astype(np.float64).sum()), rtol=1e-12)
+    assert info["wall0"] == int(fr["WALL_DISP"].reshape(-1)[0])
+    h.step(5)
+    got = pkg.codec.load(out_file)
+    assert np.array_equal(got.base, h.read_rect("BASE_CUR")) and np.array_equal(got.water, h.read_rect("WATER_0"))
+    assert np.array_equal(got.wall, h.read_rect("WALL_CUR"))
+    assert got.droplets.shape == (X * Y // 25, 5) and (got.droplets[:, 2] < 0).all()  # initRainDrops: all inactive
