@@ -116,6 +116,42 @@ def initial_temperature_profile(Y: int, sim_height: float, dry_lapse: float) -> 
     return pot.astype(np.float32)
 
 
+def sounding_arrays(raw_sounding, Y: int, sim_height: float, dry_lapse: float):
+    """``realWorldSounding_T / _W / _Vel`` (Y + 1 entries each) from a raw sounding, as app.js builds them for the
+    sounding-forcing term of the advection pass: ``rawSoundingToSimSounding`` (app.js:149-186) + app.js:5444-5463.
+
+    ``raw_sounding``: samples ordered from the TOP of the sounding to the ground (the scraper's order: the reference
+    walks the list from its last element upward), each with ``alt`` [m], ``t`` and ``td`` [deg C], ``vel`` [km/h] and
+    ``angle`` [deg]; samples with a NaN in t / td / vel are skipped. Returns float32 arrays for ``wx_set_params``:
+    potential temperature [K], total water of the dew point (maxWater), horizontal velocity in cells / iteration."""
+    s = list(raw_sounding)
+    cell_height = sim_height / Y                      # cellHeight, app.js:5476
+    time_per_iteration = 0.00008                      # hours, app.js:449
+    invalid = lambda d: any(math.isnan(float(d[k])) for k in ("t", "td", "vel"))  # sampleIsInvalid, app.js:147
+    T = np.zeros(Y + 1, np.float32)
+    W = np.zeros(Y + 1, np.float32)
+    V = np.zeros(Y + 1, np.float32)
+    idx = len(s) - 1  # start from the lowest data point
+    for y in range(Y + 1):
+        alt = y * (sim_height / Y)
+        while s[idx]["alt"] < alt or invalid(s[idx]):  # go up in the sounding until the altitude matches or exceeds
+            idx -= 1
+            if idx < 0:
+                raise ValueError(f"sounding ends below the simulated altitude {alt} m")
+        above = s[idx]
+        below = s[min(idx + 1, len(s) - 1)]
+        smp = {k: float(above[k]) for k in ("t", "td", "vel", "angle")}
+        if above["alt"] != alt and alt >= s[-1]["alt"]:
+            a = (alt - below["alt"]) / (above["alt"] - below["alt"])
+            smp = {k: float(below[k]) * (1 - a) + float(above[k]) * a for k in ("t", "td", "vel", "angle")}  # mixGeneric, app.js:33-40
+        vel_ms = smp["vel"] * math.cos(smp["angle"] * DEG2RAD) / 3.6             # km/h along the 2-D plane -> m/s
+        raw_vel = vel_ms * 3600.0 / cell_height * time_per_iteration             # msToRawVelocity, app.js:698-704
+        T[y] = (smp["t"] + 273.15) + (y / Y) * dry_lapse                         # realToPotentialT(CtoK(t), y)
+        W[y] = ((smp["td"] + 273.15) / 250.0) ** 17                              # maxWater(CtoK(td)), app.js:557-561
+        V[y] = raw_vel
+    return T, W, V
+
+
 def sun_from_angle(sun_angle_deg: float, sun_intensity_gui: float):
     """(solarZenithAngle [rad], sunIntensity [W/m2]) from guiControls.sunAngle (app.js:6538-6561)."""
     zenith = (sun_angle_deg - 90.0) * DEG2RAD

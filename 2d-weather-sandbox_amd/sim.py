@@ -55,6 +55,8 @@ class WeatherSim:
         u["airplaneValues"] = self.airplane
         # keep the engine's own 600-iteration measurement after the first push (app.js:5957-5966)
         u["inactiveDroplets"] = -1.0 if self._inactive_pushed else 0.0
+        if getattr(self, "_sounding", None) is not None:
+            u["sounding_T"], u["sounding_W"], u["sounding_Vel"] = self._sounding
         return u
 
     def _push_uniforms(self):
@@ -62,6 +64,13 @@ class WeatherSim:
         p = params.fill_struct(params.WxParams(), u)
         self._h.set_params(p, u["initial_T"], u.get("sounding_T"), u.get("sounding_W"), u.get("sounding_Vel"))
         self._inactive_pushed = True
+
+    def set_sounding(self, raw_sounding):
+        """Load a real sounding for the ``soundingForcing`` slider (app.js:5444-5463); ``raw_sounding`` as in
+        ``params.sounding_arrays`` (scraper order: top of the sounding first)."""
+        sim_h = float(self.gui["simHeight"])
+        self._sounding = params.sounding_arrays(raw_sounding, self.Y, sim_h, sim_h * float(self.gui["dryLapseRate"]) / 1000.0)
+        self._push_uniforms()
 
     def set_gui(self, **changes):
         """Change guiControls entries and push the uniforms (dat.GUI onChange + setGuiUniforms, app.js:3401-3443)."""

@@ -166,6 +166,33 @@ function initRainDrops(n, rng)
   }
   return d;
 }
+// realWorldSounding_T / _W / _Vel from a raw sounding: rawSoundingToSimSounding (app.js:149-186) + app.js:5444-5463.
+// `raw`: samples ordered from the top of the sounding down to the ground, {alt [m], t, td [deg C], vel [km/h], angle [deg]}.
+function soundingArrays(raw, Y, simHeight, dryLapse)
+{
+  const cellHeight = simHeight / Y, bad = function(d) { return isNaN(d.t) || isNaN(d.td) || isNaN(d.vel); };
+  const T = new Float32Array(Y + 1), W = new Float32Array(Y + 1), V = new Float32Array(Y + 1);
+  let idx = raw.length - 1;
+  for (let y = 0; y < Y + 1; y++) {
+    const alt = y * (simHeight / Y);
+    while (raw[idx].alt < alt || bad(raw[idx])) {
+      idx--;
+      if (idx < 0) throw new Error('sounding ends below the simulated altitude ' + alt + ' m');
+    }
+    const above = raw[idx], below = raw[Math.min(idx + 1, raw.length - 1)];
+    let s = above;
+    if (above.alt != alt && alt >= raw[raw.length - 1].alt) {
+      const a = (alt - below.alt) / (above.alt - below.alt);
+      s = {};
+      ['t', 'td', 'vel', 'angle'].forEach(function(k) { s[k] = below[k] * (1 - a) + above[k] * a; });
+    }
+    const velMs = s.vel * Math.cos(s.angle * DEG2RAD) / 3.6;
+    T[y] = (s.t + 273.15) + (y / Y) * dryLapse;
+    W[y] = Math.pow((s.td + 273.15) / 250.0, 17);
+    V[y] = velMs * 3600 / cellHeight * TIME_PER_ITERATION;
+  }
+  return {T: T, W: W, Vel: V};
+}
 function sunFromAngle(sunAngleDeg, sunIntensityGui)
 { // app.js:6538-6550
   return {
@@ -235,10 +262,16 @@ WeatherSim.prototype.pushUniforms = function() {
   const u = uniformsFromGui(this.gui, this.Y, {sunAngleDeg: this.manualSun, quadScale: this.opts.quadScale, passMask: this.opts.passMask});
   Object.assign(u, this.brush);
   u.inactiveDroplets = this.inactivePushed ? -1.0 : 0.0; // keep the engine's 600-iteration measurement (app.js:5957-5966)
-  this.addon.setParams(this.h, u, u.initial_T);
+  if (this.sounding) this.addon.setParams(this.h, u, u.initial_T, this.sounding.T, this.sounding.W, this.sounding.Vel);
+  else this.addon.setParams(this.h, u, u.initial_T);
   this.inactivePushed = true;
 };
 WeatherSim.prototype.setGui = function(changes) { Object.assign(this.gui, changes); this.pushUniforms(); };
+// load a real sounding for the `soundingForcing` slider (app.js:5444-5463); raw = scraper output, top of the sounding first
+WeatherSim.prototype.setSounding = function(raw) {
+  this.sounding = soundingArrays(raw, this.Y, this.gui.simHeight, this.gui.simHeight * this.gui.dryLapseRate / 1000.0);
+  this.pushUniforms();
+};
 WeatherSim.prototype.setBrush = function(type, x, y, intensity, brushSize, move) { // app.js:5749-5808
   this.brush = {userInputType: type, userInputValues: [x, y, intensity, brushSize * 0.5], userInputMove: move || [0, 0]};
   this.pushUniforms();
@@ -312,7 +345,7 @@ WeatherSim.newSimulation = function(X, Y, opts) {
 
 module.exports = {WeatherSim: WeatherSim, loadSave: loadSave, decodeSave: decodeSave, encodeSave: encodeSave, mergeSettings: mergeSettings,
                   uniformsFromGui: uniformsFromGui, initialTemperatureProfile: initialTemperatureProfile, sunFromAngle: sunFromAngle,
-                  sunAngleFromTime: sunAngleFromTime, terrainColumns: terrainColumns, initRainDrops: initRainDrops, GUI_DEFAULTS: GUI_DEFAULTS,
+                  sunAngleFromTime: sunAngleFromTime, terrainColumns: terrainColumns, initRainDrops: initRainDrops, soundingArrays: soundingArrays, GUI_DEFAULTS: GUI_DEFAULTS,
                   FIELD: FIELD};
 
 if (require.main === module) {

@@ -85,7 +85,7 @@ def _dec(s: str, dtype) -> np.ndarray:
 def js_uniforms(u: dict) -> dict:
     o = {}
     for k, v in u.items():
-        if k == "initial_T":
+        if k in ("initial_T", "sounding_T", "sounding_W", "sounding_Vel"):
             continue
         o[k] = list(v) if isinstance(v, tuple) else v
     return o
@@ -105,6 +105,8 @@ def run_fixture(name, X, Y, base, water, wall, drops, u, *, niter, dump_iters, p
         "uniforms": js_uniforms(u), "initial_T": [float(v) for v in u["initial_T"]],
         "niter": niter, "dump_iters": list(dump_iters), "precip": bool(precip), "iter0": iter0,
     }
+    if "sounding_T" in u:
+        job["sounding"] = {k: [float(v) for v in u["sounding_" + k]] for k in ("T", "W", "Vel")}
     if perpass_iter is not None:
         job["perpass_iter"] = perpass_iter
     probe = run_harness({"X": X, "Y": Y, "probe": True, "n_drops": 0})
@@ -120,6 +122,7 @@ def run_fixture(name, X, Y, base, water, wall, drops, u, *, niter, dump_iters, p
         # simShader.vert varyings (fragCoord.xy, texCoord.xy) as interpolated by the reference's rasteriser here
         "varyings": varyings,
         "uniforms_json": json.dumps(js_uniforms(u)),
+        **({"sounding_" + k: np.asarray(u["sounding_" + k], np.float32) for k in ("T", "W", "Vel")} if "sounding_T" in u else {}),
         "renderer": res["renderer"], "its_per_s": 1000.0 * (res["niter"] - 1) / max(res["ms_after_first"], 1e-9),
     }
     if n_drops:
@@ -241,6 +244,27 @@ def fx_synth64():
                        keep=("base_cur", "water_cur", "wall_cur", "light_0", "light_1", "water_0"))
 
 
+def fx_sounding64():
+    """Real-sounding forcing (advectionShader.frag:154-181 with soundingForcing != 0) + globalDrying + globalHeating inside
+    an altitude window: the per-row arrays are what app.js:5444-5463 builds from a sounding (here: synthetic profiles)."""
+    rng = np.random.default_rng(77)
+    X, Y = 64, 48
+    gui, u, base, water, wall = synth_terrain(X, Y, rng)
+    sim_h = float(gui["simHeight"])
+    u["soundingForcing"] = 0.6
+    u["globalDrying"] = 2e-5
+    u["globalHeating"] = 1e-4
+    u["globalEffectsStartAlt"] = 1500.0 / sim_h
+    u["globalEffectsEndAlt"] = 9000.0 / sim_h
+    y = np.arange(Y + 1, dtype=np.float64)
+    real_t = 292.0 - 70.0 * y / Y + 3.0 * np.sin(y * 0.4)  # K, with an inversion-like wiggle
+    u["sounding_T"] = (real_t + (y / Y) * u["dryLapse"]).astype(np.float32)  # realToPotentialT
+    u["sounding_W"] = (((real_t - 4.0 - 6.0 * (y / Y)) / 250.0) ** 17).astype(np.float32)  # maxWater(dew point)
+    u["sounding_Vel"] = (0.05 + 0.25 * y / Y).astype(np.float32)  # cells / iteration
+    return run_fixture("sounding64", X, Y, base, water, wall, None, u, niter=10, dump_iters=[1, 10], perpass_iter=0, precip=False,
+                       keep=("base_cur", "water_cur", "wall_cur"))
+
+
 def fx_precip64():
     """Particle pass: hand-built droplet set over a cloudy field (spawn / grow / freeze / melt / deposit)."""
     rng = np.random.default_rng(99)
@@ -360,6 +384,7 @@ FIXTURES = {
     "save100qa": lambda: fx_save100(False),
     "save100qa_precip": lambda: fx_save100(True),
     "synth64": fx_synth64,
+    "sounding64": fx_sounding64,
     "precip64": fx_precip64,
 }
 

@@ -211,6 +211,14 @@ function run(o)
   // ---- uniforms ----
   var U = o.uniforms, initT = new Float32Array(ARR * 4), sndZero = new Float32Array(ARR * 4);
   for (var y = 0; y < Y + 1; y++) initT[y] = o.initial_T[y];
+  // realWorldSounding_* (app.js:5444-5463): zero unless the job carries per-row arrays
+  var sndT = new Float32Array(ARR * 4), sndW = new Float32Array(ARR * 4), sndV = new Float32Array(ARR * 4);
+  if (o.sounding)
+    for (var ys = 0; ys < Y + 1; ys++) {
+      sndT[ys] = o.sounding.T[ys];
+      sndW[ys] = o.sounding.W[ys];
+      sndV[ys] = o.sounding.Vel[ys];
+    }
   function setU(prog, list)
   {
     gl.useProgram(P[prog]);
@@ -229,7 +237,7 @@ function run(o)
   setU('advection', [
     ['baseTex', '1i', 0], ['waterTex', '1i', 1], ['wallTex', '1i', 2], ['texelSize', '2f', texel], ['resolution', '2f', res],
     ['initial_Tv', '4fv', initT], ['dryLapse', '1f', U.dryLapse], ['waterTemperature', '1f', U.waterTemperature],
-    ['realWorldSounding_Tv', '4fv', sndZero], ['realWorldSounding_Wv', '4fv', sndZero], ['realWorldSounding_Velv', '4fv', sndZero],
+    ['realWorldSounding_Tv', '4fv', sndT], ['realWorldSounding_Wv', '4fv', sndW], ['realWorldSounding_Velv', '4fv', sndV],
     ['evapHeat', '1f', U.evapHeat], ['meltingHeat', '1f', U.meltingHeat], ['condensationRate', '1f', U.condensationRate],
     ['globalDrying', '1f', U.globalDrying], ['globalHeating', '1f', U.globalHeating], ['soundingForcing', '1f', U.soundingForcing],
     ['globalEffectsStartAlt', '1f', U.globalEffectsStartAlt], ['globalEffectsEndAlt', '1f', U.globalEffectsEndAlt],

@@ -34,6 +34,9 @@ def load_golden(name):
     g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     u = json.loads(str(g["uniforms_json"]))
     u["initial_T"] = g["initial_T"]
+    for k in ("sounding_T", "sounding_W", "sounding_Vel"):  # realWorldSounding_* arrays (only the sounding fixture has them)
+        if k in g.files:
+            u[k] = g[k]
     for k in ("userInputValues", "userInputMove", "airplaneValues"):
         u[k] = tuple(u[k])
     return g, u

@@ -39,7 +39,7 @@ def _make_pair(pkg, oracle, E, X, Y, base, water, wall, u, drops=None, iter0=0):
     h = E.Handle(X, Y, nd)
     h.upload(base, water, wall, drops)
     p = pkg.params.fill_struct(pkg.params.WxParams(), u)
-    h.set_params(p, u["initial_T"])
+    h.set_params(p, u["initial_T"], u.get("sounding_T"), u.get("sounding_W"), u.get("sounding_Vel"))
     h.iter = iter0
     o = oracle.OracleSim(X, Y, nd)
     o.upload(base, water, wall, drops)
@@ -54,7 +54,7 @@ def _assert_grid_equal(h, o, fields=GRID_FIELDS):
         assert np.array_equal(a, b), f"{f}: {np.count_nonzero(a != b)} of {a.size} values differ, max |d| = {np.abs(a.astype(np.float64) - b).max()}"
 
 
-@pytest.mark.parametrize("name", ["save100qa", "synth64", "randwalls64"])
+@pytest.mark.parametrize("name", ["save100qa", "synth64", "randwalls64", "sounding64"])
 @pytest.mark.parametrize("quad_scale", [0, 1])
 def test_bit_exact_vs_oracle_on_golden_inputs(pkg, oracle, golden, E, name, quad_scale, fused):
     g, u = golden(name)

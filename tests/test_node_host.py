@@ -115,3 +115,46 @@ def test_node_new_simulation_and_streaming(pkg, tmp_path):
     assert np.array_equal(got.base, h.read_rect("BASE_CUR")) and np.array_equal(got.water, h.read_rect("WATER_0"))
     assert np.array_equal(got.wall, h.read_rect("WALL_CUR"))
     assert got.droplets.shape == (X * Y // 25, 5) and (got.droplets[:, 2] < 0).all()  # initRainDrops: all inactive
+
+
+def _raw_sounding():
+    # top of the sounding first, as the reference's scraper delivers it; one invalid sample in the middle
+    alts = [13000, 9000, 6000, 3000, 1500, 800, 300, 0]
+    nan = float("nan")
+    return [{"alt": a, "t": 15.0 - 0.0065 * a, "td": (nan if a == 3000 else 10.0 - 0.008 * a), "vel": 10.0 + a / 500.0, "angle": 30.0 + a / 200.0}
+            for a in alts]
+
+
+def test_sounding_arrays_interpolation(pkg):
+    """params.sounding_arrays = rawSoundingToSimSounding (app.js:149-186) + app.js:5444-5463, checked by hand."""
+    Y, sim_h, lapse = 40, 12000.0, 120.0
+    T, W, V = pkg.params.sounding_arrays(_raw_sounding(), Y, sim_h, lapse)
+    assert T.shape == W.shape == V.shape == (Y + 1,) and T.dtype == np.float32
+    # y = 0 is exactly the ground sample
+    assert np.isclose(T[0], 15.0 + 273.15) and np.isclose(W[0], ((10.0 + 273.15) / 250.0) ** 17, rtol=1e-6)
+    # y = 2 -> 600 m: between 300 m and 800 m (a = 0.6)
+    a = 0.6
+    t = (15.0 - 0.0065 * 300) * (1 - a) + (15.0 - 0.0065 * 800) * a
+    assert np.isclose(T[2], t + 273.15 + (2 / Y) * lapse, rtol=1e-6)
+    vel = (10.0 + 300 / 500.0) * (1 - a) + (10.0 + 800 / 500.0) * a
+    ang = (30.0 + 300 / 200.0) * (1 - a) + (30.0 + 800 / 200.0) * a
+    assert np.isclose(V[2], vel * np.cos(ang * 0.0174533) / 3.6 * 3600.0 / (sim_h / Y) * 0.00008, rtol=1e-6)
+    # 2100 m (y = 7): the invalid 3000 m sample is skipped, interpolation runs from 1500 m to 6000 m ... with the sample
+    # BELOW taken as the next list element (the invalid one) exactly like the reference does -> NaN dew point propagates
+    assert np.isnan(W[7]) and np.isfinite(T[7])
+    with pytest.raises(ValueError):
+        pkg.params.sounding_arrays(_raw_sounding(), Y, 20000.0, lapse)  # sounding ends below the model top
+
+
+@needs_node
+def test_js_sounding_arrays_match_python(pkg):
+    Y, sim_h, lapse = 40, 12000.0, 120.0
+    raw = json.dumps(_raw_sounding()).replace("NaN", "null")
+    js = ("const H=require('%s'); const raw=JSON.parse('%s').map(function(d){for (const k in d) if (d[k]===null) d[k]=NaN; return d;});"
+          "const s=H.soundingArrays(raw,%d,%f,%f); console.log(JSON.stringify({T:Array.from(s.T),W:Array.from(s.W).map(function(x){return isNaN(x)?null:x;}),V:Array.from(s.Vel)}))"
+          % (os.path.join(ROOT, "host", "sim_host.js"), raw, Y, sim_h, lapse))
+    d = json.loads(subprocess.check_output([NODE, "-e", js]))
+    T, W, V = pkg.params.sounding_arrays(_raw_sounding(), Y, sim_h, lapse)
+    assert np.array_equal(np.asarray(d["T"], np.float32), T) and np.array_equal(np.asarray(d["V"], np.float32), V)
+    Wj = np.asarray([np.nan if x is None else x for x in d["W"]], np.float32)
+    assert np.array_equal(np.isnan(Wj), np.isnan(W)) and np.array_equal(Wj[~np.isnan(W)], W[~np.isnan(W)])

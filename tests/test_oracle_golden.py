@@ -130,6 +130,26 @@ def test_synth64_all_wall_types_and_schedules(oracle, golden):
         assert np.abs(w0 - rw0).max() <= 5e-5
 
 
+def test_sounding64_forcing_drying_heating(oracle, golden):
+    """advectionShader.frag:154-181 with soundingForcing, globalDrying and globalHeating ON inside an altitude window, fed
+    with per-row realWorldSounding_* arrays (app.js:5444-5463): the reference's own output, per pass and after 10 iterations."""
+    g, u = golden("sounding64")
+    assert u["soundingForcing"] > 0 and u["globalDrying"] > 0 and np.abs(u["sounding_Vel"]).max() > 0.1
+    u, _ = _params(oracle, g, u)
+    for it, s in _run(oracle, g, u, [1, 10]):
+        assert np.array_equal(s.field("WALL_CUR"), g[f"it{it}_wall_cur"])
+        b, rb = s.field("BASE_CUR"), g[f"it{it}_base_cur"]
+        assert np.abs(b[..., :3] - rb[..., :3]).max() <= 1e-6
+        assert np.abs(b[..., 3] - rb[..., 3]).max() <= 4 * ULP_T
+        assert np.abs(s.field("WATER_CUR") - g[f"it{it}_water_cur"]).max() <= 5e-5
+    # the forcing did something: the run without it differs visibly
+    g2, u2 = golden("sounding64")
+    u2 = dict(u2, soundingForcing=0.0, globalDrying=0.0, globalHeating=0.0)
+    u2, _ = _params(oracle, g2, u2)
+    for it, s2 in _run(oracle, g2, u2, [10]):
+        assert np.abs(s2.field("BASE_CUR")[..., 0] - g["it10_base_cur"][..., 0]).max() > 1e-4  # 100x the tolerance above
+
+
 def test_precip64_particles(oracle, golden):
     """Particle pass: spawn (integer hash), grow/freeze/melt/evaporate, deposit, 12x12 splats."""
     g, u = golden("precip64")
