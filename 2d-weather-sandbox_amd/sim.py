@@ -20,13 +20,17 @@ TIME_PER_ITERATION = 0.00008  # hours of simulated time per iteration (app.js:44
 
 class WeatherSim:
     def __init__(self, X: int, Y: int, base, water, wall, droplets=None, settings: Optional[Dict[str, Any]] = None, *,
-                 sun_angle_deg: Optional[float] = None, quad_scale: int = 0, pass_mask: int = params.PASS_ALL):
-        """``mainScript``: take the four initial arrays + saved settings (app.js:1495, 3375-3399, 5189-5317)."""
+                 sun_angle_deg: Optional[float] = None, quad_scale: int = 0, pass_mask: int = params.PASS_ALL, columns=None):
+        """``mainScript``: take the four initial arrays + saved settings (app.js:1495, 3375-3399, 5189-5317), or -- for a
+        new simulation -- the 1-D setup descriptors ``columns`` (synth.terrain_columns) that the device expands."""
         self.X, self.Y = int(X), int(Y)
         self.gui = params.merge_settings(settings)
         n_drops = 0 if droplets is None else int(np.asarray(droplets).size // 5)
         self._h = Handle(self.X, self.Y, n_drops)
-        self._h.upload(base, water, wall, droplets)
+        if columns is not None:
+            self._h.setup_columns(columns, droplets)
+        else:
+            self._h.upload(base, water, wall, droplets)
         self._quad_scale = int(quad_scale)
         self._pass_mask = int(pass_mask)
         self._manual_sun = sun_angle_deg
@@ -40,6 +44,17 @@ class WeatherSim:
         self._push_uniforms()
 
     # ---- construction helpers ----
+    @classmethod
+    def new_simulation(cls, X: int, Y: int, settings: Optional[Dict[str, Any]] = None, *, n_droplets: Optional[int] = None,
+                       seed: float = 0.5, height_mult: float = 0.3, **kw) -> "WeatherSim":
+        """Start-up without a save file: the setup pass (setupShader.frag:36-92) + ``initRainDrops`` (app.js:4901-4913),
+        one droplet per 25 cells like the reference (the save format relies on that count)."""
+        from . import synth
+        gui = params.merge_settings(settings)
+        n = codec.num_droplets(X, Y) if n_droplets is None else int(n_droplets)
+        cols = synth.terrain_columns(X, Y, gui, seed=seed, height_mult=height_mult)
+        return cls(X, Y, None, None, None, synth.init_rain_drops(n) if n else None, settings, columns=cols, **kw)
+
     @classmethod
     def from_save(cls, sf: "codec.SaveFile | str", **kw) -> "WeatherSim":
         """``loadData()`` (app.js:1256-1366)."""

@@ -549,6 +549,22 @@ def test_display_field_streaming(pkg, golden, E):
         h.stream_frame(X - 4, 0, 8, 8)  # no wrap
 
 
+def test_python_host_new_simulation_round_trip(pkg, tmp_path):
+    """WeatherSim.new_simulation (setup on the device + initRainDrops) -> frames with the day/night driver -> save ->
+    load -> identical state: the new-simulation path produces a valid .weathersandbox file."""
+    sim = pkg.WeatherSim.new_simulation(200, 100, {"dayNightCycle": True, "IterPerFrame": 10})
+    for _ in range(3):
+        sim.step()
+    sf = sim.to_save()
+    assert sf.droplets.shape == (200 * 100 // 25, 5) and np.isfinite(sf.base).all() and (sf.wall[0, :, 1] == 0).all()
+    path = str(tmp_path / "new.weathersandbox")
+    pkg.codec.save(path, sf)
+    back = pkg.codec.load(path)
+    assert np.array_equal(back.base, sf.base) and np.array_equal(back.water, sf.water) and np.array_equal(back.wall, sf.wall)
+    again = pkg.WeatherSim.from_save(back)
+    assert np.array_equal(again.to_save().wall, sf.wall)
+
+
 def test_brush_and_airplane_inputs_bit_exact(pkg, oracle, E, fused):
     """Next-row (f1): user brush (every tool of advectionShader.frag:229-401) and airplane inputs (:415-457):
     HIP == oracle bit for bit, on the inputs/uniforms of the reference goldens (tests/golden/brush64.npz)."""
