@@ -857,7 +857,8 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
 // ------------------------------------------------------------------------------------------------
 // lightingShader.frag:38-170
 // Accessor A: T(dy) -> base TEMPERATURE at (x, y+dy) with y REPEAT ; water() -> float4 ; wall() -> char4 ;
-//             light_at(dx, j) -> float4 of the source light texture at column x+dx (wrapped), ROW j (absolute,
+//             sun_at(dx, j) / ir_down_at(j) / ir_up_at(j) -> channel x / z / w of the source light texture at column x+dx
+//             (wrapped; 0 for the IR channels), ROW j (absolute,
 //             caller clamps) ; used for the bilinear sun tap and the IR taps
 // ------------------------------------------------------------------------------------------------
 template <class A>
@@ -882,8 +883,8 @@ __device__ __forceinline__ float4 lighting_cell(const Uni &u, const Geo &g, int 
     int j0 = y + (int)fv, j1 = y + (int)fv + 1;
     j0 = j0 < 0 ? 0 : (j0 > Y - 1 ? Y - 1 : j0);
     j1 = j1 < 0 ? 0 : (j1 > Y - 1 ? Y - 1 : j1);
-    const float t00 = a.light_at(dx0, j0).x, t10 = a.light_at(dx0 + 1, j0).x;
-    const float t01 = a.light_at(dx0, j1).x, t11 = a.light_at(dx0 + 1, j1).x;
+    const float t00 = a.sun_at(dx0, j0), t10 = a.sun_at(dx0 + 1, j0);
+    const float t01 = a.sun_at(dx0, j1), t11 = a.sun_at(dx0 + 1, j1);
     sunlight = (1.0f - al) * (1.0f - be) * t00 + al * (1.0f - be) * t10 + (1.0f - al) * be * t01 + al * be * t11;
   }
 
@@ -904,7 +905,7 @@ __device__ __forceinline__ float4 lighting_cell(const Uni &u, const Geo &g, int 
     }
     const int yu = (y + 1 >= Y) ? Y - 1 : y + 1; // light texture: CLAMP_TO_EDGE in T
     const int yd = (y == 0) ? 0 : y - 1;
-    float IR_down = a.light_at(0, yu).z;
+    float IR_down = a.ir_down_at(yu);
     float IR_up = 0.0f; // unassigned for air above an INERT wall (:90) -> 0
     if (wall.z == 1) {
       switch (wall.x) {
@@ -928,7 +929,7 @@ __device__ __forceinline__ float4 lighting_cell(const Uni &u, const Geo &g, int 
       default: break;
       }
     } else {
-      IR_up = a.light_at(0, yd).w;
+      IR_up = a.ir_up_at(yd);
       float emissivity = u.greenhouseGases;
       emissivity += water.x * u.waterGreenHouseEffect;
       emissivity += water.y * 5.0f;

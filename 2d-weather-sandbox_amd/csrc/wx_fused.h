@@ -39,10 +39,22 @@ constexpr int NTA = WX_NTA; // kernel A: 47 VGPRs -> two 16-wave workgroups per 
 constexpr int NTB = WX_NTB; // kernel B: three 8-wave workgroups per CU (52 KB LDS each) = 6 waves/SIMD, <= 80 VGPRs
 constexpr bool kHaveFused = true;
 
+// The light texture of the two-kernel path is stored as three planes: sunlight (x), net heating (y) and the two IR
+// fluxes (zw). The boundary stage needs x and y only (8 instead of 16 B/cell); lighting reads x at its four filter taps
+// and z / w of one row each, and writes all four channels. Both kernels are at the HBM ceiling, so bytes are time.
+template <typename F, typename F2> struct LightPlanesT {
+  F *x, *y;
+  F2 *zw;
+};
+using LightPlanes = LightPlanesT<float, float2>;
+using LightPlanesC = LightPlanesT<const float, const float2>;
+
 struct FusedAIn {
   const float4 *base;
   const char4 *wall;
-  const float4 *water, *light, *fb;
+  const float4 *water;
+  LightPlanesC light; // light_0 (boundaryShader samples lightTexture_0 only)
+  const float4 *fb;
   const float2 *dep;
 };
 // Copy-on-write of kernel A's water / wall outputs: away from terrain and without particle feedback the boundary pass
@@ -52,7 +64,7 @@ struct FusedAIn {
 struct FusedBIn {
   const float4 *base, *water;
   const char4 *wall;
-  const float4 *light;
+  LightPlanesC light;      // the source light texture of this iteration's lighting pass
   const float4 *water_alt; // what kernel A read: valid wherever clean[tile] != 0
   const char4 *wall_alt;
   const unsigned int *clean; // per tile (one dword: read with scalar loads), row pitch txn; nullptr = every tile was written
@@ -200,7 +212,8 @@ struct LBoundaryAcc {
   {
     int yy = y + dy;
     yy = yy < 0 ? 0 : (yy > Y - 1 ? Y - 1 : yy);
-    return in.light[fidx(x, yy, X)];
+    const size_t i = fidx(x, yy, X);
+    return make_float4(in.light.x[i], in.light.y[i], 0.0f, 0.0f); // the boundary pass reads sunlight and net heating only
   }
   __device__ __forceinline__ bool has_fb() const { return in.fb != nullptr; }
   __device__ __forceinline__ float4 fb() const { return in.fb ? in.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -413,13 +426,31 @@ struct LLightAcc {
   __device__ __forceinline__ float4 water() const { return water_; }
   __device__ __forceinline__ char4 wall() const { return wall_; }
   __device__ __forceinline__ float4 light_at(int dx, int j) const { return light_[fidx(wrapfast(x + dx, X), j, X)]; }
+  __device__ __forceinline__ float sun_at(int dx, int j) const { return light_at(dx, j).x; }
+  __device__ __forceinline__ float ir_down_at(int j) const { return light_at(0, j).z; }
+  __device__ __forceinline__ float ir_up_at(int j) const { return light_at(0, j).w; }
+};
+// the same over the planar light texture of the two-kernel path
+struct LLightAccP {
+  const fb_::SmemOut &so;
+  LightPlanesC light_;
+  float4 water_;
+  char4 wall_;
+  float T0;
+  int X, x, cx, cy;
+  __device__ __forceinline__ float T(int dy) const { return dy == 0 ? T0 : so.T[cy][cx + 1]; } // dy in {0,-1}
+  __device__ __forceinline__ float4 water() const { return water_; }
+  __device__ __forceinline__ char4 wall() const { return wall_; }
+  __device__ __forceinline__ float sun_at(int dx, int j) const { return light_.x[fidx(wrapfast(x + dx, X), j, X)]; }
+  __device__ __forceinline__ float ir_down_at(int j) const { return light_.zw[fidx(x, j, X)].x; }
+  __device__ __forceinline__ float ir_up_at(int j) const { return light_.zw[fidx(x, j, X)].y; }
 };
 
 template <bool WRITE_DISP, bool SMALL>
 __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u_arg, const float *__restrict__ initial_T, const float *__restrict__ snd_T,
                                                 const float *__restrict__ snd_W, const float *__restrict__ snd_Vel, FusedBIn in,
                                                 const SlowCtx *__restrict__ ctx, float4 *__restrict__ base_out, float4 *__restrict__ base_disp, float4 *__restrict__ water_out,
-                                                char4 *__restrict__ wall_out, float4 *__restrict__ light_out)
+                                                char4 *__restrict__ wall_out, LightPlanes light_out)
 {
   using namespace fb_;
   __shared__ union {
@@ -522,11 +553,33 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u_arg
     water_out[gi] = wreg[k];
     wall_out[gi] = wlreg[k];
 #ifdef WX_ABL_NOLIGHT
-    light_out[gi] = in.light[gi];
+    const float4 l = make_float4(in.light.x[gi], in.light.y[gi], in.light.zw[gi].x, in.light.zw[gi].y);
 #else
-    LLightAcc la{sm.out, in.light, wreg[k], wlreg[k], b.w, X, x, cx, cy};
-    light_out[gi] = lighting_cell(u, g, x, y, la);
+    LLightAccP la{sm.out, in.light, wreg[k], wlreg[k], b.w, X, x, cx, cy};
+    const float4 l = lighting_cell(u, g, x, y, la);
 #endif
+    light_out.x[gi] = l.x;
+    light_out.y[gi] = l.y;
+    light_out.zw[gi] = make_float2(l.z, l.w);
+  }
+}
+
+// light texture: interleaved RGBA32F (the reference's layout: per-pass / single-kernel paths, readback, halo buffers of
+// those paths) <-> the three planes of the two-kernel path
+__global__ void k_light_to_planes(size_t n, const float4 *__restrict__ src, LightPlanes dst)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 l = src[i];
+    dst.x[i] = l.x;
+    dst.y[i] = l.y;
+    dst.zw[i] = make_float2(l.z, l.w);
+  }
+}
+__global__ void k_light_from_planes(size_t n, LightPlanesC src, float4 *__restrict__ dst)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float2 zw = src.zw[i];
+    dst[i] = make_float4(src.x[i], src.y[i], zw.x, zw.y);
   }
 }
 
@@ -559,7 +612,7 @@ inline void launch_fused_a(const Geo &g, const Uni &u, const float *initial_T, c
 
 inline void launch_fused_b(const Geo &g, const Uni &u, const float *initial_T, const float *snd_T, const float *snd_W, const float *snd_Vel,
                            const FusedBIn &in, const SlowCtx *ctx, float4 *base_out, float4 *base_disp, float4 *water_out, char4 *wall_out,
-                           float4 *light_out, bool write_disp, hipStream_t stream)
+                           const LightPlanes &light_out, bool write_disp, hipStream_t stream)
 {
   const dim3 grid = tile_grid(g.X, g.Y);
   const bool small = (g.X < TX + 8) || (g.Y < TY + 8);

@@ -145,6 +145,9 @@ struct GLightAcc {
   __device__ __forceinline__ float4 water() const { return water_[cidx(x, y, X)]; }
   __device__ __forceinline__ char4 wall() const { return wall_[cidx(x, y, X)]; }
   __device__ __forceinline__ float4 light_at(int dx, int j) const { return light_[cidx(wrapmod(x + dx, X), j, X)]; }
+  __device__ __forceinline__ float sun_at(int dx, int j) const { return light_at(dx, j).x; }
+  __device__ __forceinline__ float ir_down_at(int j) const { return light_at(0, j).z; }
+  __device__ __forceinline__ float ir_up_at(int j) const { return light_at(0, j).w; }
 };
 
 __global__ __launch_bounds__(BX *BY) void k_lighting(Geo g, Uni u, const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
@@ -690,6 +693,8 @@ __global__ void k_inactive_from_count(DevState *st)
 // ------------------------------------------------------------------------------------------------
 struct HaloPtrs {
   float4 *base, *water, *light0, *light1;
+  LightPlanes lp0, lp1; // used instead of light0 / light1 while the light texture is stored as planes (lp0.x != nullptr);
+                        // the BUFFER always carries interleaved RGBA texels
   char4 *wall;
   float4 *fb;  // particle feedback / deposition textures: exchanged only on handles that carry particles
   float2 *dep; // buffer layout then: [4 x h*Y float4][fb h*Y float4][dep h*Y float2][wall h*Y char4]
@@ -702,8 +707,14 @@ __global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, int x_start, float4
     const size_t s = cidx(x_start + c, y, X);
     buf16[i] = f.base[s];
     buf16[n + i] = f.water[s];
-    buf16[2 * n + i] = f.light0[s];
-    buf16[3 * n + i] = f.light1[s];
+    if (f.lp0.x) {
+      const float2 a = f.lp0.zw[s], b = f.lp1.zw[s];
+      buf16[2 * n + i] = make_float4(f.lp0.x[s], f.lp0.y[s], a.x, a.y);
+      buf16[3 * n + i] = make_float4(f.lp1.x[s], f.lp1.y[s], b.x, b.y);
+    } else {
+      buf16[2 * n + i] = f.light0[s];
+      buf16[3 * n + i] = f.light1[s];
+    }
     buf4[i] = f.wall[s];
     if (f.fb) {
       buf16[4 * n + i] = f.fb[s];
@@ -719,8 +730,18 @@ __global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, int x_start, cons
     const size_t s = cidx(x_start + c, y, X);
     f.base[s] = buf16[i];
     f.water[s] = buf16[n + i];
-    f.light0[s] = buf16[2 * n + i];
-    f.light1[s] = buf16[3 * n + i];
+    if (f.lp0.x) {
+      const float4 a = buf16[2 * n + i], b = buf16[3 * n + i];
+      f.lp0.x[s] = a.x;
+      f.lp0.y[s] = a.y;
+      f.lp0.zw[s] = make_float2(a.z, a.w);
+      f.lp1.x[s] = b.x;
+      f.lp1.y[s] = b.y;
+      f.lp1.zw[s] = make_float2(b.z, b.w);
+    } else {
+      f.light0[s] = buf16[2 * n + i];
+      f.light1[s] = buf16[3 * n + i];
+    }
     f.wall[s] = buf4[i];
     if (f.fb) {
       f.fb[s] = buf16[4 * n + i];

@@ -101,6 +101,10 @@ struct wx_sim {
   SlowCtx slow_host[2];
   bool slow_valid[2] = {false, false};
   int slow_next = 0;
+  // light_0 / light_1 as planes (wx_fused.h, LightPlanes): the representation of the two-kernel path. `light_planar`
+  // says which copy is current; the other kernel sets, readback and streaming use the interleaved light[] buffers.
+  LightPlanes lp[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  bool light_planar = false;
   // copy-on-write of kernel A's water / wall outputs
   int cow = 1;                         // env WX_COW=0 disables it
   unsigned int *cow_clean = nullptr;   // per 64x16 tile: kernel A left water[0] / wall[1] unwritten
@@ -361,6 +365,23 @@ int iterate_per_pass(wx_sim *s, unsigned mask)
 // The same iteration as two fused kernels (wx_fused.h); results are bit-identical to iterate_per_pass.
 // write_disp: also store the post-advection base (the reference's baseTexture_1, read by the particle pass and
 // by display-side consumers) -- needed only for the last iteration of a wx_step call or when particles run.
+// light_0 / light_1: switch between the interleaved textures and the planes of the two-kernel path
+static void light_to_planes(wx_sim *s)
+{
+  if (s->light_planar) return;
+  for (int i = 0; i < 2; i++) hipLaunchKernelGGL(k_light_to_planes, dim3(2048), dim3(256), 0, s->stream, ncell(s), s->light[i], s->lp[i]);
+  s->light_planar = true;
+}
+static void light_to_rgba(wx_sim *s)
+{
+  if (!s->light_planar) return;
+  for (int i = 0; i < 2; i++) {
+    LightPlanesC src{s->lp[i].x, s->lp[i].y, s->lp[i].zw};
+    hipLaunchKernelGGL(k_light_from_planes, dim3(2048), dim3(256), 0, s->stream, ncell(s), src, s->light[i]);
+  }
+  s->light_planar = false;
+}
+
 // device-side SlowCtx matching kernel B's inputs of this iteration (two cached configurations)
 static const SlowCtx *slow_ctx_for(wx_sim *s, const FusedBIn &in)
 {
@@ -376,7 +397,7 @@ static const SlowCtx *slow_ctx_for(wx_sim *s, const FusedBIn &in)
   c.in.base = in.base;
   c.in.water = in.water;
   c.in.wall = in.wall;
-  c.in.light = nullptr; // alternates with the even / odd parity and is not used by the out-of-line path
+  c.in.light = LightPlanesC{nullptr, nullptr, nullptr}; // alternates with the even / odd parity, not used by the out-of-line path
   c.in.water_alt = in.water_alt;
   c.in.wall_alt = in.wall_alt;
   c.in.clean = in.clean;
@@ -409,19 +430,22 @@ int iterate_fused(wx_sim *s, bool write_disp)
   u.iterNum = (float)s->iter;
   u.iterI = (int)u.iterNum;
   const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
+  light_to_planes(s);
   unsigned int *clean = (s->cow && s->X >= 72 && s->Y >= 24) ? s->cow_clean : nullptr; // not for grids whose tile halo wraps twice
   {
-    FusedAIn in{s->base[0], s->wall[0], s->water[1], s->light[0], s->fb_dirty ? s->fb : nullptr, s->fb_dirty ? s->dep : nullptr};
+    FusedAIn in{s->base[0], s->wall[0], s->water[1], LightPlanesC{s->lp[0].x, s->lp[0].y, s->lp[0].zw}, s->fb_dirty ? s->fb : nullptr,
+                s->fb_dirty ? s->dep : nullptr};
     ProfScope ps(s, K_FUSED_VCVB);
     launch_fused_a(g, u, s->initial_T, in, s->base[1], s->water[0], s->wall[1], s->curl, write_disp, clean, s->stream);
   }
   {
     // B reads A's outputs (water[0], wall[1]) -- or, for tiles A left unwritten, A's inputs (water[1], wall[0]) -- and
     // writes the third buffer of each; afterwards the pointers rotate back into their usual roles
-    FusedBIn in{s->base[1], s->water[0], s->wall[1], s->light[src], s->water[1], s->wall[0], clean, (s->X + 63) / 64};
+    FusedBIn in{s->base[1], s->water[0], s->wall[1], LightPlanesC{s->lp[src].x, s->lp[src].y, s->lp[src].zw}, s->water[1], s->wall[0], clean,
+                (s->X + 63) / 64};
     const SlowCtx *ctx = slow_ctx_for(s, in);
     ProfScope ps(s, K_FUSED_APL);
-    launch_fused_b(g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, ctx, s->base[0], s->base[2], s->water[2], s->wall[2], s->light[dst],
+    launch_fused_b(g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, ctx, s->base[0], s->base[2], s->water[2], s->wall[2], s->lp[dst],
                    write_disp, s->stream);
   }
   std::swap(s->water[1], s->water[2]); // water[1] = post-advection water, water[2] = what A read (source of the clean tiles)
@@ -539,6 +563,11 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (rc == WX_OK) rc = dalloc(s, &s->state, 1);
   if (rc == WX_OK) rc = dalloc(s, &s->slow_ctx, 2);
   if (rc == WX_OK) rc = dalloc(s, &s->wall[2], n);
+  for (int i = 0; i < 2 && rc == WX_OK; i++) {
+    if ((rc = dalloc(s, &s->lp[i].x, n))) break;
+    if ((rc = dalloc(s, &s->lp[i].y, n))) break;
+    rc = dalloc(s, &s->lp[i].zw, n);
+  }
   if (rc == WX_OK) rc = dalloc(s, &s->cow_clean, (size_t)((s->X + 63) / 64) * ((Y + 15) / 16));
   if (rc == WX_OK) rc = dalloc(s, &s->full_ctx, 1);
   if (rc == WX_OK) rc = dalloc(s, &s->water[2], n);
@@ -610,6 +639,11 @@ void wx_destroy(wx_sim *s)
   hipFree(s->keys);
   hipFree(s->slow_ctx);
   hipFree(s->wall[2]);
+  for (int i = 0; i < 2; i++) {
+    hipFree(s->lp[i].x);
+    hipFree(s->lp[i].y);
+    hipFree(s->lp[i].zw);
+  }
   hipFree(s->cow_clean);
   hipFree(s->full_ctx);
   hipFree(s->water[2]);
@@ -671,6 +705,7 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   HIPCHK(s, hipStreamSynchronize(s->stream)); // the caller keeps ownership of the host arrays
   s->fb_dirty = false;
   s->cow_pending = false;
+  s->light_planar = false; // the interleaved light textures were just zeroed
   s->period_j = 0;
   s->ran_fused = false;
   s->even = 1;
@@ -762,7 +797,10 @@ int wx_step(wx_sim *s, int n_iter)
     HIPCHK(s, hipStreamWaitEvent(s->stream, s->ev_copy_done, 0));
     s->copy_in_flight = false;
   }
-  if (!(fused && s->fused == 1)) cow_resolve(s); // the other kernel sets take water[0] as a fully written buffer
+  if (!(fused && s->fused == 1)) {
+    cow_resolve(s);  // the other kernel sets take water[0] as a fully written buffer
+    light_to_rgba(s); // ... and the light textures interleaved
+  }
   for (int it = 0; it < n_iter; it++) {
     if (dry)
       iterate_dry(s, precip || it == n_iter - 1);
@@ -858,8 +896,8 @@ static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int
   case WX_FIELD_WALL_CUR: *ptr = s->wall[0]; *channels = 4; *elem = 1; return 0;
   // wallTexture_1 (post-advection) == wallTexture_0 after the pressure pass-through; the fused path keeps one copy
   case WX_FIELD_WALL_DISP: *ptr = s->ran_fused ? s->wall[0] : s->wall[1]; *channels = 4; *elem = 1; return 0;
-  case WX_FIELD_LIGHT_0: *ptr = s->light[0]; *channels = 4; *elem = 4; return 0;
-  case WX_FIELD_LIGHT_1: *ptr = s->light[1]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_LIGHT_0: light_to_rgba(s); *ptr = s->light[0]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_LIGHT_1: light_to_rgba(s); *ptr = s->light[1]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_CURL: *ptr = s->curl; *channels = 1; *elem = 4; return 0;
   case WX_FIELD_VORT: *ptr = s->vort; *channels = 2; *elem = 4; return 0;
   case WX_FIELD_PRECIP_FB: *ptr = s->fb; *channels = 4; *elem = 4; return 0;
@@ -939,18 +977,21 @@ int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst)
     HIPCHK(s, hipEventCreateWithFlags(&s->ev_fields_ready, hipEventDisableTiming));
     HIPCHK(s, hipEventCreateWithFlags(&s->ev_copy_done, hipEventDisableTiming));
   }
+  const void *ptr[6];
+  size_t texel[6];
+  for (int f = 0; f < 6; f++) { // (may enqueue a layout conversion of the light texture on the compute stream)
+    int ch, el;
+    if (field_info(s, kStreamFields[f], &ptr[f], &ch, &el)) return fail(s, WX_E_INVALID, "wx_stream_frame: field %d", kStreamFields[f]);
+    texel[f] = (size_t)ch * el;
+  }
   // the copies start when everything enqueued so far on the compute stream has produced the fields ...
   HIPCHK(s, hipEventRecord(s->ev_fields_ready, s->stream));
   HIPCHK(s, hipStreamWaitEvent(s->copy_stream, s->ev_fields_ready, 0));
   char *dst = (char *)host_dst;
   for (int f = 0; f < 6; f++) {
-    const void *ptr;
-    int ch, el;
-    if (field_info(s, kStreamFields[f], &ptr, &ch, &el)) return fail(s, WX_E_INVALID, "wx_stream_frame: field %d", kStreamFields[f]);
-    const size_t texel = (size_t)ch * el;
-    HIPCHK(s, hipMemcpy2DAsync(dst, (size_t)w * texel, (const char *)ptr + ((size_t)y * s->X + x) * texel, (size_t)s->X * texel, (size_t)w * texel, h,
-                               hipMemcpyDeviceToHost, s->copy_stream));
-    dst += (size_t)w * h * texel;
+    HIPCHK(s, hipMemcpy2DAsync(dst, (size_t)w * texel[f], (const char *)ptr[f] + ((size_t)y * s->X + x) * texel[f], (size_t)s->X * texel[f],
+                               (size_t)w * texel[f], h, hipMemcpyDeviceToHost, s->copy_stream));
+    dst += (size_t)w * h * texel[f];
   }
   // ... and the next wx_step (which overwrites them) waits for the copies on the device, not on the host
   HIPCHK(s, hipEventRecord(s->ev_copy_done, s->copy_stream));
@@ -1000,7 +1041,9 @@ int wx_halo_pack(wx_sim *s, int side, void *dev_buf)
   if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
   if (s->halo == 0) return fail(s, WX_E_STATE, "handle has no halo");
   const int n = s->halo * s->Y;
-  HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->wall[0], s->keys ? s->fb : nullptr, s->keys ? s->dep : nullptr};
+  const LightPlanes none{nullptr, nullptr, nullptr};
+  HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
+             s->keys ? s->fb : nullptr, s->keys ? s->dep : nullptr};
   const size_t o8 = (size_t)n * (s->keys ? 80 : 64), o4 = o8 + (s->keys ? (size_t)n * 8 : 0);
   ProfScope ps(s, K_HALO);
   hipLaunchKernelGGL(k_halo_pack, dim3((n + 255) / 256), dim3(256), 0, s->stream, f, s->X, s->Y, s->halo, halo_xstart(s, side, true),
@@ -1014,7 +1057,9 @@ int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
   if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
   if (s->halo == 0) return fail(s, WX_E_STATE, "handle has no halo");
   const int n = s->halo * s->Y;
-  HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->wall[0], s->keys ? s->fb : nullptr, s->keys ? s->dep : nullptr};
+  const LightPlanes none{nullptr, nullptr, nullptr};
+  HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
+             s->keys ? s->fb : nullptr, s->keys ? s->dep : nullptr};
   const size_t o8 = (size_t)n * (s->keys ? 80 : 64), o4 = o8 + (s->keys ? (size_t)n * 8 : 0);
   ProfScope ps(s, K_HALO);
   hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256), dim3(256), 0, s->stream, f, s->X, s->Y, s->halo, halo_xstart(s, side, false),

@@ -28,7 +28,8 @@ ALGO_BYTES = {
     # stores are skipped for tiles the boundary pass leaves unchanged -- still counted here, the pass semantically produces them);
     # B: R base16 water16 wall4 light16,
     # W base16 water16 wall4 light16 (+16 for the post-advection base on the last iteration of a wx_step call only)
-    "fused_vel_curl_vort_boundary": 52 + 36, "fused_advect_pressure_light": 52 + 52,
+    # (A reads only the x and y planes of the light texture: base16 wall4 water16 light8)
+    "fused_vel_curl_vort_boundary": 44 + 36, "fused_advect_pressure_light": 52 + 52,
     # single-kernel iteration: R base16 wall4 water16 light_0 16 light_src 16, W base16 wall4 water16 light16
     "fused_full_iteration": 68 + 52,
     # dry config: A_dry = base 16 R + 16 W + wall 4 R; the kernel also passes the wall texel through (+4 W)
