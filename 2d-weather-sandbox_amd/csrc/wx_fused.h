@@ -56,6 +56,10 @@ struct FusedAIn {
   LightPlanesC light; // light_0 (boundaryShader samples lightTexture_0 only)
   const float4 *fb;
   const float2 *dep;
+  // per 64x16 tile (the splat kernels use the same tiling): the feedback AND deposition textures are known to be all zero
+  // there, so the tile neither loads them (24 B/cell) nor evaluates their terms (x +- 0, x / 1: same values)
+  const unsigned char *fb_zero;
+  int fb_txn;
 };
 // Copy-on-write of kernel A's water / wall outputs: away from terrain and without particle feedback the boundary pass
 // returns both bit-identical to its inputs. Kernel A then leaves the 64x16 tile unwritten and sets clean[tile] = 1, and
@@ -200,6 +204,7 @@ struct LBoundaryAcc {
   FusedAIn in;
   float4 w00;
   int X, Y, x, y, cx, cy;
+  bool tile_fb; // wave-uniform: this tile has particle feedback
   __device__ __forceinline__ float4 base(int dx, int dy) const { return sm.b.get(cy + fa::HD + dy, cx + fa::HL + dx); }
   __device__ __forceinline__ char4 wall(int dx, int dy) const { return sm.w[cy + 2 + dy][cx + 2 + dx]; }
   __device__ __forceinline__ float2 vort(int dx, int dy) const { return make_float2(sm.vx[cy + 1 + dy][cx + 1 + dx], sm.vy[cy + 1 + dy][cx + 1 + dx]); }
@@ -215,9 +220,9 @@ struct LBoundaryAcc {
     const size_t i = fidx(x, yy, X);
     return make_float4(in.light.x[i], in.light.y[i], 0.0f, 0.0f); // the boundary pass reads sunlight and net heating only
   }
-  __device__ __forceinline__ bool has_fb() const { return in.fb != nullptr; }
-  __device__ __forceinline__ float4 fb() const { return in.fb ? in.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
-  __device__ __forceinline__ float2 dep() const { return in.dep ? in.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
+  __device__ __forceinline__ bool has_fb() const { return tile_fb; }
+  __device__ __forceinline__ float4 fb() const { return tile_fb ? in.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ float2 dep() const { return tile_fb ? in.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
 };
 
 // WRITE_CURL: the curl texture has only display-side consumers (app.js:6081-6219), so it is stored only by the last
@@ -263,6 +268,7 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
   __syncthreads();
 
   // ---- stage 4: boundary on the tile ----
+  const bool tile_fb = in.fb != nullptr && !(in.fb_zero != nullptr && in.fb_zero[tby * in.fb_txn + tbx] != 0);
   const int cx = tid & (TX - 1);
   const int x = tx0 + cx;
   constexpr int RPT = TY / (NTA / TX);
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
     const int y = ty0 + cy;
     if (x >= X || y >= Y) continue;
     const size_t gi = fidx(x, y, X);
-    LBoundaryAcc a{sm, in, in.water[gi], X, Y, x, y, cx, cy};
+    LBoundaryAcc a{sm, in, in.water[gi], X, Y, x, y, cx, cy, tile_fb};
     float4 b, w;
     char4 wl;
 #ifdef WX_ABL_NOBOUNDARY

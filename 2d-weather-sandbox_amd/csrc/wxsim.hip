@@ -434,7 +434,7 @@ int iterate_fused(wx_sim *s, bool write_disp)
   unsigned int *clean = (s->cow && s->X >= 72 && s->Y >= 24) ? s->cow_clean : nullptr; // not for grids whose tile halo wraps twice
   {
     FusedAIn in{s->base[0], s->wall[0], s->water[1], LightPlanesC{s->lp[0].x, s->lp[0].y, s->lp[0].zw}, s->fb_dirty ? s->fb : nullptr,
-                s->fb_dirty ? s->dep : nullptr};
+                s->fb_dirty ? s->dep : nullptr, s->sg.fb_zero, s->sg.TXn};
     ProfScope ps(s, K_FUSED_VCVB);
     launch_fused_a(g, u, s->initial_T, in, s->base[1], s->water[0], s->wall[1], s->curl, write_disp, clean, s->stream);
   }
