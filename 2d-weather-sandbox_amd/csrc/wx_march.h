@@ -72,7 +72,10 @@ struct MDryFp {
 };
 __device__ __forceinline__ MDryFp make_fp(const MDryAcc &a, int dx0, int dy0) { return MDryFp{a.rg, (a.yc + dy0) & 3, a.lane1 + dx0}; }
 
-template <bool WRITE_DISP>
+// WRITE_WALL = false: the host has established that advection cannot change the wall texture in this launch (no brush,
+// no airplane crash, no negative vegetation left to clamp -- the only three ways, advectionShader.frag:189-227, 229-457),
+// so the pass-through store is dropped and the wall buffers are not swapped: 36 B/cell, SURVEY's A_dry.
+template <bool WRITE_DISP, bool WRITE_WALL>
 __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u_arg, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows)
 {
   __shared__ MarchRing rg;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
         if (lane_out) {
           const size_t gi = fidx(c_out, y, X);
           out.base[gi] = p;
-          out.wall[gi] = awl;
+          if (WRITE_WALL) out.wall[gi] = awl;
           if (WRITE_DISP) out.base_disp[gi] = ab;
         }
       }
@@ -200,7 +203,7 @@ inline int march_seg_rows(int n_strips, int Y)
   if (!capacity) {
     int dev = 0, ncu = 0, nb = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_dry<false>, 64, 0) != hipSuccess || ncu <= 0 || nb <= 0)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_dry<false, true>, 64, 0) != hipSuccess || ncu <= 0 || nb <= 0)
       capacity = 256 * 4 * WX_MARCH_MINWAVES;
     else
       capacity = ncu * nb;
@@ -218,7 +221,8 @@ inline int march_seg_rows(int n_strips, int Y)
   return maxseg < Y ? maxseg : Y;
 }
 
-inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, const DryIn &in, const DryOut &out, bool write_disp, hipStream_t stream)
+inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, const DryIn &in, const DryOut &out, bool write_disp, bool write_wall,
+                             hipStream_t stream)
 {
   const int n_strips = (g.X + MOUT - 1) / MOUT;
   const int seg_rows = march_seg_rows(n_strips, g.Y), n_seg = (g.Y + seg_rows - 1) / seg_rows;
@@ -228,10 +232,13 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
     fprintf(stderr, "[wx_march] strips=%d seg_rows=%d segs=%d waves=%d\n", n_strips, seg_rows, n_seg, n_strips * n_seg);
     dbg = false;
   }
-  if (write_disp)
-    hipLaunchKernelGGL(k_march_dry<true>, grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows);
-  else
-    hipLaunchKernelGGL(k_march_dry<false>, grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows);
+#define WX_LAUNCH_M(D, W) hipLaunchKernelGGL((k_march_dry<D, W>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows)
+  if (write_disp) {
+    if (write_wall) WX_LAUNCH_M(true, true); else WX_LAUNCH_M(true, false);
+  } else {
+    if (write_wall) WX_LAUNCH_M(false, true); else WX_LAUNCH_M(false, false);
+  }
+#undef WX_LAUNCH_M
 }
 
 } // namespace wx

@@ -105,6 +105,7 @@ struct wx_sim {
   // says which copy is current; the other kernel sets, readback and streaming use the interleaved light[] buffers.
   LightPlanes lp[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   bool light_planar = false;
+  bool wall_veg_ok = false; // no negative vegetation byte anywhere (advection would clamp it: the one wall change it can make unasked)
   // copy-on-write of kernel A's water / wall outputs
   int cow = 1;                         // env WX_COW=0 disables it
   unsigned int *cow_clean = nullptr;   // per 64x16 tile: kernel A left water[0] / wall[1] unwritten
@@ -485,15 +486,19 @@ int iterate_dry(wx_sim *s, bool write_disp)
   const bool water = !(s->water_trivial && s->p.userInputType < 0 && s->p.airplaneValues[3] == 0.0f && s->p.soundingForcing == 0.0f);
   DryIn in{s->base[0], s->wall[0], s->water[1]};
   DryOut out{s->base[1], s->wall[1], s->water[2], s->base[2]};
+  // advection changes the wall texture only through the brush, an airplane crash or by clamping a negative vegetation byte
+  const bool wall_const = s->wall_veg_ok && s->p.userInputType < 0 && !(s->p.airplaneValues[3] > 0.9f);
+  bool wall_written = true;
   if (!water && s->dry_march && s->X >= 64) {
     ProfScope ps(s, K_MARCH_DRY);
-    launch_march_dry(s->geo, s->uni, s->full_ctx, in, out, write_disp, s->stream);
+    launch_march_dry(s->geo, s->uni, s->full_ctx, in, out, write_disp, !wall_const, s->stream);
+    wall_written = !wall_const;
   } else {
     ProfScope ps(s, K_FUSED_DRY);
     launch_fused_dry(s->geo, s->uni, s->full_ctx, in, out, water, write_disp, s->stream);
   }
   std::swap(s->base[0], s->base[1]);
-  std::swap(s->wall[0], s->wall[1]);
+  if (wall_written) std::swap(s->wall[0], s->wall[1]);
   if (water) {
     // reference ping-pong with the boundary pass masked off: water_0 = previous water_1, water_1 = advected water
     std::swap(s->water[0], s->water[1]);
@@ -671,6 +676,9 @@ int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wa
       trivial = (w[0] == x_expected) && w[1] == 0.0f && w[2] == 0.0f && w[3] == 0.0f && wl[3] >= 0;
     }
     s->water_trivial = trivial;
+    bool veg_ok = true;
+    for (size_t i = 0; i < n && veg_ok; i++) veg_ok = wall[4 * i + 3] >= 0;
+    s->wall_veg_ok = veg_ok;
   }
   for (int i = 0; i < 2; i++) {
     HIPCHK(s, hipMemcpyAsync(s->base[i], base, n * 16, hipMemcpyHostToDevice, s->stream));
@@ -754,6 +762,7 @@ int wx_setup_columns(wx_sim *s, const int32_t *wall_rows, const uint8_t *sea_col
   hipFree(scratch);
   if (e != hipSuccess) return fail(s, WX_E_DEVICE, "wx_setup_columns: %s", hipGetErrorString(e));
   s->water_trivial = false;
+  s->wall_veg_ok = true; // k_setup_columns clamps the vegetation to 0..127
   return reset_after_upload(s, drops);
 }
 
@@ -797,6 +806,8 @@ int wx_step(wx_sim *s, int n_iter)
     HIPCHK(s, hipStreamWaitEvent(s->stream, s->ev_copy_done, 0));
     s->copy_in_flight = false;
   }
+  // the vegetation byte stays known non-negative only while nothing but the brush-free dry iteration touches the wall texture
+  if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] > 0.9f) s->wall_veg_ok = false;
   if (!(fused && s->fused == 1)) {
     cow_resolve(s);  // the other kernel sets take water[0] as a fully written buffer
     light_to_rgba(s); // ... and the light textures interleaved
