@@ -20,7 +20,7 @@
 namespace wx {
 
 #ifndef WX_MARCH_MAXSEG
-#define WX_MARCH_MAXSEG 128 // upper bound of the rows one wave marches (3 warm-up rows per segment are redundant work)
+#define WX_MARCH_MAXSEG 64 // upper bound of the rows one wave marches (3 warm-up rows per segment are redundant work)
 #endif
 #ifndef WX_MARCH_UNI_MEM
 #define WX_MARCH_UNI_MEM 1 // measured: SGPR spills 12 -> 0, 0.31 -> 0.29 ms at 16384x2048
@@ -29,7 +29,7 @@ namespace wx {
 #define WX_MARCH_XCD 1
 #endif
 #ifndef WX_MARCH_MINWAVES
-#define WX_MARCH_MINWAVES 6
+#define WX_MARCH_MINWAVES 8
 #endif
 constexpr int MOUT = 60;           // output columns per wave (lanes 2..61)
 

@@ -32,7 +32,8 @@ ALGO_BYTES = {
     "fused_vel_curl_vort_boundary": 44 + 36, "fused_advect_pressure_light": 52 + 52,
     # single-kernel iteration: R base16 wall4 water16 light_0 16 light_src 16, W base16 wall4 water16 light16
     "fused_full_iteration": 68 + 52,
-    # dry config: A_dry = base 16 R + 16 W + wall 4 R; the kernel also passes the wall texel through (+4 W)
+    # dry config: A_dry = base 16 R + 16 W + wall 4 R; the tiled kernel also passes the wall texel through (+4 W), the
+    # marching kernel only when the brush / an airplane crash could change it
     "fused_dry_vel_advect_pressure": 36,
     "march_dry_vel_advect_pressure": 36,
 }
