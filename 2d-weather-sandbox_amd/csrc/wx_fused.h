@@ -456,7 +456,7 @@ template <bool WRITE_DISP, bool SMALL>
 __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u_arg, const float *__restrict__ initial_T, const float *__restrict__ snd_T,
                                                 const float *__restrict__ snd_W, const float *__restrict__ snd_Vel, FusedBIn in,
                                                 const SlowCtx *__restrict__ ctx, float4 *__restrict__ base_out, float4 *__restrict__ base_disp, float4 *__restrict__ water_out,
-                                                char4 *__restrict__ wall_out, LightPlanes light_out)
+                                                char4 *__restrict__ wall_out, LightPlanes light_out, float *__restrict__ t_disp)
 {
   using namespace fb_;
   __shared__ union {
@@ -556,6 +556,7 @@ __global__ __launch_bounds__(NTB, WX_B_MINWAVES) void k_fused_b(Geo g, Uni u_arg
     const char4 wd = sm.out.w[cy][cx + 1];
     base_out[gi] = pressure_cell(b, sm.out.vx[cy + 1][cx], sm.out.vy[cy][cx + 1], sm.out.T[cy][cx + 1], wd.x, wd.y);
     if (WRITE_DISP) base_disp[gi] = b;
+    if (t_disp) t_disp[gi] = b.w; // post-advection temperature for the droplets (wave-uniform pointer test)
     water_out[gi] = wreg[k];
     wall_out[gi] = wlreg[k];
 #ifdef WX_ABL_NOLIGHT
@@ -618,13 +619,13 @@ inline void launch_fused_a(const Geo &g, const Uni &u, const float *initial_T, c
 
 inline void launch_fused_b(const Geo &g, const Uni &u, const float *initial_T, const float *snd_T, const float *snd_W, const float *snd_Vel,
                            const FusedBIn &in, const SlowCtx *ctx, float4 *base_out, float4 *base_disp, float4 *water_out, char4 *wall_out,
-                           const LightPlanes &light_out, bool write_disp, hipStream_t stream)
+                           const LightPlanes &light_out, bool write_disp, float *t_disp, hipStream_t stream)
 {
   const dim3 grid = tile_grid(g.X, g.Y);
   const bool small = (g.X < TX + 8) || (g.Y < TY + 8);
 #define WX_LAUNCH_B(D, S)                                                                                                                  \
   hipLaunchKernelGGL((k_fused_b<D, S>), grid, dim3(NTB), 0, stream, g, u, initial_T, snd_T, snd_W, snd_Vel, in, ctx, base_out, base_disp, \
-                     water_out, wall_out, light_out)
+                     water_out, wall_out, light_out, t_disp)
   if (write_disp) {
     if (small) WX_LAUNCH_B(true, true); else WX_LAUNCH_B(true, false);
   } else {

@@ -292,8 +292,12 @@ __device__ __forceinline__ void atomic_add_f(float *p, float v)
 
 __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops, const float *__restrict__ drops_in,
                                                         const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
-                                                        DevState *__restrict__ st, float *__restrict__ drops_out, SplatGrid sg, SlabP sp)
+                                                        DevState *__restrict__ st, float *__restrict__ drops_out, SplatGrid sg, SlabP sp,
+                                                        const float *__restrict__ t_in)
 {
+  // t_in != nullptr (two-kernel path): base_in is the POST-pressure base texture, whose velocity components equal the
+  // post-advection ones the reference samples (pressure_cell only touches P and T), and t_in holds the post-advection
+  // temperature -- kernel B then stores 4 instead of 16 extra bytes per cell for the droplets.
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = i < n_drops;
   const int Y = g.Y;
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
       tcy = random2d(m1, dpx + u.iterNum * 0.073162f);
       const size_t t = texel(g, tcx, tcy);
       base = base_in[t];
+      if (t_in) base.w = t_in[t];
       water = water_in[t];
       realTemp = base.w - tcy * u.dryLapse;
       const float threshold = (realTemp > CtoK(0.0f)) ? u.aboveZeroThreshold : u.subZeroThreshold;
@@ -388,6 +393,7 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
         const size_t t = texel(g, tcx, tcy);
         water = water_in[t];
         base = base_in[t];
+        if (t_in) base.w = t_in[t];
         realTemp = base.w - tcy * u.dryLapse;
       }
       const float totalMass = newM0 + newM1;
@@ -397,7 +403,8 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
         newM0 = -2.0f - dpx;
         newM1 = dpy;
       } else if (newPosy < -1.0f || water.x > 1000.0f) {
-        if (base_in[texel(g, tcx, tcy + g.texY)].w > 500.0f) newPosy += g.texY * 1.0f;
+        const size_t tu = texel(g, tcx, tcy + g.texY);
+        if ((t_in ? t_in[tu] : base_in[tu].w) > 500.0f) newPosy += g.texY * 1.0f;
         deposition[0] = newM0;
         deposition[1] = newM1;
         newM0 = -2.0f - dpx;

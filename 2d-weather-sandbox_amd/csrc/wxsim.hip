@@ -105,6 +105,7 @@ struct wx_sim {
   // says which copy is current; the other kernel sets, readback and streaming use the interleaved light[] buffers.
   LightPlanes lp[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   bool light_planar = false;
+  float *tdisp = nullptr;   // post-advection temperature for the droplets (two-kernel path, instead of the whole base_disp)
   bool wall_veg_ok = false; // no negative vegetation byte anywhere (advection would clamp it: the one wall change it can make unasked)
   // copy-on-write of kernel A's water / wall outputs
   int cow = 1;                         // env WX_COW=0 disables it
@@ -424,7 +425,7 @@ static void cow_resolve(wx_sim *s)
   s->cow_pending = false;
 }
 
-int iterate_fused(wx_sim *s, bool write_disp)
+int iterate_fused(wx_sim *s, bool write_disp, bool precip)
 {
   const Geo g = s->geo;
   Uni u = s->uni;
@@ -447,7 +448,7 @@ int iterate_fused(wx_sim *s, bool write_disp)
     const SlowCtx *ctx = slow_ctx_for(s, in);
     ProfScope ps(s, K_FUSED_APL);
     launch_fused_b(g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, ctx, s->base[0], s->base[2], s->water[2], s->wall[2], s->lp[dst],
-                   write_disp, s->stream);
+                   write_disp, precip ? s->tdisp : nullptr, s->stream);
   }
   std::swap(s->water[1], s->water[2]); // water[1] = post-advection water, water[2] = what A read (source of the clean tiles)
   std::swap(s->wall[0], s->wall[2]);
@@ -568,6 +569,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (rc == WX_OK) rc = dalloc(s, &s->state, 1);
   if (rc == WX_OK) rc = dalloc(s, &s->slow_ctx, 2);
   if (rc == WX_OK) rc = dalloc(s, &s->wall[2], n);
+  if (rc == WX_OK && n_droplets > 0) rc = dalloc(s, &s->tdisp, n);
   for (int i = 0; i < 2 && rc == WX_OK; i++) {
     if ((rc = dalloc(s, &s->lp[i].x, n))) break;
     if ((rc = dalloc(s, &s->lp[i].y, n))) break;
@@ -644,6 +646,7 @@ void wx_destroy(wx_sim *s)
   hipFree(s->keys);
   hipFree(s->slow_ctx);
   hipFree(s->wall[2]);
+  hipFree(s->tdisp);
   for (int i = 0; i < 2; i++) {
     hipFree(s->lp[i].x);
     hipFree(s->lp[i].y);
@@ -818,7 +821,7 @@ int wx_step(wx_sim *s, int n_iter)
     else if (fused && s->fused >= 2)
       iterate_full(s, precip || it == n_iter - 1);
     else if (fused)
-      iterate_fused(s, precip || it == n_iter - 1);
+      iterate_fused(s, it == n_iter - 1, precip);
     else
       iterate_per_pass(s, mask);
     s->ran_fused = fused || dry;
@@ -827,6 +830,7 @@ int wx_step(wx_sim *s, int n_iter)
     // 8-10 clear feedback/deposition, precipitation, lightning location (app.js:5933-5983). The clear and the
     // blend-unit splats are replaced by: deposit at the sprite anchors -> 12x12 box sum that (re)writes both textures.
     if (precip) {
+      const bool two_kernel = fused && s->fused == 1 && !dry; // droplets sample base[0] (velocity) + tdisp (temperature)
       Uni u = s->uni;
       u.iterNum = (float)s->iter;
       u.iterI = (int)u.iterNum;
@@ -843,7 +847,8 @@ int wx_step(wx_sim *s, int n_iter)
           sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, (s->period_j + 1) * 2048 + (1023 - s->rank), s->keys};
         }
         hipLaunchKernelGGL(k_precipitation, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, u, s->n_drops, s->drops[src],
-                           (fused || dry) ? s->base[2] : s->base[1], s->water[1], s->state, s->drops[dst], s->sg, sp);
+                           two_kernel ? s->base[0] : ((fused || dry) ? s->base[2] : s->base[1]), s->water[1], s->state, s->drops[dst], s->sg, sp,
+                           two_kernel ? s->tdisp : nullptr);
       }
       {
         ProfScope ps(s, K_SPLAT);
