@@ -113,6 +113,26 @@ def test_bit_exact_terrain_grid(pkg, oracle, E, X, Y, fused):
         _assert_grid_equal(h, o)
 
 
+@pytest.mark.parametrize("X,Y", [(20, 12), (63, 17), (71, 24), (72, 23), (127, 15), (2, 4)])
+def test_bit_exact_tiny_and_ragged_grids(pkg, oracle, E, fused, X, Y):
+    """Grids smaller than a tile, one column past a tile, halo wrapping more than once (the SMALL kernel variants,
+    copy-on-write switched off below 72 x 24): all passes and the dry mask, every kernel set."""
+    base, water, wall = pkg.synth.terrain_grid(X, Y) if Y >= 12 else pkg.synth.dry_grid(X, Y)
+    rng = np.random.default_rng(X * 100 + Y)
+    air = wall[..., 1] != 0
+    base[..., 0] += np.where(air, rng.normal(0, 0.2, (Y, X)), 0).astype(np.float32)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 40.0
+    for mask in (pkg.params.PASS_ALL, pkg.params.PASS_DRY):
+        u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, pass_mask=mask)
+        u["enablePrecipitation"] = 0
+        h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
+        h.step(9)
+        o.step(9)
+        _assert_grid_equal(h, o)
+        h.close()
+
+
 @pytest.mark.parametrize("moist", [False, True], ids=["dry", "moist"])
 @pytest.mark.parametrize("X,Y", [(256, 128), (130, 50)])
 def test_dry_config_pass_mask(pkg, oracle, E, fused, X, Y, moist):
