@@ -64,3 +64,13 @@ def test_create_rejects_bad_geometry(engine):
     assert L.wx_create_slab(100, 100, 0, 50, 0, 0, C.byref(h)) == -1  # slab without halo
     assert b"halo" in L.wx_last_error(None)
     assert L.wx_step(None, 1) == -1 and L.wx_sync(None) == -1
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() is the driver's 'does it build' check: it must succeed on a CPU-only box."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
