@@ -201,7 +201,11 @@ __device__ __forceinline__ float4 pressure_cell(float4 b, float vx_l, float vy_d
 // ------------------------------------------------------------------------------------------------
 // boundaryShader.frag:72-531
 // Accessor A: base(dx,dy) water(dx,dy) -> float4 ; wall(dx,dy) -> char4 ; vort(dx,dy) -> float2 ;
-//             light(dy) -> float4 at (x, clamp(y+dy)) ; fb() -> float4 ; dep() -> float2
+//             light_y0() -> NET_HEATING of lightTexture_0 at the own cell ; light_x0() -> its SUNLIGHT (asked for only next
+//             to walls) ; light_xy_up() -> (SUNLIGHT, NET_HEATING) at (x, clamp(y+1)) (surface wall cells only) ;
+//             fb() -> float4 ; dep() -> float2 ; has_fb() (wave-uniform)
+// iterNum / iterI: the per-iteration uniform (float as the reference passes it, and int(iterNum)); separate from Uni so that
+// Uni can live in read-only device memory for a whole wx_step call
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float calcEvaporation(const Uni &u, float T, float W, float V, float M)
 {
@@ -213,8 +217,8 @@ __device__ __forceinline__ float calcFireIntensity(int veg, float moist, float p
 }
 
 template <class A>
-__device__ __forceinline__ void boundary_cell(const Uni &u, const Geo &g, const float *__restrict__ initial_T, int x, int y,
-                                              const A &a, float4 &base_out, float4 &water_out, char4 &wall_out)
+__device__ __forceinline__ void boundary_cell(const Uni &u, const float iterNum, const int iterI, const Geo &g, const float *__restrict__ initial_T,
+                                              int x, int y, const A &a, float4 &base_out, float4 &water_out, char4 &wall_out)
 {
   const float gravMult = 0.0001f;
   const float exchangeRate = 0.015f;
@@ -232,11 +236,11 @@ __device__ __forceinline__ void boundary_cell(const Uni &u, const Geo &g, const 
   wl[VERT_DISTANCE] = wD.z + 1;
 
   if (wl[DISTANCE] != 0) { // fluid
-    const float4 light = a.light(0);
+    const float light_y = a.light_y0();
     const bool has_fb = a.has_fb(); // wave-uniform: false while no particle has ever written feedback
     const float4 fb = a.fb();
     wl[TYPE] = wD.x;
-    if (wl[TYPE] != WALLTYPE_WATER) b.w += light.y; // NET_HEATING
+    if (wl[TYPE] != WALLTYPE_WATER) b.w += light_y; // NET_HEATING
     if (has_fb) {
       b.w += fb.y; // HEAT
 
@@ -307,9 +311,10 @@ __device__ __forceinline__ void boundary_cell(const Uni &u, const Geo &g, const 
     if (nextToWall) {
       if (wl[TYPE] != WALLTYPE_WATER) {
         float lightPower = 0.0f;
-        if (wD.y == 0) lightPower += fmaxf(light.x * u.cos_a, 0.0f);
-        if (wL.y == 0) lightPower += fmaxf(light.x * u.sin_a, 0.0f);
-        if (wR.y == 0) lightPower += fmaxf(light.x * u.sin_ma, 0.0f);
+        const float light_x = a.light_x0();
+        if (wD.y == 0) lightPower += fmaxf(light_x * u.cos_a, 0.0f);
+        if (wL.y == 0) lightPower += fmaxf(light_x * u.sin_a, 0.0f);
+        if (wR.y == 0) lightPower += fmaxf(light_x * u.sin_ma, 0.0f);
         float albedoTotal = 1.0f;
         if (wl[TYPE] == WALLTYPE_LAND || wl[TYPE] == WALLTYPE_FIRE) {
           float albedoSoil = map_rangeC(soilMoisture, 0.0f, 20.0f, ALBEDO_DRYSOIL, ALBEDO_WETSOIL);
@@ -412,7 +417,7 @@ __device__ __forceinline__ void boundary_cell(const Uni &u, const Geo &g, const 
     } else if (wl[VERT_DISTANCE] == 0) {
       const float4 waterX0Yp = a.water(0, 1);
       const float2 precipDeposition = a.dep();
-      const float4 lightAboveSurface = a.light(1);
+      const float2 lightAboveSurface = a.light_xy_up();
       const int t = wl[TYPE];
       if (t == WALLTYPE_INDUSTRIAL) wl[VEGETATION] = min(wl[VEGETATION], 15);
       if (t == WALLTYPE_INDUSTRIAL || t == WALLTYPE_URBAN) wl[VEGETATION] = min(wl[VEGETATION], 75);
@@ -421,7 +426,7 @@ __device__ __forceinline__ void boundary_cell(const Uni &u, const Geo &g, const 
           const float fireIntensity = calcFireIntensity(wl[VEGETATION], w.z, waterX0Yp.z);
           if (fireIntensity < 0.002f) {
             wl[TYPE] = WALLTYPE_LAND;
-          } else if (u.iterI % ((int)(10.0f / fireIntensity) + 1) == 0) {
+          } else if (iterI % ((int)(10.0f / fireIntensity) + 1) == 0) {
             wl[VEGETATION] -= 1;
             if (wl[VEGETATION] < 10) wl[TYPE] = WALLTYPE_LAND;
           }
@@ -436,7 +441,7 @@ __device__ __forceinline__ void boundary_cell(const Uni &u, const Geo &g, const 
         const float evaporation = calcEvaporation(u, realTempAboveSurface, waterX0Yp.x, (float)wl[VEGETATION], w.z) * 0.10f;
         w.z -= evaporation;
 
-        if (u.iterI % 100 == 0) {
+        if (iterI % 100 == 0) {
           const float snowSmoothingRate = 0.02f, moistureSmoothingRate = 0.02f;
           float numNeighbors = 0.0f, totalNeighborSnow = 0.0f, totalNeighborSoilMoisture = 0.0f;
           if (wL.z == 0 && (wL.x == WALLTYPE_LAND || wL.x == WALLTYPE_URBAN)) {
@@ -460,11 +465,11 @@ __device__ __forceinline__ void boundary_cell(const Uni &u, const Geo &g, const 
           const int vegetationGrowthRate = (int)(w.z * sqrtf(lightAboveSurface.x) * 0.01f);
           if (vegetationGrowthRate > 0) {
             const int interval = (100 / vegetationGrowthRate) * 100;
-            if (interval != 0 && u.iterI % interval == 0) { // x % 0 is undefined in GLSL -> false
+            if (interval != 0 && iterI % interval == 0) { // x % 0 is undefined in GLSL -> false
               if ((int)map_rangeC(realTempAboveSurface, CtoK(0.0f), CtoK(25.0f), 0.0f, 127.0f) > wl[VEGETATION]) wl[VEGETATION] += 1;
             }
           }
-          const int subInterval = u.iterI / 100;
+          const int subInterval = iterI / 100;
           if (subInterval % ((int)(w.z * 0.1f + w.w * 0.5f) + 10) == 0 && wl[VEGETATION] >= 20 &&
               (wL.x == WALLTYPE_FIRE || wR.x == WALLTYPE_FIRE || waterX0Yp.w > 4.5f)) {
             wl[TYPE] = WALLTYPE_FIRE;
@@ -473,7 +478,7 @@ __device__ __forceinline__ void boundary_cell(const Uni &u, const Geo &g, const 
       } else if (t == WALLTYPE_WATER) {
         const float waterTempUpdateInterval = 20.0f;
         if (u.dynamicWaterTemperature >= 1.0f &&
-            (u.iterNum - waterTempUpdateInterval * floorf(u.iterNum / waterTempUpdateInterval)) < 0.5f) {
+            (iterNum - waterTempUpdateInterval * floorf(iterNum / waterTempUpdateInterval)) < 0.5f) {
           float numNeighbors = 0.0f, totalNeighborTemp = 0.0f;
           if (wL.x == WALLTYPE_WATER) {
             totalNeighborTemp += a.base(-1, 0).w;

@@ -91,6 +91,9 @@ struct FBoundaryAcc {
     yy = yy < 0 ? 0 : (yy > Y - 1 ? Y - 1 : yy);
     return in.light0[fidx(x, yy, X)];
   }
+  __device__ __forceinline__ float light_y0() const { return light(0).y; }
+  __device__ __forceinline__ float light_x0() const { return light(0).x; }
+  __device__ __forceinline__ float2 light_xy_up() const { const float4 l = light(1); return make_float2(l.x, l.y); }
   __device__ __forceinline__ bool has_fb() const { return in.fb != nullptr; }
   __device__ __forceinline__ float4 fb() const { return in.fb ? in.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ __forceinline__ float2 dep() const { return in.dep ? in.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
@@ -142,6 +145,9 @@ struct GRecomputeAcc {
     yy = yy < 0 ? 0 : (yy > Y - 1 ? Y - 1 : yy);
     return in_.light0[fidx(x, yy, X)];
   }
+  __device__ __forceinline__ float light_y0() const { return light(0).y; }
+  __device__ __forceinline__ float light_x0() const { return light(0).x; }
+  __device__ __forceinline__ float2 light_xy_up() const { const float4 l = light(1); return make_float2(l.x, l.y); }
   __device__ __forceinline__ bool has_fb() const { return in_.fb != nullptr; }
   __device__ __forceinline__ float4 fb() const { return in_.fb ? in_.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ __forceinline__ float2 dep() const { return in_.dep ? in_.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
@@ -159,7 +165,7 @@ __device__ __noinline__ BOut boundary_texel_global(const SlowArgs *__restrict__ 
   u.iterI = (int)sa->iterNum;
   GRecomputeAcc a{u, sa->in, c->g.X, c->g.Y, x, y};
   BOut o;
-  boundary_cell(u, c->g, c->initial_T, x, y, a, o.b, o.w, o.wl);
+  boundary_cell(u, u.iterNum, u.iterI, c->g, c->initial_T, x, y, a, o.b, o.w, o.wl);
   return o;
 }
 
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(NTF, WX_F_MINWAVES) void k_fused_full(const FullCtx
         const int cx = rx - BL, cy = ry - BL;
         const int x = WX_WRAPX(tx0 + cx), y = WX_WRAPY(ty0 + cy);
         FBoundaryAcc a{sm.p1, in, bw00[k], X, Y, x, y, cx, cy};
-        boundary_cell(u, g, initial_T, x, y, a, bb[k], bq[k], bwl[k]);
+        boundary_cell(u, u.iterNum, u.iterI, g, initial_T, x, y, a, bb[k], bq[k], bwl[k]);
         if (OPT_OUT) {
           if (cx >= 0 && cx < TX && cy >= 0 && cy < TY && tx0 + cx < X && ty0 + cy < Y) {
             const size_t gi = fidx(tx0 + cx, ty0 + cy, X);

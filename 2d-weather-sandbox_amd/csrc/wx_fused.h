@@ -220,6 +220,9 @@ struct LBoundaryAcc {
     const size_t i = fidx(x, yy, X);
     return make_float4(in.light.x[i], in.light.y[i], 0.0f, 0.0f); // the boundary pass reads sunlight and net heating only
   }
+  __device__ __forceinline__ float light_y0() const { return light(0).y; }
+  __device__ __forceinline__ float light_x0() const { return light(0).x; }
+  __device__ __forceinline__ float2 light_xy_up() const { const float4 l = light(1); return make_float2(l.x, l.y); }
   __device__ __forceinline__ bool has_fb() const { return tile_fb; }
   __device__ __forceinline__ float4 fb() const { return tile_fb ? in.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ __forceinline__ float2 dep() const { return tile_fb ? in.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(NTA) void k_fused_a(Geo g, Uni u, const float *__re
     wl = a.wall(0, 0);
     b.x += a.vort(0, 0).x + a.vort(-1, 0).y + a.vort(0, -1).x;
 #else
-    boundary_cell(u, g, initial_T, x, y, a, b, w, wl);
+    boundary_cell(u, u.iterNum, u.iterI, g, initial_T, x, y, a, b, w, wl);
 #endif
     base_out[gi] = b;
     if (WRITE_CURL) curl_out[gi] = sm.c[cy + 2][cx + 2];

@@ -72,6 +72,9 @@ struct GBoundaryAcc {
     yy = yy < 0 ? 0 : (yy > Y - 1 ? Y - 1 : yy);
     return p.light[cidx(x, yy, X)];
   }
+  __device__ __forceinline__ float light_y0() const { return light(0).y; }
+  __device__ __forceinline__ float light_x0() const { return light(0).x; }
+  __device__ __forceinline__ float2 light_xy_up() const { const float4 l = light(1); return make_float2(l.x, l.y); }
   __device__ __forceinline__ bool has_fb() const { return p.fb != nullptr; }
   __device__ __forceinline__ float4 fb() const { return p.fb ? p.fb[cidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
   __device__ __forceinline__ float2 dep() const { return p.dep ? p.dep[cidx(x, y, X)] : make_float2(0.f, 0.f); }
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(BX *BY) void k_boundary(Geo g, Uni u, const float *
   GBoundaryAcc a{in, g.X, g.Y, x, y};
   float4 b, w;
   char4 wl;
-  boundary_cell(u, g, initial_T, x, y, a, b, w, wl);
+  boundary_cell(u, u.iterNum, u.iterI, g, initial_T, x, y, a, b, w, wl);
   const size_t i = cidx(x, y, g.X);
   base_out[i] = b;
   water_out[i] = w;
@@ -227,6 +230,8 @@ struct DevState {
   float lightning[4];     // lightningDataTexture (1x1 RGBA32F)
   float px_count;         // this iteration's 1-px blends into texel (0,0): +1 per still-inactive droplet
   float px_light[4];      // this iteration's 1-px blends into texel (1,0): lightning requests
+  int ghost_nontrivial;   // set by k_halo_unpack when a neighbour's ghost columns carry water (or a negative vegetation byte):
+                          // the host then stops treating the water texture as identically zero (wx_step, dry iteration)
 };
 
 // Splat accumulation: a 12x12 point sprite anchored at pixel (i0,j0) adds the same value to pixels
@@ -729,14 +734,21 @@ __global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, int x_start, float4
     }
   }
 }
-__global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, int x_start, const float4 *buf16, const float2 *buf8, const char4 *buf4)
+__global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, int x_start, const float4 *buf16, const float2 *buf8, const char4 *buf4,
+                              int *ghost_nontrivial)
 {
   const int n = h * Y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int y = i / h, c = i - y * h;
     const size_t s = cidx(x_start + c, y, X);
     f.base[s] = buf16[i];
-    f.water[s] = buf16[n + i];
+    const float4 q = buf16[n + i];
+    f.water[s] = q;
+    if (ghost_nontrivial) { // same test as wx_upload's: 0 in air, only the wall marker in wall cells, vegetation >= 0
+      const char4 wl = buf4[i];
+      const float x_expected = wl.y == 0 ? (wl.x == 2 ? 1002.0f : 1001.0f) : 0.0f;
+      if (!(q.x == x_expected && q.y == 0.0f && q.z == 0.0f && q.w == 0.0f && wl.w >= 0)) *ghost_nontrivial = 1;
+    }
     if (f.lp0.x) {
       const float4 a = buf16[2 * n + i], b = buf16[3 * n + i];
       f.lp0.x[s] = a.x;

@@ -1,0 +1,562 @@
+// wx_wet.h -- the WHOLE wet iteration (reference draws 1-7, app.js:5832-5930: velocity -> curl -> vorticity -> boundary ->
+// advection -> pressure -> lighting) as ONE row-MARCHING kernel (gfx950). One wavefront = one workgroup owns a 64-column
+// strip and walks up the rows of its segment; per step (newest input row r) it
+//
+//   loads row r+1 (prefetch)  |  velocity(r-1)  |  curl(r-2)  |  vortForce(r-3)  |  boundary(r-3)  |  advection(r-4)  |
+//   pressure(r-4) + lighting(r-4) -> stores row r-4
+//
+// * every intermediate texture of the reference (velocity output, curl, vortForce, post-boundary base / water / wall,
+//   advection output) lives in registers or in a wave-PRIVATE LDS ring of the last six rows; nothing but the iteration's
+//   inputs and outputs touches HBM: base 16 R + 16 W, water 16 R + 16 W, wall 4 R + 4 W, light 16 R + 16 W = 104 B/cell
+//   (two-kernel form: 184 B/cell; reference pass structure: ~380 B/cell);
+// * vertical neighbours are the wave's own earlier rows (ring or carried registers), horizontal neighbours of values that
+//   were just computed come from whole-wave DPP shifts (v_mov_b32_dpp wave_shr / wave_shl: one VALU instruction, no LDS
+//   round trip), data-dependent taps (advection's back-trace, the sun ray) from the ring;
+// * the boundary stage overwrites its input rows IN PLACE (the only later readers of the pre-boundary values are the same
+//   lane one row up: carried in registers), so six ring rows serve both the pre- and the post-boundary state;
+// * no vertical halo is re-loaded or re-computed, there are no workgroup barriers (the wave's LDS queue is in order;
+//   wavefront-scope fences keep the compiler from reordering across stages); 56 of the 64 lanes produce output
+//   (cone of the seven chained stencils: 4 columns per side for |v| < 0.9 cell/iteration; longer back-traces take the
+//   exact out-of-line path that recomputes post-boundary texels from global memory);
+// * global loads are issued one step ahead of their use (software prefetch), each with the lag its consumer has:
+//   base / wall row r+1, water row r-2 (first needed by boundary), source light row r-1 (sun taps of lighting).
+// Same per-cell arithmetic as every other kernel set (wx_cells.h): bit-identical results.
+#pragma once
+#include "wx_cells.h"
+#include "wx_fused.h"
+#include <cstddef>
+
+namespace wx {
+
+#ifndef WX_WET_MINWAVES
+#define WX_WET_MINWAVES 3
+#endif
+#ifndef WX_WET_MAXSEG
+#define WX_WET_MAXSEG 640 // upper bound of the rows one wave marches (8 warm-up rows per segment are redundant work)
+#endif
+
+struct FullCtx { // static per wx_set_params; the per-launch items (buffer pointers, iterNum) travel as arguments
+  Geo g;
+  Uni u;
+  const float *initial_T, *snd_T, *snd_W, *snd_Vel;
+};
+
+struct WetIn {
+  const float4 *base;   // base_0: post-pressure state of the previous iteration
+  const char4 *wall;    // wall_0
+  const float4 *water;  // water_1: post-advection water of the previous iteration
+  LightPlanesC l0;      // lightTexture_0 (what boundaryShader samples)
+  LightPlanesC lsrc;    // source of this iteration's lighting pass (light_0 or light_1)
+  const float4 *fb;     // precipitation feedback / deposition, or NULL when known to be zero
+  const float2 *dep;
+  const unsigned char *fb_zero; // per 64x16 tile: feedback AND deposition all zero there (may be NULL)
+  int fb_txn;
+};
+struct WetOut {
+  float4 *base;      // post-pressure
+  char4 *wall;
+  float4 *water;     // post-advection
+  LightPlanes light;
+  float4 *base_disp; // optional (OPT_OUT): post-advection base (baseTexture_1)
+  float4 *water0;    // optional (OPT_OUT): post-boundary water (waterTexture_0)
+  float *curl;       // optional (OPT_OUT)
+  float *t_disp;     // optional (runtime): post-advection temperature for the droplets
+};
+
+// ---- exact out-of-line path: the post-boundary texel of an ARBITRARY cell recomputed from global memory (velocity, curl
+//      and vortForce evaluated on the fly). Only reached by cells whose back-trace is longer than 0.9 cells. ----
+struct WetSlowArgs {
+  const FullCtx *ctx;
+  WetIn in;
+  float iterNum;
+};
+struct GWetRecomputeAcc {
+  const Uni &u_;
+  const WetIn &in_;
+  int X, Y, x, y;
+  __device__ __forceinline__ int wx_(int dx) const { return wrapmod(x + dx, X); }
+  __device__ __forceinline__ int wy_(int dy) const { return wrapmod(y + dy, Y); }
+  __device__ __forceinline__ float4 vel_at(int xx, int yy) const
+  { // velocity pass output at (xx,yy) (already wrapped)
+    const int xr = xx + 1 == X ? 0 : xx + 1, yu = yy + 1 == Y ? 0 : yy + 1;
+    return velocity_cell(u_, in_.base[fidx(xx, yy, X)], in_.base[fidx(xr, yy, X)].z, in_.base[fidx(xx, yu, X)].z, in_.wall[fidx(xx, yy, X)].y);
+  }
+  __device__ __forceinline__ float curl_at(int xx, int yy) const
+  {
+    const int xr = xx + 1 == X ? 0 : xx + 1, yu = yy + 1 == Y ? 0 : yy + 1;
+    const float4 v = vel_at(xx, yy);
+    return curl_cell(v.x, v.y, vel_at(xr, yy).y, vel_at(xx, yu).x);
+  }
+  __device__ __forceinline__ float4 base(int dx, int dy) const { return vel_at(wx_(dx), wy_(dy)); }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return in_.wall[fidx(wx_(dx), wy_(dy), X)]; }
+  __device__ __forceinline__ float4 water(int dx, int dy) const { return in_.water[fidx(wx_(dx), wy_(dy), X)]; }
+  __device__ __forceinline__ float2 vort(int dx, int dy) const
+  {
+    const int xx = wx_(dx), yy = wy_(dy);
+    const int xl = xx == 0 ? X - 1 : xx - 1, xr = xx + 1 == X ? 0 : xx + 1, yd = yy == 0 ? Y - 1 : yy - 1, yu = yy + 1 == Y ? 0 : yy + 1;
+    return vorticity_cell(curl_at(xx, yy), curl_at(xl, yy), curl_at(xr, yy), curl_at(xx, yd), curl_at(xx, yu));
+  }
+  __device__ __forceinline__ float light_y0() const { return in_.l0.y[fidx(x, y, X)]; }
+  __device__ __forceinline__ float light_x0() const { return in_.l0.x[fidx(x, y, X)]; }
+  __device__ __forceinline__ float2 light_xy_up() const
+  {
+    const size_t i = fidx(x, y + 1 > Y - 1 ? Y - 1 : y + 1, X); // light textures: CLAMP_TO_EDGE in T
+    return make_float2(in_.l0.x[i], in_.l0.y[i]);
+  }
+  __device__ __forceinline__ bool has_fb() const { return in_.fb != nullptr; }
+  __device__ __forceinline__ float4 fb() const { return in_.fb ? in_.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ float2 dep() const { return in_.dep ? in_.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
+};
+struct BOut {
+  float4 b, w;
+  char4 wl;
+};
+__device__ __noinline__ BOut wet_boundary_texel_global(const WetSlowArgs *__restrict__ sa, int x, int y)
+{
+  const FullCtx *c = sa->ctx;
+  GWetRecomputeAcc a{c->u, sa->in, c->g.X, c->g.Y, x, y};
+  BOut o;
+  boundary_cell(c->u, sa->iterNum, (int)sa->iterNum, c->g, c->initial_T, x, y, a, o.b, o.w, o.wl);
+  return o;
+}
+struct GWetAdvectAcc {
+  const WetSlowArgs *sa;
+  int X, Y, x, y;
+  __device__ __forceinline__ BOut at(int dx, int dy) const { return wet_boundary_texel_global(sa, wrapmod(x + dx, X), wrapmod(y + dy, Y)); }
+  __device__ __forceinline__ float4 base(int dx, int dy) const { return at(dx, dy).b; }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return at(dx, dy).wl; }
+  __device__ __forceinline__ float4 base_off(int dx, int dy) const { return at(dx, dy).b; }
+  __device__ __forceinline__ float4 water_off(int dx, int dy) const { return at(dx, dy).w; }
+  __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return at(dx, dy).wl; }
+};
+__device__ __noinline__ AdvOut wet_advection_cell_recompute(const FullCtx *__restrict__ c, const WetIn *__restrict__ in, float iterNum, int x, int y)
+{
+  const WetSlowArgs sa{c, *in, iterNum};
+  GWetAdvectAcc a{&sa, c->g.X, c->g.Y, x, y};
+  AdvOut o;
+  advection_cell(c->u, c->g, c->initial_T, c->snd_T, c->snd_W, c->snd_Vel, x, y, a, o.b, o.w, o.wl);
+  return o;
+}
+
+// ---- the wave-private ring ----
+constexpr int WOUT = 56;          // output columns per wave: lanes 4 .. 59
+constexpr int WLO = 4;            // first output lane
+constexpr int WPAD = 1;           // never-written pad entry on each side of a ring row (lane -1 / lane 64 reads land there)
+constexpr int WRW = 64 + 2 * WPAD;
+constexpr int WD = 6;             // rows r-5 .. r of the base / wall planes: slot = row mod 6
+constexpr int WQ = 3;             // rows r-5 .. r-3 of the post-boundary water planes: slot = row mod 3
+constexpr int WL = 4;             // rows r-5 .. r-2 of the source light planes: slot = row & 3
+struct WetRing {
+  float P[WD][WRW], T[WD][WRW], vx[WD][WRW], vy[WD][WRW];
+  char4 wl[WD][WRW];
+  float qx[WQ][WRW], qy[WQ][WRW], qz[WQ][WRW], qw[WQ][WRW];
+  float lx[WL][WRW], lw[WL][WRW]; // sunlight and upward IR of the source light texture
+};
+static_assert(sizeof(WetRing) == (5 * WD + 4 * WQ + 2 * WL) * WRW * 4, "ring layout");
+
+// whole-wave shifts: lane i <- lane i-1 / lane i+1; the edge lane keeps its own value
+__device__ __forceinline__ float wave_from_left(float v)
+{
+  const int i = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_from_right(float v)
+{
+  const int i = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+// orders the wave's LDS traffic across stages for the compiler; the hardware executes one wave's LDS operations in order
+__device__ __forceinline__ void wave_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ char4 unpack_wall(int w)
+{
+  return make_char4((signed char)(w & 0xff), (signed char)((w >> 8) & 0xff), (signed char)((w >> 16) & 0xff), (signed char)(w >> 24));
+}
+
+// boundary stage, row yb: own texel and the row below in registers, the row above and the horizontal wall neighbours in the ring
+struct MWBoundaryAcc {
+  const WetRing &rg;
+  const WetIn &in;
+  int li, o0, o1;          // ring column; in-plane offsets of ring rows yb and yb+1
+  float4 b00, q00;         // velocity output / pre-boundary water of the own cell
+  char4 w00, wD;
+  float vxD, TD, qzD, qwD; // row below: velocity-pass vx, pre-boundary T, soil moisture / snow of the pre-boundary water
+  float2 vf;
+  float vfLy, vfDx;
+  float ly;
+  float4 fb_;
+  float2 dep_;
+  bool hasfb;
+  int X, Y, x, y;
+  __device__ __forceinline__ float4 base(int dx, int dy) const
+  {
+    if (dx == 0 && dy == 0) return b00;
+    if (dy == 1) return make_float4((&rg.vx[0][0])[o1 + li], 0.f, 0.f, (&rg.T[0][0])[o1 + li]);
+    if (dy == -1) return make_float4(vxD, 0.f, 0.f, TD);
+    return make_float4(0.f, 0.f, 0.f, (&rg.T[0][0])[o0 + li + dx]); // (+-1, 0): temperature of the neighbouring sea cell
+  }
+  __device__ __forceinline__ float4 water(int dx, int dy) const
+  {
+    if (dx == 0 && dy == 0) return q00;
+    if (dx == 0 && dy == -1) return make_float4(0.f, 0.f, qzD, qwD);
+    return in.water[fidx(wrapi(x + dx, X), wrapi(y + dy, Y), X)]; // surface wall cells only
+  }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const
+  {
+    if (dx == 0 && dy == 0) return w00;
+    if (dy == -1) return wD;
+    if (dy == 1) return (&rg.wl[0][0])[o1 + li];
+    return (&rg.wl[0][0])[o0 + li + dx];
+  }
+  __device__ __forceinline__ float2 vort(int dx, int dy) const
+  {
+    if (dx == 0 && dy == 0) return vf;
+    if (dx == -1) return make_float2(0.f, vfLy); // the boundary pass uses .y of the left and .x of the lower neighbour only
+    return make_float2(vfDx, 0.f);
+  }
+  __device__ __forceinline__ float light_y0() const { return ly; }
+  __device__ __forceinline__ float light_x0() const { return in.l0.x[fidx(x, y, X)]; } // cells next to a wall only
+  __device__ __forceinline__ float2 light_xy_up() const
+  {
+    const size_t i = fidx(x, y + 1 > Y - 1 ? Y - 1 : y + 1, X);
+    return make_float2(in.l0.x[i], in.l0.y[i]);
+  }
+  __device__ __forceinline__ bool has_fb() const { return hasfb; }
+  __device__ __forceinline__ float4 fb() const { return fb_; }
+  __device__ __forceinline__ float2 dep() const { return dep_; }
+};
+
+// advection stage, row ya: post-boundary rows ya-1 .. ya+1 in the ring
+struct MWAdvAcc {
+  const WetRing &rg;
+  int li;
+  int ob[3], oq[3]; // in-plane offsets of rows ya-1, ya, ya+1 in the base planes / the water planes (wave-uniform)
+  __device__ __forceinline__ float4 base(int dx, int dy) const
+  {
+    const int o = ob[dy + 1] + li + dx;
+    return make_float4((&rg.vx[0][0])[o], (&rg.vy[0][0])[o], (&rg.P[0][0])[o], (&rg.T[0][0])[o]);
+  }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return (&rg.wl[0][0])[ob[dy + 1] + li + dx]; }
+  __device__ __forceinline__ float4 base_off(int dx, int dy) const { return base(dx, dy); }
+  __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return wall(dx, dy); }
+  __device__ __forceinline__ float4 water_off(int dx, int dy) const
+  {
+    const int o = oq[dy + 1] + li + dx;
+    return make_float4((&rg.qx[0][0])[o], (&rg.qy[0][0])[o], (&rg.qz[0][0])[o], (&rg.qw[0][0])[o]);
+  }
+};
+// bilinear footprint (dx0, dy0 in {-1, 0}): the two rows are picked per lane from the three wave-uniform row offsets
+struct MWFp {
+  const WetRing &rg;
+  int b0, b1, q0, q1; // offsets (row offset + column) of the lower / upper footprint row in the base and water planes
+  __device__ __forceinline__ float4 base(int i, int j) const
+  {
+    const int o = (j ? b1 : b0) + i;
+    return make_float4((&rg.vx[0][0])[o], (&rg.vy[0][0])[o], (&rg.P[0][0])[o], (&rg.T[0][0])[o]);
+  }
+  __device__ __forceinline__ char4 wall(int i, int j) const { return (&rg.wl[0][0])[(j ? b1 : b0) + i]; }
+  __device__ __forceinline__ float4 water(int i, int j) const
+  {
+    const int o = (j ? q1 : q0) + i;
+    return make_float4((&rg.qx[0][0])[o], (&rg.qy[0][0])[o], (&rg.qz[0][0])[o], (&rg.qw[0][0])[o]);
+  }
+};
+__device__ __forceinline__ MWFp make_fp(const MWAdvAcc &a, int dx0, int dy0)
+{
+  const bool lo = dy0 < 0; // fast path: dy0 is -1 or 0
+  const int c = a.li + dx0;
+  return MWFp{a.rg, (lo ? a.ob[0] : a.ob[1]) + c, (lo ? a.ob[1] : a.ob[2]) + c, (lo ? a.oq[0] : a.oq[1]) + c, (lo ? a.oq[1] : a.oq[2]) + c};
+}
+
+// lighting stage, row y (an OUTPUT row: unwrapped == wrapped row index); ring row k of the light planes holds texture row clamp(k)
+struct MWLightAcc {
+  const WetRing &rg;
+  int li, y;
+  float T0, Tdown, lz_up;
+  float4 water_;
+  char4 wall_;
+  __device__ __forceinline__ float T(int dy) const { return dy == 0 ? T0 : Tdown; } // dy in {0,-1}
+  __device__ __forceinline__ float4 water() const { return water_; }
+  __device__ __forceinline__ char4 wall() const { return wall_; }
+  __device__ __forceinline__ float sun_at(int dx, int j) const { return rg.lx[(j + 8) & (WL - 1)][li + dx]; }
+  __device__ __forceinline__ float ir_down_at(int) const { return lz_up; }                           // row min(y+1, Y-1): carried register
+  __device__ __forceinline__ float ir_up_at(int j) const { return rg.lw[(j + 8) & (WL - 1)][li]; } // row max(y-1, 0)
+};
+
+// OPT_OUT: also store what only display-side consumers see (curl, post-boundary water, post-advection base): last iteration of a
+// wx_step call. HAS_FB: the precipitation feedback / deposition textures may be non-zero.
+template <bool OPT_OUT, bool HAS_FB>
+__global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out, int n_strips,
+                                                                    int seg_rows)
+{
+  __shared__ WetRing rg;
+  const Uni &u = ctx->u;
+  const Geo g = ctx->g;
+  const int X = g.X, Y = g.Y;
+  const int lane = threadIdx.x, li = lane + WPAD;
+  const int iterI = (int)iterNum;
+  // XCD-aware placement (see wx_march.h): XCD k takes a contiguous range of the segment-major (segment, strip) items
+  const int total = n_strips * ((Y + seg_rows - 1) / seg_rows), k = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int first = (int)(((long long)k * total) >> 3), count = (int)(((long long)(k + 1) * total) >> 3) - first;
+  if (j >= count) return;
+  const int item = first + j, seg = item / n_strips, strip = item - seg * n_strips;
+  const int c_out = strip * WOUT + lane - WLO; // output column of this lane (may be >= X in the last strip, < 0 in the first)
+  const int col = wrapmod(c_out, X);           // column this lane loads / computes
+  const bool lane_out = lane >= WLO && lane < WLO + WOUT && c_out < X;
+  const int y_lo = seg * seg_rows, y_hi = min(y_lo + seg_rows, Y);
+  const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
+
+  // ---- registers carried from step to step ----
+  float4 pf_b, pf_q = make_float4(0.f, 0.f, 0.f, 0.f);                // prefetched: base row r, water row r-3
+  int pf_w;                                                          // wall row r (raw dword)
+  float pf_lx = 0.f, pf_ly = 0.f;                                     // source sunlight row r-2, light_0 net heating row r-2
+  float2 pf_lzw = make_float2(0.f, 0.f);                              // source IR fluxes row r-2
+  float4 pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);                     // feedback / deposition row r-3 (HAS_FB)
+  float2 pf_dep = make_float2(0.f, 0.f);
+  bool fb_need_next = false, fb_have = false;                         // wave-uniform: the tile(s) of that row hold feedback
+  float4 b_prev = make_float4(0.f, 0.f, 0.f, 0.f);                    // base_0 row r-1
+  int w_prev = 0;
+  float v1x = 0.f, v1y = 0.f;                                         // velocity row r-2
+  float c1 = 0.f, c2 = 0.f;                                           // curl rows r-3, r-4
+  float vfDx = 0.f;                                                   // vortForce.x row r-4
+  float TD = 0.f, vxD = 0.f, qzD = 0.f, qwD = 0.f;                    // pre-boundary values of row r-4 (see MWBoundaryAcc)
+  char4 wD = make_char4(0, 0, 0, 0);
+  float ly1 = 0.f, lz1 = 0.f;                                         // light_0 net heating / source IR_down of row r-3
+  float adv_vy_prev = 0.f, adv_T_prev = 0.f;                          // advection output row r-5
+  char4 adv_w_prev = make_char4(0, 0, 0, 0);
+  int big1 = 0, big2 = 0, big3 = 0;                                   // "some |v| >= 0.9" of post-boundary rows r-3, r-4, r-5
+
+  int r = y_lo - 4;
+  { // prefetch of the first row
+    const size_t gi = fidx(col, wrapmod(r, Y), X);
+    pf_b = in.base[gi];
+    pf_w = wall_raw[gi];
+  }
+  for (int t = 0; r <= y_hi + 3; r++, t++) {
+    const int rc = r + 12;                         // non-negative ring counter (r >= -4)
+    const float4 b_cur = pf_b, q_cur = pf_q;       // base row r, water row r-3
+    int w_raw = pf_w;
+    const float lx_cur = pf_lx, ly_cur = pf_ly;    // light row r-2
+    const float2 lzw_cur = pf_lzw;
+    const float4 fb_cur = pf_fb;
+    const float2 dep_cur = pf_dep;
+    const bool fb_cur_have = fb_have;
+    asm volatile("" : "+v"(w_raw)); // keeps the byte unpacking on this side of the prefetch
+    const char4 w_cur = unpack_wall(w_raw);
+    // ---- software prefetch: the loads of the next step are in flight while this one computes ----
+    if (r < y_hi + 3) {
+      {
+        const size_t gi = fidx(col, wrapmod(r + 1, Y), X);
+        pf_b = in.base[gi];
+        pf_w = wall_raw[gi];
+      }
+      {
+        const int yq = wrapmod(r - 2, Y);
+        const size_t gi = fidx(col, yq, X);
+        pf_q = in.water[gi];
+        if (HAS_FB) {
+          fb_have = fb_need_next; // decided one step ago for this very row
+          if (fb_have) {
+            pf_fb = in.fb[gi];
+            pf_dep = in.dep[gi];
+          }
+          // the row after: does any of the (up to three) 64x16 tiles under this strip hold feedback?
+          const int yn = wrapmod(r - 1, Y);
+          const bool zero = in.fb_zero != nullptr && in.fb_zero[(yn >> 4) * in.fb_txn + (col >> 6)] != 0;
+          fb_need_next = in.fb != nullptr && __any(!zero);
+        }
+      }
+      {
+        const int rl = r - 1;
+        const size_t gl = fidx(col, rl < 0 ? 0 : (rl > Y - 1 ? Y - 1 : rl), X); // light textures clamp in y ...
+        pf_lx = in.lsrc.x[gl];
+        pf_lzw = in.lsrc.zw[gl];
+        pf_ly = in.l0.y[fidx(col, wrapmod(rl, Y), X)]; // ... but the boundary pass samples light_0 at its own (wrapped) row
+      }
+    }
+    // ---- row r enters the ring: P, T and wall (velocity leaves them unchanged); light row r-2 ----
+    {
+      const int s = rc % WD;
+      rg.P[s][li] = b_cur.z;
+      rg.T[s][li] = b_cur.w;
+      rg.wl[s][li] = w_cur;
+      rg.lx[(r - 2 + 8) & (WL - 1)][li] = lx_cur;
+      rg.lw[(r - 2 + 8) & (WL - 1)][li] = lzw_cur.y;
+    }
+    // ---- velocity of row r-1 ----
+    float v0x = 0.f, v0y = 0.f;
+    if (t >= 1) {
+      const float4 v = velocity_cell(u, b_prev, wave_from_right(b_prev.z), b_cur.z, unpack_wall(w_prev).y);
+      v0x = v.x;
+      v0y = v.y;
+      const int s = (rc - 1) % WD;
+      rg.vx[s][li] = v0x;
+      rg.vy[s][li] = v0y;
+    }
+    // ---- curl of row r-2, vortForce of row r-3 (registers + wave shifts only) ----
+    float c0 = 0.f;
+    if (t >= 2) {
+      c0 = curl_cell(v1x, v1y, wave_from_right(v1y), v0x);
+      if (OPT_OUT) {
+        const int yc = r - 2;
+        if (lane_out && yc >= y_lo && yc < y_hi) out.curl[fidx(c_out, yc, X)] = c0;
+      }
+    }
+    float2 vf = make_float2(0.f, 0.f);
+    if (t >= 4) vf = vorticity_cell(c1, wave_from_left(c1), wave_from_right(c1), c2, c0);
+    const float vfLy = wave_from_left(vf.y);
+    wave_fence();
+
+    // ---- boundary of row yb = r-3, written back in place ----
+    if (t >= 4) {
+      const int ob0 = ((rc - 3) % WD) * WRW, ob1 = ((rc - 2) % WD) * WRW;
+      const float4 b00 = make_float4((&rg.vx[0][0])[ob0 + li], (&rg.vy[0][0])[ob0 + li], (&rg.P[0][0])[ob0 + li], (&rg.T[0][0])[ob0 + li]);
+      const char4 w00 = (&rg.wl[0][0])[ob0 + li];
+      if (t >= 5) {
+        const int yb = wrapmod(r - 3, Y);
+        MWBoundaryAcc a{rg, in, li, ob0, ob1, b00, q_cur, w00, wD, vxD, TD, qzD, qwD, vf, vfLy, vfDx, ly1, fb_cur, dep_cur, HAS_FB && fb_cur_have, X, Y, col, yb};
+        float4 bb, bq;
+        char4 bwl;
+        boundary_cell(u, iterNum, iterI, g, ctx->initial_T, col, yb, a, bb, bq, bwl);
+        wave_fence(); // every lane has read its neighbours' pre-boundary values
+        (&rg.vx[0][0])[ob0 + li] = bb.x;
+        (&rg.vy[0][0])[ob0 + li] = bb.y;
+        (&rg.T[0][0])[ob0 + li] = bb.w;
+        (&rg.wl[0][0])[ob0 + li] = bwl;
+        const int oq = ((rc - 3) % WQ) * WRW;
+        (&rg.qx[0][0])[oq + li] = bq.x;
+        (&rg.qy[0][0])[oq + li] = bq.y;
+        (&rg.qz[0][0])[oq + li] = bq.z;
+        (&rg.qw[0][0])[oq + li] = bq.w;
+        // back-traces of this row that may leave the 3x3 cells? (lanes 2 .. 60 feed an advection that is used)
+        big1 = __any(lane >= 2 && lane <= 60 && !(fmaxf(fabsf(bb.x), fabsf(bb.y)) < 0.9f));
+        if (OPT_OUT) {
+          const int yo = r - 3;
+          if (lane_out && yo >= y_lo && yo < y_hi) out.water0[fidx(c_out, yo, X)] = bq;
+        }
+      }
+      // the pre-boundary values of this row are what the row above reads as its lower neighbour
+      TD = b00.w;
+      vxD = b00.x;
+      wD = w00;
+      qzD = q_cur.z;
+      qwD = q_cur.w;
+    }
+    wave_fence();
+
+    // ---- advection of row ya = r-4 ----
+    if (t >= 7) {
+      const int ya = wrapmod(r - 4, Y);
+      float4 ab, aw;
+      char4 awl;
+      MWAdvAcc a{rg, li, {((rc - 5) % WD) * WRW, ((rc - 4) % WD) * WRW, ((rc - 3) % WD) * WRW}, {((rc - 5) % WQ) * WRW, ((rc - 4) % WQ) * WRW, ((rc - 3) % WQ) * WRW}};
+      bool fast = true;
+      if (big1 | big2 | big3) { // wave-uniform: some velocity of rows ya-1 .. ya+1 is large -> per-lane test of the eight that matter
+        const float *vxp = &rg.vx[0][0], *vyp = &rg.vy[0][0];
+        const int o0 = a.ob[1] + li, om = a.ob[0] + li, op = a.ob[2] + li;
+        const float m = fmaxf(fmaxf(fmaxf(fabsf(vxp[o0]), fabsf(vxp[o0 - 1])), fmaxf(fabsf(vxp[op]), fabsf(vxp[op - 1]))),
+                              fmaxf(fmaxf(fabsf(vyp[o0]), fabsf(vyp[om])), fmaxf(fabsf(vyp[o0 + 1]), fabsf(vyp[om + 1]))));
+        fast = m < 0.9f || lane < 3 || lane > 59; // (lanes outside 3 .. 59 feed nothing)
+      }
+      if (fast) {
+        advection_cell(u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, col, ya, a, ab, aw, awl);
+      } else { // exact out-of-line path (post-boundary texels recomputed from global memory)
+        // the out-of-line function takes the input pointers from memory: the kernel-argument segment already holds them
+        struct KArgs {
+          const FullCtx *ctx;
+          float iterNum;
+          WetIn in;
+        };
+        const WetIn *in_mem = reinterpret_cast<const WetIn *>((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KArgs, in));
+        const AdvOut o = wet_advection_cell_recompute(ctx, in_mem, iterNum, col, ya);
+        ab = o.b;
+        aw = o.w;
+        awl = o.wl;
+      }
+      // ---- pressure + lighting of row ya -> stores ----
+      const float vx_l = wave_from_left(ab.x);
+      if (t >= 8) {
+        const float4 p = pressure_cell(ab, vx_l, adv_vy_prev, adv_T_prev, adv_w_prev.x, adv_w_prev.y);
+        MWLightAcc la{rg, li, r - 4, ab.w, adv_T_prev, lz1, aw, awl};
+        const float4 l = lighting_cell(u, g, col, r - 4, la);
+        if (lane_out) {
+          const size_t gi = fidx(c_out, r - 4, X);
+          out.base[gi] = p;
+          out.water[gi] = aw;
+          out.wall[gi] = awl;
+          out.light.x[gi] = l.x;
+          out.light.y[gi] = l.y;
+          out.light.zw[gi] = make_float2(l.z, l.w);
+          if (OPT_OUT) out.base_disp[gi] = ab;
+          if (out.t_disp) out.t_disp[gi] = ab.w;
+        }
+      }
+      adv_vy_prev = ab.y;
+      adv_T_prev = ab.w;
+      adv_w_prev = awl;
+    }
+    // ---- rotate the carried rows ----
+    b_prev = b_cur;
+    w_prev = w_raw;
+    v1x = v0x;
+    v1y = v0y;
+    c2 = c1;
+    c1 = c0;
+    vfDx = vf.x;
+    ly1 = ly_cur;
+    lz1 = lzw_cur.x;
+    big3 = big2;
+    big2 = big1;
+  }
+}
+
+// Segment height: as in wx_march.h -- the number of waves is just under a whole multiple of what the device holds at once.
+inline int wet_seg_rows(int n_strips, int Y)
+{
+  static int capacity = 0;
+  if (!capacity) {
+    int dev = 0, ncu = 0, nb = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_wet<false, false>, 64, 0) != hipSuccess || ncu <= 0 || nb <= 0)
+      capacity = 256 * 4 * WX_WET_MINWAVES;
+    else
+      capacity = ncu * nb;
+    if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] CUs=%d blocks/CU=%d capacity=%d\n", ncu, nb, capacity);
+  }
+  if (const char *e = getenv("WX_WET_SEG")) return atoi(e) < Y ? (atoi(e) > 0 ? atoi(e) : Y) : Y;
+  int maxseg = WX_WET_MAXSEG;
+  if (const char *e = getenv("WX_WET_MAXSEG")) maxseg = atoi(e) > 0 ? atoi(e) : maxseg;
+  for (int k = 1; k < 64; k++) {
+    const int nseg = (int)((long long)k * capacity / n_strips);
+    if (nseg < 1) continue;
+    const int rows = (Y + nseg - 1) / nseg;
+    if (rows <= maxseg) return rows < 32 ? (Y < 32 ? Y : 32) : rows;
+  }
+  return maxseg < Y ? maxseg : Y;
+}
+
+inline void launch_march_wet(const Geo &g, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, bool opt_out, hipStream_t stream)
+{
+  const int n_strips = (g.X + WOUT - 1) / WOUT;
+  const int seg_rows = wet_seg_rows(n_strips, g.Y), n_seg = (g.Y + seg_rows - 1) / seg_rows;
+  const dim3 grid(8 * ((n_strips * n_seg + 7) / 8));
+  static bool dbg = getenv("WX_MARCH_DEBUG") != nullptr;
+  if (dbg) {
+    fprintf(stderr, "[wx_wet] strips=%d seg_rows=%d segs=%d waves=%d\n", n_strips, seg_rows, n_seg, n_strips * n_seg);
+    dbg = false;
+  }
+  const bool has_fb = in.fb != nullptr;
+#define WX_LAUNCH_W(O, F) hipLaunchKernelGGL((k_march_wet<O, F>), grid, dim3(64), 0, stream, ctx, iterNum, in, out, n_strips, seg_rows)
+  if (opt_out) {
+    if (has_fb) WX_LAUNCH_W(true, true); else WX_LAUNCH_W(true, false);
+  } else {
+    if (has_fb) WX_LAUNCH_W(false, true); else WX_LAUNCH_W(false, false);
+  }
+#undef WX_LAUNCH_W
+}
+
+} // namespace wx

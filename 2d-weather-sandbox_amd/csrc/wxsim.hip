@@ -114,7 +114,9 @@ struct wx_sim {
   FullCtx *full_ctx = nullptr;
   SplatGrid sg{};              // particle splat accumulation (allocated when the handle has droplets)
   bool fb_dirty = false; // feedback/deposition hold non-zero data (particles ran last iteration)
-  bool water_trivial = false; // uploaded water texture: 0 in air cells, only the wall marker in wall cells
+  bool water_trivial = false; // the water texture is known to be 0 in air cells and only the wall marker in wall cells: set by wx_upload,
+                              // cleared by every step that can put water there (anything but the water-free dry iteration)
+  bool ghost_check = false;   // ghost columns were unpacked while water_trivial: DevState::ghost_nontrivial must be read before relying on it
   // profiling
   bool profiling = false;
   std::vector<ProfRec> prof;
@@ -706,7 +708,7 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 16, s->stream));
   HIPCHK(s, hipMemsetAsync(s->dep, 0, n * 8, s->stream));
   HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
-  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 20, s->stream));
+  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 24, s->stream)); // px_count, px_light[4], ghost_nontrivial
   if (s->sg.acc4) {
     HIPCHK(s, hipMemsetAsync(s->sg.acc4, 0, (size_t)s->sg.AP * s->sg.AH * 16, s->stream));
     HIPCHK(s, hipMemsetAsync(s->sg.acc2, 0, (size_t)s->sg.AP * s->sg.AH * 8, s->stream));
@@ -715,6 +717,7 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   }
   HIPCHK(s, hipStreamSynchronize(s->stream)); // the caller keeps ownership of the host arrays
   s->fb_dirty = false;
+  s->ghost_check = false;
   s->cow_pending = false;
   s->light_planar = false; // the interleaved light textures were just zeroed
   s->period_j = 0;
@@ -809,8 +812,23 @@ int wx_step(wx_sim *s, int n_iter)
     HIPCHK(s, hipStreamWaitEvent(s->stream, s->ev_copy_done, 0));
     s->copy_in_flight = false;
   }
+  if (dry && s->water_trivial && s->ghost_check) { // a neighbour's ghost columns arrived since the last look: do they carry water?
+    int flag = 0;
+    HIPCHK(s, hipMemcpyAsync(&flag, &s->state->ghost_nontrivial, 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    s->ghost_check = false;
+    if (flag) s->water_trivial = s->wall_veg_ok = false;
+  }
   // the vegetation byte stays known non-negative only while nothing but the brush-free dry iteration touches the wall texture
   if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] > 0.9f) s->wall_veg_ok = false;
+  // ... and the water texture stays known trivial only through water-free dry iterations (iterate_dry's `water == false` case)
+  if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] != 0.0f || s->p.soundingForcing != 0.0f) s->water_trivial = false;
+  if (precip && s->keys && n_iter > 0) { // slab with particles: refuse an over-long call BEFORE any iteration runs
+    const int allowed = (s->halo - 6) / WX_SLAB_CONE - s->period_j;
+    if (n_iter > allowed)
+      return fail(s, WX_E_STATE, "wx_step: %d iterations asked, %d done since the last halo exchange; %d ghost columns allow %d per period with particles",
+                  n_iter, s->period_j, s->halo, (s->halo - 6) / WX_SLAB_CONE);
+  }
   if (!(fused && s->fused == 1)) {
     cow_resolve(s);  // the other kernel sets take water[0] as a fully written buffer
     light_to_rgba(s); // ... and the light textures interleaved
@@ -840,10 +858,7 @@ int wx_step(wx_sim *s, int n_iter)
         if (s->keys) { // slab: the grid of this iteration is valid on the owned columns + (halo - 6*(j+1)) ghost columns; the
           // feedback texture is exact where every droplet within a sprite radius (6 px) was processed, so the owned columns
           // need 6 valid ghost columns even in the last iteration of a period
-          const int margin = s->halo - WX_SLAB_CONE * (s->period_j + 1);
-          if (margin < 6)
-            return fail(s, WX_E_STATE, "wx_step: %d iterations since the last halo exchange, %d ghost columns allow %d with particles",
-                        s->period_j + 1, s->halo, (s->halo - 6) / WX_SLAB_CONE);
+          const int margin = s->halo - WX_SLAB_CONE * (s->period_j + 1); // >= 6: checked before the loop
           sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, (s->period_j + 1) * 2048 + (1023 - s->rank), s->keys};
         }
         hipLaunchKernelGGL(k_precipitation, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, u, s->n_drops, s->drops[src],
@@ -1079,7 +1094,9 @@ int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
   const size_t o8 = (size_t)n * (s->keys ? 80 : 64), o4 = o8 + (s->keys ? (size_t)n * 8 : 0);
   ProfScope ps(s, K_HALO);
   hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256), dim3(256), 0, s->stream, f, s->X, s->Y, s->halo, halo_xstart(s, side, false),
-                     (const float4 *)dev_buf, (const float2 *)((const char *)dev_buf + o8), (const char4 *)((const char *)dev_buf + o4));
+                     (const float4 *)dev_buf, (const float2 *)((const char *)dev_buf + o8), (const char4 *)((const char *)dev_buf + o4),
+                     s->water_trivial ? &s->state->ghost_nontrivial : nullptr);
+  if (s->water_trivial) s->ghost_check = true;
   if (s->keys) { // the ghost tiles of the feedback texture now hold a neighbour's values: nothing is "known zero" any more
     hipMemsetAsync(s->sg.fb_zero, 0, (size_t)s->sg.TXn * s->sg.TYn, s->stream);
     s->fb_dirty = true;

@@ -16,6 +16,28 @@ from . import codec, params
 from .engine import Handle
 
 TIME_PER_ITERATION = 0.00008  # hours of simulated time per iteration (app.js:449)
+_EPOCH = _dt.datetime(1970, 1, 1)
+
+
+def _js_date(year: int, month_index: int, day: int, hour: int = 0, minute: int = 0, second: int = 0) -> _dt.datetime:
+    """``new Date(year, monthIndex, day, h, m, s)`` with JavaScript's roll-over rules (month index 12 = January of the
+    next year, day 0 = last day of the previous month); the arguments are already truncated to integers."""
+    year += month_index // 12
+    return _dt.datetime(year, month_index % 12 + 1, 1) + _dt.timedelta(days=day - 1, hours=hour, minutes=minute, seconds=second)
+
+
+def initial_sim_datetime(month: float, time_of_day: float, day_night_cycle: bool) -> _dt.datetime:
+    """startSimulation()'s clock (app.js:3902-3910): ``new Date(2000, floor(month) - 1, (month % 1) * 30.417)`` -- the
+    Date constructor truncates the fractional day -- and, with the day/night cycle on, ``onUpdateTimeOfDaySlider`` /
+    ``onUpdateMonthSlider`` (app.js:6494-6507): ``setHours(timeOfDay, (timeOfDay % 1) * 60)`` then
+    ``setMonth(month - 0.96, ((month - 0.96) % 1) * 30)``, every argument truncated toward zero."""
+    import math
+    t = _js_date(2000, math.floor(month) - 1, int((month % 1) * 30.417))
+    if day_night_cycle:
+        t = t.replace(hour=0, minute=0) + _dt.timedelta(hours=int(time_of_day), minutes=int((time_of_day % 1) * 60))
+        m = month - 0.96
+        t = _js_date(t.year, int(m), int((m % 1) * 30), t.hour, t.minute, t.second)
+    return t
 
 
 class WeatherSim:
@@ -36,9 +58,7 @@ class WeatherSim:
         self._manual_sun = sun_angle_deg
         self._inactive_pushed = False
         # startSimulation(): clock from the saved month / time of day (app.js:3902-3910)
-        month = float(self.gui["month"])
-        self.sim_datetime = _dt.datetime(2000, int(month), 1) + _dt.timedelta(days=(month % 1) * 30.417 - 1 + 1e-9,
-                                                                           hours=float(self.gui["timeOfDay"]))
+        self.sim_datetime = initial_sim_datetime(float(self.gui["month"]), float(self.gui["timeOfDay"]), bool(self.gui.get("dayNightCycle")))
         self.brush = {"userInputType": -1, "userInputValues": (0.0, 0.0, 0.0, 0.0), "userInputMove": (0.0, 0.0)}
         self.airplane = (0.0, 0.0, 0.0, 0.0)
         self._push_uniforms()
@@ -104,7 +124,9 @@ class WeatherSim:
     def update_sunlight(self, delta_hours: Optional[float]):
         """``updateSunlight(deltaT_hours)`` (app.js:6510-6561): advance the clock, recompute the sun."""
         if delta_hours is not None:
-            self.sim_datetime += _dt.timedelta(hours=delta_hours)
+            # `new Date(getTime() + deltaT_hours * 3600 * 1000)`: a Date holds whole milliseconds (the sum is truncated)
+            ms = int((self.sim_datetime - _EPOCH) / _dt.timedelta(milliseconds=1) + delta_hours * 3600 * 1000)
+            self.sim_datetime = _EPOCH + _dt.timedelta(milliseconds=ms)
             t = self.sim_datetime
             self.gui["timeOfDay"] = t.hour + t.minute / 60.0 + t.second / 3600.0
             self.gui["month"] = t.month + t.day / 30.5 + t.hour / 720.0

@@ -18,4 +18,7 @@ assert.strictEqual(gui.condensationRate, 0.005);
 const u = H.uniformsFromGui(H.mergeSettings({sunAngle: 67.45275198770811, sunIntensity: 1}), 100);
 assert.strictEqual(u.dryLapse, 120); assert.ok(Math.abs(u.sunAngle + 0.39352388) < 1e-7); assert.ok(Math.abs(u.sunIntensity - 1289.7039) < 1e-3);
 assert.strictEqual(u.initial_T[0], Math.fround(288.15)); assert.ok(Math.abs(u.initial_T[100] - 333.15) < 1e-4);
-console.log(JSON.stringify({ok: true, initial_T: Array.from(u.initial_T.slice(0, 4)), sunAngle: u.sunAngle, sunIntensity: u.sunIntensity}));
+// the clock of startSimulation() for a few (month, timeOfDay, dayNightCycle) settings, as [month index, date, h, min, s]
+const clocks = [[6.65, 9.9, true], [6.65, 9.9, false], [6.67, 11.44416, true], [1.0, 0.0, true], [12.99, 23.99, true], [13.016, 5.5, true], [3.5, 12.25, false]]
+  .map(function(c) { const t = H.initialSimDateTime(c[0], c[1], c[2]); return [t.getFullYear(), t.getMonth(), t.getDate(), t.getHours(), t.getMinutes(), t.getSeconds()]; });
+console.log(JSON.stringify({ok: true, clocks: clocks, initial_T: Array.from(u.initial_T.slice(0, 4)), sunAngle: u.sunAngle, sunIntensity: u.sunIntensity}));

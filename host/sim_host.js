@@ -209,6 +209,18 @@ function sunAngleFromTime(timeOfDay, month, latitude)
   if (latitude - tiltDeg < 0.0) ang = 180.0 - ang;
   return ang;
 }
+// startSimulation()'s clock (app.js:3902-3910) + onUpdateTimeOfDaySlider / onUpdateMonthSlider (app.js:6494-6507); the Date
+// methods truncate their fractional arguments
+function initialSimDateTime(month, timeOfDay, dayNightCycle)
+{
+  const t = new Date(2000, Math.floor(month) - 1, (month % 1) * 30.417);
+  if (dayNightCycle) {
+    t.setHours(timeOfDay, (timeOfDay % 1) * 60);
+    const m = month - 0.96;
+    t.setMonth(m, (m % 1) * 30);
+  }
+  return t;
+}
 function uniformsFromGui(gui, Y, opts)
 {
   opts = opts || {};
@@ -252,8 +264,7 @@ function WeatherSim(sf, opts)
   }
   // startSimulation(): clock from month / timeOfDay (app.js:3902)
   const m = this.gui.month;
-  this.simDateTime = new Date(2000, Math.floor(m) - 1, (m % 1) * 30.417);
-  this.simDateTime = new Date(this.simDateTime.getTime() + this.gui.timeOfDay * 3600 * 1000);
+  this.simDateTime = initialSimDateTime(m, this.gui.timeOfDay, this.gui.dayNightCycle);
   this.brush = {userInputType: -1, userInputValues: [0, 0, 0, 0], userInputMove: [0, 0]};
   this.inactivePushed = false;
   this.pushUniforms();
@@ -343,7 +354,7 @@ WeatherSim.newSimulation = function(X, Y, opts) {
   return new WeatherSim({X: X, Y: Y, settings: gui, columns: terrainColumns(X, Y, gui, opts), droplets: nDrops ? initRainDrops(nDrops, opts.rng) : null}, opts);
 };
 
-module.exports = {WeatherSim: WeatherSim, loadSave: loadSave, decodeSave: decodeSave, encodeSave: encodeSave, mergeSettings: mergeSettings,
+module.exports = {WeatherSim: WeatherSim, initialSimDateTime: initialSimDateTime, loadSave: loadSave, decodeSave: decodeSave, encodeSave: encodeSave, mergeSettings: mergeSettings,
                   uniformsFromGui: uniformsFromGui, initialTemperatureProfile: initialTemperatureProfile, sunFromAngle: sunFromAngle,
                   sunAngleFromTime: sunAngleFromTime, terrainColumns: terrainColumns, initRainDrops: initRainDrops, soundingArrays: soundingArrays, GUI_DEFAULTS: GUI_DEFAULTS,
                   FIELD: FIELD};

@@ -55,6 +55,13 @@ static napi_value throw_wx(napi_env env, wx_sim *s, int rc, const char *what)
   return NULL;
 }
 
+/* what the external wraps: the C handle plus the dimensions the array arguments are checked against. wx_sim * stays the
+ * first member, so a slot pointer also reads as wx_sim ** */
+typedef struct {
+  wx_sim *s;
+  int32_t X, Y, N;
+} wx_slot;
+
 static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv)
 {
   size_t argc = want;
@@ -74,11 +81,44 @@ static wx_sim *get_handle(napi_env env, napi_value v)
   }
   return *(wx_sim **)p;
 }
+static wx_slot *get_slot(napi_env env, napi_value v)
+{
+  void *p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((wx_slot *)p)->s) {
+    napi_throw_type_error(env, NULL, "expected a simulation handle");
+    return NULL;
+  }
+  return (wx_slot *)p;
+}
+/* a typed array of the wanted type holding at least `need` elements, else a thrown RangeError / TypeError and NULL */
+static void *typed_data(napi_env env, napi_value v, napi_typedarray_type want, size_t *len);
+static void *typed_at_least(napi_env env, napi_value v, napi_typedarray_type want, size_t need, const char *what)
+{
+  size_t len = 0;
+  void *d = typed_data(env, v, want, &len);
+  char buf[160];
+  if (!d) {
+    snprintf(buf, sizeof(buf), "%s: typed array of the wrong type (or not a typed array)", what);
+    napi_throw_type_error(env, NULL, buf);
+    return NULL;
+  }
+  if (len < need) {
+    snprintf(buf, sizeof(buf), "%s: %zu elements, %zu needed", what, len, need);
+    napi_throw_range_error(env, NULL, buf);
+    return NULL;
+  }
+  return d;
+}
+static int is_nullish(napi_env env, napi_value v)
+{
+  napi_valuetype t;
+  return napi_typeof(env, v, &t) != napi_ok || t == napi_null || t == napi_undefined;
+}
 
 static void finalize_handle(napi_env env, void *data, void *hint)
 {
-  wx_sim **slot = (wx_sim **)data;
-  if (*slot) L.destroy(*slot);
+  wx_slot *slot = (wx_slot *)data;
+  if (slot->s) L.destroy(slot->s);
   free(slot);
 }
 
@@ -104,8 +144,11 @@ static napi_value Create(napi_env env, napi_callback_info info)
   wx_sim *s = NULL;
   int rc = L.create(X, Y, N, &s);
   if (rc) return throw_wx(env, NULL, rc, "wx_create");
-  wx_sim **slot = (wx_sim **)malloc(sizeof(*slot));
-  *slot = s;
+  wx_slot *slot = (wx_slot *)malloc(sizeof(*slot));
+  slot->s = s;
+  slot->X = X;
+  slot->Y = Y;
+  slot->N = N;
   napi_value ext;
   NAPI_CALL(env, napi_create_external(env, slot, finalize_handle, NULL, &ext));
   return ext;
@@ -130,14 +173,19 @@ static napi_value Upload(napi_env env, napi_callback_info info)
   if (get_args(env, info, 5, a)) return NULL;
   wx_sim *s = get_handle(env, a[0]);
   if (!s) return NULL;
-  size_t n;
-  const float *base = (const float *)typed_data(env, a[1], napi_float32_array, &n);
-  const float *water = (const float *)typed_data(env, a[2], napi_float32_array, &n);
-  const int8_t *wall = (const int8_t *)typed_data(env, a[3], napi_int8_array, &n);
-  const float *drops = (const float *)typed_data(env, a[4], napi_float32_array, &n);
-  if (!base || !water || !wall) {
-    napi_throw_type_error(env, NULL, "upload: base/water must be Float32Array, wall Int8Array");
-    return NULL;
+  const wx_slot *sl = get_slot(env, a[0]);
+  if (!sl) return NULL;
+  const size_t n4 = (size_t)sl->X * sl->Y * 4; /* wx_upload reads X*Y texels of 4 channels from each grid array */
+  const float *base = (const float *)typed_at_least(env, a[1], napi_float32_array, n4, "upload: base (Float32Array, X*Y*4)");
+  if (!base) return NULL;
+  const float *water = (const float *)typed_at_least(env, a[2], napi_float32_array, n4, "upload: water (Float32Array, X*Y*4)");
+  if (!water) return NULL;
+  const int8_t *wall = (const int8_t *)typed_at_least(env, a[3], napi_int8_array, n4, "upload: wall (Int8Array, X*Y*4)");
+  if (!wall) return NULL;
+  const float *drops = NULL;
+  if (!is_nullish(env, a[4]) && sl->N > 0) {
+    drops = (const float *)typed_at_least(env, a[4], napi_float32_array, (size_t)sl->N * 5, "upload: drops (Float32Array, nDroplets*5)");
+    if (!drops) return NULL;
   }
   int rc = L.upload(s, base, water, wall, drops);
   if (rc) return throw_wx(env, s, rc, "wx_upload");
@@ -200,10 +248,20 @@ static napi_value SetParams(napi_env env, napi_callback_info info)
   if (get_f(env, o, "enablePrecipitation", &t)) p.enablePrecipitation = (int32_t)t;
   if (get_f(env, o, "quad_scale", &t)) p.quad_scale = (int32_t)t;
   if (get_f(env, o, "pass_mask", &t)) p.pass_mask = (uint32_t)t;
-  size_t n;
-  const float *T0 = (const float *)typed_data(env, a[2], napi_float32_array, &n);
+  const wx_slot *sl = get_slot(env, a[0]);
+  if (!sl) return NULL;
+  const size_t ny = (size_t)sl->Y + 1; /* wx_set_params copies Y+1 entries of every profile array it is given */
+  const float *T0 = NULL;
+  if (!is_nullish(env, a[2])) {
+    T0 = (const float *)typed_at_least(env, a[2], napi_float32_array, ny, "setParams: initial_T (Float32Array, Y+1)");
+    if (!T0) return NULL;
+  }
   const float *snd[3] = {NULL, NULL, NULL};
-  for (size_t i = 3; i < argc && i < 6; i++) snd[i - 3] = (const float *)typed_data(env, a[i], napi_float32_array, &n);
+  for (size_t i = 3; i < argc && i < 6; i++) {
+    if (is_nullish(env, a[i])) continue;
+    snd[i - 3] = (const float *)typed_at_least(env, a[i], napi_float32_array, ny, "setParams: sounding array (Float32Array, Y+1)");
+    if (!snd[i - 3]) return NULL;
+  }
   int rc = L.set_params(s, &p, T0, snd[0], snd[1], snd[2]);
   if (rc) return throw_wx(env, s, rc, "wx_set_params");
   return NULL;
@@ -316,18 +374,27 @@ static napi_value SetupColumns(napi_env env, napi_callback_info info)
   if (get_args(env, info, 9, a)) return NULL;
   wx_sim *s = get_handle(env, a[0]);
   if (!s) return NULL;
-  size_t n;
-  const int32_t *rows = (const int32_t *)typed_data(env, a[1], napi_int32_array, &n);
-  const uint8_t *sea = (const uint8_t *)typed_data(env, a[2], napi_uint8_array, &n);
-  const double *veg = (const double *)typed_data(env, a[3], napi_float64_array, &n);
-  const float *snow = (const float *)typed_data(env, a[4], napi_float32_array, &n);
-  const float *T = (const float *)typed_data(env, a[5], napi_float32_array, &n);
-  const float *tot = (const float *)typed_data(env, a[6], napi_float32_array, &n);
-  const float *cloud = (const float *)typed_data(env, a[7], napi_float32_array, &n);
-  const float *drops = (const float *)typed_data(env, a[8], napi_float32_array, &n);
-  if (!rows || !sea || !veg || !snow || !T || !tot || !cloud) {
-    napi_throw_type_error(env, NULL, "setupColumns: Int32Array, Uint8Array, Float64Array, then four Float32Array expected");
-    return NULL;
+  const wx_slot *sl = get_slot(env, a[0]);
+  if (!sl) return NULL;
+  const size_t nx = (size_t)sl->X, ny = (size_t)sl->Y; /* per-column descriptors: X entries; per-row sounding: Y entries */
+  const int32_t *rows = (const int32_t *)typed_at_least(env, a[1], napi_int32_array, nx, "setupColumns: wallRows (Int32Array, X)");
+  if (!rows) return NULL;
+  const uint8_t *sea = (const uint8_t *)typed_at_least(env, a[2], napi_uint8_array, nx, "setupColumns: sea (Uint8Array, X)");
+  if (!sea) return NULL;
+  const double *veg = (const double *)typed_at_least(env, a[3], napi_float64_array, nx, "setupColumns: vegNoise (Float64Array, X)");
+  if (!veg) return NULL;
+  const float *snow = (const float *)typed_at_least(env, a[4], napi_float32_array, nx, "setupColumns: snow (Float32Array, X)");
+  if (!snow) return NULL;
+  const float *T = (const float *)typed_at_least(env, a[5], napi_float32_array, ny, "setupColumns: T_air (Float32Array, Y)");
+  if (!T) return NULL;
+  const float *tot = (const float *)typed_at_least(env, a[6], napi_float32_array, ny, "setupColumns: totalWater (Float32Array, Y)");
+  if (!tot) return NULL;
+  const float *cloud = (const float *)typed_at_least(env, a[7], napi_float32_array, ny, "setupColumns: cloudWater (Float32Array, Y)");
+  if (!cloud) return NULL;
+  const float *drops = NULL;
+  if (!is_nullish(env, a[8]) && sl->N > 0) {
+    drops = (const float *)typed_at_least(env, a[8], napi_float32_array, (size_t)sl->N * 5, "setupColumns: drops (Float32Array, nDroplets*5)");
+    if (!drops) return NULL;
   }
   int rc = L.setup_columns(s, rows, sea, veg, snow, T, tot, cloud, drops);
   if (rc) return throw_wx(env, s, rc, "wx_setup_columns");

@@ -1,0 +1,167 @@
+"""GPU parity at the sizes BASELINE.json names: the HIP path against the CPU ORACLE (not kernel set against kernel set).
+
+configs[1] 4096 x 1024 dry, configs[2] 16384 x 2048 wet, configs[3]'s grid 32768 x 4096 (dry and wet on one GPU, and cut
+into the eight 4096-column slabs of the 8-GPU partitioning, all eight handles on the one GPU of the box). The oracle runs
+on the box's host cores (OpenMP): a few iterations cost seconds. All grid fields must be BIT-EXACT: a 32-bit index or
+row-table bug that every kernel set shares (they instantiate the same csrc/wx_cells.h) would show here and nowhere else.
+"""
+import gc
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS_WET = ["BASE_CUR", "BASE_DISP", "WATER_0", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1"]
+FIELDS_DRY = ["BASE_CUR", "BASE_DISP", "WATER_CUR", "WALL_CUR"]
+
+
+@pytest.fixture(scope="module")
+def E(pkg):
+    from weather_sandbox_amd import engine
+    engine.build()
+    return engine
+
+
+def _assert_equal(h, o, fields):
+    for f in fields:
+        a, b = h.read_rect(f), o.field(f)
+        if not np.array_equal(a, b):
+            bad = np.argwhere(a != b)
+            raise AssertionError(f"{f}: {len(bad)} of {a.size} values differ, first at (y, x, c) = {tuple(bad[0])}, "
+                                 f"max |d| = {np.abs(a.astype(np.float64) - b).max()}")
+        del a, b
+
+
+def _wet_state(pkg, X, Y, seed):
+    """setupShader-style terrain with a seeded perturbation of velocity and humidity, so that advection,
+    phase change and buoyancy all have something to do in the first iterations."""
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    rng = np.random.Generator(np.random.Philox(seed))
+    air = wall[..., 1] != 0
+    for c, s in ((0, 0.08), (1, 0.05)):
+        n = rng.standard_normal((Y, X), dtype=np.float32)
+        n *= np.float32(s)
+        base[..., c] += np.where(air, n, np.float32(0))
+        del n
+    f = rng.random((Y, X), dtype=np.float32)
+    f *= np.float32(0.4)
+    f += np.float32(1.0)
+    water[..., 0] *= np.where(air, f, np.float32(1))
+    del f, air
+    return base, water, wall
+
+
+def _uniforms(pkg, Y, **kw):
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 40.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, **kw)
+    u["enablePrecipitation"] = 0
+    return u
+
+
+def _run_pair(pkg, oracle, E, X, Y, state, u, steps, fields):
+    base, water, wall = state
+    h = E.Handle(X, Y, 0)
+    h.upload(base, water, wall)
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    o = oracle.OracleSim(X, Y, 0)
+    o.upload(base, water, wall)
+    o.set_params(u)
+    del base, water, wall
+    for n in steps:
+        h.step(n)
+        o.step(n)
+        _assert_equal(h, o, fields)
+    assert h.iter == o.iter == sum(steps)
+    b = h.read_rect("BASE_CUR")
+    assert np.isfinite(b).all() and np.abs(b[..., :2]).max() > 1e-3  # something moved
+    h.close()
+    o.close()
+    gc.collect()
+
+
+def test_config1_dry_4096x1024_vs_oracle(pkg, oracle, E):
+    """BASELINE configs[1]: 4096 x 1024 dry air, pass_mask = velocity | advection | pressure (the row-marching kernel)."""
+    X, Y = 4096, 1024
+    base, water, wall = pkg.synth.dry_grid(X, Y)
+    rng = np.random.Generator(np.random.Philox(21))
+    base[1:, :, 0] += rng.normal(0, 0.2, (Y - 1, X)).astype(np.float32)  # includes |v| > 0.9 (exact out-of-line back-trace)
+    base[1:, :, 2] += rng.normal(0, 1e-3, (Y - 1, X)).astype(np.float32)
+    u = _uniforms(pkg, Y, pass_mask=pkg.params.PASS_DRY)
+    _run_pair(pkg, oracle, E, X, Y, (base, water, wall), u, (1, 4, 7), FIELDS_DRY)
+
+
+def test_config2_wet_16384x2048_vs_oracle(pkg, oracle, E):
+    """BASELINE configs[2] (the grid the metric is quoted on): all grid passes + lighting, default kernel set."""
+    X, Y = 16384, 2048
+    _run_pair(pkg, oracle, E, X, Y, _wet_state(pkg, X, Y, 31), _uniforms(pkg, Y), (1, 4), FIELDS_WET)
+
+
+def test_config3_grid_32768x4096_dry_vs_oracle(pkg, oracle, E):
+    """The north-star size on one GPU, dry stencil (initial_T[Y+1] with Y = 4096, indices beyond 2^27 cells)."""
+    X, Y = 32768, 4096
+    base, water, wall = pkg.synth.dry_grid(X, Y)
+    rng = np.random.Generator(np.random.Philox(22))
+    n = rng.standard_normal((Y - 1, X), dtype=np.float32)
+    n *= np.float32(0.15)
+    base[1:, :, 0] += n
+    del n
+    u = _uniforms(pkg, Y, pass_mask=pkg.params.PASS_DRY)
+    _run_pair(pkg, oracle, E, X, Y, (base, water, wall), u, (1, 2), FIELDS_DRY)
+
+
+def test_config3_grid_32768x4096_wet_vs_oracle(pkg, oracle, E):
+    """configs[3]'s grid with the full wet iteration on one GPU (33 GB of device state)."""
+    X, Y = 32768, 4096
+    _run_pair(pkg, oracle, E, X, Y, _wet_state(pkg, X, Y, 32), _uniforms(pkg, Y), (1, 2), FIELDS_WET)
+
+
+def test_config3_eight_slabs_equal_whole_domain(pkg, E):
+    """configs[3]'s partitioning: 32768 x 4096 cut into eight 4096-column slabs (one per GPU of the node; here all eight
+    handles live on the one GPU of the box), ghost columns exchanged through wx_halo_pack / wx_halo_unpack in ring order
+    every halo // 6 iterations, for three exchange periods -- bit for bit the undecomposed handle (which the test above
+    pins against the oracle)."""
+    import torch
+    X, Y, nslab, halo = 32768, 4096, 8, 24
+    per, n_iter = halo // 6, 3 * (halo // 6)
+    base, water, wall = _wet_state(pkg, X, Y, 33)
+    u = _uniforms(pkg, Y)
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    xo = X // nslab
+    slabs, bufs = [], []
+    for r in range(nslab):
+        h = E.Handle(xo, Y, 0, X_global=X, x0=r * xo, halo=halo)
+        idx = (r * xo - halo + np.arange(xo + 2 * halo)) % X
+        h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]))
+        h.set_params(p, u["initial_T"])
+        slabs.append(h)
+        bufs.append([torch.empty(h.halo_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2)])
+    done = 0
+    while done < n_iter:
+        for h in slabs:
+            h.step(per)
+        done += per
+        for r, h in enumerate(slabs):
+            h.halo_pack(0, bufs[r][0].data_ptr())
+            h.halo_pack(1, bufs[r][1].data_ptr())
+        for h in slabs:
+            h.sync()
+        for r, h in enumerate(slabs):
+            h.halo_unpack(0, bufs[(r - 1) % nslab][1].data_ptr())
+            h.halo_unpack(1, bufs[(r + 1) % nslab][0].data_ptr())
+        for h in slabs:
+            h.sync()
+    whole = E.Handle(X, Y, 0)
+    whole.upload(base, water, wall)
+    del base, water, wall
+    whole.set_params(p, u["initial_T"])
+    whole.step(n_iter)
+    for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1"):
+        ref = whole.read_rect(f)
+        for r, h in enumerate(slabs):
+            assert np.array_equal(h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]), (f, r)
+        del ref
+    for h in slabs:
+        h.close()
+    whole.close()

@@ -178,6 +178,40 @@ def test_dry_marching_kernel(pkg, oracle, E, X, Y, monkeypatch):
     assert prof["march_dry_vel_advect_pressure"][1] == 21, prof  # the marching kernel is what ran
 
 
+def test_dry_water_free_flag_is_dropped_when_water_appears(pkg, oracle, E, monkeypatch):
+    """The water-free specialisation of the dry iteration (NO_WATER marching / tiled kernel) is only valid while the water
+    texture is identically zero in air. A moisture brush during a dry step, or a full step in between, puts water there:
+    the following brush-free dry steps must advect and condense it like the oracle does."""
+    monkeypatch.setenv("WX_FUSED", "1")
+    X, Y = 256, 96
+    base, water, wall = pkg.synth.dry_grid(X, Y)
+    rng = np.random.default_rng(13)
+    base[1:, :, 0] += rng.normal(0, 0.1, (Y - 1, X)).astype(np.float32)
+    gui = pkg.params.merge_settings(None)
+    for scenario in ("brush", "full_step"):
+        u_dry = pkg.params.uniforms_from_gui(gui, Y, pass_mask=pkg.params.PASS_DRY)
+        h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u_dry)
+        h.profile(True)
+        h.step(2)
+        o.step(2)
+        assert h.profile_read()["march_dry_vel_advect_pressure"][1] == 2  # water-free so far: the marching kernel ran
+        if scenario == "brush":
+            u2 = dict(u_dry, userInputType=2, userInputValues=(0.5, 0.5, 0.8, 20.0))  # TOOL_WATER: adds vapour (and cloud)
+        else:
+            u2 = pkg.params.uniforms_from_gui(gui, Y, pass_mask=pkg.params.PASS_ALL)
+            u2["enablePrecipitation"] = 0
+        for sim_u in (u2, u_dry):  # two steps with the change, then brush-free dry steps again
+            h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), sim_u), sim_u["initial_T"])
+            o.set_params(sim_u)
+            h.step(3)
+            o.step(3)
+            _assert_grid_equal(h, o, ["BASE_CUR", "WATER_CUR", "WALL_CUR"])
+        if scenario == "brush":
+            assert h.read_rect("WATER_CUR")[Y // 2, X // 2, 0] > 0.1
+        assert "march_dry_vel_advect_pressure" not in h.profile_read()  # the water-carrying kernels took over
+        h.close()
+
+
 def test_particles_vs_oracle(pkg, oracle, golden, E, fused):
     g, u = golden("precip64")
     u = dict(u, quad_scale=0, enablePrecipitation=1)
@@ -435,18 +469,9 @@ def test_slab_particles_equal_whole_domain(pkg, E, nslab):
     keys = [torch.zeros(N, dtype=torch.int32, device="cuda") for _ in range(nslab)]
     state = [torch.zeros(5 * N, dtype=torch.float32, device="cuda") for _ in range(nslab)]
     per = (halo - 6) // 6  # a sprite radius of valid ghost columns must remain in the last iteration
-    with pytest.raises(E.WxError):  # more iterations than the ghost columns allow
+    with pytest.raises(E.WxError):  # more iterations than the ghost columns allow: refused before any iteration runs
         slabs[0].step(per + 1)
-    for h in slabs:  # ... the failed call did run `per` iterations on slab 0: start over
-        h.close()
-    slabs = []
-    for r in range(nslab):
-        h = E.Handle(xo, Y, N, X_global=X, x0=r * xo, halo=halo)
-        h.slab_set_rank(r)
-        idx = (r * xo - halo + np.arange(xo + 2 * halo)) % X
-        h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]), drops)
-        h.set_params(p, u["initial_T"])
-        slabs.append(h)
+    assert slabs[0].iter == 0
     done = 0
     while done < n_iter:
         k = min(per, n_iter - done)
