@@ -6,7 +6,7 @@
 // WX_E_DEVICE otherwise.
 #include "../../include/wxsim.h"
 #include "wx_fused.h"
-#include "wx_full.h"
+#include "wx_wet.h"
 #include "wx_dry.h"
 #include "wx_march.h"
 #include "wx_kernels.h"
@@ -46,11 +46,13 @@ enum KernelId {
   K_FUSED_FULL, // the whole iteration in one kernel
   K_FUSED_DRY,  // velocity + advection + pressure (pass_mask WX_PASS_DRY)
   K_MARCH_DRY,  // the same as a row-marching wavefront kernel (wx_march.h)
+  K_MARCH_WET,  // the whole iteration as one row-marching wavefront kernel (wx_wet.h)
   K_COUNT
 };
 const char *const kKernelNames[K_COUNT] = {"velocity", "curl", "vorticity", "boundary", "advection", "pressure", "lighting",
                                            "precipitation", "lightning", "splat_box", "copy", "halo", "fused_vel_curl_vort_boundary",
-                                           "fused_advect_pressure_light", "fused_full_iteration", "fused_dry_vel_advect_pressure", "march_dry_vel_advect_pressure"};
+                                           "fused_advect_pressure_light", "fused_full_iteration", "fused_dry_vel_advect_pressure", "march_dry_vel_advect_pressure",
+                                           "march_wet_full_iteration"};
 
 struct ProfRec {
   hipEvent_t a, b;
@@ -74,7 +76,7 @@ struct wx_sim {
   int64_t iter = 0;
   int dry_march = 1;     // water-free dry iteration: 1 = row-marching wavefront kernel (wx_march.h, default: 0.32 vs 0.38 ms at
                          // 16384x2048), 0 = LDS-tiled kernel (wx_dry.h); env WX_DRY_MARCH
-  int fused = 1;         // 1: two fused LDS-tiled kernels (default, fastest measured); 2: whole iteration in one kernel; 0: one kernel
+  int fused = 1;         // 1: two fused LDS-tiled kernels; 2: the whole iteration as one row-marching kernel (wx_wet.h); 0: one kernel
                          // per reference pass (env WX_FUSED)
   wx_params p{};
   Geo geo{};
@@ -86,7 +88,7 @@ struct wx_sim {
   bool copy_in_flight = false;
   // device storage
   float4 *base[3] = {nullptr, nullptr, nullptr}; // [2]: post-advection base of the fused path (= baseTexture_1)
-  float4 *water[3] = {nullptr, nullptr, nullptr}, *light[3] = {nullptr, nullptr, nullptr}; // [2]: spare of the single-kernel ping-pong
+  float4 *water[3] = {nullptr, nullptr, nullptr}, *light[2] = {nullptr, nullptr}; // water[2]: spare of the copy-on-write / single-kernel ping-pong
   bool ran_fused = false; // the last iteration used the fused ping-pong (field mapping differs)
   char4 *wall[3] = {nullptr, nullptr, nullptr}; // [2]: third buffer of the copy-on-write scheme (wx_fused.h, FusedBIn)
   float *curl = nullptr;
@@ -103,7 +105,7 @@ struct wx_sim {
   int slow_next = 0;
   // light_0 / light_1 as planes (wx_fused.h, LightPlanes): the representation of the two-kernel path. `light_planar`
   // says which copy is current; the other kernel sets, readback and streaming use the interleaved light[] buffers.
-  LightPlanes lp[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  LightPlanes lp[3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; // [2]: spare of the marching kernel
   bool light_planar = false;
   float *tdisp = nullptr;   // post-advection temperature for the droplets (two-kernel path, instead of the whole base_disp)
   bool wall_veg_ok = false; // no negative vegetation byte anywhere (advection would clamp it: the one wall change it can make unasked)
@@ -458,27 +460,28 @@ int iterate_fused(wx_sim *s, bool write_disp, bool precip)
   return WX_OK;
 }
 
-// The whole iteration as ONE kernel (wx_full.h). Reads base[0], wall[0], water[1], light[0], light[src]; writes the
-// other buffer of each pair and swaps the pointers, so that afterwards the usual roles hold again
-// (base[0]/wall[0] = post-pressure state, water[1] = post-advection water, light[0]/light[1] as in the reference).
-int iterate_full(wx_sim *s, bool opt_out)
+// The whole iteration as ONE row-marching kernel (wx_wet.h). Reads base[0], wall[0], water[1], the light_0 planes and the source
+// light planes; writes the other buffer of each pair and swaps the pointers, so that afterwards the usual roles hold again
+// (base[0] / wall[0] = post-pressure state, water[1] = post-advection water, lp[0] / lp[1] = light_0 / light_1 as in the reference).
+int iterate_march_wet(wx_sim *s, bool opt_out, bool precip)
 {
-  const Geo g = s->geo;
-  Uni u = s->uni;
-  u.iterNum = (float)s->iter;
-  u.iterI = (int)u.iterNum;
   const int src = s->even ? 0 : 1;
-  float4 *light_dst = s->even ? s->light[1] : s->light[2]; // never the light[0] that other tiles' boundary stage reads
-  FullIn in{s->base[0], s->wall[0], s->water[1], s->light[0], s->light[src], s->fb_dirty ? s->fb : nullptr, s->fb_dirty ? s->dep : nullptr};
-  FullOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], s->water[0], s->curl};
+  light_to_planes(s);
+  // lighting writes light_1 (even) or light_0 (odd); waves that are still at their boundary stage read light_0, so the odd
+  // iterations write the spare plane set, which then becomes light_0
+  const LightPlanes light_dst = s->even ? s->lp[1] : s->lp[2];
+  const bool fb = s->fb_dirty;
+  WetIn in{s->base[0], s->wall[0], s->water[1], LightPlanesC{s->lp[0].x, s->lp[0].y, s->lp[0].zw},
+           LightPlanesC{s->lp[src].x, s->lp[src].y, s->lp[src].zw}, fb ? s->fb : nullptr, fb ? s->dep : nullptr, fb ? s->sg.fb_zero : nullptr, s->sg.TXn};
+  WetOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], s->water[0], s->curl, precip ? s->tdisp : nullptr};
   {
-    ProfScope ps(s, K_FUSED_FULL);
-    launch_fused_full(g, u.iterNum, in, s->full_ctx, out, opt_out, s->stream);
+    ProfScope ps(s, K_MARCH_WET);
+    launch_march_wet(s->geo, (float)s->iter, s->full_ctx, in, out, opt_out, s->stream);
   }
   std::swap(s->base[0], s->base[1]);
   std::swap(s->wall[0], s->wall[1]);
   std::swap(s->water[1], s->water[2]);
-  if (!s->even) std::swap(s->light[0], s->light[2]);
+  if (!s->even) std::swap(s->lp[0], s->lp[2]);
   return WX_OK;
 }
 
@@ -572,7 +575,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (rc == WX_OK) rc = dalloc(s, &s->slow_ctx, 2);
   if (rc == WX_OK) rc = dalloc(s, &s->wall[2], n);
   if (rc == WX_OK && n_droplets > 0) rc = dalloc(s, &s->tdisp, n);
-  for (int i = 0; i < 2 && rc == WX_OK; i++) {
+  for (int i = 0; i < 3 && rc == WX_OK; i++) {
     if ((rc = dalloc(s, &s->lp[i].x, n))) break;
     if ((rc = dalloc(s, &s->lp[i].y, n))) break;
     rc = dalloc(s, &s->lp[i].zw, n);
@@ -580,7 +583,6 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (rc == WX_OK) rc = dalloc(s, &s->cow_clean, (size_t)((s->X + 63) / 64) * ((Y + 15) / 16));
   if (rc == WX_OK) rc = dalloc(s, &s->full_ctx, 1);
   if (rc == WX_OK) rc = dalloc(s, &s->water[2], n);
-  if (rc == WX_OK) rc = dalloc(s, &s->light[2], n);
   if (rc == WX_OK && n_droplets > 0) {
     SplatGrid &sg = s->sg;
     sg.AP = s->X + 8;
@@ -649,7 +651,7 @@ void wx_destroy(wx_sim *s)
   hipFree(s->slow_ctx);
   hipFree(s->wall[2]);
   hipFree(s->tdisp);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < 3; i++) {
     hipFree(s->lp[i].x);
     hipFree(s->lp[i].y);
     hipFree(s->lp[i].zw);
@@ -657,7 +659,6 @@ void wx_destroy(wx_sim *s)
   hipFree(s->cow_clean);
   hipFree(s->full_ctx);
   hipFree(s->water[2]);
-  hipFree(s->light[2]);
   hipFree(s->sg.acc4);
   hipFree(s->sg.acc2);
   hipFree(s->sg.dirty);
@@ -699,7 +700,6 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   const size_t n = ncell(s);
   for (int i = 0; i < 2; i++) {
     HIPCHK(s, hipMemsetAsync(s->light[i], 0, n * 16, s->stream));
-    if (i == 0) HIPCHK(s, hipMemsetAsync(s->light[2], 0, n * 16, s->stream));
     if (drops && s->n_drops > 0)
       HIPCHK(s, hipMemcpyAsync(s->drops[i], drops, (size_t)s->n_drops * 20, hipMemcpyHostToDevice, s->stream));
   }
@@ -829,15 +829,13 @@ int wx_step(wx_sim *s, int n_iter)
       return fail(s, WX_E_STATE, "wx_step: %d iterations asked, %d done since the last halo exchange; %d ghost columns allow %d per period with particles",
                   n_iter, s->period_j, s->halo, (s->halo - 6) / WX_SLAB_CONE);
   }
-  if (!(fused && s->fused == 1)) {
-    cow_resolve(s);  // the other kernel sets take water[0] as a fully written buffer
-    light_to_rgba(s); // ... and the light textures interleaved
-  }
+  if (!(fused && s->fused == 1)) cow_resolve(s);    // the other kernel sets take water[0] as a fully written buffer
+  if (!(fused && s->fused >= 1)) light_to_rgba(s);  // ... and the per-pass / dry kernels the light textures interleaved
   for (int it = 0; it < n_iter; it++) {
     if (dry)
       iterate_dry(s, precip || it == n_iter - 1);
     else if (fused && s->fused >= 2)
-      iterate_full(s, precip || it == n_iter - 1);
+      iterate_march_wet(s, it == n_iter - 1, precip);
     else if (fused)
       iterate_fused(s, it == n_iter - 1, precip);
     else
@@ -848,7 +846,7 @@ int wx_step(wx_sim *s, int n_iter)
     // 8-10 clear feedback/deposition, precipitation, lightning location (app.js:5933-5983). The clear and the
     // blend-unit splats are replaced by: deposit at the sprite anchors -> 12x12 box sum that (re)writes both textures.
     if (precip) {
-      const bool two_kernel = fused && s->fused == 1 && !dry; // droplets sample base[0] (velocity) + tdisp (temperature)
+      const bool two_kernel = fused && !dry; // fused / marching kernels: droplets sample base[0] (velocity) + tdisp (temperature)
       Uni u = s->uni;
       u.iterNum = (float)s->iter;
       u.iterI = (int)u.iterNum;

@@ -30,8 +30,9 @@ ALGO_BYTES = {
     # W base16 water16 wall4 light16 (+16 for the post-advection base on the last iteration of a wx_step call only)
     # (A reads only the x and y planes of the light texture: base16 wall4 water16 light8)
     "fused_vel_curl_vort_boundary": 44 + 36, "fused_advect_pressure_light": 52 + 52,
-    # single-kernel iteration: R base16 wall4 water16 light_0 16 light_src 16, W base16 wall4 water16 light16
-    "fused_full_iteration": 68 + 52,
+    # the whole iteration as one row-marching kernel: R base16 wall4 water16 light16 (source x, zw + light_0 y), W base16 wall4 water16
+    # light16 -- every compulsory byte of the iteration exactly once
+    "march_wet_full_iteration": 52 + 52,
     # dry config: A_dry = base 16 R + 16 W + wall 4 R; the tiled kernel also passes the wall texel through (+4 W), the
     # marching kernel only when the brush / an airplane crash could change it
     "fused_dry_vel_advect_pressure": 36,
@@ -82,7 +83,7 @@ def cpu_baseline(pkg, budget_s=12.0):
 
 
 KERNEL_SYMBOL = {  # profile name -> substring of the kernel symbol rocprofv3 reports
-    "fused_vel_curl_vort_boundary": "k_fused_a", "fused_advect_pressure_light": "k_fused_b", "fused_full_iteration": "k_fused_full",
+    "fused_vel_curl_vort_boundary": "k_fused_a", "fused_advect_pressure_light": "k_fused_b", "march_wet_full_iteration": "k_march_wet",
     "fused_dry_vel_advect_pressure": "k_fused_dry", "march_dry_vel_advect_pressure": "k_march_dry", "advection": "k_advection", "boundary": "k_boundary", "lighting": "k_lighting",
     "velocity": "k_velocity", "pressure": "k_pressure", "curl": "k_curl", "vorticity": "k_vorticity", "precipitation": "k_precipitation",
 }

@@ -21,7 +21,7 @@ def E(pkg):
     return engine
 
 
-@pytest.fixture(params=[2, 1, 0], ids=["full", "fused", "perpass"])
+@pytest.fixture(params=[2, 1, 0], ids=["march", "fused", "perpass"])
 def fused(request):
     """Both kernel sets go through every parity test: WX_FUSED is read by wx_create."""
     import os
