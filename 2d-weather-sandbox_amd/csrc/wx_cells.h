@@ -61,7 +61,9 @@ struct Geo {
   float texX, texY;
 };
 
-// Uniforms (wx_params) plus host-derived constants.
+// Uniforms (wx_params) plus host-derived constants. The per-cell functions below take them as `const UT &u`: UT is Uni, or Uni
+// in the constant address space (CUni) -- loads through it are scalar loads the compiler may re-issue anywhere, so a long
+// kernel neither holds 60 uniforms in SGPRs nor falls back to vector loads once it has stored something.
 struct Uni {
   float dragMultiplier, wind;
   float vorticity, landEvaporation, waterEvaporation, dynamicWaterTemperature;
@@ -90,6 +92,12 @@ struct Uni {
   float iterNum;
   int iterI; // int(iterNum)
 };
+
+typedef const __attribute__((address_space(4))) Uni CUni;
+__device__ __forceinline__ CUni &as_constant(const Uni &u) { return *(CUni *)(&u); }
+// the per-row profile arrays (initial_T, sounding) through the same address space: FP is `const float *` or CFloatP
+typedef const __attribute__((address_space(4))) float *CFloatP;
+__device__ __forceinline__ CFloatP as_constant(const float *p) { return (CFloatP)p; }
 
 struct CellCoord {
   float fx, fy;   // fragCoord
@@ -159,7 +167,7 @@ __device__ __forceinline__ float IR_emitted(float T) { return pow4(T * 0.01f) * 
 // ------------------------------------------------------------------------------------------------
 // velocityShader.frag:32-61.  b: own texel, Pr/Pu: PRESSURE of right / up neighbour
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 velocity_cell(const Uni &u, float4 b, float Pr, float Pu, int wall_dist)
+template <class UT> __device__ __forceinline__ float4 velocity_cell(const UT &u, float4 b, float Pr, float Pu, int wall_dist)
 {
   if (wall_dist == 0) {
     b.x = 0.0f;
@@ -207,7 +215,7 @@ __device__ __forceinline__ float4 pressure_cell(float4 b, float vx_l, float vy_d
 // iterNum / iterI: the per-iteration uniform (float as the reference passes it, and int(iterNum)); separate from Uni so that
 // Uni can live in read-only device memory for a whole wx_step call
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float calcEvaporation(const Uni &u, float T, float W, float V, float M)
+template <class UT> __device__ __forceinline__ float calcEvaporation(const UT &u, float T, float W, float V, float M)
 {
   return fmaxf((maxWater(T) - W) * u.landEvaporation * (V / 127.0f + 0.1f) * fminf(M + 1.0f, 50.0f) * 0.05f, 0.0f);
 }
@@ -216,8 +224,8 @@ __device__ __forceinline__ float calcFireIntensity(int veg, float moist, float p
   return fmaxf((float)veg * 0.00025f - moist * 0.00020f - precip * 0.02f, 0.0f);
 }
 
-template <class A>
-__device__ __forceinline__ void boundary_cell(const Uni &u, const float iterNum, const int iterI, const Geo &g, const float *__restrict__ initial_T,
+template <class UT, class FP, class A>
+__device__ __forceinline__ void boundary_cell(const UT &u, const float iterNum, const int iterI, const Geo &g, const FP initial_T,
                                               int x, int y, const A &a, float4 &base_out, float4 &water_out, char4 &wall_out)
 {
   const float gravMult = 0.0001f;
@@ -564,10 +572,9 @@ __device__ __forceinline__ float smoothstepf(float e0, float e1, float x)
 // NO_WATER: the water texture is identically zero in air cells (BASELINE config 1, checked by the host) and no
 // sounding forcing is active: the water interpolation and the phase-change block then provably leave base unchanged
 // (condensation = max(negative * 0.2, -0) = -0, dT = -0) and water zero, so they are not evaluated.
-template <bool NO_WATER = false, class A>
-__device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const float *__restrict__ initial_T,
-                                               const float *__restrict__ snd_T, const float *__restrict__ snd_W,
-                                               const float *__restrict__ snd_Vel, int x, int y, const A &a, float4 &base_out,
+template <bool NO_WATER = false, class UT, class FP, class A>
+__device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const FP initial_T, const FP snd_T, const FP snd_W, const FP snd_Vel, int x, int y,
+                                               const A &a, float4 &base_out,
                                                float4 &water_out, char4 &wall_out)
 {
   const CellCoord cc = cellcoord(g, x, y);
@@ -866,8 +873,8 @@ __device__ __forceinline__ void advection_cell(const Uni &u, const Geo &g, const
 //             (wrapped; 0 for the IR channels), ROW j (absolute,
 //             caller clamps) ; used for the bilinear sun tap and the IR taps
 // ------------------------------------------------------------------------------------------------
-template <class A>
-__device__ __forceinline__ float4 lighting_cell(const Uni &u, const Geo &g, int x, int y, const A &a)
+template <class UT, class A>
+__device__ __forceinline__ float4 lighting_cell(const UT &u, const Geo &g, int x, int y, const A &a)
 {
   const CellCoord cc = cellcoord(g, x, y);
   const float fy = cc.fy, tcy = cc.tcy;

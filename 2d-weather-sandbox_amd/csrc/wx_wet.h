@@ -16,10 +16,15 @@
 //   lane one row up: carried in registers), so six ring rows serve both the pre- and the post-boundary state;
 // * no vertical halo is re-loaded or re-computed, there are no workgroup barriers (the wave's LDS queue is in order;
 //   wavefront-scope fences keep the compiler from reordering across stages); 56 of the 64 lanes produce output
-//   (cone of the seven chained stencils: 4 columns per side for |v| < 0.9 cell/iteration; longer back-traces take the
-//   exact out-of-line path that recomputes post-boundary texels from global memory);
-// * global loads are issued one step ahead of their use (software prefetch), each with the lag its consumer has:
-//   base / wall row r+1, water row r-2 (first needed by boundary), source light row r-1 (sun taps of lighting).
+//   (cone of the seven chained stencils: 4 columns per side for |v| < 0.9 cell/iteration);
+// * cells whose back-trace is longer than that (never in a physical run: the shaders document velocities as -1 .. 1) are
+//   only RECORDED by the marching loop (one lane mask per row); after its last row the wave recomputes the three output
+//   cells each of them feeds with the exact out-of-line path (post-boundary texels rebuilt from global memory) and
+//   overwrites them. The hot loop therefore contains no call and no scratch access;
+// * global loads are issued one step ahead of their use (software prefetch), each with the lag its consumer has (base / wall
+//   row r+1, water and light row r-1, feedback row r-2), and the stores of a row are issued at the top of the NEXT step, right
+//   behind the prefetch: the only vmcnt wait of the common path (top of the step) then covers operations that have had a
+//   whole step to complete -- gfx9 counts loads and stores in one in-order counter.
 // Same per-cell arithmetic as every other kernel set (wx_cells.h): bit-identical results.
 #pragma once
 #include "wx_cells.h"
@@ -30,6 +35,9 @@ namespace wx {
 
 #ifndef WX_WET_MINWAVES
 #define WX_WET_MINWAVES 3
+#endif
+#ifndef WX_WET_UNI_COPY
+#define WX_WET_UNI_COPY 0
 #endif
 #ifndef WX_WET_MAXSEG
 #define WX_WET_MAXSEG 640 // upper bound of the rows one wave marches (8 warm-up rows per segment are redundant work)
@@ -64,7 +72,7 @@ struct WetOut {
 };
 
 // ---- exact out-of-line path: the post-boundary texel of an ARBITRARY cell recomputed from global memory (velocity, curl
-//      and vortForce evaluated on the fly). Only reached by cells whose back-trace is longer than 0.9 cells. ----
+//      and vortForce evaluated on the fly). Only used for output cells fed by a back-trace longer than 0.9 cells. ----
 struct WetSlowArgs {
   const FullCtx *ctx;
   WetIn in;
@@ -129,13 +137,48 @@ struct GWetAdvectAcc {
   __device__ __forceinline__ float4 water_off(int dx, int dy) const { return at(dx, dy).w; }
   __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return at(dx, dy).wl; }
 };
-__device__ __noinline__ AdvOut wet_advection_cell_recompute(const FullCtx *__restrict__ c, const WetIn *__restrict__ in, float iterNum, int x, int y)
+__device__ __noinline__ AdvOut wet_advection_cell_recompute(const WetSlowArgs *__restrict__ sa, int x, int y)
 {
-  const WetSlowArgs sa{c, *in, iterNum};
-  GWetAdvectAcc a{&sa, c->g.X, c->g.Y, x, y};
+  const FullCtx *c = sa->ctx;
+  GWetAdvectAcc a{sa, c->g.X, c->g.Y, x, y};
   AdvOut o;
   advection_cell(c->u, c->g, c->initial_T, c->snd_T, c->snd_W, c->snd_Vel, x, y, a, o.b, o.w, o.wl);
   return o;
+}
+struct GWetLightAcc {
+  LightPlanesC l;
+  float4 water_;
+  char4 wall_;
+  float T0, Td;
+  int X, x;
+  __device__ __forceinline__ float T(int dy) const { return dy == 0 ? T0 : Td; }
+  __device__ __forceinline__ float4 water() const { return water_; }
+  __device__ __forceinline__ char4 wall() const { return wall_; }
+  __device__ __forceinline__ float sun_at(int dx, int j) const { return l.x[fidx(wrapmod(x + dx, X), j, X)]; }
+  __device__ __forceinline__ float ir_down_at(int j) const { return l.zw[fidx(x, j, X)].x; }
+  __device__ __forceinline__ float ir_up_at(int j) const { return l.zw[fidx(x, j, X)].y; }
+};
+// every output of the iteration at cell (x, y) -- post-pressure base, post-advection water / wall, light -- from the
+// iteration's inputs alone, any back-trace length
+__device__ __noinline__ void wet_output_cell_exact(const FullCtx *__restrict__ c, const WetIn *__restrict__ in, const WetOut *__restrict__ out, float iterNum,
+                                                   int opt_out, int x, int y)
+{
+  const WetSlowArgs sa{c, *in, iterNum};
+  const int X = c->g.X, Y = c->g.Y;
+  const AdvOut o0 = wet_advection_cell_recompute(&sa, x, y);
+  const AdvOut oL = wet_advection_cell_recompute(&sa, x == 0 ? X - 1 : x - 1, y);
+  const AdvOut oD = wet_advection_cell_recompute(&sa, x, y == 0 ? Y - 1 : y - 1);
+  const size_t gi = fidx(x, y, X);
+  out->base[gi] = pressure_cell(o0.b, oL.b.x, oD.b.y, oD.b.w, oD.wl.x, oD.wl.y);
+  out->water[gi] = o0.w;
+  out->wall[gi] = o0.wl;
+  GWetLightAcc la{in->lsrc, o0.w, o0.wl, o0.b.w, oD.b.w, X, x};
+  const float4 l = lighting_cell(c->u, c->g, x, y, la);
+  out->light.x[gi] = l.x;
+  out->light.y[gi] = l.y;
+  out->light.zw[gi] = make_float2(l.z, l.w);
+  if (opt_out) out->base_disp[gi] = o0.b;
+  if (out->t_disp) out->t_disp[gi] = o0.b.w;
 }
 
 // ---- the wave-private ring ----
@@ -177,21 +220,21 @@ __device__ __forceinline__ char4 unpack_wall(int w)
   return make_char4((signed char)(w & 0xff), (signed char)((w >> 8) & 0xff), (signed char)((w >> 16) & 0xff), (signed char)(w >> 24));
 }
 
-// boundary stage, row yb: own texel and the row below in registers, the row above and the horizontal wall neighbours in the ring
+// boundary stage, row yb: own texel, the row below and the water / light_0 texels of the row above in registers, the base / wall
+// texels of the row above and the horizontal wall neighbours in the ring
 struct MWBoundaryAcc {
   const WetRing &rg;
-  const WetIn &in;
   int li, o0, o1;          // ring column; in-plane offsets of ring rows yb and yb+1
-  float4 b00, q00;         // velocity output / pre-boundary water of the own cell
+  float4 b00, q00, qU;     // velocity output / pre-boundary water of the own cell; pre-boundary water of the cell above
   char4 w00, wD;
   float vxD, TD, qzD, qwD; // row below: velocity-pass vx, pre-boundary T, soil moisture / snow of the pre-boundary water
+  float qzL, qwL, qzR, qwR; // left / right neighbour's soil moisture / snow (fetched only in the iterations that use them)
   float2 vf;
   float vfLy, vfDx;
-  float ly;
+  float l0x, l0y, l0xU, l0yU; // light_0 sunlight / net heating at the own cell and the cell above (row clamped)
   float4 fb_;
   float2 dep_;
   bool hasfb;
-  int X, Y, x, y;
   __device__ __forceinline__ float4 base(int dx, int dy) const
   {
     if (dx == 0 && dy == 0) return b00;
@@ -203,7 +246,8 @@ struct MWBoundaryAcc {
   {
     if (dx == 0 && dy == 0) return q00;
     if (dx == 0 && dy == -1) return make_float4(0.f, 0.f, qzD, qwD);
-    return in.water[fidx(wrapi(x + dx, X), wrapi(y + dy, Y), X)]; // surface wall cells only
+    if (dx == 0 && dy == 1) return qU;
+    return dx < 0 ? make_float4(0.f, 0.f, qzL, qwL) : make_float4(0.f, 0.f, qzR, qwR);
   }
   __device__ __forceinline__ char4 wall(int dx, int dy) const
   {
@@ -218,13 +262,9 @@ struct MWBoundaryAcc {
     if (dx == -1) return make_float2(0.f, vfLy); // the boundary pass uses .y of the left and .x of the lower neighbour only
     return make_float2(vfDx, 0.f);
   }
-  __device__ __forceinline__ float light_y0() const { return ly; }
-  __device__ __forceinline__ float light_x0() const { return in.l0.x[fidx(x, y, X)]; } // cells next to a wall only
-  __device__ __forceinline__ float2 light_xy_up() const
-  {
-    const size_t i = fidx(x, y + 1 > Y - 1 ? Y - 1 : y + 1, X);
-    return make_float2(in.l0.x[i], in.l0.y[i]);
-  }
+  __device__ __forceinline__ float light_y0() const { return l0y; }
+  __device__ __forceinline__ float light_x0() const { return l0x; }
+  __device__ __forceinline__ float2 light_xy_up() const { return make_float2(l0xU, l0yU); }
   __device__ __forceinline__ bool has_fb() const { return hasfb; }
   __device__ __forceinline__ float4 fb() const { return fb_; }
   __device__ __forceinline__ float2 dep() const { return dep_; }
@@ -267,7 +307,7 @@ struct MWFp {
 };
 __device__ __forceinline__ MWFp make_fp(const MWAdvAcc &a, int dx0, int dy0)
 {
-  const bool lo = dy0 < 0; // fast path: dy0 is -1 or 0
+  const bool lo = dy0 < 0; // dy0 is -1 or 0 for every cell that takes this path
   const int c = a.li + dx0;
   return MWFp{a.rg, (lo ? a.ob[0] : a.ob[1]) + c, (lo ? a.ob[1] : a.ob[2]) + c, (lo ? a.oq[0] : a.oq[1]) + c, (lo ? a.oq[1] : a.oq[2]) + c};
 }
@@ -275,7 +315,7 @@ __device__ __forceinline__ MWFp make_fp(const MWAdvAcc &a, int dx0, int dy0)
 // lighting stage, row y (an OUTPUT row: unwrapped == wrapped row index); ring row k of the light planes holds texture row clamp(k)
 struct MWLightAcc {
   const WetRing &rg;
-  int li, y;
+  int li;
   float T0, Tdown, lz_up;
   float4 water_;
   char4 wall_;
@@ -287,48 +327,74 @@ struct MWLightAcc {
   __device__ __forceinline__ float ir_up_at(int j) const { return rg.lw[(j + 8) & (WL - 1)][li]; } // row max(y-1, 0)
 };
 
+__device__ __forceinline__ int ring_back(int s, int k, int n) // slot of the row k steps behind the one in slot s (ring of n)
+{
+  const int v = s - k;
+  return v < 0 ? v + n : v;
+}
+
 // OPT_OUT: also store what only display-side consumers see (curl, post-boundary water, post-advection base): last iteration of a
 // wx_step call. HAS_FB: the precipitation feedback / deposition textures may be non-zero.
+// slow_rows: per wave (seg_rows + 1) 64-bit lane masks, one per advected row, of the cells left to the exact path.
 template <bool OPT_OUT, bool HAS_FB>
-__global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out, int n_strips,
-                                                                    int seg_rows)
+__global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out,
+                                                                    unsigned long long *__restrict__ slow_rows, int n_strips, int seg_rows)
 {
   __shared__ WetRing rg;
-  const Uni &u = ctx->u;
+  // Everything the wave reads from the context goes through the constant address space: scalar loads that the compiler may
+  // issue (and re-issue) anywhere. Through a generic pointer every such load behind the kernel's first store becomes a VECTOR
+  // load with a uniform address, and waiting for it means waiting for the row prefetch issued just before (one in-order counter).
+#if WX_WET_UNI_COPY
+  const Uni u = ctx->u; // read before the first store of the kernel: scalar loads, kept in SGPRs
+#else
+  CUni &u = as_constant(ctx->u);
+#endif
   const Geo g = ctx->g;
+  const CFloatP initial_T = as_constant(ctx->initial_T), snd_T = as_constant(ctx->snd_T), snd_W = as_constant(ctx->snd_W), snd_Vel = as_constant(ctx->snd_Vel);
   const int X = g.X, Y = g.Y;
   const int lane = threadIdx.x, li = lane + WPAD;
   const int iterI = (int)iterNum;
-  // XCD-aware placement (see wx_march.h): XCD k takes a contiguous range of the segment-major (segment, strip) items
-  const int total = n_strips * ((Y + seg_rows - 1) / seg_rows), k = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int first = (int)(((long long)k * total) >> 3), count = (int)(((long long)(k + 1) * total) >> 3) - first;
-  if (j >= count) return;
-  const int item = first + j, seg = item / n_strips, strip = item - seg * n_strips;
+  const bool smooth_iter = iterI % 100 == 0; // the only iterations in which the boundary pass reads its horizontal water neighbours
+  // XCD-aware placement: workgroup id lands on XCD id % 8 (MI355X_MICROARCH.md), every XCD has its own L2. XCD k takes the
+  // column block of strips [k*S/8, (k+1)*S/8) of EVERY segment: neighbouring strips (which share two 128-byte lines of halo
+  // columns per field) hit the same L2, and every XCD gets the same mix of cheap free-air rows and expensive rows near terrain
+  // (a contiguous range of segment-major items would hand all the terrain segments to XCD 0). Bottom segments first.
+  const int n_seg = (Y + seg_rows - 1) / seg_rows, k = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int sk0 = (k * n_strips) >> 3, nk = (((k + 1) * n_strips) >> 3) - sk0;
+  if (j >= nk * n_seg) return;
+  const int seg = j / nk, strip = sk0 + (j - seg * nk), item = seg * n_strips + strip;
   const int c_out = strip * WOUT + lane - WLO; // output column of this lane (may be >= X in the last strip, < 0 in the first)
   const int col = wrapmod(c_out, X);           // column this lane loads / computes
   const bool lane_out = lane >= WLO && lane < WLO + WOUT && c_out < X;
   const int y_lo = seg * seg_rows, y_hi = min(y_lo + seg_rows, Y);
   const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
+  unsigned long long *__restrict__ my_slow = slow_rows + (size_t)item * (seg_rows + 1);
 
   // ---- registers carried from step to step ----
-  float4 pf_b, pf_q = make_float4(0.f, 0.f, 0.f, 0.f);                // prefetched: base row r, water row r-3
+  float4 pf_b, pf_q = make_float4(0.f, 0.f, 0.f, 0.f);                // prefetched: base row r, water row r-2
   int pf_w;                                                          // wall row r (raw dword)
-  float pf_lx = 0.f, pf_ly = 0.f;                                     // source sunlight row r-2, light_0 net heating row r-2
+  float pf_lx = 0.f, pf_l0x = 0.f, pf_l0y = 0.f;                      // source sunlight, light_0 sunlight / net heating, row r-2
   float2 pf_lzw = make_float2(0.f, 0.f);                              // source IR fluxes row r-2
   float4 pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);                     // feedback / deposition row r-3 (HAS_FB)
   float2 pf_dep = make_float2(0.f, 0.f);
   bool fb_need_next = false, fb_have = false;                         // wave-uniform: the tile(s) of that row hold feedback
   float4 b_prev = make_float4(0.f, 0.f, 0.f, 0.f);                    // base_0 row r-1
   int w_prev = 0;
+  float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);                        // pre-boundary water row r-3
   float v1x = 0.f, v1y = 0.f;                                         // velocity row r-2
   float c1 = 0.f, c2 = 0.f;                                           // curl rows r-3, r-4
   float vfDx = 0.f;                                                   // vortForce.x row r-4
   float TD = 0.f, vxD = 0.f, qzD = 0.f, qwD = 0.f;                    // pre-boundary values of row r-4 (see MWBoundaryAcc)
   char4 wD = make_char4(0, 0, 0, 0);
-  float ly1 = 0.f, lz1 = 0.f;                                         // light_0 net heating / source IR_down of row r-3
+  float l0x1 = 0.f, l0y1 = 0.f, lz1 = 0.f;                            // light_0 sunlight / net heating, source IR_down of row r-3
   float adv_vy_prev = 0.f, adv_T_prev = 0.f;                          // advection output row r-5
   char4 adv_w_prev = make_char4(0, 0, 0, 0);
   int big1 = 0, big2 = 0, big3 = 0;                                   // "some |v| >= 0.9" of post-boundary rows r-3, r-4, r-5
+  // outputs of the previous step, stored at the top of this one
+  float4 st_p = make_float4(0.f, 0.f, 0.f, 0.f), st_q = st_p, st_l = st_p, st_ab = st_p;
+  char4 st_w = make_char4(0, 0, 0, 0);
+  bool st_valid = false;
+  int first_slow = 0x7fffffff; // index (row - (y_lo - 1)) of the first row with cells left to the exact path
 
   int r = y_lo - 4;
   { // prefetch of the first row
@@ -336,13 +402,15 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
     pf_b = in.base[gi];
     pf_w = wall_raw[gi];
   }
+  int s0 = (r + 12) % WD, sq3 = (r - 3 + 12) % WQ; // ring slots of row r (base / wall planes) and of row r-3 (water planes)
+  // wrapped (REPEAT) row indices of rows r+1, r-1 .. r-4, advanced by one per step (a general modulo costs ~20 scalar instructions)
+  int yw_p1 = wrapmod(r + 1, Y), yw_m1 = wrapmod(r - 1, Y), yw_m2 = wrapmod(r - 2, Y), yw_m3 = wrapmod(r - 3, Y), yw_m4 = wrapmod(r - 4, Y);
   for (int t = 0; r <= y_hi + 3; r++, t++) {
-    const int rc = r + 12;                         // non-negative ring counter (r >= -4)
-    const float4 b_cur = pf_b, q_cur = pf_q;       // base row r, water row r-3
+    const float4 b_cur = pf_b, q_up = pf_q;       // base row r, water row r-2
     int w_raw = pf_w;
-    const float lx_cur = pf_lx, ly_cur = pf_ly;    // light row r-2
+    const float lx_cur = pf_lx, l0x_cur = pf_l0x, l0y_cur = pf_l0y; // light row r-2
     const float2 lzw_cur = pf_lzw;
-    const float4 fb_cur = pf_fb;
+    const float4 fb_cur = pf_fb;                   // feedback row r-3
     const float2 dep_cur = pf_dep;
     const bool fb_cur_have = fb_have;
     asm volatile("" : "+v"(w_raw)); // keeps the byte unpacking on this side of the prefetch
@@ -350,40 +418,54 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
     // ---- software prefetch: the loads of the next step are in flight while this one computes ----
     if (r < y_hi + 3) {
       {
-        const size_t gi = fidx(col, wrapmod(r + 1, Y), X);
+        const size_t gi = fidx(col, yw_p1, X);
         pf_b = in.base[gi];
         pf_w = wall_raw[gi];
       }
       {
-        const int yq = wrapmod(r - 2, Y);
-        const size_t gi = fidx(col, yq, X);
-        pf_q = in.water[gi];
-        if (HAS_FB) {
-          fb_have = fb_need_next; // decided one step ago for this very row
-          if (fb_have) {
-            pf_fb = in.fb[gi];
-            pf_dep = in.dep[gi];
-          }
-          // the row after: does any of the (up to three) 64x16 tiles under this strip hold feedback?
-          const int yn = wrapmod(r - 1, Y);
-          const bool zero = in.fb_zero != nullptr && in.fb_zero[(yn >> 4) * in.fb_txn + (col >> 6)] != 0;
-          fb_need_next = in.fb != nullptr && __any(!zero);
-        }
-      }
-      {
         const int rl = r - 1;
-        const size_t gl = fidx(col, rl < 0 ? 0 : (rl > Y - 1 ? Y - 1 : rl), X); // light textures clamp in y ...
+        const size_t gw = fidx(col, yw_m1, X);
+        pf_q = in.water[gw];
+        // light textures clamp in y (sun ray / IR taps of the lighting pass) ...
+        const size_t gl = fidx(col, rl < 0 ? 0 : (rl > Y - 1 ? Y - 1 : rl), X);
         pf_lx = in.lsrc.x[gl];
         pf_lzw = in.lsrc.zw[gl];
-        pf_ly = in.l0.y[fidx(col, wrapmod(rl, Y), X)]; // ... but the boundary pass samples light_0 at its own (wrapped) row
+        // ... while the boundary pass samples light_0 at its own (wrapped) row and at the row above it, clamped
+        pf_l0x = in.l0.x[gw];
+        pf_l0y = in.l0.y[gw];
+      }
+      if (HAS_FB) {
+        fb_have = fb_need_next; // decided one step ago for this very row (r-2)
+        if (fb_have) {
+          const size_t gi = fidx(col, yw_m2, X);
+          pf_fb = in.fb[gi];
+          pf_dep = in.dep[gi];
+        }
+        // the row after: does any of the (up to three) 64x16 tiles under this strip hold feedback?
+        const int yn = yw_m1;
+        const bool zero = in.fb_zero != nullptr && in.fb_zero[(yn >> 4) * in.fb_txn + (col >> 6)] != 0;
+        fb_need_next = in.fb != nullptr && __any(!zero);
       }
     }
+    // ---- the stores of the previous step's row (r-5), issued behind the prefetch ----
+    if (st_valid && lane_out) {
+      const size_t gi = fidx(c_out, r - 5, X);
+      out.base[gi] = st_p;
+      out.water[gi] = st_q;
+      out.wall[gi] = st_w;
+      out.light.x[gi] = st_l.x;
+      out.light.y[gi] = st_l.y;
+      out.light.zw[gi] = make_float2(st_l.z, st_l.w);
+      if (OPT_OUT) out.base_disp[gi] = st_ab;
+      if (out.t_disp) out.t_disp[gi] = st_ab.w;
+    }
+    st_valid = false;
     // ---- row r enters the ring: P, T and wall (velocity leaves them unchanged); light row r-2 ----
     {
-      const int s = rc % WD;
-      rg.P[s][li] = b_cur.z;
-      rg.T[s][li] = b_cur.w;
-      rg.wl[s][li] = w_cur;
+      const int o = s0 * WRW + li;
+      (&rg.P[0][0])[o] = b_cur.z;
+      (&rg.T[0][0])[o] = b_cur.w;
+      (&rg.wl[0][0])[o] = w_cur;
       rg.lx[(r - 2 + 8) & (WL - 1)][li] = lx_cur;
       rg.lw[(r - 2 + 8) & (WL - 1)][li] = lzw_cur.y;
     }
@@ -393,9 +475,9 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
       const float4 v = velocity_cell(u, b_prev, wave_from_right(b_prev.z), b_cur.z, unpack_wall(w_prev).y);
       v0x = v.x;
       v0y = v.y;
-      const int s = (rc - 1) % WD;
-      rg.vx[s][li] = v0x;
-      rg.vy[s][li] = v0y;
+      const int o = ring_back(s0, 1, WD) * WRW + li;
+      (&rg.vx[0][0])[o] = v0x;
+      (&rg.vy[0][0])[o] = v0y;
     }
     // ---- curl of row r-2, vortForce of row r-3 (registers + wave shifts only) ----
     float c0 = 0.f;
@@ -409,29 +491,45 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
     float2 vf = make_float2(0.f, 0.f);
     if (t >= 4) vf = vorticity_cell(c1, wave_from_left(c1), wave_from_right(c1), c2, c0);
     const float vfLy = wave_from_left(vf.y);
+    float qzL = 0.f, qwL = 0.f, qzR = 0.f, qwR = 0.f;
+    if (smooth_iter) { // (wave-uniform) soil moisture / snow smoothing between surface cells: the neighbours' water texels
+      qzL = wave_from_left(q1.z);
+      qwL = wave_from_left(q1.w);
+      qzR = wave_from_right(q1.z);
+      qwR = wave_from_right(q1.w);
+    }
     wave_fence();
 
     // ---- boundary of row yb = r-3, written back in place ----
     if (t >= 4) {
-      const int ob0 = ((rc - 3) % WD) * WRW, ob1 = ((rc - 2) % WD) * WRW;
+      const int ob0 = ring_back(s0, 3, WD) * WRW, ob1 = ring_back(s0, 2, WD) * WRW;
       const float4 b00 = make_float4((&rg.vx[0][0])[ob0 + li], (&rg.vy[0][0])[ob0 + li], (&rg.P[0][0])[ob0 + li], (&rg.T[0][0])[ob0 + li]);
       const char4 w00 = (&rg.wl[0][0])[ob0 + li];
       if (t >= 5) {
-        const int yb = wrapmod(r - 3, Y);
-        MWBoundaryAcc a{rg, in, li, ob0, ob1, b00, q_cur, w00, wD, vxD, TD, qzD, qwD, vf, vfLy, vfDx, ly1, fb_cur, dep_cur, HAS_FB && fb_cur_have, X, Y, col, yb};
+        const int yb = yw_m3;
+        const bool top = yb + 1 > Y - 1; // light_0 is CLAMP_TO_EDGE in y: the row "above" the top row is the top row itself
+        MWBoundaryAcc a{rg, li, ob0, ob1, b00, q1, q_up, w00, wD, vxD, TD, qzD, qwD, qzL, qwL, qzR, qwR, vf, vfLy, vfDx,
+                        l0x1, l0y1, top ? l0x1 : l0x_cur, top ? l0y1 : l0y_cur, fb_cur, dep_cur, HAS_FB && fb_cur_have};
         float4 bb, bq;
         char4 bwl;
-        boundary_cell(u, iterNum, iterI, g, ctx->initial_T, col, yb, a, bb, bq, bwl);
+#ifdef WX_ABL_NOBOUNDARY // (ablation builds for the per-stage instruction budget; not bit-exact)
+        bb = a.base(0, 0);
+        bq = a.water(0, 0);
+        bwl = a.wall(0, 0);
+        bb.x += vf.x + vfLy + vfDx;
+#else
+        boundary_cell(u, iterNum, iterI, g, initial_T, col, yb, a, bb, bq, bwl);
+#endif
         wave_fence(); // every lane has read its neighbours' pre-boundary values
         (&rg.vx[0][0])[ob0 + li] = bb.x;
         (&rg.vy[0][0])[ob0 + li] = bb.y;
         (&rg.T[0][0])[ob0 + li] = bb.w;
         (&rg.wl[0][0])[ob0 + li] = bwl;
-        const int oq = ((rc - 3) % WQ) * WRW;
-        (&rg.qx[0][0])[oq + li] = bq.x;
-        (&rg.qy[0][0])[oq + li] = bq.y;
-        (&rg.qz[0][0])[oq + li] = bq.z;
-        (&rg.qw[0][0])[oq + li] = bq.w;
+        const int oq = sq3 * WRW + li;
+        (&rg.qx[0][0])[oq] = bq.x;
+        (&rg.qy[0][0])[oq] = bq.y;
+        (&rg.qz[0][0])[oq] = bq.z;
+        (&rg.qw[0][0])[oq] = bq.w;
         // back-traces of this row that may leave the 3x3 cells? (lanes 2 .. 60 feed an advection that is used)
         big1 = __any(lane >= 2 && lane <= 60 && !(fmaxf(fabsf(bb.x), fabsf(bb.y)) < 0.9f));
         if (OPT_OUT) {
@@ -443,17 +541,18 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
       TD = b00.w;
       vxD = b00.x;
       wD = w00;
-      qzD = q_cur.z;
-      qwD = q_cur.w;
+      qzD = q1.z;
+      qwD = q1.w;
     }
     wave_fence();
 
     // ---- advection of row ya = r-4 ----
     if (t >= 7) {
-      const int ya = wrapmod(r - 4, Y);
+      const int ya = yw_m4;
       float4 ab, aw;
       char4 awl;
-      MWAdvAcc a{rg, li, {((rc - 5) % WD) * WRW, ((rc - 4) % WD) * WRW, ((rc - 3) % WD) * WRW}, {((rc - 5) % WQ) * WRW, ((rc - 4) % WQ) * WRW, ((rc - 3) % WQ) * WRW}};
+      MWAdvAcc a{rg, li, {ring_back(s0, 5, WD) * WRW, ring_back(s0, 4, WD) * WRW, ring_back(s0, 3, WD) * WRW},
+                 {ring_back(sq3, 2, WQ) * WRW, ring_back(sq3, 1, WQ) * WRW, sq3 * WRW}};
       bool fast = true;
       if (big1 | big2 | big3) { // wave-uniform: some velocity of rows ya-1 .. ya+1 is large -> per-lane test of the eight that matter
         const float *vxp = &rg.vx[0][0], *vyp = &rg.vy[0][0];
@@ -461,39 +560,39 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
         const float m = fmaxf(fmaxf(fmaxf(fabsf(vxp[o0]), fabsf(vxp[o0 - 1])), fmaxf(fabsf(vxp[op]), fabsf(vxp[op - 1]))),
                               fmaxf(fmaxf(fabsf(vyp[o0]), fabsf(vyp[om])), fmaxf(fabsf(vyp[o0 + 1]), fabsf(vyp[om + 1]))));
         fast = m < 0.9f || lane < 3 || lane > 59; // (lanes outside 3 .. 59 feed nothing)
+        // rows with such cells are recorded (from the first one on, every row: the array is not cleared between launches)
+        const unsigned long long mask = __ballot(!fast);
+        const int idx = t - 7; // == (r - 4) - (y_lo - 1)
+        if (mask != 0ull && first_slow == 0x7fffffff) first_slow = idx;
       }
+      if (first_slow != 0x7fffffff) {
+        const unsigned long long mask = __ballot(!fast);
+        if (lane == 0) __hip_atomic_store(&my_slow[t - 7], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#ifdef WX_ABL_NOADV
+      fast = false;
+#endif
       if (fast) {
-        advection_cell(u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, col, ya, a, ab, aw, awl);
-      } else { // exact out-of-line path (post-boundary texels recomputed from global memory)
-        // the out-of-line function takes the input pointers from memory: the kernel-argument segment already holds them
-        struct KArgs {
-          const FullCtx *ctx;
-          float iterNum;
-          WetIn in;
-        };
-        const WetIn *in_mem = reinterpret_cast<const WetIn *>((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KArgs, in));
-        const AdvOut o = wet_advection_cell_recompute(ctx, in_mem, iterNum, col, ya);
-        ab = o.b;
-        aw = o.w;
-        awl = o.wl;
+        advection_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
+      } else { // placeholder (the post-boundary texel): this cell and the two it feeds are recomputed after the loop
+        ab = a.base(0, 0);
+        aw = a.water_off(0, 0);
+        awl = a.wall(0, 0);
       }
-      // ---- pressure + lighting of row ya -> stores ----
+      // ---- pressure + lighting of row ya: kept in registers, stored at the top of the next step ----
       const float vx_l = wave_from_left(ab.x);
       if (t >= 8) {
-        const float4 p = pressure_cell(ab, vx_l, adv_vy_prev, adv_T_prev, adv_w_prev.x, adv_w_prev.y);
-        MWLightAcc la{rg, li, r - 4, ab.w, adv_T_prev, lz1, aw, awl};
-        const float4 l = lighting_cell(u, g, col, r - 4, la);
-        if (lane_out) {
-          const size_t gi = fidx(c_out, r - 4, X);
-          out.base[gi] = p;
-          out.water[gi] = aw;
-          out.wall[gi] = awl;
-          out.light.x[gi] = l.x;
-          out.light.y[gi] = l.y;
-          out.light.zw[gi] = make_float2(l.z, l.w);
-          if (OPT_OUT) out.base_disp[gi] = ab;
-          if (out.t_disp) out.t_disp[gi] = ab.w;
-        }
+        st_p = pressure_cell(ab, vx_l, adv_vy_prev, adv_T_prev, adv_w_prev.x, adv_w_prev.y);
+        MWLightAcc la{rg, li, ab.w, adv_T_prev, lz1, aw, awl};
+#ifdef WX_ABL_NOLIGHT
+        st_l = make_float4(la.sun_at(0, r - 4), la.ir_up_at(r - 5), lz1, ab.w);
+#else
+        st_l = lighting_cell(u, g, col, r - 4, la);
+#endif
+        st_q = aw;
+        st_w = awl;
+        st_ab = ab;
+        st_valid = true;
       }
       adv_vy_prev = ab.y;
       adv_T_prev = ab.w;
@@ -502,19 +601,67 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
     // ---- rotate the carried rows ----
     b_prev = b_cur;
     w_prev = w_raw;
+    q1 = q_up;
     v1x = v0x;
     v1y = v0y;
     c2 = c1;
     c1 = c0;
     vfDx = vf.x;
-    ly1 = ly_cur;
+    l0x1 = l0x_cur;
+    l0y1 = l0y_cur;
     lz1 = lzw_cur.x;
     big3 = big2;
     big2 = big1;
+    s0 = s0 + 1 == WD ? 0 : s0 + 1;
+    sq3 = sq3 + 1 == WQ ? 0 : sq3 + 1;
+    yw_m4 = yw_m3;
+    yw_m3 = yw_m2;
+    yw_m2 = yw_m1;
+    yw_m1 = yw_m1 + 1 == Y ? 0 : yw_m1 + 1;
+    yw_p1 = yw_p1 + 1 == Y ? 0 : yw_p1 + 1;
+  }
+  // ---- the last row ----
+  if (st_valid && lane_out) {
+    const size_t gi = fidx(c_out, y_hi - 1, X);
+    out.base[gi] = st_p;
+    out.water[gi] = st_q;
+    out.wall[gi] = st_w;
+    out.light.x[gi] = st_l.x;
+    out.light.y[gi] = st_l.y;
+    out.light.zw[gi] = make_float2(st_l.z, st_l.w);
+    if (OPT_OUT) out.base_disp[gi] = st_ab;
+    if (out.t_disp) out.t_disp[gi] = st_ab.w;
+  }
+  // ---- exact path for the recorded cells: cell (x, y) feeds the outputs (x, y), (x+1, y) [pressure: vx of the left neighbour]
+  //      and (x, y+1) [pressure / lighting: vy, T and wall of the lower neighbour]; each lane redoes those of them this wave owns ----
+  if (first_slow != 0x7fffffff) {
+    struct KArgs { // the kernel-argument segment holds the pointer structs the out-of-line function takes from memory
+      const FullCtx *ctx;
+      float iterNum;
+      WetIn in;
+      WetOut out;
+    };
+    const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+    const WetIn *in_mem = reinterpret_cast<const WetIn *>(ka + offsetof(KArgs, in));
+    const WetOut *out_mem = reinterpret_cast<const WetOut *>(ka + offsetof(KArgs, out));
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // own stores (placeholder rows) before the corrections, masks before their read-back
+    for (int idx = first_slow; idx <= y_hi - y_lo; idx++) {
+      const unsigned long long mask = __hip_atomic_load(&my_slow[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!((mask >> lane) & 1ull)) continue;
+      const int yu = y_lo - 1 + idx; // unwrapped row of the recorded cell
+      if (lane_out && idx >= 1) wet_output_cell_exact(ctx, in_mem, out_mem, iterNum, OPT_OUT, c_out, yu);
+      if (lane + 1 >= WLO && lane + 1 < WLO + WOUT && c_out + 1 < X && idx >= 1) wet_output_cell_exact(ctx, in_mem, out_mem, iterNum, OPT_OUT, c_out + 1, yu);
+      if (lane_out && yu + 1 < y_hi) wet_output_cell_exact(ctx, in_mem, out_mem, iterNum, OPT_OUT, c_out, yu + 1);
+    }
   }
 }
 
-// Segment height: as in wx_march.h -- the number of waves is just under a whole multiple of what the device holds at once.
+// Segment height: the hardware deals workgroups to CUs as earlier ones retire, and rows near terrain cost more than free air
+// (surface branches of the boundary pass), so the grid is cut into about WX_WET_ROUNDS times as many waves as the device holds
+// at once: the expensive bottom segments are dispatched first, the cheap ones fill the gaps.
+#ifndef WX_WET_ROUNDS
+#define WX_WET_ROUNDS 2
+#endif
 inline int wet_seg_rows(int n_strips, int Y)
 {
   static int capacity = 0;
@@ -528,9 +675,10 @@ inline int wet_seg_rows(int n_strips, int Y)
     if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] CUs=%d blocks/CU=%d capacity=%d\n", ncu, nb, capacity);
   }
   if (const char *e = getenv("WX_WET_SEG")) return atoi(e) < Y ? (atoi(e) > 0 ? atoi(e) : Y) : Y;
-  int maxseg = WX_WET_MAXSEG;
+  int maxseg = WX_WET_MAXSEG, rounds = WX_WET_ROUNDS;
   if (const char *e = getenv("WX_WET_MAXSEG")) maxseg = atoi(e) > 0 ? atoi(e) : maxseg;
-  for (int k = 1; k < 64; k++) {
+  if (const char *e = getenv("WX_WET_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
+  for (int k = rounds; k < 64; k++) {
     const int nseg = (int)((long long)k * capacity / n_strips);
     if (nseg < 1) continue;
     const int rows = (Y + nseg - 1) / nseg;
@@ -539,18 +687,31 @@ inline int wet_seg_rows(int n_strips, int Y)
   return maxseg < Y ? maxseg : Y;
 }
 
-inline void launch_march_wet(const Geo &g, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, bool opt_out, hipStream_t stream)
+struct WetLaunch {
+  int n_strips, seg_rows, n_seg;
+  size_t slow_entries; // 64-bit masks the launch may write
+};
+inline WetLaunch wet_launch_shape(const Geo &g)
 {
-  const int n_strips = (g.X + WOUT - 1) / WOUT;
-  const int seg_rows = wet_seg_rows(n_strips, g.Y), n_seg = (g.Y + seg_rows - 1) / seg_rows;
-  const dim3 grid(8 * ((n_strips * n_seg + 7) / 8));
+  WetLaunch w;
+  w.n_strips = (g.X + WOUT - 1) / WOUT;
+  w.seg_rows = wet_seg_rows(w.n_strips, g.Y);
+  w.n_seg = (g.Y + w.seg_rows - 1) / w.seg_rows;
+  w.slow_entries = (size_t)w.n_strips * w.n_seg * (w.seg_rows + 1);
+  return w;
+}
+
+inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, unsigned long long *slow_rows,
+                             bool opt_out, hipStream_t stream)
+{
+  const dim3 grid(8 * ((w.n_strips + 7) / 8) * w.n_seg); // 8 XCDs x (largest column block) x segments; surplus workgroups exit at once
   static bool dbg = getenv("WX_MARCH_DEBUG") != nullptr;
   if (dbg) {
-    fprintf(stderr, "[wx_wet] strips=%d seg_rows=%d segs=%d waves=%d\n", n_strips, seg_rows, n_seg, n_strips * n_seg);
+    fprintf(stderr, "[wx_wet] strips=%d seg_rows=%d segs=%d waves=%d\n", w.n_strips, w.seg_rows, w.n_seg, w.n_strips * w.n_seg);
     dbg = false;
   }
   const bool has_fb = in.fb != nullptr;
-#define WX_LAUNCH_W(O, F) hipLaunchKernelGGL((k_march_wet<O, F>), grid, dim3(64), 0, stream, ctx, iterNum, in, out, n_strips, seg_rows)
+#define WX_LAUNCH_W(O, F) hipLaunchKernelGGL((k_march_wet<O, F>), grid, dim3(64), 0, stream, ctx, iterNum, in, out, slow_rows, w.n_strips, w.seg_rows)
   if (opt_out) {
     if (has_fb) WX_LAUNCH_W(true, true); else WX_LAUNCH_W(true, false);
   } else {

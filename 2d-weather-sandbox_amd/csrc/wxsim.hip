@@ -114,6 +114,8 @@ struct wx_sim {
   unsigned int *cow_clean = nullptr;   // per 64x16 tile: kernel A left water[0] / wall[1] unwritten
   bool cow_pending = false;            // water[0] has unwritten tiles whose values live in water[2]
   FullCtx *full_ctx = nullptr;
+  unsigned long long *slow_rows = nullptr; // marching wet kernel: per-wave row masks of the cells left to the exact path
+  size_t slow_cap = 0;
   SplatGrid sg{};              // particle splat accumulation (allocated when the handle has droplets)
   bool fb_dirty = false; // feedback/deposition hold non-zero data (particles ran last iteration)
   bool water_trivial = false; // the water texture is known to be 0 in air cells and only the wall marker in wall cells: set by wx_upload,
@@ -474,9 +476,18 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip)
   WetIn in{s->base[0], s->wall[0], s->water[1], LightPlanesC{s->lp[0].x, s->lp[0].y, s->lp[0].zw},
            LightPlanesC{s->lp[src].x, s->lp[src].y, s->lp[src].zw}, fb ? s->fb : nullptr, fb ? s->dep : nullptr, fb ? s->sg.fb_zero : nullptr, s->sg.TXn};
   WetOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], s->water[0], s->curl, precip ? s->tdisp : nullptr};
+  const WetLaunch shape = wet_launch_shape(s->geo);
+  if (shape.slow_entries > s->slow_cap) { // (once per handle; the kernel writes a row's mask before it reads it: no clearing)
+    hipStreamSynchronize(s->stream);
+    hipFree(s->slow_rows);
+    s->slow_rows = nullptr;
+    s->slow_cap = 0;
+    if (hipMalloc((void **)&s->slow_rows, shape.slow_entries * 8) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_step: %zu bytes for the marching kernel's row masks", shape.slow_entries * 8);
+    s->slow_cap = shape.slow_entries;
+  }
   {
     ProfScope ps(s, K_MARCH_WET);
-    launch_march_wet(s->geo, (float)s->iter, s->full_ctx, in, out, opt_out, s->stream);
+    launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream);
   }
   std::swap(s->base[0], s->base[1]);
   std::swap(s->wall[0], s->wall[1]);
@@ -658,6 +669,7 @@ void wx_destroy(wx_sim *s)
   }
   hipFree(s->cow_clean);
   hipFree(s->full_ctx);
+  hipFree(s->slow_rows);
   hipFree(s->water[2]);
   hipFree(s->sg.acc4);
   hipFree(s->sg.acc2);
@@ -834,8 +846,10 @@ int wx_step(wx_sim *s, int n_iter)
   for (int it = 0; it < n_iter; it++) {
     if (dry)
       iterate_dry(s, precip || it == n_iter - 1);
-    else if (fused && s->fused >= 2)
-      iterate_march_wet(s, it == n_iter - 1, precip);
+    else if (fused && s->fused >= 2) {
+      const int rc = iterate_march_wet(s, it == n_iter - 1, precip);
+      if (rc != WX_OK) return rc;
+    }
     else if (fused)
       iterate_fused(s, it == n_iter - 1, precip);
     else
