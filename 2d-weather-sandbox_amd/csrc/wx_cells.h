@@ -88,6 +88,10 @@ struct Uni {
   float a_invTexY;                 // 1.0 / texelSize.y                     (advectionShader.frag:162)
   float a_aspect;                  // texelSize.y / texelSize.x             (advectionShader.frag:247)
   float chc;                       // cellHeightCompensation = 300. / resolution.y (lightingShader.frag:44)
+  // the sun-ray tap of the lighting pass (lightingShader.frag:48-49) when fragCoord is exactly x + 0.5 (quad_scale == 0): offset,
+  // filter weights and their four products are then the same for every cell
+  int sun_uniform, sun_dx0, sun_fv;
+  float sun_w00, sun_w10, sun_w01, sun_w11;
   // per iteration
   float iterNum;
   int iterI; // int(iterNum)
@@ -224,7 +228,14 @@ __device__ __forceinline__ float calcFireIntensity(int veg, float moist, float p
   return fmaxf((float)veg * 0.00025f - moist * 0.00020f - precip * 0.02f, 0.0f);
 }
 
-template <class UT, class FP, class A>
+// AIR (a wave-uniform fact established by the caller, see air_cell()): the cell and its four neighbours are fluid and the wall
+// below is at least 8 rows away -- every surface branch below is then statically dead; the arithmetic that remains is
+// the same instruction sequence, so the results are bit-identical to the general instantiation.
+__device__ __forceinline__ bool air_cell(char4 w0, char4 wL, char4 wD, char4 wR, char4 wU)
+{
+  return w0.y != 0 && wL.y != 0 && wD.y != 0 && wR.y != 0 && wU.y != 0 && wD.z >= 8;
+}
+template <bool AIR = false, class UT, class FP, class A>
 __device__ __forceinline__ void boundary_cell(const UT &u, const float iterNum, const int iterI, const Geo &g, const FP initial_T,
                                               int x, int y, const A &a, float4 &base_out, float4 &water_out, char4 &wall_out)
 {
@@ -243,7 +254,7 @@ __device__ __forceinline__ void boundary_cell(const UT &u, const float iterNum, 
 
   wl[VERT_DISTANCE] = wD.z + 1;
 
-  if (wl[DISTANCE] != 0) { // fluid
+  if (AIR || wl[DISTANCE] != 0) { // fluid
     const float light_y = a.light_y0();
     const bool has_fb = a.has_fb(); // wave-uniform: false while no particle has ever written feedback
     const float4 fb = a.fb();
@@ -280,7 +291,7 @@ __device__ __forceinline__ void boundary_cell(const UT &u, const float iterNum, 
 
     float snowCover = 0.0f, soilMoisture = 0.0f;
 
-    if (wD.y == 0) { // below is wall
+    if (!AIR && wD.y == 0) { // below is wall
       nextToWall = true;
       wl[DISTANCE] = 1;
       const float4 wtD = a.water(0, -1);
@@ -288,7 +299,7 @@ __device__ __forceinline__ void boundary_cell(const UT &u, const float iterNum, 
       soilMoisture = wtD.z;
       wl[VERT_DISTANCE] = 1;
     }
-    if (wL.y == 0) { // left is wall
+    if (!AIR && wL.y == 0) { // left is wall
       nextToWall = true;
       wl[DISTANCE] = 1;
       if (wL.x == WALLTYPE_WATER) {
@@ -296,7 +307,7 @@ __device__ __forceinline__ void boundary_cell(const UT &u, const float iterNum, 
         wl[DISTANCE] = 0;
       }
       if (wR.y == 0) wl[DISTANCE] = 0;
-    } else if (wR.y == 0) { // right is wall
+    } else if (!AIR && wR.y == 0) { // right is wall
       nextToWall = true;
       wl[DISTANCE] = 1;
       if (wR.x == WALLTYPE_WATER) {
@@ -304,7 +315,7 @@ __device__ __forceinline__ void boundary_cell(const UT &u, const float iterNum, 
         wl[DISTANCE] = 0;
       }
     }
-    if (wU.y == 0) { // above is wall
+    if (!AIR && wU.y == 0) { // above is wall
       nextToWall = true;
       wl[DISTANCE] = 1;
       if (tcy < 0.99f) wl[DISTANCE] = 0;
@@ -316,7 +327,7 @@ __device__ __forceinline__ void boundary_cell(const UT &u, const float iterNum, 
     b.x += (vf00.x + vfD.x) * (u.vorticity + velocityFactor);
     b.y += (vf00.y + vfL.y) * (u.vorticity + velocityFactor);
 
-    if (nextToWall) {
+    if (!AIR && nextToWall) {
       if (wl[TYPE] != WALLTYPE_WATER) {
         float lightPower = 0.0f;
         const float light_x = a.light_x0();
@@ -342,7 +353,7 @@ __device__ __forceinline__ void boundary_cell(const UT &u, const float iterNum, 
       }
     }
 
-    if (!nextToWall) {
+    if (AIR || !nextToWall) {
       int nearest = 255;
       if (wD.y < nearest) nearest = wD.y;
       if (wU.y < nearest) nearest = wU.y;
@@ -351,7 +362,7 @@ __device__ __forceinline__ void boundary_cell(const UT &u, const float iterNum, 
       wl[DISTANCE] = nearest + 1;
     }
 
-    if (wl[VERT_DISTANCE] <= 5) { // surfaceWindSmootingDist :271-303
+    if (!AIR && wl[VERT_DISTANCE] <= 5) { // surfaceWindSmootingDist :271-303
       if (wl[VERT_DISTANCE] == 1) {
         float surfaceDrag = 0.0015f;
         if (wl[TYPE] == WALLTYPE_URBAN)
@@ -364,7 +375,7 @@ __device__ __forceinline__ void boundary_cell(const UT &u, const float iterNum, 
       if (wD.z > 0) b.x -= (b.x - a.base(0, -1).x) * exchangeRate;
     }
 
-    if (wl[VERT_DISTANCE] <= 8) { // :305-372
+    if (!AIR && wl[VERT_DISTANCE] <= 8) { // :305-372
       wl[VEGETATION] = wD.w;
       const float4 waterInSurface = a.water(0, -1);
       const int t = wl[TYPE];
@@ -572,7 +583,9 @@ __device__ __forceinline__ float smoothstepf(float e0, float e1, float x)
 // NO_WATER: the water texture is identically zero in air cells (BASELINE config 1, checked by the host) and no
 // sounding forcing is active: the water interpolation and the phase-change block then provably leave base unchanged
 // (condensation = max(negative * 0.2, -0) = -0, dT = -0) and water zero, so they are not evaluated.
-template <bool NO_WATER = false, class UT, class FP, class A>
+// NO_WALL (wave-uniform, established by the caller): neither the cell nor any texel of its back-trace footprints is a wall
+// cell, so the wall-aware interpolation reduces to the plain one (same weights, same operations) and the wall branch is dead.
+template <bool NO_WATER = false, bool NO_WALL = false, class UT, class FP, class A>
 __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const FP initial_T, const FP snd_T, const FP snd_W, const FP snd_Vel, int x, int y,
                                                const A &a, float4 &base_out,
                                                float4 &water_out, char4 &wall_out)
@@ -584,7 +597,7 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
   int wl[4] = {w0.x, w0.y, w0.z, w0.w};
   float4 b, w;
 
-  if (wl[DISTANCE] != 0) { // not wall
+  if (NO_WALL || wl[DISTANCE] != 0) { // not wall
     const float4 c00 = a.base(0, 0), cL = a.base(-1, 0), cD = a.base(0, -1), cR = a.base(1, 0), cU = a.base(0, 1);
     const float4 cLU = a.base(-1, 1), cRD = a.base(1, -1);
 
@@ -606,21 +619,23 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
       // bilerpWall at velAtP (common.glsl:216-254): P, T and water.xyw share one footprint
       const Taps t = mktaps(cc, y, fx - velAtP_x, fy - velAtP_y);
       const auto f = make_fp(a, t.dx0, t.dy0);
-      const int wa = f.wall(0, 0).y, wb = f.wall(1, 0).y;
-      const int wc = f.wall(0, 1).y, wd = f.wall(1, 1).y;
       float mAB = t.fx, mCD = t.fx, mY = t.fy;
-      if (wa == 0)
-        mAB = 1.0f;
-      else if (wb == 0)
-        mAB = 0.0f;
-      if (wc == 0)
-        mCD = 1.0f;
-      else if (wd == 0)
-        mCD = 0.0f;
-      if (wa == 0 && wb == 0)
-        mY = 1.0f;
-      else if (wc == 0 && wd == 0)
-        mY = 0.0f;
+      if (!NO_WALL) {
+        const int wa = f.wall(0, 0).y, wb = f.wall(1, 0).y;
+        const int wc = f.wall(0, 1).y, wd = f.wall(1, 1).y;
+        if (wa == 0)
+          mAB = 1.0f;
+        else if (wb == 0)
+          mAB = 0.0f;
+        if (wc == 0)
+          mCD = 1.0f;
+        else if (wd == 0)
+          mCD = 0.0f;
+        if (wa == 0 && wb == 0)
+          mY = 1.0f;
+        else if (wc == 0 && wd == 0)
+          mY = 0.0f;
+      }
       const float4 ba = f.base(0, 0), bb = f.base(1, 0);
       const float4 bc = f.base(0, 1), bd = f.base(1, 1);
       b.z = bilerp4(ba.z, bb.z, bc.z, bd.z, mAB, mCD, mY);
@@ -641,21 +656,23 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
       // precipitation visualisation channel, +0.05 in y (:103)
       const Taps t = mktaps(cc, y, fx - velAtP_x + 0.0f, fy - velAtP_y + 0.05f);
       const auto f = make_fp(a, t.dx0, t.dy0);
-      const int wa = f.wall(0, 0).y, wb = f.wall(1, 0).y;
-      const int wc = f.wall(0, 1).y, wd = f.wall(1, 1).y;
       float mAB = t.fx, mCD = t.fx, mY = t.fy;
-      if (wa == 0)
-        mAB = 1.0f;
-      else if (wb == 0)
-        mAB = 0.0f;
-      if (wc == 0)
-        mCD = 1.0f;
-      else if (wd == 0)
-        mCD = 0.0f;
-      if (wa == 0 && wb == 0)
-        mY = 1.0f;
-      else if (wc == 0 && wd == 0)
-        mY = 0.0f;
+      if (!NO_WALL) {
+        const int wa = f.wall(0, 0).y, wb = f.wall(1, 0).y;
+        const int wc = f.wall(0, 1).y, wd = f.wall(1, 1).y;
+        if (wa == 0)
+          mAB = 1.0f;
+        else if (wb == 0)
+          mAB = 0.0f;
+        if (wc == 0)
+          mCD = 1.0f;
+        else if (wd == 0)
+          mCD = 0.0f;
+        if (wa == 0 && wb == 0)
+          mY = 1.0f;
+        else if (wc == 0 && wd == 0)
+          mY = 0.0f;
+      }
       w.z = bilerp4(f.water(0, 0).z, f.water(1, 0).z, f.water(0, 1).z, f.water(1, 1).z, mAB, mCD, mY);
     }
 
@@ -873,7 +890,8 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
 //             (wrapped; 0 for the IR channels), ROW j (absolute,
 //             caller clamps) ; used for the bilinear sun tap and the IR taps
 // ------------------------------------------------------------------------------------------------
-template <class UT, class A>
+// AIR (wave-uniform, established by the caller): the cell is fluid and not directly above a wall (wall.y != 0, wall.z != 1).
+template <bool AIR = false, class UT, class A>
 __device__ __forceinline__ float4 lighting_cell(const UT &u, const Geo &g, int x, int y, const A &a)
 {
   const CellCoord cc = cellcoord(g, x, y);
@@ -886,7 +904,15 @@ __device__ __forceinline__ float4 lighting_cell(const UT &u, const Geo &g, int x
   // :48-49 LINEAR tap at texCoord + (sin a, cos a) texels, S=REPEAT T=CLAMP_TO_EDGE. The filter weights are
   // the exact fp32 fractions of the offset (weight precision is implementation defined in GL).
   float sunlight;
-  {
+  if (u.sun_uniform) { // (uniform branch) the same taps and the same products as below, computed once on the host
+    const int dx0 = u.sun_dx0;
+    int j0 = y + u.sun_fv, j1 = y + u.sun_fv + 1;
+    j0 = j0 < 0 ? 0 : (j0 > Y - 1 ? Y - 1 : j0);
+    j1 = j1 < 0 ? 0 : (j1 > Y - 1 ? Y - 1 : j1);
+    const float t00 = a.sun_at(dx0, j0), t10 = a.sun_at(dx0 + 1, j0);
+    const float t01 = a.sun_at(dx0, j1), t11 = a.sun_at(dx0 + 1, j1);
+    sunlight = u.sun_w00 * t00 + u.sun_w10 * t10 + u.sun_w01 * t01 + u.sun_w11 * t11;
+  } else {
     const float ox = (cc.fx - ((float)cc.gx + 0.5f)) + u.sin_a;
     const float oy = (fy - ((float)y + 0.5f)) + u.cos_a;
     const float fu = floorf(ox), fv = floorf(oy);
@@ -904,7 +930,7 @@ __device__ __forceinline__ float4 lighting_cell(const UT &u, const Geo &g, int x
   const float4 water = a.water();
   const char4 wall = a.wall();
 
-  if (wall.y != 0) {
+  if (AIR || wall.y != 0) {
     float net_heating = 0.0f;
     if (fy < resY - 2.0f) {
       float reflection = fminf(sqrtf(water.y * 0.0010f + water.z * 0.00020f) * cellHeightCompensation, 1.0f); // pow(x, 0.5)
@@ -919,7 +945,7 @@ __device__ __forceinline__ float4 lighting_cell(const UT &u, const Geo &g, int x
     const int yd = (y == 0) ? 0 : y - 1;
     float IR_down = a.ir_down_at(yu);
     float IR_up = 0.0f; // unassigned for air above an INERT wall (:90) -> 0
-    if (wall.z == 1) {
+    if (!AIR && wall.z == 1) {
       switch (wall.x) {
       case WALLTYPE_RUNWAY:
       case WALLTYPE_URBAN:

@@ -39,6 +39,9 @@ namespace wx {
 #ifndef WX_WET_UNI_COPY
 #define WX_WET_UNI_COPY 0
 #endif
+#ifndef WX_WET_AIR
+#define WX_WET_AIR 1 // wave-uniform free-air instantiations of the boundary / advection / lighting stages
+#endif
 #ifndef WX_WET_MAXSEG
 #define WX_WET_MAXSEG 640 // upper bound of the rows one wave marches (8 warm-up rows per segment are redundant work)
 #endif
@@ -327,6 +330,35 @@ struct MWLightAcc {
   __device__ __forceinline__ float ir_up_at(int j) const { return rg.lw[(j + 8) & (WL - 1)][li]; } // row max(y-1, 0)
 };
 
+// global access as (wave-uniform row pointer) + (per-lane 32-bit byte offset): the form the hardware addresses with a scalar base
+// register pair and one offset VGPR -- no 64-bit vector arithmetic per access
+// (the readfirstlane pair pins the row pointer to scalar registers and keeps the loop optimiser from turning the access into a
+// per-lane 64-bit pointer induction variable)
+__device__ __forceinline__ unsigned long long uniform_addr(const void *p)
+{
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> __device__ __forceinline__ T ld_row(const T *row, unsigned byte_off)
+{
+  typedef const __attribute__((address_space(1))) char *GBytes; // (an integer round trip would otherwise yield a generic "flat" pointer)
+  typedef const __attribute__((address_space(1))) T *GPtr;
+  asm("" : "+v"(byte_off)); // keeps the zero-extension next to the access: instruction selection folds it only within a block
+  return *(GPtr)((GBytes)uniform_addr(row) + byte_off);
+}
+template <class T> __device__ __forceinline__ void st_row(T *row, unsigned byte_off, T v)
+{
+  typedef __attribute__((address_space(1))) char *GBytes;
+  typedef __attribute__((address_space(1))) T *GPtr;
+  asm("" : "+v"(byte_off));
+  *(GPtr)((GBytes)uniform_addr(row) + byte_off) = v;
+}
+#else // host pass of the single-source compile: same meaning, never executed
+template <class T> __device__ __forceinline__ T ld_row(const T *row, unsigned byte_off) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(row) + byte_off); }
+template <class T> __device__ __forceinline__ void st_row(T *row, unsigned byte_off, T v) { *reinterpret_cast<T *>(reinterpret_cast<char *>(row) + byte_off) = v; }
+#endif
 __device__ __forceinline__ int ring_back(int s, int k, int n) // slot of the row k steps behind the one in slot s (ring of n)
 {
   const int v = s - k;
@@ -366,6 +398,8 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
   const int c_out = strip * WOUT + lane - WLO; // output column of this lane (may be >= X in the last strip, < 0 in the first)
   const int col = wrapmod(c_out, X);           // column this lane loads / computes
   const bool lane_out = lane >= WLO && lane < WLO + WOUT && c_out < X;
+  const unsigned lo4 = (unsigned)col * 4u, lo8 = (unsigned)col * 8u, lo16 = (unsigned)col * 16u; // byte offsets of the loaded column
+  const unsigned so4 = lane_out ? (unsigned)c_out * 4u : 0u, so8 = so4 * 2u, so16 = so4 * 4u;    // ... of the stored column
   const int y_lo = seg * seg_rows, y_hi = min(y_lo + seg_rows, Y);
   const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
   unsigned long long *__restrict__ my_slow = slow_rows + (size_t)item * (seg_rows + 1);
@@ -390,6 +424,7 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
   float adv_vy_prev = 0.f, adv_T_prev = 0.f;                          // advection output row r-5
   char4 adv_w_prev = make_char4(0, 0, 0, 0);
   int big1 = 0, big2 = 0, big3 = 0;                                   // "some |v| >= 0.9" of post-boundary rows r-3, r-4, r-5
+  int nowall1 = 0, nowall2 = 0, nowall3 = 0;                          // "no wall cell" of the same rows
   // outputs of the previous step, stored at the top of this one
   float4 st_p = make_float4(0.f, 0.f, 0.f, 0.f), st_q = st_p, st_l = st_p, st_ab = st_p;
   char4 st_w = make_char4(0, 0, 0, 0);
@@ -398,9 +433,9 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
 
   int r = y_lo - 4;
   { // prefetch of the first row
-    const size_t gi = fidx(col, wrapmod(r, Y), X);
-    pf_b = in.base[gi];
-    pf_w = wall_raw[gi];
+    const size_t e = (size_t)wrapmod(r, Y) * X;
+    pf_b = ld_row(in.base + e, lo16);
+    pf_w = ld_row(wall_raw + e, lo4);
   }
   int s0 = (r + 12) % WD, sq3 = (r - 3 + 12) % WQ; // ring slots of row r (base / wall planes) and of row r-3 (water planes)
   // wrapped (REPEAT) row indices of rows r+1, r-1 .. r-4, advanced by one per step (a general modulo costs ~20 scalar instructions)
@@ -418,28 +453,28 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
     // ---- software prefetch: the loads of the next step are in flight while this one computes ----
     if (r < y_hi + 3) {
       {
-        const size_t gi = fidx(col, yw_p1, X);
-        pf_b = in.base[gi];
-        pf_w = wall_raw[gi];
+        const size_t e = (size_t)yw_p1 * X;
+        pf_b = ld_row(in.base + e, lo16);
+        pf_w = ld_row(wall_raw + e, lo4);
       }
       {
         const int rl = r - 1;
-        const size_t gw = fidx(col, yw_m1, X);
-        pf_q = in.water[gw];
+        const size_t ew = (size_t)yw_m1 * X;
+        pf_q = ld_row(in.water + ew, lo16);
         // light textures clamp in y (sun ray / IR taps of the lighting pass) ...
-        const size_t gl = fidx(col, rl < 0 ? 0 : (rl > Y - 1 ? Y - 1 : rl), X);
-        pf_lx = in.lsrc.x[gl];
-        pf_lzw = in.lsrc.zw[gl];
+        const size_t el = (size_t)(rl < 0 ? 0 : (rl > Y - 1 ? Y - 1 : rl)) * X;
+        pf_lx = ld_row(in.lsrc.x + el, lo4);
+        pf_lzw = ld_row(in.lsrc.zw + el, lo8);
         // ... while the boundary pass samples light_0 at its own (wrapped) row and at the row above it, clamped
-        pf_l0x = in.l0.x[gw];
-        pf_l0y = in.l0.y[gw];
+        pf_l0x = ld_row(in.l0.x + ew, lo4);
+        pf_l0y = ld_row(in.l0.y + ew, lo4);
       }
       if (HAS_FB) {
         fb_have = fb_need_next; // decided one step ago for this very row (r-2)
         if (fb_have) {
-          const size_t gi = fidx(col, yw_m2, X);
-          pf_fb = in.fb[gi];
-          pf_dep = in.dep[gi];
+          const size_t e = (size_t)yw_m2 * X;
+          pf_fb = ld_row(in.fb + e, lo16);
+          pf_dep = ld_row(in.dep + e, lo8);
         }
         // the row after: does any of the (up to three) 64x16 tiles under this strip hold feedback?
         const int yn = yw_m1;
@@ -449,15 +484,15 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
     }
     // ---- the stores of the previous step's row (r-5), issued behind the prefetch ----
     if (st_valid && lane_out) {
-      const size_t gi = fidx(c_out, r - 5, X);
-      out.base[gi] = st_p;
-      out.water[gi] = st_q;
-      out.wall[gi] = st_w;
-      out.light.x[gi] = st_l.x;
-      out.light.y[gi] = st_l.y;
-      out.light.zw[gi] = make_float2(st_l.z, st_l.w);
-      if (OPT_OUT) out.base_disp[gi] = st_ab;
-      if (out.t_disp) out.t_disp[gi] = st_ab.w;
+      const size_t e = (size_t)(r - 5) * X;
+      st_row(out.base + e, so16, st_p);
+      st_row(out.water + e, so16, st_q);
+      st_row(out.wall + e, so4, st_w);
+      st_row(out.light.x + e, so4, st_l.x);
+      st_row(out.light.y + e, so4, st_l.y);
+      st_row(out.light.zw + e, so8, make_float2(st_l.z, st_l.w));
+      if (OPT_OUT) st_row(out.base_disp + e, so16, st_ab);
+      if (out.t_disp) st_row(out.t_disp + e, so4, st_ab.w);
     }
     st_valid = false;
     // ---- row r enters the ring: P, T and wall (velocity leaves them unchanged); light row r-2 ----
@@ -485,7 +520,7 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
       c0 = curl_cell(v1x, v1y, wave_from_right(v1y), v0x);
       if (OPT_OUT) {
         const int yc = r - 2;
-        if (lane_out && yc >= y_lo && yc < y_hi) out.curl[fidx(c_out, yc, X)] = c0;
+        if (lane_out && yc >= y_lo && yc < y_hi) st_row(out.curl + (size_t)yc * X, so4, c0);
       }
     }
     float2 vf = make_float2(0.f, 0.f);
@@ -518,7 +553,12 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
         bwl = a.wall(0, 0);
         bb.x += vf.x + vfLy + vfDx;
 #else
-        boundary_cell(u, iterNum, iterI, g, initial_T, col, yb, a, bb, bq, bwl);
+        // free air (no wall within one cell, terrain at least 8 rows below) in every lane that feeds something: the
+        // branch-free instantiation. Most rows of most strips; the general one handles everything else.
+        if (WX_WET_AIR && __all(lane < 2 || lane > 60 || air_cell(w00, a.wall(-1, 0), wD, a.wall(1, 0), a.wall(0, 1))))
+          boundary_cell<true>(u, iterNum, iterI, g, initial_T, col, yb, a, bb, bq, bwl);
+        else
+          boundary_cell<false>(u, iterNum, iterI, g, initial_T, col, yb, a, bb, bq, bwl);
 #endif
         wave_fence(); // every lane has read its neighbours' pre-boundary values
         (&rg.vx[0][0])[ob0 + li] = bb.x;
@@ -532,9 +572,10 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
         (&rg.qw[0][0])[oq] = bq.w;
         // back-traces of this row that may leave the 3x3 cells? (lanes 2 .. 60 feed an advection that is used)
         big1 = __any(lane >= 2 && lane <= 60 && !(fmaxf(fabsf(bb.x), fabsf(bb.y)) < 0.9f));
+        nowall1 = __all(lane < 2 || lane > 60 || bwl.y != 0); // no wall cell in this post-boundary row (as far as advection reads it)
         if (OPT_OUT) {
           const int yo = r - 3;
-          if (lane_out && yo >= y_lo && yo < y_hi) out.water0[fidx(c_out, yo, X)] = bq;
+          if (lane_out && yo >= y_lo && yo < y_hi) st_row(out.water0 + (size_t)yo * X, so16, bq);
         }
       }
       // the pre-boundary values of this row are what the row above reads as its lower neighbour
@@ -573,7 +614,10 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
       fast = false;
 #endif
       if (fast) {
-        advection_cell(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
+        if (WX_WET_AIR && (nowall1 & nowall2 & nowall3)) // (wave-uniform) plain instead of wall-aware interpolation, no wall branch
+          advection_cell<false, true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
+        else
+          advection_cell<false, false>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
       } else { // placeholder (the post-boundary texel): this cell and the two it feeds are recomputed after the loop
         ab = a.base(0, 0);
         aw = a.water_off(0, 0);
@@ -587,7 +631,10 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
 #ifdef WX_ABL_NOLIGHT
         st_l = make_float4(la.sun_at(0, r - 4), la.ir_up_at(r - 5), lz1, ab.w);
 #else
-        st_l = lighting_cell(u, g, col, r - 4, la);
+        if (WX_WET_AIR && __all(lane < WLO || lane >= WLO + WOUT || (awl.y != 0 && awl.z != 1)))
+          st_l = lighting_cell<true>(u, g, col, r - 4, la);
+        else
+          st_l = lighting_cell<false>(u, g, col, r - 4, la);
 #endif
         st_q = aw;
         st_w = awl;
@@ -612,6 +659,8 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
     lz1 = lzw_cur.x;
     big3 = big2;
     big2 = big1;
+    nowall3 = nowall2;
+    nowall2 = nowall1;
     s0 = s0 + 1 == WD ? 0 : s0 + 1;
     sq3 = sq3 + 1 == WQ ? 0 : sq3 + 1;
     yw_m4 = yw_m3;
@@ -622,15 +671,15 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
   }
   // ---- the last row ----
   if (st_valid && lane_out) {
-    const size_t gi = fidx(c_out, y_hi - 1, X);
-    out.base[gi] = st_p;
-    out.water[gi] = st_q;
-    out.wall[gi] = st_w;
-    out.light.x[gi] = st_l.x;
-    out.light.y[gi] = st_l.y;
-    out.light.zw[gi] = make_float2(st_l.z, st_l.w);
-    if (OPT_OUT) out.base_disp[gi] = st_ab;
-    if (out.t_disp) out.t_disp[gi] = st_ab.w;
+    const size_t e = (size_t)(y_hi - 1) * X;
+    st_row(out.base + e, so16, st_p);
+    st_row(out.water + e, so16, st_q);
+    st_row(out.wall + e, so4, st_w);
+    st_row(out.light.x + e, so4, st_l.x);
+    st_row(out.light.y + e, so4, st_l.y);
+    st_row(out.light.zw + e, so8, make_float2(st_l.z, st_l.w));
+    if (OPT_OUT) st_row(out.base_disp + e, so16, st_ab);
+    if (out.t_disp) st_row(out.t_disp + e, so4, st_ab.w);
   }
   // ---- exact path for the recorded cells: cell (x, y) feeds the outputs (x, y), (x+1, y) [pressure: vx of the left neighbour]
   //      and (x, y+1) [pressure / lighting: vy, T and wall of the lower neighbour]; each lane redoes those of them this wave owns ----

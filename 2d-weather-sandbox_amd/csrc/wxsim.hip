@@ -281,6 +281,21 @@ void build_uni(wx_sim *s)
   u.a_invTexY = 1.0f / u.a_texY;
   u.a_aspect = u.a_texY / u.a_texX;
   u.chc = 300.0f / (float)s->Y;
+  u.sun_uniform = s->p.quad_scale == 0;
+  if (u.sun_uniform) { // lighting_cell's per-cell expressions with fragCoord - (x + 0.5) == 0, in the same fp32 operations
+    const float ox = 0.0f + u.sin_a, oy = 0.0f + u.cos_a;
+    const float fu = floorf(ox), fv = floorf(oy);
+    const float al = ox - fu, be = oy - fv;
+    u.sun_dx0 = (int)fu;
+    u.sun_fv = (int)fv;
+    u.sun_w00 = (1.0f - al) * (1.0f - be);
+    u.sun_w10 = al * (1.0f - be);
+    u.sun_w01 = (1.0f - al) * be;
+    u.sun_w11 = al * be;
+  } else {
+    u.sun_dx0 = u.sun_fv = 0;
+    u.sun_w00 = u.sun_w10 = u.sun_w01 = u.sun_w11 = 0.0f;
+  }
 }
 
 template <class T> int dalloc(wx_sim *s, T **p, size_t n)
