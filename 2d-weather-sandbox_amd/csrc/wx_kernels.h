@@ -230,6 +230,7 @@ struct DevState {
   float lightning[4];     // lightningDataTexture (1x1 RGBA32F)
   float px_count;         // this iteration's 1-px blends into texel (0,0): +1 per still-inactive droplet
   float px_light[4];      // this iteration's 1-px blends into texel (1,0): lightning requests
+  int scratch_int;        // small device-side result slot (terrain scan of the marching wet kernel)
   int ghost_nontrivial;   // set by k_halo_unpack when a neighbour's ghost columns carry water (or a negative vegetation byte):
                           // the host then stops treating the water texture as identically zero (wx_step, dry iteration)
 };

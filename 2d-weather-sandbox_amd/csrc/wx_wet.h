@@ -39,11 +39,12 @@ namespace wx {
 #ifndef WX_WET_UNI_COPY
 #define WX_WET_UNI_COPY 0
 #endif
+#ifndef WX_WET_WPB
+#define WX_WET_WPB 4 // wavefronts per workgroup: independent strips (no barrier between them); the dispatcher spreads the waves of
+                     // ONE workgroup evenly over the four SIMDs of a CU, which it does not guarantee for single-wave workgroups
+#endif
 #ifndef WX_WET_AIR
 #define WX_WET_AIR 1 // wave-uniform free-air instantiations of the boundary / advection / lighting stages
-#endif
-#ifndef WX_WET_MAXSEG
-#define WX_WET_MAXSEG 640 // upper bound of the rows one wave marches (8 warm-up rows per segment are redundant work)
 #endif
 
 struct FullCtx { // static per wx_set_params; the per-launch items (buffer pointers, iterNum) travel as arguments
@@ -368,11 +369,21 @@ __device__ __forceinline__ int ring_back(int s, int k, int n) // slot of the row
 // OPT_OUT: also store what only display-side consumers see (curl, post-boundary water, post-advection base): last iteration of a
 // wx_step call. HAS_FB: the precipitation feedback / deposition textures may be non-zero.
 // slow_rows: per wave (seg_rows + 1) 64-bit lane masks, one per advected row, of the cells left to the exact path.
+// The rows are cut into segments of (possibly) different heights: start[s] .. start[s+1]. Rows near terrain take the general,
+// branchy instantiations and cost about twice as much as free air, so the host makes the bottom segments shorter
+// (wet_launch_shape) and all waves of a launch finish together.
+constexpr int WMAXSEG = 128;
+struct WetSegs {
+  int n_seg, slow_stride; // slow_stride: entries per wave in slow_rows (tallest segment + 1)
+  int start[WMAXSEG + 1];
+};
 template <bool OPT_OUT, bool HAS_FB>
-__global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out,
-                                                                    unsigned long long *__restrict__ slow_rows, int n_strips, int seg_rows)
+__global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out,
+                                                                    unsigned long long *__restrict__ slow_rows, int n_strips, WetSegs segs)
 {
-  __shared__ WetRing rg;
+  __shared__ WetRing rings[WX_WET_WPB];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  WetRing &rg = rings[wave];
   // Everything the wave reads from the context goes through the constant address space: scalar loads that the compiler may
   // issue (and re-issue) anywhere. Through a generic pointer every such load behind the kernel's first store becomes a VECTOR
   // load with a uniform address, and waiting for it means waiting for the row prefetch issued just before (one in-order counter).
@@ -384,25 +395,28 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
   const Geo g = ctx->g;
   const CFloatP initial_T = as_constant(ctx->initial_T), snd_T = as_constant(ctx->snd_T), snd_W = as_constant(ctx->snd_W), snd_Vel = as_constant(ctx->snd_Vel);
   const int X = g.X, Y = g.Y;
-  const int lane = threadIdx.x, li = lane + WPAD;
+  const int lane = threadIdx.x & 63, li = lane + WPAD;
   const int iterI = (int)iterNum;
   const bool smooth_iter = iterI % 100 == 0; // the only iterations in which the boundary pass reads its horizontal water neighbours
   // XCD-aware placement: workgroup id lands on XCD id % 8 (MI355X_MICROARCH.md), every XCD has its own L2. XCD k takes the
   // column block of strips [k*S/8, (k+1)*S/8) of EVERY segment: neighbouring strips (which share two 128-byte lines of halo
   // columns per field) hit the same L2, and every XCD gets the same mix of cheap free-air rows and expensive rows near terrain
   // (a contiguous range of segment-major items would hand all the terrain segments to XCD 0). Bottom segments first.
-  const int n_seg = (Y + seg_rows - 1) / seg_rows, k = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int sk0 = (k * n_strips) >> 3, nk = (((k + 1) * n_strips) >> 3) - sk0;
-  if (j >= nk * n_seg) return;
-  const int seg = j / nk, strip = sk0 + (j - seg * nk), item = seg * n_strips + strip;
+  // A workgroup = WX_WET_WPB neighbouring strips of one segment, one wavefront each.
+  const int n_seg = segs.n_seg, k = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int sk0 = (k * n_strips) >> 3, nk = (((k + 1) * n_strips) >> 3) - sk0, gk = (nk + WX_WET_WPB - 1) / WX_WET_WPB;
+  if (j >= gk * n_seg) return;
+  const int seg = j / gk, sloc = (j - seg * gk) * WX_WET_WPB + wave;
+  if (sloc >= nk) return;
+  const int strip = sk0 + sloc, item = seg * n_strips + strip;
   const int c_out = strip * WOUT + lane - WLO; // output column of this lane (may be >= X in the last strip, < 0 in the first)
   const int col = wrapmod(c_out, X);           // column this lane loads / computes
   const bool lane_out = lane >= WLO && lane < WLO + WOUT && c_out < X;
   const unsigned lo4 = (unsigned)col * 4u, lo8 = (unsigned)col * 8u, lo16 = (unsigned)col * 16u; // byte offsets of the loaded column
   const unsigned so4 = lane_out ? (unsigned)c_out * 4u : 0u, so8 = so4 * 2u, so16 = so4 * 4u;    // ... of the stored column
-  const int y_lo = seg * seg_rows, y_hi = min(y_lo + seg_rows, Y);
+  const int y_lo = segs.start[seg], y_hi = segs.start[seg + 1];
   const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
-  unsigned long long *__restrict__ my_slow = slow_rows + (size_t)item * (seg_rows + 1);
+  unsigned long long *__restrict__ my_slow = slow_rows + (size_t)item * segs.slow_stride;
 
   // ---- registers carried from step to step ----
   float4 pf_b, pf_q = make_float4(0.f, 0.f, 0.f, 0.f);                // prefetched: base row r, water row r-2
@@ -705,68 +719,106 @@ __global__ __launch_bounds__(64, WX_WET_MINWAVES) void k_march_wet(const FullCtx
   }
 }
 
-// Segment height: the hardware deals workgroups to CUs as earlier ones retire, and rows near terrain cost more than free air
-// (surface branches of the boundary pass), so the grid is cut into about WX_WET_ROUNDS times as many waves as the device holds
-// at once: the expensive bottom segments are dispatched first, the cheap ones fill the gaps.
+// Segmentation. The grid is cut into about WX_WET_ROUNDS times as many waves as the device holds at once (the hardware deals
+// workgroups to CUs as earlier ones retire; bottom segments are dispatched first), and rows below `air_from_row` -- the lowest
+// row above which every cell is free air, -1 if unknown -- count WX_WET_ALPHA times a free-air row when the segment borders
+// are placed. Measured at 16384x2048 (gpurun_out/r2j..r2l): 1 round 29-34, 2 rounds 36-37, 4 rounds 38-40, 6 rounds 38-40
+// Gcell-steps/s -- many short waves in scattered phases of their pipeline beat few long ones although each segment re-runs
+// 8 warm-up rows; weighting terrain rows (alpha 2-2.5) is worth +15 % with one round and nothing from two rounds on.
 #ifndef WX_WET_ROUNDS
-#define WX_WET_ROUNDS 2
+#define WX_WET_ROUNDS 4
 #endif
-inline int wet_seg_rows(int n_strips, int Y)
+struct WetLaunch {
+  int n_strips;
+  WetSegs segs;
+  size_t slow_entries; // 64-bit masks the launch may write
+};
+inline int wet_capacity()
 {
   static int capacity = 0;
   if (!capacity) {
     int dev = 0, ncu = 0, nb = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_wet<false, false>, 64, 0) != hipSuccess || ncu <= 0 || nb <= 0)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_wet<false, false>, 64 * WX_WET_WPB, 0) != hipSuccess || ncu <= 0 || nb <= 0)
       capacity = 256 * 4 * WX_WET_MINWAVES;
     else
-      capacity = ncu * nb;
+      capacity = ncu * nb * WX_WET_WPB;
     if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] CUs=%d blocks/CU=%d capacity=%d\n", ncu, nb, capacity);
   }
-  if (const char *e = getenv("WX_WET_SEG")) return atoi(e) < Y ? (atoi(e) > 0 ? atoi(e) : Y) : Y;
-  int maxseg = WX_WET_MAXSEG, rounds = WX_WET_ROUNDS;
-  if (const char *e = getenv("WX_WET_MAXSEG")) maxseg = atoi(e) > 0 ? atoi(e) : maxseg;
-  if (const char *e = getenv("WX_WET_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
-  for (int k = rounds; k < 64; k++) {
-    const int nseg = (int)((long long)k * capacity / n_strips);
-    if (nseg < 1) continue;
-    const int rows = (Y + nseg - 1) / nseg;
-    if (rows <= maxseg) return rows < 32 ? (Y < 32 ? Y : 32) : rows;
-  }
-  return maxseg < Y ? maxseg : Y;
+  return capacity;
 }
-
-struct WetLaunch {
-  int n_strips, seg_rows, n_seg;
-  size_t slow_entries; // 64-bit masks the launch may write
-};
-inline WetLaunch wet_launch_shape(const Geo &g)
+inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
 {
   WetLaunch w;
+  const int Y = g.Y;
   w.n_strips = (g.X + WOUT - 1) / WOUT;
-  w.seg_rows = wet_seg_rows(w.n_strips, g.Y);
-  w.n_seg = (g.Y + w.seg_rows - 1) / w.seg_rows;
-  w.slow_entries = (size_t)w.n_strips * w.n_seg * (w.seg_rows + 1);
+  int rounds = WX_WET_ROUNDS, minrows = 32;
+  double alpha = 2.0;
+  if (const char *e = getenv("WX_WET_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
+  if (const char *e = getenv("WX_WET_ALPHA")) alpha = atof(e) >= 1.0 ? atof(e) : alpha;
+  if (const char *e = getenv("WX_WET_MINROWS")) minrows = atoi(e) > 0 ? atoi(e) : minrows;
+  int n_seg = (int)((long long)rounds * wet_capacity() / w.n_strips);
+  if (const char *e = getenv("WX_WET_SEG")) n_seg = atoi(e) > 0 ? (Y + atoi(e) - 1) / atoi(e) : n_seg;
+  n_seg = n_seg < 1 ? 1 : (n_seg > WMAXSEG ? WMAXSEG : n_seg);
+  if (n_seg > (Y + minrows - 1) / minrows) n_seg = (Y + minrows - 1) / minrows; // (8 warm-up rows per segment are redundant work)
+  const int A = (air_from_row < 0 || air_from_row > Y) ? 0 : air_from_row;           // unknown: uniform segments
+  const double total = alpha * A + (Y - A), per = total / n_seg;
+  // border s at the row where the accumulated cost reaches s * per
+  w.segs.start[0] = 0;
+  for (int sg = 1; sg < n_seg; sg++) {
+    const double c = per * sg;
+    int y = c <= alpha * A ? (int)(c / alpha + 0.5) : A + (int)(c - alpha * A + 0.5);
+    if (y <= w.segs.start[sg - 1]) y = w.segs.start[sg - 1] + 1;
+    w.segs.start[sg] = y < Y ? y : Y;
+  }
+  w.segs.start[n_seg] = Y;
+  while (n_seg > 1 && w.segs.start[n_seg - 1] >= Y) n_seg--; // (tiny grids: drop empty segments)
+  w.segs.start[n_seg] = Y;
+  w.segs.n_seg = n_seg;
+  int tallest = 1;
+  for (int sg = 0; sg < n_seg; sg++) tallest = w.segs.start[sg + 1] - w.segs.start[sg] > tallest ? w.segs.start[sg + 1] - w.segs.start[sg] : tallest;
+  w.segs.slow_stride = tallest + 1;
+  w.slow_entries = (size_t)w.n_strips * n_seg * w.segs.slow_stride;
   return w;
 }
 
 inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, unsigned long long *slow_rows,
                              bool opt_out, hipStream_t stream)
 {
-  const dim3 grid(8 * ((w.n_strips + 7) / 8) * w.n_seg); // 8 XCDs x (largest column block) x segments; surplus workgroups exit at once
+  // 8 XCDs x (workgroups of the largest column block) x segments; surplus workgroups / waves exit at once
+  const dim3 grid(8 * (((w.n_strips + 7) / 8 + WX_WET_WPB - 1) / WX_WET_WPB) * w.segs.n_seg);
   static bool dbg = getenv("WX_MARCH_DEBUG") != nullptr;
   if (dbg) {
-    fprintf(stderr, "[wx_wet] strips=%d seg_rows=%d segs=%d waves=%d\n", w.n_strips, w.seg_rows, w.n_seg, w.n_strips * w.n_seg);
+    fprintf(stderr, "[wx_wet] strips=%d segs=%d waves=%d first/last segment rows=%d/%d\n", w.n_strips, w.segs.n_seg, w.n_strips * w.segs.n_seg,
+            w.segs.start[1] - w.segs.start[0], w.segs.start[w.segs.n_seg] - w.segs.start[w.segs.n_seg - 1]);
     dbg = false;
   }
   const bool has_fb = in.fb != nullptr;
-#define WX_LAUNCH_W(O, F) hipLaunchKernelGGL((k_march_wet<O, F>), grid, dim3(64), 0, stream, ctx, iterNum, in, out, slow_rows, w.n_strips, w.seg_rows)
+#define WX_LAUNCH_W(O, F) hipLaunchKernelGGL((k_march_wet<O, F>), grid, dim3(64 * WX_WET_WPB), 0, stream, ctx, iterNum, in, out, slow_rows, w.n_strips, w.segs)
   if (opt_out) {
     if (has_fb) WX_LAUNCH_W(true, true); else WX_LAUNCH_W(true, false);
   } else {
     if (has_fb) WX_LAUNCH_W(false, true); else WX_LAUNCH_W(false, false);
   }
 #undef WX_LAUNCH_W
+}
+
+// lowest row above which every cell is free air in the sense of air_cell(): 1 + the highest row holding a wall cell, a cell next
+// to one, or a cell less than 9 rows above one (block-wise maximum into *out, which the caller zeroes)
+__global__ void k_air_from_row(int X, int Y, const char4 *__restrict__ wall, int *__restrict__ out)
+{
+  int best = 0;
+  const size_t n = (size_t)X * Y;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const char4 w = wall[i];
+    if (w.y <= 1 || w.z <= 9) {
+      const int row = (int)(i / X) + 1;
+      // (the top row always sees the wall row 0 through the y-wrap: it is not terrain, and one row does not matter to the cost model)
+      if (row < Y) best = row > best ? row : best;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+  if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(out, best);
 }
 
 } // namespace wx

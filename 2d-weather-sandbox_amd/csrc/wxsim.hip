@@ -76,7 +76,7 @@ struct wx_sim {
   int64_t iter = 0;
   int dry_march = 1;     // water-free dry iteration: 1 = row-marching wavefront kernel (wx_march.h, default: 0.32 vs 0.38 ms at
                          // 16384x2048), 0 = LDS-tiled kernel (wx_dry.h); env WX_DRY_MARCH
-  int fused = 1;         // 1: two fused LDS-tiled kernels; 2: the whole iteration as one row-marching kernel (wx_wet.h); 0: one kernel
+  int fused = 2;         // 2 (default): the whole iteration as one row-marching kernel (wx_wet.h); 1: two fused LDS-tiled kernels; 0: one kernel
                          // per reference pass (env WX_FUSED)
   wx_params p{};
   Geo geo{};
@@ -116,6 +116,9 @@ struct wx_sim {
   FullCtx *full_ctx = nullptr;
   unsigned long long *slow_rows = nullptr; // marching wet kernel: per-wave row masks of the cells left to the exact path
   size_t slow_cap = 0;
+  int air_from_row = -1;       // lowest row above which every cell is free air (cost model of the row segmentation); -1: to be measured
+  WetLaunch wet_shape{};       // cached launch shape for that value
+  bool wet_shape_valid = false;
   SplatGrid sg{};              // particle splat accumulation (allocated when the handle has droplets)
   bool fb_dirty = false; // feedback/deposition hold non-zero data (particles ran last iteration)
   bool water_trivial = false; // the water texture is known to be 0 in air cells and only the wall marker in wall cells: set by wx_upload,
@@ -491,7 +494,21 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip)
   WetIn in{s->base[0], s->wall[0], s->water[1], LightPlanesC{s->lp[0].x, s->lp[0].y, s->lp[0].zw},
            LightPlanesC{s->lp[src].x, s->lp[src].y, s->lp[src].zw}, fb ? s->fb : nullptr, fb ? s->dep : nullptr, fb ? s->sg.fb_zero : nullptr, s->sg.TXn};
   WetOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], s->water[0], s->curl, precip ? s->tdisp : nullptr};
-  const WetLaunch shape = wet_launch_shape(s->geo);
+  if (s->air_from_row < 0) { // after an upload or a wall edit: where does the terrain end? (one small kernel + a 4-byte readback)
+    int *d = &s->state->scratch_int, v = 0;
+    hipMemsetAsync(d, 0, 4, s->stream);
+    hipLaunchKernelGGL(k_air_from_row, dim3(1024), dim3(256), 0, s->stream, s->X, s->Y, s->wall[0], d);
+    hipMemcpyAsync(&v, d, 4, hipMemcpyDeviceToHost, s->stream);
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return fail(s, WX_E_DEVICE, "wx_step: terrain scan failed");
+    s->air_from_row = v < s->Y ? v : s->Y;
+    s->wet_shape_valid = false;
+  }
+  if (!s->wet_shape_valid) {
+    s->wet_shape = wet_launch_shape(s->geo, s->air_from_row);
+    s->wet_shape_valid = true;
+    if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] air_from_row=%d of %d\n", s->air_from_row, s->Y);
+  }
+  const WetLaunch &shape = s->wet_shape;
   if (shape.slow_entries > s->slow_cap) { // (once per handle; the kernel writes a row's mask before it reads it: no clearing)
     hipStreamSynchronize(s->stream);
     hipFree(s->slow_rows);
@@ -735,7 +752,7 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 16, s->stream));
   HIPCHK(s, hipMemsetAsync(s->dep, 0, n * 8, s->stream));
   HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
-  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 24, s->stream)); // px_count, px_light[4], ghost_nontrivial
+  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 28, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial
   if (s->sg.acc4) {
     HIPCHK(s, hipMemsetAsync(s->sg.acc4, 0, (size_t)s->sg.AP * s->sg.AH * 16, s->stream));
     HIPCHK(s, hipMemsetAsync(s->sg.acc2, 0, (size_t)s->sg.AP * s->sg.AH * 8, s->stream));
@@ -744,6 +761,7 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   }
   HIPCHK(s, hipStreamSynchronize(s->stream)); // the caller keeps ownership of the host arrays
   s->fb_dirty = false;
+  s->air_from_row = -1;
   s->ghost_check = false;
   s->cow_pending = false;
   s->light_planar = false; // the interleaved light textures were just zeroed
@@ -850,6 +868,7 @@ int wx_step(wx_sim *s, int n_iter)
   if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] > 0.9f) s->wall_veg_ok = false;
   // ... and the water texture stays known trivial only through water-free dry iterations (iterate_dry's `water == false` case)
   if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] != 0.0f || s->p.soundingForcing != 0.0f) s->water_trivial = false;
+  if (s->p.userInputType >= 10) s->air_from_row = -1; // wall tools: the terrain may grow (re-measured after the call)
   if (precip && s->keys && n_iter > 0) { // slab with particles: refuse an over-long call BEFORE any iteration runs
     const int allowed = (s->halo - 6) / WX_SLAB_CONE - s->period_j;
     if (n_iter > allowed)

@@ -6,7 +6,10 @@ reference's shader files from /root/reference at run time, and stores inputs + o
 fixtures under tests/golden/. Only data (arrays, uniform values) is stored -- no reference source.
 
 SwiftShader caveat: advectionShader output is corrupted for air pixels that share a
-2x2 pixel quad with a wall pixel, so every fixture here keeps wall/air boundaries on even x and even y.
+2x2 pixel quad with a wall pixel when the pass is drawn as the reference's full-screen quad. The round-1 fixtures therefore
+keep wall/air boundaries on even x and even y; the round-2 fixtures (save100raw, randwalls64p, lightning64, airplane64,
+setup256) draw every pass as one GL_POINT per pixel instead (harness.js, job option `points`), which has no neighbouring
+fragments to go wrong with, and put walls anywhere -- including the reference's unmodified save.
 
 usage:  python oracle/golden/gen_golden.py [fixture ...]     (default: all)
 """
@@ -92,7 +95,8 @@ def js_uniforms(u: dict) -> dict:
 
 
 def run_fixture(name, X, Y, base, water, wall, drops, u, *, niter, dump_iters, perpass_iter=None, precip=False,
-                iter0=0, keep=("base_cur", "water_cur", "wall_cur", "light_0", "light_1", "water_0", "base_disp")):
+                iter0=0, keep=("base_cur", "water_cur", "wall_cur", "light_0", "light_1", "water_0", "base_disp"), points=False,
+                dump_emitted=False, keep_particles=("drops", "lightning", "precip_fb", "precip_dep"), timeout=600.0):
     tmp = tempfile.mkdtemp(prefix="wxgold_")
     np.ascontiguousarray(base, np.float32).tofile(os.path.join(tmp, "base.f32"))
     np.ascontiguousarray(water, np.float32).tofile(os.path.join(tmp, "water.f32"))
@@ -103,15 +107,16 @@ def run_fixture(name, X, Y, base, water, wall, drops, u, *, niter, dump_iters, p
     job = {
         "X": X, "Y": Y, "n_drops": n_drops, "dir": "file://" + tmp + "/",
         "uniforms": js_uniforms(u), "initial_T": [float(v) for v in u["initial_T"]],
-        "niter": niter, "dump_iters": list(dump_iters), "precip": bool(precip), "iter0": iter0,
+        "niter": niter, "dump_iters": list(dump_iters), "precip": bool(precip), "iter0": iter0, "points": bool(points),
+        "dump_emitted": bool(dump_emitted),
     }
     if "sounding_T" in u:
         job["sounding"] = {k: [float(v) for v in u["sounding_" + k]] for k in ("T", "W", "Vel")}
     if perpass_iter is not None:
         job["perpass_iter"] = perpass_iter
-    probe = run_harness({"X": X, "Y": Y, "probe": True, "n_drops": 0})
+    probe = run_harness({"X": X, "Y": Y, "probe": True, "n_drops": 0, "points": bool(points)})
     varyings = _dec(probe["probe"], np.float32).reshape(Y, X, 4)
-    res = run_harness(job)
+    res = run_harness(job, timeout=timeout)
     print(f"[{name}] renderer={res['renderer']!r} err={res['err']} {res['niter']} it, "
           f"{res['ms_after_first']:.1f} ms after first -> {1000.0 * (res['niter'] - 1) / max(res['ms_after_first'], 1e-9):.1f} it/s")
     out = {
@@ -124,13 +129,14 @@ def run_fixture(name, X, Y, base, water, wall, drops, u, *, niter, dump_iters, p
         "uniforms_json": json.dumps(js_uniforms(u)),
         **({"sounding_" + k: np.asarray(u["sounding_" + k], np.float32) for k in ("T", "W", "Vel")} if "sounding_T" in u else {}),
         "renderer": res["renderer"], "its_per_s": 1000.0 * (res["niter"] - 1) / max(res["ms_after_first"], 1e-9),
+        "points": int(bool(points)),  # 1: every pass drawn as one GL_POINT per pixel (see harness.js), 0: as the reference's quad
     }
     if n_drops:
         out["in_drops"] = np.asarray(drops, np.float32).reshape(n_drops, 5)
     shapes = {"curl": (Y, X), "vort": (Y, X, 2), "precip_dep": (Y, X, 2), "drops": (-1, 5), "precip_drops": (-1, 5), "lightning": (4,)}
     for it, d in res["dumps"].items():
         for k, v in d.items():
-            if k not in keep and k not in ("drops", "lightning", "precip_fb", "precip_dep"):
+            if k not in keep and k not in keep_particles:
                 continue
             dt = np.int8 if "wall" in k else np.float32
             out[f"it{it}_{k}"] = _dec(v, dt).reshape(shapes.get(k, (Y, X, 4)))
@@ -378,6 +384,135 @@ def fx_randwalls64():
     return keep
 
 
+# ------------------------------------------------------------------------------------------------
+# round-2 fixtures: every pass drawn as GL_POINTS (harness.js `points`), which side-steps SwiftShader's mixed-quad bug, so
+# walls no longer have to sit on even x / even y
+# ------------------------------------------------------------------------------------------------
+def fx_save100raw():
+    """BASELINE configs[0]: the reference's UNMODIFIED save (one-row sea, 20 x 2 island: nothing quad aligned), 1000
+    iterations, sun fixed at the saved angle, precipitation off. Early dumps carry everything, late ones the three
+    state textures."""
+    sf = pkg.codec.load(REF_SAVE)
+    gui = pkg.params.merge_settings(sf.settings)
+    u = pkg.params.uniforms_from_gui(gui, sf.Y)
+    return run_fixture("save100raw", sf.X, sf.Y, sf.base, sf.water, sf.wall, None, u, niter=1000, dump_iters=[1, 10, 50, 200, 1000],
+                       perpass_iter=0, precip=False, keep=("base_cur", "water_cur", "wall_cur"), points=True, timeout=1800.0)
+
+
+def fx_randwalls64p():
+    """Random 1-cell-granular wall blocks of every type (floating islands, overhangs, caves, one-cell gaps, sea next to air,
+    walls in the top rows) through the WHOLE iteration for 12 iterations from iterNum = 95 (crosses % 100 and % 20): bilerpWall
+    next to irregular walls, the wall branch of advection, pressure and lighting on real terrain."""
+    rng = np.random.default_rng(777)
+    X, Y = 64, 48
+    gui, u, base, water, wall = synth_terrain(X, Y, rng)
+    for _ in range(90):
+        bx, by = int(rng.integers(0, X)), int(rng.integers(2, Y))
+        w, h = int(rng.integers(1, 6)), int(rng.integers(1, 4))
+        t = int(rng.integers(0, 7))
+        ys, xs = slice(by, min(by + h, Y)), slice(bx, min(bx + w, X))
+        wall[ys, xs, 0] = t
+        wall[ys, xs, 1] = 0
+        wall[ys, xs, 2] = 0
+        wall[ys, xs, 3] = int(rng.integers(0, 120))
+        base[ys, xs, 0:2] = 0.0
+        base[ys, xs, 3] = 298.15 if t == 2 else 1000.0
+        water[ys, xs, 0] = 1002.0 if t == 2 else 1001.0
+        water[ys, xs, 1] = 0.0
+        water[ys, xs, 2] = float(rng.integers(0, 60))
+        water[ys, xs, 3] = float(rng.integers(0, 3)) * 6.0
+    return run_fixture("randwalls64p", X, Y, base, water, wall, None, u, niter=12, dump_iters=[1, 2, 6, 12], perpass_iter=0, precip=False,
+                       iter0=95, keep=("base_cur", "water_cur", "wall_cur", "light_0", "light_1", "water_0"), points=True,
+                       dump_emitted=True)
+
+
+def fx_lightning64():
+    """Lightning: a cold, very dense cloud deck (cloud + precipitation > 2.5 below 0 C) and a large pool of inactive droplets,
+    from iterNum = 40 (> the 30-iteration lock-out of a fresh lightning texture), so that precipitationShader.vert:121-140
+    requests strikes and lightningLocationShader.frag:24-38 accepts single ones, rejects double ones and the lock-out holds.
+    EVERY iteration is dumped (post-advection base / water, droplets, feedback, lightning texture): the oracle's particle pass is
+    checked per iteration on the reference's own inputs, because the strike decision hashes temperature BITS."""
+    rng = np.random.default_rng(2024)
+    X, Y = 64, 48
+    gui, u, base, water, wall = synth_terrain(X, Y, rng)
+    yy = np.arange(Y)[:, None]
+    air = wall[..., 1] != 0
+    deck = air & (yy >= 22) & (yy < 44)  # rows where the real temperature is below freezing
+    water[..., 1] = np.where(deck, 4.0 + 5.0 * rng.random((Y, X)), water[..., 1]).astype(np.float32)
+    water[..., 0] = np.where(deck, water[..., 0] + water[..., 1], water[..., 0]).astype(np.float32)
+    water[..., 2] = np.where(deck, 1.0 * rng.random((Y, X)), water[..., 2]).astype(np.float32)
+    u["spawnChanceMult"] = 0.02
+    u["enablePrecipitation"] = 1
+    n = 1024
+    drops = np.zeros((n, 5), np.float32)
+    drops[:, 0] = rng.random(n)
+    drops[:, 1] = rng.random(n)
+    drops[:, 2] = -10.0 + rng.random(n)
+    drops[:, 3] = rng.random(n)
+    drops[:, 4] = rng.random(n)
+    u["inactiveDroplets"] = float(n)
+    niter = 48
+    return run_fixture("lightning64", X, Y, base, water, wall, drops, u, niter=niter, dump_iters=list(range(1, niter + 1)), precip=True,
+                       iter0=40, keep=("base_disp", "water_cur"), points=True)
+
+
+AIRPLANE_CASES = [
+    # airplaneValues = (x, y, -, mode): mode < 0 dumps water (advectionShader.frag:436-439), mode > 0.9 is a crash (:441-456)
+    ("airplane_dump", (0.4, 0.5, 0.7, -1.0)), ("airplane_crash_air", (0.6, 0.6, 0.0, 1.0)), ("airplane_crash_ground", (0.2, 0.09, 0.0, 1.0)),
+]
+
+
+def fx_airplane64():
+    """Airplane inputs of advectionShader.frag:415-457 on the synth64 terrain, 2 iterations each."""
+    rng = np.random.default_rng(1234)
+    X, Y = 64, 48
+    gui, u, base, water, wall = synth_terrain(X, Y, rng)
+    probe = run_harness({"X": X, "Y": Y, "probe": True, "n_drops": 0, "points": True})
+    out = {"X": X, "Y": Y, "in_base": base, "in_water": water, "in_wall": wall, "initial_T": np.asarray(u["initial_T"], np.float32),
+           "varyings": _dec(probe["probe"], np.float32).reshape(Y, X, 4), "cases": json.dumps([c[0] for c in AIRPLANE_CASES]), "points": 1}
+    tmp = tempfile.mkdtemp(prefix="wxgold_")
+    base.tofile(os.path.join(tmp, "base.f32"))
+    water.tofile(os.path.join(tmp, "water.f32"))
+    wall.tofile(os.path.join(tmp, "wall.i8"))
+    nit = 2
+    for name, av in AIRPLANE_CASES:
+        uu = dict(u, userInputType=-1, airplaneValues=av)
+        job = {"X": X, "Y": Y, "n_drops": 0, "dir": "file://" + tmp + "/", "uniforms": js_uniforms(uu), "points": True,
+               "initial_T": [float(v) for v in u["initial_T"]], "niter": nit, "dump_iters": [nit], "precip": False, "iter0": 0}
+        res = run_harness(job)
+        d = res["dumps"][str(nit)]
+        out[f"{name}_uniforms"] = json.dumps(js_uniforms(uu))
+        out[f"{name}_niter"] = nit
+        out[f"{name}_base"] = _dec(d["base_cur"], np.float32).reshape(Y, X, 4)
+        out[f"{name}_water"] = _dec(d["water_cur"], np.float32).reshape(Y, X, 4)
+        out[f"{name}_wall"] = _dec(d["wall_cur"], np.int8).reshape(Y, X, 4)
+        print(f"[airplane64] {name}: err={res['err']}, wall cells changed vs input: {int((out[f'{name}_wall'] != wall).any(-1).sum())}")
+    path = os.path.join(OUT_DIR, "airplane64.npz")
+    np.savez_compressed(path, **out)
+    print(f"[airplane64] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def fx_setup256():
+    """The setup draw of a new simulation (setupShader.frag:36-92; uniforms app.js:5479-5485, 5732-5734) at 4096 x 96 (the noise
+    terrain needs a few thousand columns to rise out of the sea) with the defaults synth.terrain_grid documents (seed 0.5,
+    heightMult 0.3). Stored compactly: per-column wall height / type / vegetation / snow, per-row air state."""
+    X, Y = 4096, 96
+    gui = pkg.params.merge_settings(None)
+    u = pkg.params.uniforms_from_gui(gui, Y)
+    job = {"X": X, "Y": Y, "n_drops": 0, "points": True, "initial_T": [float(v) for v in u["initial_T"]],
+           "setup": {"seed": 0.5, "heightMult": 0.3, "simHeight": float(gui["simHeight"]), "dryLapse": float(u["dryLapse"])}}
+    res = run_harness(job)
+    out = {"X": X, "Y": Y, "seed": 0.5, "heightMult": 0.3, "simHeight": float(gui["simHeight"]), "dryLapse": float(u["dryLapse"]),
+           "initial_T": np.asarray(u["initial_T"], np.float32), "renderer": res["renderer"],
+           "base": _dec(res["base"], np.float32).reshape(Y, X, 4), "water": _dec(res["water"], np.float32).reshape(Y, X, 4),
+           "wall": _dec(res["wall"], np.int8).reshape(Y, X, 4)}
+    path = os.path.join(OUT_DIR, "setup256.npz")
+    # the output is column / row structured: keep the full wall texture (int8, compresses well) and float planes as they are
+    np.savez_compressed(path, **out)
+    print(f"[setup256] err={res['err']} wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); wall cells: {int((out['wall'][..., 1] == 0).sum())}")
+    return out
+
+
 FIXTURES = {
     "randwalls64": fx_randwalls64,
     "brush64": fx_brush64,
@@ -386,6 +521,11 @@ FIXTURES = {
     "synth64": fx_synth64,
     "sounding64": fx_sounding64,
     "precip64": fx_precip64,
+    "save100raw": fx_save100raw,
+    "randwalls64p": fx_randwalls64p,
+    "lightning64": fx_lightning64,
+    "airplane64": fx_airplane64,
+    "setup256": fx_setup256,
 }
 
 if __name__ == "__main__":

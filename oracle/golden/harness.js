@@ -70,10 +70,25 @@ function run(o)
     return sh;
   }
   var simVert = compile(gl.VERTEX_SHADER, source('vertex', 'simShader.vert'), 'simShader.vert');
+  // Point-drawn variant (job option `points`): one GL_POINT per pixel instead of the full-screen quad. SwiftShader corrupts
+  // advectionShader output for air pixels that share a 2x2 pixel quad with a wall pixel when the pass is drawn as two triangles
+  // (SURVEY Appendix C); a point primitive has no neighbouring fragments, so unaligned terrain renders correctly. The vertex
+  // stage is the reference's simShader.vert with its two attributes turned into globals that a wrapper main() fills from
+  // gl_VertexID: vertTexCoord = (pixel + 0.5) * uvScale, uvScale = f32(res * 1.0000001) / res, i.e. exactly the value the
+  // quad's interpolated texture coordinate has at the pixel centre in exact arithmetic (app.js:4770-4788).
+  var simVertPoints = null;
+  if (o.points) {
+    var sv = source('vertex', 'simShader.vert');
+    sv = sv.replace('in vec2 vertPosition;', 'vec2 vertPosition;').replace('in vec2 vertTexCoord;', 'vec2 vertTexCoord;').replace('void main()', 'void simMain()');
+    sv += '\nuniform vec2 wxRes;\nuniform vec2 wxUvScale;\nvoid main(){ int id = gl_VertexID; int W = int(wxRes.x); float px = float(id - (id / W) * W), py = float(id / W);' +
+          ' vertPosition = vec2((px + 0.5) / wxRes.x * 2.0 - 1.0, (py + 0.5) / wxRes.y * 2.0 - 1.0);' +
+          ' vertTexCoord = vec2((px + 0.5) * wxUvScale.x, (py + 0.5) * wxUvScale.y); simMain(); gl_PointSize = 1.0; }\n';
+    simVertPoints = compile(gl.VERTEX_SHADER, sv, 'simShader.vert (points)');
+  }
   function fragProgram(name)
   {
     var p = gl.createProgram();
-    gl.attachShader(p, simVert);
+    gl.attachShader(p, o.points ? simVertPoints : simVert);
     gl.attachShader(p, compile(gl.FRAGMENT_SHADER, source('fragment', name), name));
     gl.bindAttribLocation(p, 0, 'vertPosition');
     gl.bindAttribLocation(p, 1, 'vertTexCoord');
@@ -82,8 +97,15 @@ function run(o)
     return p;
   }
   var P = {};
-  ['velocity', 'curl', 'vorticity', 'boundary', 'advection', 'pressure', 'lighting', 'lightningLocation'].forEach(function(n) {
+  var progNames = ['velocity', 'curl', 'vorticity', 'boundary', 'advection', 'pressure', 'lighting', 'lightningLocation'];
+  if (o.setup) progNames.push('setup');
+  progNames.forEach(function(n) {
     P[n] = fragProgram(n + 'Shader.frag');
+    if (o.points) {
+      gl.useProgram(P[n]);
+      gl.uniform2f(gl.getUniformLocation(P[n], 'wxRes'), X, Y);
+      gl.uniform2f(gl.getUniformLocation(P[n], 'wxUvScale'), Math.fround(Math.fround(X * 1.0000001) / X), Math.fround(Math.fround(Y * 1.0000001) / Y));
+    }
   });
   // particle program with transform feedback (app.js:4879-4881)
   P.precipitation = gl.createProgram();
@@ -114,13 +136,17 @@ function run(o)
   if (o.probe) {
     var pf = '#version 300 es\nprecision highp float;\nin vec2 fragCoord;\nin vec2 texCoord;\nout vec4 o;\nvoid main(){ o = vec4(fragCoord, texCoord); }';
     var pp = gl.createProgram();
-    gl.attachShader(pp, simVert);
+    gl.attachShader(pp, o.points ? simVertPoints : simVert);
     gl.attachShader(pp, compile(gl.FRAGMENT_SHADER, pf, 'probe'));
     gl.bindAttribLocation(pp, 0, 'vertPosition');
     gl.bindAttribLocation(pp, 1, 'vertTexCoord');
     gl.linkProgram(pp);
     gl.useProgram(pp);
     gl.uniform2f(gl.getUniformLocation(pp, 'texelSize'), 1.0 / X, 1.0 / Y);
+    if (o.points) {
+      gl.uniform2f(gl.getUniformLocation(pp, 'wxRes'), X, Y);
+      gl.uniform2f(gl.getUniformLocation(pp, 'wxUvScale'), Math.fround(Math.fround(X * 1.0000001) / X), Math.fround(Math.fround(Y * 1.0000001) / Y));
+    }
     var pt = gl.createTexture();
     gl.bindTexture(gl.TEXTURE_2D, pt);
     gl.texImage2D(gl.TEXTURE_2D, 0, gl.RGBA32F, X, Y, 0, gl.RGBA, gl.FLOAT, null);
@@ -130,10 +156,71 @@ function run(o)
     gl.viewport(0, 0, X, Y);
     gl.bindVertexArray(fluidVao);
     gl.drawBuffers([gl.COLOR_ATTACHMENT0]);
-    gl.drawArrays(gl.TRIANGLE_STRIP, 0, 4);
+    if (o.points) {
+      gl.bindVertexArray(gl.createVertexArray());
+      gl.drawArrays(gl.POINTS, 0, X * Y);
+    } else {
+      gl.drawArrays(gl.TRIANGLE_STRIP, 0, 4);
+    }
     var pa = new Float32Array(4 * X * Y);
     gl.readPixels(0, 0, X, Y, gl.RGBA, gl.FLOAT, pa);
     return {probe: b64(pa), renderer: gl.getParameter(gl.RENDERER)};
+  }
+
+  // ---- job option `setup`: the setup draw of a new simulation (setupShader.frag, uniforms app.js:5479-5485, 5732-5734) ----
+  if (o.setup) {
+    var sT = {};
+    function stex(ifmt, fmt, type)
+    {
+      var t = gl.createTexture();
+      gl.bindTexture(gl.TEXTURE_2D, t);
+      gl.texImage2D(gl.TEXTURE_2D, 0, ifmt, X, Y, 0, fmt, type, null);
+      gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_MIN_FILTER, gl.NEAREST);
+      gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_MAG_FILTER, gl.NEAREST);
+      return t;
+    }
+    sT.base = stex(gl.RGBA32F, gl.RGBA, gl.FLOAT);
+    sT.water = stex(gl.RGBA32F, gl.RGBA, gl.FLOAT);
+    sT.wall = stex(gl.RGBA8I, gl.RGBA_INTEGER, gl.BYTE);
+    var sfb = gl.createFramebuffer();
+    gl.bindFramebuffer(gl.FRAMEBUFFER, sfb);
+    gl.framebufferTexture2D(gl.FRAMEBUFFER, gl.COLOR_ATTACHMENT0, gl.TEXTURE_2D, sT.base, 0);
+    gl.framebufferTexture2D(gl.FRAMEBUFFER, gl.COLOR_ATTACHMENT1, gl.TEXTURE_2D, sT.water, 0);
+    gl.framebufferTexture2D(gl.FRAMEBUFFER, gl.COLOR_ATTACHMENT2, gl.TEXTURE_2D, sT.wall, 0);
+    gl.useProgram(P.setup);
+    var sInit = new Float32Array(ARR * 4);
+    for (var sy = 0; sy < Y + 1; sy++) sInit[sy] = o.initial_T[sy];
+    gl.uniform2f(gl.getUniformLocation(P.setup, 'texelSize'), 1.0 / X, 1.0 / Y);
+    gl.uniform2f(gl.getUniformLocation(P.setup, 'resolution'), X, Y);
+    gl.uniform1f(gl.getUniformLocation(P.setup, 'dryLapse'), o.setup.dryLapse);
+    gl.uniform1f(gl.getUniformLocation(P.setup, 'simHeight'), o.setup.simHeight);
+    gl.uniform4fv(gl.getUniformLocation(P.setup, 'initial_Tv'), sInit);
+    gl.uniform1f(gl.getUniformLocation(P.setup, 'seed'), o.setup.seed);
+    gl.uniform1f(gl.getUniformLocation(P.setup, 'heightMult'), o.setup.heightMult);
+    gl.viewport(0, 0, X, Y);
+    gl.bindVertexArray(fluidVao);
+    gl.drawBuffers([gl.COLOR_ATTACHMENT0, gl.COLOR_ATTACHMENT1, gl.COLOR_ATTACHMENT2]);
+    if (o.points) {
+      gl.bindVertexArray(gl.createVertexArray());
+      gl.drawArrays(gl.POINTS, 0, X * Y);
+    } else {
+      gl.drawArrays(gl.TRIANGLE_STRIP, 0, 4);
+    }
+    var so = {renderer: gl.getParameter(gl.RENDERER), err: 0};
+    var sa = new Float32Array(4 * X * Y);
+    gl.readBuffer(gl.COLOR_ATTACHMENT0);
+    gl.readPixels(0, 0, X, Y, gl.RGBA, gl.FLOAT, sa);
+    so.base = b64(sa);
+    gl.readBuffer(gl.COLOR_ATTACHMENT1);
+    gl.readPixels(0, 0, X, Y, gl.RGBA, gl.FLOAT, sa);
+    so.water = b64(sa);
+    var si = new Int32Array(4 * X * Y), s8 = new Int8Array(4 * X * Y);
+    gl.readBuffer(gl.COLOR_ATTACHMENT2);
+    gl.readPixels(0, 0, X, Y, gl.RGBA_INTEGER, gl.INT, si);
+    for (var q = 0; q < si.length; q++) s8[q] = si[q];
+    so.wall = b64(s8);
+    so.err = gl.getError();
+    return so;
   }
 
   // ---- fixture ----
@@ -322,7 +409,17 @@ function run(o)
     gl.activeTexture(gl.TEXTURE0 + unit);
     gl.bindTexture(gl.TEXTURE_2D, t);
   }
-  function quadDraw() { gl.drawArrays(gl.TRIANGLE_STRIP, 0, 4); }
+  var emptyVao = gl.createVertexArray();
+  function quadDraw()
+  {
+    if (o.points) { // attribute-less draw: the wrapper vertex stage derives everything from gl_VertexID
+      gl.bindVertexArray(emptyVao);
+      gl.drawArrays(gl.POINTS, 0, X * Y);
+      gl.bindVertexArray(fluidVao);
+    } else {
+      gl.drawArrays(gl.TRIANGLE_STRIP, 0, 4);
+    }
+  }
 
   // ---- the iteration (app.js:5830-6005) ----
   var even = true, iterNum = o.iter0 || 0, lastDst = 0;
@@ -458,6 +555,7 @@ function run(o)
     put(d, 'wall_disp', readI8(F.fb1, 2));
     put(d, 'light_0', readF(F.light0, 0, 4));
     put(d, 'light_1', readF(F.light1, 0, 4));
+    if (o.dump_emitted) put(d, 'emitted', readF(F.light0, 1, 4)); // emittedLight (lightingShader's second output, RGBA16F)
     if (o.precip && N > 0) {
       put(d, 'drops', readDrops(D[lastDst]));
       put(d, 'lightning', readLightning());
