@@ -11,6 +11,7 @@
 #pragma once
 #include "wx_cells.h"
 #include "wx_fused.h"
+#include "wx_wet.h" // FullCtx
 
 namespace wx {
 

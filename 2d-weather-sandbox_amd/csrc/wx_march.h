@@ -16,11 +16,12 @@
 #pragma once
 #include "wx_cells.h"
 #include "wx_dry.h"
+#include "wx_wet.h" // ld_row / st_row (scalar-base addressing), wave_from_left (DPP shift)
 
 namespace wx {
 
 #ifndef WX_MARCH_MAXSEG
-#define WX_MARCH_MAXSEG 64 // upper bound of the rows one wave marches (3 warm-up rows per segment are redundant work)
+#define WX_MARCH_MAXSEG 32 // upper bound of the rows one wave marches (3 warm-up rows per segment are redundant work; measured at 32768x4096: 32 rows 143.7, 64 rows 140.6, 128 rows 135.7 Gcell-steps/s)
 #endif
 #ifndef WX_MARCH_UNI_MEM
 #define WX_MARCH_UNI_MEM 1 // measured: SGPR spills 12 -> 0, 0.31 -> 0.29 ms at 16384x2048
@@ -80,10 +81,14 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
 {
   __shared__ MarchRing rg;
 #if WX_MARCH_UNI_MEM
-  const Uni &u = ctx->u; // (the dry passes do not use iterNum)
+  // uniforms and the per-row profiles through the constant address space: scalar loads the compiler may re-issue anywhere
+  // (through a generic pointer every load behind the first store of the kernel turns into a vector load, and waiting for it
+  // means waiting for the row prefetch issued just before). The dry passes do not use iterNum.
+  CUni &u = as_constant(ctx->u);
 #else
   const Uni &u = u_arg;
 #endif
+  const CFloatP initial_T = as_constant(ctx->initial_T), snd_T = as_constant(ctx->snd_T), snd_W = as_constant(ctx->snd_W), snd_Vel = as_constant(ctx->snd_Vel);
   const int X = g.X, Y = g.Y;
   const int lane = threadIdx.x;
 #if WX_MARCH_XCD
@@ -102,6 +107,8 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
   const int col = wrapmod(c_out, X);                 // column this lane loads / computes
   const bool lane_out = lane >= 2 && lane <= 61 && c_out < X;
   const int y_lo = seg * seg_rows, y_hi = min(y_lo + seg_rows, Y);
+  const unsigned lo4 = (unsigned)col * 4u, lo16 = (unsigned)col * 16u;                      // byte offsets of the loaded column
+  const unsigned so4 = lane_out ? (unsigned)c_out * 4u : 0u, so16 = so4 * 4u;              // ... of the stored column
 
   const int lr = lane < 1 ? 1 : (lane > 62 ? 62 : lane); // ring column the advection of this lane reads around
   const int lright = lane < 63 ? lane + 1 : 63;          // right neighbour for the velocity stage
@@ -113,13 +120,19 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
   float adv_vy_prev = 0.f, adv_T_prev = 0.f;
   char4 adv_w_prev = make_char4(0, 0, 0, 0);
   int big1 = 0, big2 = 0, big3 = 0; // "some |v| >= 0.9" of velocity rows r-1, r-2, r-3
+  // the output row of the previous step, stored at the top of this one (right behind the prefetch): the single vmcnt wait of a
+  // step then covers a load and a store that have both had a whole step to complete (gfx9: one in-order counter for both)
+  float4 st_p = make_float4(0.f, 0.f, 0.f, 0.f), st_ab = st_p;
+  char4 st_w = make_char4(0, 0, 0, 0);
+  bool st_valid = false;
 
   // prefetch of the first row
   int r = y_lo - 2;
+  int yw_p1 = wrapmod(r + 1, Y), yw_m2 = wrapmod(r - 2, Y); // wrapped rows r+1 and r-2, advanced by one per step
   {
-    const size_t gi = fidx(col, wrapmod(r, Y), X);
-    b_new = in.base[gi];
-    w_new = wall_raw[gi];
+    const size_t e = (size_t)wrapmod(r, Y) * X;
+    b_new = ld_row(in.base + e, lo16);
+    w_new = ld_row(wall_raw + e, lo4);
   }
   for (; r <= y_hi + 1; r++) {
     const int rc = r + 8; // non-negative ring counter
@@ -129,10 +142,17 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     const char4 w_cur = make_char4((signed char)(w_raw & 0xff), (signed char)((w_raw >> 8) & 0xff), (signed char)((w_raw >> 16) & 0xff), (signed char)(w_raw >> 24));
     // software prefetch: next row's loads are in flight while this row is processed
     if (r < y_hi + 1) {
-      const size_t gi = fidx(col, wrapmod(r + 1, Y), X);
-      b_new = in.base[gi];
-      w_new = wall_raw[gi];
+      const size_t e = (size_t)yw_p1 * X;
+      b_new = ld_row(in.base + e, lo16);
+      w_new = ld_row(wall_raw + e, lo4);
     }
+    if (st_valid && lane_out) { // row r-3
+      const size_t e = (size_t)(r - 3) * X;
+      st_row(out.base + e, so16, st_p);
+      if (WRITE_WALL) st_row(out.wall + e, so4, st_w);
+      if (WRITE_DISP) st_row(out.base_disp + e, so16, st_ab);
+    }
+    st_valid = false;
     // row r: P, T and wall enter the ring (velocity leaves them unchanged)
     MarchRing::put(rg.P, rc & 3, lane, b_cur.z);
     MarchRing::put(rg.T, rc & 3, lane, b_cur.w);
@@ -151,7 +171,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     __syncthreads();
 
     if (r >= y_lo + 1) { // advection of row y = r-2 (velocity rows r-3 .. r-1 are in the ring)
-      const int y = wrapmod(r - 2, Y);
+      const int y = yw_m2;
       float4 ab, aw;
       char4 awl;
       {
@@ -166,7 +186,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
         }
         if (fast) {
           MDryAcc a{rg, l1, yc};
-          advection_cell<true>(u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, col, y, a, ab, aw, awl);
+          advection_cell<true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
         } else { // exact out-of-line path (velocity recomputed from global memory)
           const AdvOut o = advection_cell_dry_global(ctx, in, false, col, y);
           ab = o.b;
@@ -174,15 +194,12 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
           awl = o.wl;
         }
       }
-      if (r >= y_lo + 2) { // pressure of row y: left neighbour by wavefront shuffle, row below from registers
-        const float vx_l = __shfl_up(ab.x, 1);
-        const float4 p = pressure_cell(ab, vx_l, adv_vy_prev, adv_T_prev, adv_w_prev.x, adv_w_prev.y);
-        if (lane_out) {
-          const size_t gi = fidx(c_out, y, X);
-          out.base[gi] = p;
-          if (WRITE_WALL) out.wall[gi] = awl;
-          if (WRITE_DISP) out.base_disp[gi] = ab;
-        }
+      if (r >= y_lo + 2) { // pressure of row y: left neighbour by a whole-wave shift, row below from registers
+        const float vx_l = wave_from_left(ab.x);
+        st_p = pressure_cell(ab, vx_l, adv_vy_prev, adv_T_prev, adv_w_prev.x, adv_w_prev.y);
+        st_w = awl;
+        st_ab = ab;
+        st_valid = true;
       }
       adv_vy_prev = ab.y;
       adv_T_prev = ab.w;
@@ -192,6 +209,14 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     w_prev = w_cur;
     big3 = big2;
     big2 = big1;
+    yw_p1 = yw_p1 + 1 == Y ? 0 : yw_p1 + 1;
+    yw_m2 = yw_m2 + 1 == Y ? 0 : yw_m2 + 1;
+  }
+  if (st_valid && lane_out) { // the last row
+    const size_t e = (size_t)(y_hi - 1) * X;
+    st_row(out.base + e, so16, st_p);
+    if (WRITE_WALL) st_row(out.wall + e, so4, st_w);
+    if (WRITE_DISP) st_row(out.base_disp + e, so16, st_ab);
   }
 }
 

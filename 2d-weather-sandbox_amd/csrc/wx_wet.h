@@ -366,6 +366,8 @@ __device__ __forceinline__ int ring_back(int s, int k, int n) // slot of the row
   return v < 0 ? v + n : v;
 }
 
+// A launch covers the strips [strip_lo, strip_lo + n_strips) of the n_strips_all strips of the (slab of the) grid: the whole
+// width normally; the edge strips and the interior separately where a slab overlaps its halo exchange with compute.
 // OPT_OUT: also store what only display-side consumers see (curl, post-boundary water, post-advection base): last iteration of a
 // wx_step call. HAS_FB: the precipitation feedback / deposition textures may be non-zero.
 // slow_rows: per wave (seg_rows + 1) 64-bit lane masks, one per advected row, of the cells left to the exact path.
@@ -379,7 +381,8 @@ struct WetSegs {
 };
 template <bool OPT_OUT, bool HAS_FB>
 __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out,
-                                                                    unsigned long long *__restrict__ slow_rows, int n_strips, WetSegs segs)
+                                                                    unsigned long long *__restrict__ slow_rows, int n_strips, int strip_lo,
+                                                                    int n_strips_all, WetSegs segs)
 {
   __shared__ WetRing rings[WX_WET_WPB];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   if (j >= gk * n_seg) return;
   const int seg = j / gk, sloc = (j - seg * gk) * WX_WET_WPB + wave;
   if (sloc >= nk) return;
-  const int strip = sk0 + sloc, item = seg * n_strips + strip;
+  const int strip = strip_lo + sk0 + sloc, item = seg * n_strips_all + strip;
   const int c_out = strip * WOUT + lane - WLO; // output column of this lane (may be >= X in the last strip, < 0 in the first)
   const int col = wrapmod(c_out, X);           // column this lane loads / computes
   const bool lane_out = lane >= WLO && lane < WLO + WOUT && c_out < X;
@@ -783,10 +786,12 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
 }
 
 inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, unsigned long long *slow_rows,
-                             bool opt_out, hipStream_t stream)
+                             bool opt_out, hipStream_t stream, int strip_lo = 0, int strip_count = -1)
 {
+  const int ns = strip_count < 0 ? w.n_strips : strip_count;
+  if (ns <= 0) return;
   // 8 XCDs x (workgroups of the largest column block) x segments; surplus workgroups / waves exit at once
-  const dim3 grid(8 * (((w.n_strips + 7) / 8 + WX_WET_WPB - 1) / WX_WET_WPB) * w.segs.n_seg);
+  const dim3 grid(8 * (((ns + 7) / 8 + WX_WET_WPB - 1) / WX_WET_WPB) * w.segs.n_seg);
   static bool dbg = getenv("WX_MARCH_DEBUG") != nullptr;
   if (dbg) {
     fprintf(stderr, "[wx_wet] strips=%d segs=%d waves=%d first/last segment rows=%d/%d\n", w.n_strips, w.segs.n_seg, w.n_strips * w.segs.n_seg,
@@ -794,7 +799,8 @@ inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *c
     dbg = false;
   }
   const bool has_fb = in.fb != nullptr;
-#define WX_LAUNCH_W(O, F) hipLaunchKernelGGL((k_march_wet<O, F>), grid, dim3(64 * WX_WET_WPB), 0, stream, ctx, iterNum, in, out, slow_rows, w.n_strips, w.segs)
+#define WX_LAUNCH_W(O, F) \
+  hipLaunchKernelGGL((k_march_wet<O, F>), grid, dim3(64 * WX_WET_WPB), 0, stream, ctx, iterNum, in, out, slow_rows, ns, strip_lo, w.n_strips, w.segs)
   if (opt_out) {
     if (has_fb) WX_LAUNCH_W(true, true); else WX_LAUNCH_W(true, false);
   } else {

@@ -2,11 +2,14 @@
 """Benchmark of the hot path: Mcell-steps/s of the simulation iteration on MI355X.
 
 `python bench.py --gpus N --steps K --warmup W`. A "step" is ONE simulation iteration (all grid passes +
-lighting; BASELINE.json configs[2]) over the 16384 x 2048 synthetic terrain grid; for N > 1 the same grid
-is cut into N column slabs (strong scaling) with one halo exchange per iteration over RCCL.
+lighting; BASELINE.json configs[2]) over the 16384 x 2048 synthetic terrain grid, issued the way the reference's
+frame loop issues them: frames of IterPerFrame = 10 iterations (app.js:398), i.e. the display-only outputs (curl,
+post-boundary water, post-advection base) are produced once per 10 iterations. For N > 1 the same grid is cut into
+N column slabs (strong scaling) with a ring halo exchange over RCCL.
 Prints one JSON line on rank 0 (contract in the task description): throughput with inputs resident in HBM,
-plus `roofline` (dominant kernel, HIP-event timed on the engine's stream) and `cpu_baseline` (the CPU
-oracle timed on this box's host cores, N=1 only).
+plus `roofline` (dominant kernel, HIP-event timed on the engine's stream), `cpu_baseline` (the CPU oracle timed on
+this box's host cores, N=1 only) and `north_star_dry` (N=1 only): BASELINE.json's north-star stencil -- the fused
+pressure + velocity + advection kernel on a 32768 x 4096 dry grid -- measured in the same process with its own roofline.
 """
 import argparse
 import json
@@ -52,6 +55,8 @@ def parse():
     ap.add_argument("--workload", choices=["wet", "dry"], default="wet",
                     help="wet: BASELINE configs[2] (default, the metric's config); dry: configs[1] pressure+velocity+advection only")
     ap.add_argument("--particles", type=int, default=0, help="also run the particle pass with N droplets (BASELINE configs[4]; N=1 GPU only)")
+    ap.add_argument("--frame", type=int, default=10, help="iterations per wx_step call (the reference's IterPerFrame, app.js:398)")
+    ap.add_argument("--no-north-star", action="store_true", help="skip the 32768 x 4096 dry north-star measurement (N=1)")
     return ap.parse_args()
 
 
@@ -89,7 +94,7 @@ KERNEL_SYMBOL = {  # profile name -> substring of the kernel symbol rocprofv3 re
 }
 
 
-def pmc_traffic(a, kernel):
+def pmc_traffic(a, kernel, X=None, Y=None, workload=None):
     """HBM bytes per launch of `kernel` from the PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE
     in SEPARATE rocprofv3 --pmc passes (kernel-trace only), units of KiB, FETCH_SIZE doubled (on gfx950 it reports half of a
     wide coalesced read stream). Re-runs this script for a few steps under rocprofv3; returns None on any problem."""
@@ -106,7 +111,8 @@ def pmc_traffic(a, kernel):
         for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             d = tempfile.mkdtemp(prefix="wxpmc_", dir="/tmp")
             cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2",
-                   "--X", str(a.X), "--Y", str(a.Y), "--workload", a.workload, "--no-cpu-baseline", "--no-pmc"]
+                   "--X", str(X or a.X), "--Y", str(Y or a.Y), "--workload", workload or a.workload, "--no-cpu-baseline", "--no-pmc",
+                   "--no-north-star", "--frame", str(a.frame)]
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
@@ -124,6 +130,55 @@ def pmc_traffic(a, kernel):
         return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, vals["SQ_INSTS_VALU"]
     except Exception:
         return None, None
+
+
+def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
+    """BASELINE.json north_star: the fused pressure + velocity + advection stencil on a 32768 x 4096 dry grid (configs[1]'s
+    passes at configs[3]'s size) on one GPU, same process, own roofline. A_dry = 36 B/cell-step."""
+    import numpy as np
+    import torch
+    gui = pkg.params.merge_settings(None)
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, pass_mask=pkg.params.PASS_DRY)
+    u["enablePrecipitation"] = 0
+    h = pkg.engine.Handle(X, Y, 0)
+    base, water, wall = pkg.synth.dry_grid(X, Y)
+    h.upload(base, water, wall)
+    del base, water, wall
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    for _ in range(warmup // a.frame):
+        h.step(a.frame)
+    h.sync()
+    runs = []
+    for _ in range(3):  # three timed runs: the slowest one is the claim
+        h.profile(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps // a.frame):
+            h.step(a.frame)
+        h.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = h.profile_read()
+        h.profile(False)
+        runs.append((dt, prof))
+    h.close()
+    dt, prof = max(runs, key=lambda r: r[0])
+    name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
+    avg_ms = ms / cnt
+    achieved = ALGO_BYTES[name] * X * Y / (avg_ms * 1e-3) / 1e9
+    n = (steps // a.frame) * a.frame
+    res = {"workload": f"{X}x{Y} dry-air grid, pressure+velocity+advection only (BASELINE north_star / configs[1] passes), frames of {a.frame}",
+           "value": X * Y * n / dt / 1e6, "unit": "Mcell-steps/s", "steps": n, "ms_per_step": dt / n * 1e3,
+           "runs_Mcell_steps_per_s": [X * Y * n / r[0] / 1e6 for r in runs], "claim": "slowest of three runs",
+           "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "algo_bytes_per_cell": ALGO_BYTES[name], "avg_launch_ms": avg_ms, "launches": cnt, "traffic": None}}
+    if not a.no_pmc:
+        traffic, valu = pmc_traffic(a, name, X, Y, "dry")
+        res["roofline"]["traffic"] = traffic
+        res["roofline"]["traffic_unit"] = "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, KiB counters)"
+        if valu:
+            res["roofline"]["valu"] = {"wave_insts_per_launch": valu, "busy_frac": valu * 4.0 / (1024 * 2.4e9 * avg_ms * 1e-3)}
+    return res
 
 
 def main():
@@ -188,7 +243,14 @@ def main():
         sync = lambda: (drv.sync(), torch.cuda.synchronize())
         barrier = dist.barrier
 
-    step(a.warmup)
+    def run_frames(n):  # n iterations as frames of --frame iterations, like the reference's draw() loop
+        done = 0
+        while done < n:
+            k = min(a.frame, n - done)
+            step(k)
+            done += k
+
+    run_frames(a.warmup)
     sync()
     barrier()
     # per-kernel HIP events (4 event records per iteration) are cheap next to a 1 ms iteration on one GPU; on N GPUs an
@@ -198,7 +260,7 @@ def main():
         stepper.profile(True)
     sync()
     t0 = time.perf_counter()
-    step(a.steps)
+    run_frames(a.steps)
     sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -246,7 +308,8 @@ def main():
             if valu:
                 # the second limiter: a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
                 roof["valu"] = {"wave_insts_per_launch": valu, "busy_frac": valu * 4.0 / (1024 * 2.4e9 * avg_ms * 1e-3),
-                                "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time)"}
+                                "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time); 4 cycles is what SQ_ACTIVE_INST_VALU "
+                                        "charges per instruction, an all-v_mul_f32 micro-benchmark issues one per 3.05 cycles (profiles/r02_ubench_valu.txt)"}
         out = {
             "metric": "Mcell-steps/s", "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -259,6 +322,9 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg)
+        if world == 1 and not a.no_north_star and a.workload == "wet" and not a.particles:
+            stepper.close()
+            out["north_star_dry"] = north_star_dry(a, pkg)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -54,7 +54,7 @@ def _assert_grid_equal(h, o, fields=GRID_FIELDS):
         assert np.array_equal(a, b), f"{f}: {np.count_nonzero(a != b)} of {a.size} values differ, max |d| = {np.abs(a.astype(np.float64) - b).max()}"
 
 
-@pytest.mark.parametrize("name", ["save100qa", "synth64", "randwalls64", "sounding64"])
+@pytest.mark.parametrize("name", ["save100qa", "synth64", "randwalls64", "sounding64", "save100raw", "randwalls64p"])
 @pytest.mark.parametrize("quad_scale", [0, 1])
 def test_bit_exact_vs_oracle_on_golden_inputs(pkg, oracle, golden, E, name, quad_scale, fused):
     g, u = golden(name)
@@ -90,6 +90,72 @@ def test_vs_swiftshader_goldens(pkg, golden, E, fused):
         assert np.abs(b[..., :3] - rb[..., :3]).max() <= tv
         assert np.abs(b[..., 3] - rb[..., 3]).max() <= tT
         assert np.abs(h.read_rect("WATER_CUR") - g[f"it{it}_water_cur"]).max() <= tw
+
+
+def test_reference_raw_save_1000_iterations(pkg, golden, E, fused):
+    """BASELINE configs[0]: the reference's UNMODIFIED `100 X 100 Test` save through the HIP path (quad_scale = 1: the
+    reference's own fragment coordinates), 1000 iterations, straight against the reference's output (fixture save100raw, drawn
+    as GL_POINTS). Wall / cell-type masks bit-exact at every dump; v, P, T, water inside the calibrated 1-ulp perturbation
+    envelope (tests/golden/envelope_save100raw.json, oracle/golden/calibrate_envelope.py)."""
+    import json, os
+    g, u = golden("save100raw")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "envelope_save100raw.json")) as f:
+        env = {int(k): v for k, v in json.load(f)["envelope"].items()}
+    u = dict(u, quad_scale=1, enablePrecipitation=0)
+    X, Y = int(g["X"]), int(g["Y"])
+    h = E.Handle(X, Y, 0)
+    h.upload(g["in_base"], g["in_water"], g["in_wall"])
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    done = 0
+    for it in (1, 10, 50, 200, 1000):
+        h.step(it - done)
+        done = it
+        e = env[it]
+        assert np.array_equal(h.read_rect("WALL_CUR"), g[f"it{it}_wall_cur"]), f"wall masks must be bit-exact (iteration {it})"
+        b, rb = h.read_rect("BASE_CUR"), g[f"it{it}_base_cur"]
+        assert np.abs(b[..., :2] - rb[..., :2]).max() <= e["v"], it
+        assert np.abs(b[..., 2] - rb[..., 2]).max() <= e["P"], it
+        assert np.abs(b[..., 3] - rb[..., 3]).max() <= e["T"], it
+        assert np.abs(h.read_rect("WATER_CUR") - g[f"it{it}_water_cur"]).max() <= e["water"], it
+    assert h.iter == 1000
+    h.close()
+
+
+def test_lightning_vs_reference(pkg, golden, E):
+    """Lightning (precipitationShader.vert:121-140, lightningLocationShader.frag:24-38) through the HIP path against the
+    reference, iteration by iteration on the reference's own inputs (fixture lightning64; pass_mask = precipitation only, the
+    post-advection textures uploaded as the state): the rejected double strike, the accepted single strike, the 30-iteration
+    lock-out and the multi-strikes after it. The strike decision hashes temperature bits, hence no free-running comparison."""
+    g, u = golden("lightning64")
+    X, Y, n = int(g["X"]), int(g["Y"]), len(g["in_drops"])
+    iter0, niter = int(g["iter0"]), int(g["niter"])
+    u = dict(u, quad_scale=1, enablePrecipitation=1, pass_mask=pkg.params.PASS_PRECIPITATION)
+    h = E.Handle(X, Y, n)
+    drops, light = g["in_drops"].copy(), np.zeros(4, np.float32)
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    flipped = accepted = 0
+    for k in range(1, niter + 1):
+        h.upload(g[f"it{k}_base_disp"], g[f"it{k}_water_cur"], g["in_wall"], drops)
+        h.set_params(p, u["initial_T"])
+        h.set_lightning(light)
+        h.iter = iter0 + k - 1
+        h.step(1)
+        d, rd, rfb, rl = h.read_particles(), g[f"it{k}_drops"], g[f"it{k}_precip_fb"], g[f"it{k}_lightning"]
+        flip = np.abs(d - rd).max(1) > 2.5e-7  # spawn threshold fract(pow(cloud * 10, 2)): one driver-pow ulp flips ~1 droplet in 1000
+        assert flip.sum() <= 2, (k, int(flip.sum()))
+        flipped += int(flip.sum())
+        assert np.array_equal((d[:, 2] >= 0)[~flip], (rd[:, 2] >= 0)[~flip]), k
+        fb = h.read_rect("PRECIP_FB", 0, 0, 2, 1)
+        assert abs(fb[0, 0, 0] - rfb[0, 0, 0]) <= flip.sum(), k
+        if not flip.any():  # (1,0) is the SUM of that iteration's strike requests: exact for one, atomics-order rounding for several
+            assert np.abs(fb[0, 1] - rfb[0, 1]).max() <= 2e-7 * max(1.0, np.abs(rfb[0, 1]).max()), (k, fb[0, 1], rfb[0, 1])
+            if rfb[0, 1, 2] <= iter0 + k - 1:
+                assert np.array_equal(fb[0, 1], rfb[0, 1]), (k, fb[0, 1], rfb[0, 1])
+        assert np.array_equal(h.read_rect("LIGHTNING"), rl), (k, h.read_rect("LIGHTNING"), rl)
+        accepted += int(rl[2] != light[2])
+        drops, light = rd.copy(), rl.copy()
+    assert accepted >= 1 and flipped <= 0.001 * n * niter
+    h.close()
 
 
 @pytest.mark.parametrize("X,Y", [(512, 128), (192, 96), (130, 50), (4100, 20)])
