@@ -116,6 +116,11 @@ struct wx_sim {
   FullCtx *full_ctx = nullptr;
   unsigned long long *slow_rows = nullptr; // marching wet kernel: per-wave row masks of the cells left to the exact path
   size_t slow_cap = 0;
+  // overlap of the halo exchange with compute (wx_set_comm_stream / wx_step_overlap)
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_edges = nullptr, ev_unpacked = nullptr; // edge strips of the last iteration done (compute stream) / ghosts written (comm stream)
+  bool edges_recorded = false;   // ev_edges was recorded behind the edge strips of the latest iteration
+  bool unpack_pending = false;   // ghost columns were unpacked on the comm stream since the compute stream last waited
   int air_from_row = -1;       // lowest row above which every cell is free air (cost model of the row segmentation); -1: to be measured
   WetLaunch wet_shape{};       // cached launch shape for that value
   bool wet_shape_valid = false;
@@ -480,10 +485,20 @@ int iterate_fused(wx_sim *s, bool write_disp, bool precip)
   return WX_OK;
 }
 
+// the compute stream may not touch ghost columns before the comm stream has written them
+static void wait_unpacked(wx_sim *s)
+{
+  if (!s->unpack_pending) return;
+  hipStreamWaitEvent(s->stream, s->ev_unpacked, 0);
+  s->unpack_pending = false;
+}
+
 // The whole iteration as ONE row-marching kernel (wx_wet.h). Reads base[0], wall[0], water[1], the light_0 planes and the source
 // light planes; writes the other buffer of each pair and swaps the pointers, so that afterwards the usual roles hold again
 // (base[0] / wall[0] = post-pressure state, water[1] = post-advection water, lp[0] / lp[1] = light_0 / light_1 as in the reference).
-int iterate_march_wet(wx_sim *s, bool opt_out, bool precip)
+// edge_mode: 0 = one launch over all strips; 1 = edge strips first, event, interior (last iteration before an exchange);
+// 2 = interior first, wait for the unpack event, edge strips (first iteration after an exchange); 3 = a one-iteration period: both
+int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
 {
   const int src = s->even ? 0 : 1;
   light_to_planes(s);
@@ -519,7 +534,26 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip)
   }
   {
     ProfScope ps(s, K_MARCH_WET);
-    launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream);
+    // edge strips: every output column wx_halo_pack reads ([halo, 2*halo) and its mirror) and every strip that reads ghost columns
+    const int nl = s->halo > 0 ? (2 * s->halo - 1) / WOUT + 1 : 0, nr0 = s->halo > 0 ? (s->X - 2 * s->halo) / WOUT : shape.n_strips;
+    const float itn = (float)s->iter;
+    if (edge_mode == 0 || s->halo == 0 || nl >= nr0) {
+      if (edge_mode & 2) wait_unpacked(s);
+      launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream);
+    } else {
+      const bool interior_first = (edge_mode & 2) && s->unpack_pending;
+      if (interior_first) { // ghosts still in flight: everything that does not read them goes first
+        launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream, nl, nr0 - nl);
+        wait_unpacked(s);
+      }
+      launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream, 0, nl);
+      launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream, nr0, shape.n_strips - nr0);
+      if (edge_mode & 1) { // the columns the neighbours need are final: let the comm stream pack them while the interior computes
+        hipEventRecord(s->ev_edges, s->stream);
+        s->edges_recorded = true;
+      }
+      if (!interior_first) launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream, nl, nr0 - nl);
+    }
   }
   std::swap(s->base[0], s->base[1]);
   std::swap(s->wall[0], s->wall[1]);
@@ -689,6 +723,10 @@ void wx_destroy(wx_sim *s)
     hipEventDestroy(s->ev_copy_done);
     hipStreamDestroy(s->copy_stream);
   }
+  if (s->ev_edges) {
+    hipEventDestroy(s->ev_edges);
+    hipEventDestroy(s->ev_unpacked);
+  }
   hipFree(s->state);
   hipFree(s->keys);
   hipFree(s->slow_ctx);
@@ -842,7 +880,9 @@ int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const f
   return WX_OK;
 }
 
-int wx_step(wx_sim *s, int n_iter)
+int wx_step(wx_sim *s, int n_iter) { return wx_step_overlap(s, n_iter, 0u); }
+
+int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
 {
   if (!s) return WX_E_INVALID;
   if (n_iter < 0) return fail(s, WX_E_INVALID, "wx_step: n_iter < 0");
@@ -877,11 +917,18 @@ int wx_step(wx_sim *s, int n_iter)
   }
   if (!(fused && s->fused == 1)) cow_resolve(s);    // the other kernel sets take water[0] as a fully written buffer
   if (!(fused && s->fused >= 1)) light_to_rgba(s);  // ... and the per-pass / dry kernels the light textures interleaved
+  // overlap needs the kernel that can be launched per strip range; everything else orders the exchange on the compute stream
+  const bool can_split = fused && s->fused >= 2 && !precip && s->comm_stream != nullptr && s->halo > 0;
+  if (!can_split) wait_unpacked(s);
+  s->edges_recorded = false;
   for (int it = 0; it < n_iter; it++) {
+    int edge_mode = 0;
+    if (can_split) edge_mode = ((flags & WX_OVERLAP_EDGES_LAST) && it == 0 ? 2 : 0) | ((flags & WX_OVERLAP_EDGES_FIRST) && it == n_iter - 1 ? 1 : 0);
+    if (can_split && it == 0 && !(edge_mode & 2)) wait_unpacked(s);
     if (dry)
       iterate_dry(s, precip || it == n_iter - 1);
     else if (fused && s->fused >= 2) {
-      const int rc = iterate_march_wet(s, it == n_iter - 1, precip);
+      const int rc = iterate_march_wet(s, it == n_iter - 1, precip, edge_mode);
       if (rc != WX_OK) return rc;
     }
     else if (fused)
@@ -951,6 +998,7 @@ int wx_step(wx_sim *s, int n_iter)
 int wx_sync(wx_sim *s)
 {
   if (!s) return WX_E_INVALID;
+  if (s->comm_stream) HIPCHK(s, hipStreamSynchronize(s->comm_stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
   return WX_OK;
 }
@@ -992,6 +1040,7 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return WX_OK;
   }
+  wait_unpacked(s); // ghost columns written on the comm stream are part of what a readback sees
   const void *ptr;
   int ch, el;
   if (field_info(s, field, &ptr, &ch, &el)) return fail(s, WX_E_INVALID, "wx_read_rect: unknown field %d", field);
@@ -1091,6 +1140,20 @@ int wx_set_stream(wx_sim *s, void *hip_stream)
   return WX_OK;
 }
 
+int wx_set_comm_stream(wx_sim *s, void *hip_stream)
+{
+  if (!s) return WX_E_INVALID;
+  HIPCHK(s, hipStreamSynchronize(s->stream));
+  if (s->comm_stream) HIPCHK(s, hipStreamSynchronize(s->comm_stream));
+  s->comm_stream = (hipStream_t)hip_stream;
+  s->edges_recorded = s->unpack_pending = false;
+  if (hip_stream && !s->ev_edges) {
+    HIPCHK(s, hipEventCreateWithFlags(&s->ev_edges, hipEventDisableTiming));
+    HIPCHK(s, hipEventCreateWithFlags(&s->ev_unpacked, hipEventDisableTiming));
+  }
+  return WX_OK;
+}
+
 void *wx_device_ptr(wx_sim *s, int field)
 {
   if (!s) return nullptr;
@@ -1122,8 +1185,17 @@ int wx_halo_pack(wx_sim *s, int side, void *dev_buf)
   HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
              s->keys ? s->fb : nullptr, s->keys ? s->dep : nullptr};
   const size_t o8 = (size_t)n * (s->keys ? 80 : 64), o4 = o8 + (s->keys ? (size_t)n * 8 : 0);
+  hipStream_t st = s->stream;
+  if (s->comm_stream) { // the packed columns are final behind ev_edges (or, without an edge-first step, behind everything enqueued so far)
+    if (!s->edges_recorded) {
+      HIPCHK(s, hipEventRecord(s->ev_edges, s->stream));
+      s->edges_recorded = true;
+    }
+    HIPCHK(s, hipStreamWaitEvent(s->comm_stream, s->ev_edges, 0));
+    st = s->comm_stream;
+  }
   ProfScope ps(s, K_HALO);
-  hipLaunchKernelGGL(k_halo_pack, dim3((n + 255) / 256), dim3(256), 0, s->stream, f, s->X, s->Y, s->halo, halo_xstart(s, side, true),
+  hipLaunchKernelGGL(k_halo_pack, dim3((n + 255) / 256), dim3(256), 0, st, f, s->X, s->Y, s->halo, halo_xstart(s, side, true),
                      (float4 *)dev_buf, (float2 *)((char *)dev_buf + o8), (char4 *)((char *)dev_buf + o4));
   HIPCHK(s, hipGetLastError());
   return WX_OK;
@@ -1138,11 +1210,16 @@ int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
   HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
              s->keys ? s->fb : nullptr, s->keys ? s->dep : nullptr};
   const size_t o8 = (size_t)n * (s->keys ? 80 : 64), o4 = o8 + (s->keys ? (size_t)n * 8 : 0);
+  hipStream_t st = s->comm_stream ? s->comm_stream : s->stream;
   ProfScope ps(s, K_HALO);
-  hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256), dim3(256), 0, s->stream, f, s->X, s->Y, s->halo, halo_xstart(s, side, false),
+  hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256), dim3(256), 0, st, f, s->X, s->Y, s->halo, halo_xstart(s, side, false),
                      (const float4 *)dev_buf, (const float2 *)((const char *)dev_buf + o8), (const char4 *)((const char *)dev_buf + o4),
                      s->water_trivial ? &s->state->ghost_nontrivial : nullptr);
   if (s->water_trivial) s->ghost_check = true;
+  if (s->comm_stream) { // whoever touches the ghost columns next on the compute stream waits for this
+    HIPCHK(s, hipEventRecord(s->ev_unpacked, s->comm_stream));
+    s->unpack_pending = true;
+  }
   if (s->keys) { // the ghost tiles of the feedback texture now hold a neighbour's values: nothing is "known zero" any more
     hipMemsetAsync(s->sg.fb_zero, 0, (size_t)s->sg.TXn * s->sg.TYn, s->stream);
     s->fb_dirty = true;

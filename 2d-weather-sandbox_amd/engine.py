@@ -32,7 +32,7 @@ EXPORTS = [
     "wx_device_ptr", "wx_local_width", "wx_halo_bytes", "wx_halo_pack", "wx_halo_unpack", "wx_profile",
     "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_particles_keys",
     "wx_particles_contribute", "wx_particles_adopt", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns",
-    "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait",
+    "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait", "wx_set_comm_stream", "wx_step_overlap",
 ]
 
 
@@ -76,6 +76,8 @@ def lib() -> C.CDLL:
     L.wx_upload.argtypes = [vp, vp, vp, vp, vp]
     L.wx_set_params.argtypes = [vp, C.POINTER(WxParams), vp, vp, vp, vp]
     L.wx_step.argtypes = [vp, i32]
+    L.wx_step_overlap.argtypes = [vp, i32, C.c_uint]
+    L.wx_set_comm_stream.argtypes = [vp, vp]
     L.wx_sync.argtypes = [vp]
     L.wx_get_iter.argtypes = [vp]
     L.wx_get_iter.restype = i64
@@ -184,8 +186,16 @@ class Handle:
         ptr = [None if a is None else a.ctypes.data for a in arrs]
         self._chk(lib().wx_set_params(self._h, C.byref(p), *ptr))
 
-    def step(self, n: int = 1):
-        self._chk(lib().wx_step(self._h, int(n)))
+    OVERLAP_EDGES_FIRST, OVERLAP_EDGES_LAST = 1, 2
+
+    def step(self, n: int = 1, overlap: int = 0):
+        """n iterations; ``overlap`` (slab handles with a comm stream): OVERLAP_EDGES_FIRST -- edge strips of the last iteration
+        first, so that the halo can be packed and sent while the interior computes; OVERLAP_EDGES_LAST -- interior strips of the
+        first iteration first, the edge strips once the ghost columns have arrived (wx_step_overlap)."""
+        if overlap:
+            self._chk(lib().wx_step_overlap(self._h, int(n), int(overlap)))
+        else:
+            self._chk(lib().wx_step(self._h, int(n)))
 
     def sync(self):
         self._chk(lib().wx_sync(self._h))
@@ -225,6 +235,10 @@ class Handle:
     # ---- plumbing ----
     def set_stream(self, stream_ptr: int):
         self._chk(lib().wx_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_comm_stream(self, stream_ptr: int):
+        """Run wx_halo_pack / wx_halo_unpack on this stream (the one the host issues send / recv on), event-fenced against compute."""
+        self._chk(lib().wx_set_comm_stream(self._h, C.c_void_p(stream_ptr)))
 
     def device_ptr(self, field: str) -> int:
         return lib().wx_device_ptr(self._h, FIELD_IDS[field])

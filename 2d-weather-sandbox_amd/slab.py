@@ -9,6 +9,12 @@ owned columns of the carried state (base_0, wall_0, water_1, both light textures
 ring neighbours with point-to-point send/recv (RCCL over xGMI on GPUs, gloo in the CPU tests) and unpacked
 into their ghost columns. There is no collective on the data path.
 
+Overlap (``HipSlabEngine`` without particles): pack, send / recv and unpack run on a side stream (``wx_set_comm_stream``). The
+last iteration before an exchange launches the edge strips first (``wx_step_overlap(..., EDGES_FIRST)``): the exchange starts as
+soon as the columns the neighbours need are final and proceeds while the interior strips compute; the first iteration after it
+launches the interior strips first and the edge strips -- the only ones that read ghost columns -- once the unpack event has
+fired (``EDGES_LAST``). The host never blocks.
+
 Particles (``n_droplets > 0``): every rank holds the whole droplet pool and processes, redundantly in the ghost
 zones, the droplets whose sample position lies where its grid is still valid (csrc/wx_kernels.h, ``SlabP``). At every
 halo exchange (which then also carries the feedback / deposition textures) the pool is reconciled: all-reduce(MAX)
@@ -20,6 +26,8 @@ engine (``HipSlabEngine``, device tensors + NCCL) and on a checker engine in the
 """
 from __future__ import annotations
 
+import contextlib
+import os
 from typing import Any, Dict, Optional
 
 import numpy as np
@@ -50,9 +58,33 @@ class HipSlabEngine:
         self.n_droplets = n_droplets
         self.h = Handle(X_owned, Y, n_droplets, X_global=X_global, x0=x0, halo=halo)
         self.h.slab_set_rank(rank)
-        # run the kernels on torch's current stream so that they are ordered with the NCCL send/recv ops
+        # compute on torch's current stream; the halo exchange (pack -> send / recv -> unpack) on a side stream that the library
+        # fences against compute with events. With particles the exchange stays in order on the compute stream: the pool
+        # reconciliation needs the finished iteration anyway.
         self.h.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        self.comm = None
+        if n_droplets == 0 and os.environ.get("WX_SLAB_OVERLAP", "1") != "0":
+            self.comm = torch.cuda.Stream(device)
+            self.h.set_comm_stream(self.comm.cuda_stream)
         self.nbytes = self.h.halo_bytes()
+        self._light = None
+
+    @property
+    def supports_overlap(self) -> bool:
+        return self.comm is not None
+
+    def comm_context(self):
+        """Stream context for the host's send / recv calls: the stream pack and unpack run on."""
+        return torch.cuda.stream(self.comm) if self.comm is not None else contextlib.nullcontext()
+
+    def lightning_tensor(self) -> torch.Tensor:
+        """Live device view of the handle's 4-float lightning state (x, y, start iteration, intensity): no host round trip."""
+        if self._light is None:
+            class _Dev:  # the CUDA array interface is all torch needs to wrap a foreign device pointer
+                def __init__(self, ptr):
+                    self.__cuda_array_interface__ = {"shape": (4,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+            self._light = torch.as_tensor(_Dev(self.h.device_ptr("LIGHTNING")), device=self.device)
+        return self._light
 
     def upload(self, base, water, wall, drops=None):
         self.h.upload(base, water, wall, drops)
@@ -94,8 +126,8 @@ class HipSlabEngine:
     def unpack(self, side: int, buf: torch.Tensor):
         self.h.halo_unpack(side, buf.data_ptr())
 
-    def step(self, n: int):
-        self.h.step(n)
+    def step(self, n: int, overlap: int = 0):
+        self.h.step(n, overlap)
 
     def sync(self):
         self.h.sync()
@@ -114,6 +146,8 @@ class SlabSim:
         self.left, self.right = (rank - 1) % world, (rank + 1) % world
         self._since_exchange = 0
         self._iters = 0
+        self._exchanged = False  # ghost columns of the current period came from an exchange (not from the upload)
+        self._overlap = world > 1 and bool(getattr(engine, "supports_overlap", False))
         if world > 1:
             self.send = [engine.new_buffer(), engine.new_buffer()]  # [to left, to right]
             self.recv = [engine.new_buffer(), engine.new_buffer()]  # [from left, from right]
@@ -130,62 +164,82 @@ class SlabSim:
         return getattr(self.engine, "h", self.engine)
 
     def exchange(self):
-        """Ring exchange: my left edge -> left neighbour's right ghosts, my right edge -> right neighbour's left ghosts."""
+        """Ring exchange: my left edge -> left neighbour's right ghosts, my right edge -> right neighbour's left ghosts. Everything
+        is enqueued (on the engine's comm stream when it has one); nothing here waits on the host except the gloo staging path."""
         if self.world == 1:
             return
         e = self.engine
-        e.pack(0, self.send[0])
-        e.pack(1, self.send[1])
-        send, recv = self.send, self.recv
-        if self._stage:
-            e.sync()
-            for hb, b in zip(self._hsend, self.send):
-                hb.copy_(b)
-            send, recv = self._hsend, self._hrecv
-        if self.world == 2:
-            # both neighbours are the same rank: order the two messages identically on both sides
-            ops = [dist.P2POp(dist.isend, send[0], self.left), dist.P2POp(dist.isend, send[1], self.right),
-                   dist.P2POp(dist.irecv, recv[1], self.right), dist.P2POp(dist.irecv, recv[0], self.left)]
-        else:
-            ops = [dist.P2POp(dist.isend, send[0], self.left), dist.P2POp(dist.irecv, recv[1], self.right),
-                   dist.P2POp(dist.isend, send[1], self.right), dist.P2POp(dist.irecv, recv[0], self.left)]
-        for r in dist.batch_isend_irecv(ops):
-            r.wait()
-        if self._stage:
-            for hb, b in zip(self._hrecv, self.recv):
-                b.copy_(hb)
-        e.unpack(0, self.recv[0])  # left ghosts  <- left neighbour's right edge
-        e.unpack(1, self.recv[1])  # right ghosts <- right neighbour's left edge
+        ctx = e.comm_context() if hasattr(e, "comm_context") else contextlib.nullcontext()
+        with ctx:
+            e.pack(0, self.send[0])
+            e.pack(1, self.send[1])
+            send, recv = self.send, self.recv
+            if self._stage:
+                e.sync()
+                for hb, b in zip(self._hsend, self.send):
+                    hb.copy_(b)
+                send, recv = self._hsend, self._hrecv
+            if self.world == 2:
+                # both neighbours are the same rank: order the two messages identically on both sides
+                ops = [dist.P2POp(dist.isend, send[0], self.left), dist.P2POp(dist.isend, send[1], self.right),
+                       dist.P2POp(dist.irecv, recv[1], self.right), dist.P2POp(dist.irecv, recv[0], self.left)]
+            else:
+                ops = [dist.P2POp(dist.isend, send[0], self.left), dist.P2POp(dist.irecv, recv[1], self.right),
+                       dist.P2POp(dist.isend, send[1], self.right), dist.P2POp(dist.irecv, recv[0], self.left)]
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()  # NCCL / RCCL: orders the current (comm) stream behind the transfer, does not block the host
+            if self._stage:
+                for hb, b in zip(self._hrecv, self.recv):
+                    b.copy_(hb)
+            e.unpack(0, self.recv[0])  # left ghosts  <- left neighbour's right edge
+            e.unpack(1, self.recv[1])  # right ghosts <- right neighbour's left edge
         if self.particles:
             self.reconcile_particles()
         self._since_exchange = 0
+        self._exchanged = True
 
     def reconcile_particles(self):
         """Make every rank's copy of the droplet pool the copy of the rank that tracked each droplet last, and every
         rank's lightning state the latest strike any rank registered. Two all-reduces: MAX over the claim keys (+ the
-        strike iteration), SUM over the winners' states (+ the winning strike)."""
+        strike key), SUM over the winners' states (+ the winning strike). Device tensors only: no host round trip.
+
+        Strike key = start iteration * 1024 + (1023 - rank): the latest strike wins; two ranks that registered different strikes
+        in the same iteration are told apart by the rank, so exactly one of them contributes (no averaging of two bolts)."""
         e, n = self.engine, self.engine.n_droplets
         e.particle_keys(self.keys)
-        strike = np.asarray(e.lightning(), np.float32)  # (x, y, iteration, intensity), lightningLocationShader.frag:24-38
-        self.keys[n] = int(strike[2])
+        live = hasattr(e, "lightning_tensor")
+        light = e.lightning_tensor() if live else torch.from_numpy(np.asarray(e.lightning(), np.float32).copy()).to(self.keys.device)
+        it = light[2].to(torch.int64) % (1 << 20)
+        my_key = torch.where(light[2] > 0, it * 1024 + (1023 - self.rank), torch.zeros_like(it)).to(torch.int32)
+        self.keys[n:n + 1] = my_key
         dist.all_reduce(self.keys, op=dist.ReduceOp.MAX)
         e.particle_contribute(self.keys, self.state)
-        mine = strike[2] > 0 and int(strike[2]) == int(self.keys[n])
-        self.state[5 * n:] = torch.tensor([1.0, *strike] if mine else [0.0] * 5, dtype=torch.float32)
+        mine = ((my_key > 0) & (my_key == self.keys[n])).to(torch.float32)
+        self.state[5 * n] = mine
+        self.state[5 * n + 1:] = light * mine
         dist.all_reduce(self.state, op=dist.ReduceOp.SUM)
         # the reference refreshes the `inactiveDroplets` uniform every 600 iterations (app.js:5957-5966)
         refresh = (self._iters // 600) != ((self._iters - self._since_exchange) // 600)
         e.particle_adopt(self.keys, self.state, refresh)
-        tail = self.state[5 * n:].cpu().numpy()
-        if tail[0] > 0:
-            e.set_lightning(tail[1:] / tail[0])  # identical copies from the ranks that share the strike
+        tail = self.state[5 * n:]
+        new_light = torch.where(tail[0] > 0, tail[1:], light)  # exactly one rank contributed the winning strike
+        if live:
+            light.copy_(new_light)
+        else:
+            e.set_lightning(new_light.cpu().numpy())
         e.period_begin()
 
     def step(self, n: int):
         done = 0
         while done < n:
             k = min(self.iters_per_exchange - self._since_exchange, n - done)
-            self.engine.step(k)
+            if self._overlap:
+                # first iteration after an exchange: interior strips first, edge strips once the ghosts have arrived;
+                # last iteration before one: edge strips first, so that the exchange starts while the interior computes
+                flags = (2 if (self._since_exchange == 0 and self._exchanged) else 0) | (1 if self._since_exchange + k >= self.iters_per_exchange else 0)
+                self.engine.step(k, flags)
+            else:
+                self.engine.step(k)
             done += k
             self._since_exchange += k
             self._iters += k

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WX_ABI_VERSION 2
+#define WX_ABI_VERSION 3
 
 /* error codes */
 #define WX_OK 0
@@ -179,6 +179,22 @@ int wx_local_width(const wx_sim *s);                /* X_owned + 2*halo */
 size_t wx_halo_bytes(const wx_sim *s);
 int wx_halo_pack(wx_sim *s, int side, void *dev_buf);
 int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf);
+/* Overlap of the halo exchange with compute (no reference counterpart; BASELINE north_star: "halo exchange ... overlapped on a
+ * side HIP stream"). After wx_set_comm_stream(s, stream) the pack / unpack kernels run on `stream` -- the stream the host also
+ * issues its send / recv on -- fenced against the handle's compute stream by events inside the library:
+ *   wx_step_overlap(s, n, WX_OVERLAP_EDGES_FIRST): in the LAST iteration of the call the edge strips (every column
+ *     wx_halo_pack reads) are launched first and an event is recorded behind them; wx_halo_pack waits for that event only,
+ *     so packing and sending run while the interior strips of that iteration still compute;
+ *   wx_step_overlap(s, n, WX_OVERLAP_EDGES_LAST): in the FIRST iteration the interior strips are launched first; the compute
+ *     stream then waits for the event wx_halo_unpack recorded on the comm stream and launches the edge strips, the only ones
+ *     that read ghost columns.
+ * Both flags may be combined. The split needs the row-marching wet kernel (default kernel set, all grid passes on, particles
+ * off) and a slab wide enough to have interior strips; otherwise the call degrades to the in-order exchange: wx_halo_pack waits
+ * for everything enqueued on the compute stream, the next wx_step waits for the unpack. wx_step(s, n) == wx_step_overlap(s, n, 0). */
+#define WX_OVERLAP_EDGES_FIRST 1u
+#define WX_OVERLAP_EDGES_LAST 2u
+int wx_set_comm_stream(wx_sim *s, void *hip_stream); /* NULL: pack / unpack on the compute stream again */
+int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags);
 
 /* Particles on slabs (n_droplets > 0 with halo > 0; halo and X_owned multiples of 64). Every rank holds the WHOLE droplet
  * pool (same wx_upload drops array on every rank) and, in each iteration, processes the droplets whose sample position

@@ -487,6 +487,83 @@ def test_slab_handles_equal_whole_domain(pkg, E, fused, nslab, halo):
             assert np.array_equal(h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]), (f, r)
 
 
+@pytest.mark.parametrize("nslab,halo,X", [(2, 12, 1024), (4, 24, 4096), (2, 6, 128)])
+def test_slab_overlapped_exchange_equals_whole_domain(pkg, E, monkeypatch, nslab, halo, X):
+    """The exchange / compute overlap (wx_set_comm_stream + wx_step_overlap): N slab handles on one GPU, each with its own compute
+    stream and its own comm stream, nothing synchronised on the host between the steps -- the edge strips of the last iteration
+    run first, pack + copy + unpack proceed on the comm streams while the interior strips compute, the edge strips of the next
+    iteration wait for the unpack event. Ten exchange periods, bit for bit the undecomposed handle. (A slab too narrow to have
+    interior strips, the third case, degrades to the in-order exchange through the same calls.)"""
+    import torch
+    monkeypatch.setenv("WX_FUSED", "2")
+    Y = 64
+    per, n_iter = halo // 6, 10 * (halo // 6) + 1
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    rng = np.random.default_rng(2)
+    air = wall[..., 1] != 0
+    base[..., 0] += np.where(air, rng.normal(0, 0.2, (Y, X)), 0).astype(np.float32)
+    base[..., 1] += np.where(air, rng.normal(0, 0.1, (Y, X)), 0).astype(np.float32)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 35.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=1)
+    u["enablePrecipitation"] = 0
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    xo = X // nslab
+    slabs, bufs, main, comm = [], [], [], []
+    for r in range(nslab):
+        h = E.Handle(xo, Y, 0, X_global=X, x0=r * xo, halo=halo)
+        idx = (r * xo - halo + np.arange(xo + 2 * halo)) % X
+        h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]))
+        h.set_params(p, u["initial_T"])
+        main.append(torch.cuda.Stream())
+        comm.append(torch.cuda.Stream())
+        h.set_stream(main[r].cuda_stream)
+        h.set_comm_stream(comm[r].cuda_stream)
+        slabs.append(h)
+        bufs.append([torch.empty(h.halo_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2)])
+    done, exchanged = 0, False
+    while done < n_iter:
+        k = min(per, n_iter - done)
+        flags = (E.Handle.OVERLAP_EDGES_LAST if exchanged else 0) | (E.Handle.OVERLAP_EDGES_FIRST if k == per else 0)
+        for h in slabs:
+            h.step(k, flags)
+        done += k
+        if k < per:
+            break
+        packed = []
+        for r, h in enumerate(slabs):  # pack on each handle's comm stream (the library waits for the edge-strip event only)
+            h.halo_pack(0, bufs[r][0].data_ptr())
+            h.halo_pack(1, bufs[r][1].data_ptr())
+            ev = torch.cuda.Event()
+            ev.record(comm[r])
+            packed.append(ev)
+        for r, h in enumerate(slabs):  # "recv": a handle's unpack may start once BOTH neighbours have packed
+            comm[r].wait_event(packed[(r - 1) % nslab])
+            comm[r].wait_event(packed[(r + 1) % nslab])
+            h.halo_unpack(0, bufs[(r - 1) % nslab][1].data_ptr())
+            h.halo_unpack(1, bufs[(r + 1) % nslab][0].data_ptr())
+        # a neighbour's NEXT pack overwrites the buffers this handle's unpack reads: fence the comm streams among themselves
+        unpacked = []
+        for r in range(nslab):
+            ev = torch.cuda.Event()
+            ev.record(comm[r])
+            unpacked.append(ev)
+        for r in range(nslab):
+            comm[r].wait_event(unpacked[(r - 1) % nslab])
+            comm[r].wait_event(unpacked[(r + 1) % nslab])
+        exchanged = True
+    whole = E.Handle(X, Y, 0)
+    whole.upload(base, water, wall)
+    whole.set_params(p, u["initial_T"])
+    whole.step(n_iter)
+    for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1"):
+        ref = whole.read_rect(f)
+        for r, h in enumerate(slabs):
+            assert np.array_equal(h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]), (f, r)
+    for h in slabs:
+        h.close()
+
+
 @pytest.mark.parametrize("nslab", [2, 4])
 def test_slab_particles_equal_whole_domain(pkg, E, nslab):
     """Particles on column slabs (replicated droplet pool, ghost-zone processing, claim-key reconciliation): N slab

@@ -6,14 +6,14 @@ sys.path.insert(0, ROOT)
 rows = []
 
 def bench(label, args):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-pmc"] + args, capture_output=True, text=True).stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-pmc", "--no-north-star"] + args, capture_output=True, text=True).stdout
     d = json.loads(out.strip().split("\n")[-1])
     rows.append((label, " ".join(args), d["ms_per_step"], d["value"], d["roofline"]["kernels_ms_per_step"]))
 
-# C1: the reference's own 100 x 100 test save (quad-aligned derivative stored as golden inputs), 1000 iterations, Python host
+# C1: the reference's own, unmodified 100 x 100 test save (inputs of the save100raw golden), 1000 iterations, Python host
 import wxpkg
 pkg = wxpkg.load_package()
-g = np.load(os.path.join(ROOT, "tests", "golden", "save100qa.npz"))
+g = np.load(os.path.join(ROOT, "tests", "golden", "save100raw.npz"))
 u = json.loads(str(g["uniforms_json"]))
 u["initial_T"] = g["initial_T"]
 for k in ("userInputValues", "userInputMove", "airplaneValues"):
