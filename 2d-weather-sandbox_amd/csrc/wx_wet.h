@@ -428,7 +428,8 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   float2 pf_lzw = make_float2(0.f, 0.f);                              // source IR fluxes row r-2
   float4 pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);                     // feedback / deposition row r-3 (HAS_FB)
   float2 pf_dep = make_float2(0.f, 0.f);
-  bool fb_need_next = false, fb_have = false;                         // wave-uniform: the tile(s) of that row hold feedback
+  bool fb_have = false;                                               // wave-uniform: the tile(s) of that row hold feedback
+  unsigned char pf_flag = 1;                                          // "feedback tile is all zero" flag of the row prefetched next
   float4 b_prev = make_float4(0.f, 0.f, 0.f, 0.f);                    // base_0 row r-1
   int w_prev = 0;
   float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);                        // pre-boundary water row r-3
@@ -487,16 +488,15 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         pf_l0y = ld_row(in.l0.y + ew, lo4);
       }
       if (HAS_FB) {
-        fb_have = fb_need_next; // decided one step ago for this very row (r-2)
+        // does any of the (up to three) 64x16 tiles under this strip hold feedback in row r-2? The flag byte was loaded one step
+        // ago (pf_flag), so the vote costs no wait of its own
+        fb_have = in.fb != nullptr && __any(pf_flag == 0);
         if (fb_have) {
           const size_t e = (size_t)yw_m2 * X;
           pf_fb = ld_row(in.fb + e, lo16);
           pf_dep = ld_row(in.dep + e, lo8);
         }
-        // the row after: does any of the (up to three) 64x16 tiles under this strip hold feedback?
-        const int yn = yw_m1;
-        const bool zero = in.fb_zero != nullptr && in.fb_zero[(yn >> 4) * in.fb_txn + (col >> 6)] != 0;
-        fb_need_next = in.fb != nullptr && __any(!zero);
+        pf_flag = in.fb_zero != nullptr ? in.fb_zero[(yw_m1 >> 4) * in.fb_txn + (col >> 6)] : 0; // row r-1, voted on next step
       }
     }
     // ---- the stores of the previous step's row (r-5), issued behind the prefetch ----
