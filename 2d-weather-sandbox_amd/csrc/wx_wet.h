@@ -43,6 +43,12 @@ namespace wx {
 #define WX_WET_WPB 4 // wavefronts per workgroup: independent strips (no barrier between them); the dispatcher spreads the waves of
                      // ONE workgroup evenly over the four SIMDs of a CU, which it does not guarantee for single-wave workgroups
 #endif
+#ifndef WX_WET_SKIP_LOADS
+#define WX_WET_SKIP_LOADS 1 // no water / light loads in the first two warm-up steps; light_0.x only near walls
+#endif
+#ifndef WX_WET_NT_STORES
+#define WX_WET_NT_STORES 0
+#endif
 #ifndef WX_WET_AIR
 #define WX_WET_AIR 1 // wave-uniform free-air instantiations of the boundary / advection / lighting stages
 #endif
@@ -62,6 +68,7 @@ struct WetIn {
   const float4 *fb;     // precipitation feedback / deposition, or NULL when known to be zero
   const float2 *dep;
   const unsigned char *fb_zero; // per 64x16 tile: feedback AND deposition all zero there (may be NULL)
+  const float4 *zero_row;       // one row (X texels) of zeros: what rows of all-zero tiles are "loaded" from
   int fb_txn;
 };
 struct WetOut {
@@ -349,12 +356,24 @@ template <class T> __device__ __forceinline__ T ld_row(const T *row, unsigned by
   asm("" : "+v"(byte_off)); // keeps the zero-extension next to the access: instruction selection folds it only within a block
   return *(GPtr)((GBytes)uniform_addr(row) + byte_off);
 }
+template <int N> struct NativeVec;
+template <> struct NativeVec<4> { typedef unsigned type; };
+template <> struct NativeVec<8> { typedef unsigned type __attribute__((ext_vector_type(2))); };
+template <> struct NativeVec<16> { typedef unsigned type __attribute__((ext_vector_type(4))); };
 template <class T> __device__ __forceinline__ void st_row(T *row, unsigned byte_off, T v)
 {
   typedef __attribute__((address_space(1))) char *GBytes;
-  typedef __attribute__((address_space(1))) T *GPtr;
   asm("" : "+v"(byte_off));
+#if WX_WET_NT_STORES
+  // streamed once, read again only by the next launch: keep the output rows from evicting the input lines that neighbouring
+  // strips still share (halo columns) out of the 4 MB L2
+  typedef typename NativeVec<sizeof(T)>::type NV;
+  typedef __attribute__((address_space(1))) NV *GPtr;
+  __builtin_nontemporal_store(__builtin_bit_cast(NV, v), (GPtr)((GBytes)uniform_addr(row) + byte_off));
+#else
+  typedef __attribute__((address_space(1))) T *GPtr;
   *(GPtr)((GBytes)uniform_addr(row) + byte_off) = v;
+#endif
 }
 #else // host pass of the single-source compile: same meaning, never executed
 template <class T> __device__ __forceinline__ T ld_row(const T *row, unsigned byte_off) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(row) + byte_off); }
@@ -443,6 +462,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   char4 adv_w_prev = make_char4(0, 0, 0, 0);
   int big1 = 0, big2 = 0, big3 = 0;                                   // "some |v| >= 0.9" of post-boundary rows r-3, r-4, r-5
   int nowall1 = 0, nowall2 = 0, nowall3 = 0;                          // "no wall cell" of the same rows
+  int near1 = 1, near2 = 1, near3 = 1, near4 = 1;                     // "some cell at or next to a wall" of input rows r .. r-3
   // outputs of the previous step, stored at the top of this one
   float4 st_p = make_float4(0.f, 0.f, 0.f, 0.f), st_q = st_p, st_l = st_p, st_ab = st_p;
   char4 st_w = make_char4(0, 0, 0, 0);
@@ -466,6 +486,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     const float4 fb_cur = pf_fb;                   // feedback row r-3
     const float2 dep_cur = pf_dep;
     const bool fb_cur_have = fb_have;
+    // (the feedback texel's fourth channel is never read: without this "use" the register allocator hands its register to another
+    // value while the 16-byte load that also writes it is still in flight, and overwriting it then costs a wait for that load)
+    if (HAS_FB) asm volatile("" ::"v"(fb_cur.w));
     asm volatile("" : "+v"(w_raw)); // keeps the byte unpacking on this side of the prefetch
     const char4 w_cur = unpack_wall(w_raw);
     // ---- software prefetch: the loads of the next step are in flight while this one computes ----
@@ -475,7 +498,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         pf_b = ld_row(in.base + e, lo16);
         pf_w = ld_row(wall_raw + e, lo4);
       }
-      {
+      if (!WX_WET_SKIP_LOADS || t >= 2) { // (the first warm-up steps of a segment only feed velocity / curl: no water, no light yet)
         const int rl = r - 1;
         const size_t ew = (size_t)yw_m1 * X;
         pf_q = ld_row(in.water + ew, lo16);
@@ -484,17 +507,22 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         pf_lx = ld_row(in.lsrc.x + el, lo4);
         pf_lzw = ld_row(in.lsrc.zw + el, lo8);
         // ... while the boundary pass samples light_0 at its own (wrapped) row and at the row above it, clamped
-        pf_l0x = ld_row(in.l0.x + ew, lo4);
         pf_l0y = ld_row(in.l0.y + ew, lo4);
+        // light_0's sunlight is only read by cells next to a wall and by surface wall cells, of rows r-1 and r-2: skipped while
+        // none of the wall rows loaded so far (r-3 .. r) has such a cell (in even iterations the load coincides with pf_lx anyway)
+        if (WX_WET_SKIP_LOADS) near1 = __any(w_cur.y <= 1);
+        if (!WX_WET_SKIP_LOADS || (near1 | near2 | near3 | near4)) pf_l0x = ld_row(in.l0.x + ew, lo4);
       }
       if (HAS_FB) {
         // does any of the (up to three) 64x16 tiles under this strip hold feedback in row r-2? The flag byte was loaded one step
         // ago (pf_flag), so the vote costs no wait of its own
-        fb_have = in.fb != nullptr && __any(pf_flag == 0);
-        if (fb_have) {
+        fb_have = __any(pf_flag == 0);
+        {
+          // always the same two loads -- from the textures' row, or from a row of zeros (L2 resident) where the tiles are known
+          // to be zero: a conditional load would make the number of loads per step, which the waits are built on, vary
           const size_t e = (size_t)yw_m2 * X;
-          pf_fb = ld_row(in.fb + e, lo16);
-          pf_dep = ld_row(in.dep + e, lo8);
+          pf_fb = ld_row(fb_have ? in.fb + e : in.zero_row, lo16);
+          pf_dep = ld_row(fb_have ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
         }
         pf_flag = in.fb_zero != nullptr ? in.fb_zero[(yw_m1 >> 4) * in.fb_txn + (col >> 6)] : 0; // row r-1, voted on next step
       }
@@ -678,6 +706,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     big2 = big1;
     nowall3 = nowall2;
     nowall2 = nowall1;
+    near4 = near3;
+    near3 = near2;
+    near2 = near1;
     s0 = s0 + 1 == WD ? 0 : s0 + 1;
     sq3 = sq3 + 1 == WQ ? 0 : sq3 + 1;
     yw_m4 = yw_m3;

@@ -114,6 +114,7 @@ struct wx_sim {
   unsigned int *cow_clean = nullptr;   // per 64x16 tile: kernel A left water[0] / wall[1] unwritten
   bool cow_pending = false;            // water[0] has unwritten tiles whose values live in water[2]
   FullCtx *full_ctx = nullptr;
+  float4 *zero_row = nullptr;              // X texels of zeros (marching wet kernel: rows of feedback tiles that are known to be zero)
   unsigned long long *slow_rows = nullptr; // marching wet kernel: per-wave row masks of the cells left to the exact path
   size_t slow_cap = 0;
   // overlap of the halo exchange with compute (wx_set_comm_stream / wx_step_overlap)
@@ -507,7 +508,8 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
   const LightPlanes light_dst = s->even ? s->lp[1] : s->lp[2];
   const bool fb = s->fb_dirty;
   WetIn in{s->base[0], s->wall[0], s->water[1], LightPlanesC{s->lp[0].x, s->lp[0].y, s->lp[0].zw},
-           LightPlanesC{s->lp[src].x, s->lp[src].y, s->lp[src].zw}, fb ? s->fb : nullptr, fb ? s->dep : nullptr, fb ? s->sg.fb_zero : nullptr, s->sg.TXn};
+           LightPlanesC{s->lp[src].x, s->lp[src].y, s->lp[src].zw}, fb ? s->fb : nullptr, fb ? s->dep : nullptr, fb ? s->sg.fb_zero : nullptr,
+           s->zero_row, s->sg.TXn};
   WetOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], s->water[0], s->curl, precip ? s->tdisp : nullptr};
   if (s->air_from_row < 0) { // after an upload or a wall edit: where does the terrain end? (one small kernel + a 4-byte readback)
     int *d = &s->state->scratch_int, v = 0;
@@ -659,6 +661,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   }
   if (rc == WX_OK) rc = dalloc(s, &s->cow_clean, (size_t)((s->X + 63) / 64) * ((Y + 15) / 16));
   if (rc == WX_OK) rc = dalloc(s, &s->full_ctx, 1);
+  if (rc == WX_OK) rc = dalloc(s, &s->zero_row, (size_t)s->X);
   if (rc == WX_OK) rc = dalloc(s, &s->water[2], n);
   if (rc == WX_OK && n_droplets > 0) {
     SplatGrid &sg = s->sg;
@@ -739,6 +742,7 @@ void wx_destroy(wx_sim *s)
   }
   hipFree(s->cow_clean);
   hipFree(s->full_ctx);
+  hipFree(s->zero_row);
   hipFree(s->slow_rows);
   hipFree(s->water[2]);
   hipFree(s->sg.acc4);
