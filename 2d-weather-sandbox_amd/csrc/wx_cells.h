@@ -92,6 +92,10 @@ struct Uni {
   // filter weights and their four products are then the same for every cell
   int sun_uniform, sun_dx0, sun_fv;
   float sun_w00, sun_w10, sun_w01, sun_w11;
+  // display-only second output of the lighting pass (emittedLight, lightingShader.frag:58-60, 98-101): the sunlight colour for
+  // this sun angle, sunColor(scattering) (common.glsl:367-378), and "abs(sunAngle) > 85 degrees" (urban areas glow at night)
+  float sun_col[3];
+  int night_glow;
   // per iteration
   float iterNum;
   int iterI; // int(iterNum)
@@ -883,6 +887,18 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
   wall_out = pack_wall(wl);
 }
 
+// common.glsl:367-372; mix() lowered like mixf()
+__host__ __device__ __forceinline__ void hsv2rgb(float h, float sv, float v, float rgb[3])
+{
+  const float K[3] = {1.0f, 2.0f / 3.0f, 1.0f / 3.0f};
+  for (int i = 0; i < 3; i++) {
+    const float t = h + K[i];
+    const float pch = fabsf((t - floorf(t)) * 6.0f - 3.0f);
+    const float c = fminf(fmaxf(pch - 1.0f, 0.0f), 1.0f);
+    rgb[i] = v * (1.0f + sv * (c - 1.0f));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // lightingShader.frag:38-170
 // Accessor A: T(dy) -> base TEMPERATURE at (x, y+dy) with y REPEAT ; water() -> float4 ; wall() -> char4 ;
@@ -891,14 +907,18 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
 //             caller clamps) ; used for the bilinear sun tap and the IR taps
 // ------------------------------------------------------------------------------------------------
 // AIR (wave-uniform, established by the caller): the cell is fluid and not directly above a wall (wall.y != 0, wall.z != 1).
-template <bool AIR = false, class UT, class A>
-__device__ __forceinline__ float4 lighting_cell(const UT &u, const Geo &g, int x, int y, const A &a)
+// EMIT: also produce the pass's second output (`reflectedLight`, bound to the RGBA16F emittedLight texture that only the display
+// shaders read): rgb in *emit, alpha is never written by the shader (stays 0). The accumulating `+=` on the never-initialised
+// output variable starts from 0, as SwiftShader (and every WebGL implementation, which must zero-initialise) does.
+template <bool AIR = false, bool EMIT = false, class UT, class A>
+__device__ __forceinline__ float4 lighting_cell(const UT &u, const Geo &g, int x, int y, const A &a, float4 *emit = nullptr)
 {
   const CellCoord cc = cellcoord(g, x, y);
   const float fy = cc.fy, tcy = cc.tcy;
   const int Y = g.Y;
   const float resY = (float)Y;
-  if (fy >= resY - 1.0f) return make_float4(u.sunIntensity, 0.0f, 0.0f, 0.0f); // :40-41
+  if (EMIT) *emit = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (fy >= resY - 1.0f) return make_float4(u.sunIntensity, 0.0f, 0.0f, 0.0f); // :40-41 (the top row leaves emittedLight untouched: 0)
   const float cellHeightCompensation = u.chc;
 
   // :48-49 LINEAR tap at texCoord + (sin a, cos a) texels, S=REPEAT T=CLAMP_TO_EDGE. The filter weights are
@@ -930,8 +950,15 @@ __device__ __forceinline__ float4 lighting_cell(const UT &u, const Geo &g, int x
   const float4 water = a.water();
   const char4 wall = a.wall();
 
+  const float standardSunBrightness = 1250.0f; // common.glsl:11
   if (AIR || wall.y != 0) {
     float net_heating = 0.0f;
+    float er = 0.0f, eg = 0.0f, eb = 0.0f;
+    if (EMIT) { // scattering in air (:60)
+      er = u.sun_col[0] * sunlight * (1.0f - tcy) * 2.0f / standardSunBrightness;
+      eg = u.sun_col[1] * sunlight * (1.0f - tcy) * 2.0f / standardSunBrightness;
+      eb = u.sun_col[2] * sunlight * (1.0f - tcy) * 2.0f / standardSunBrightness;
+    }
     if (fy < resY - 2.0f) {
       float reflection = fminf(sqrtf(water.y * 0.0010f + water.z * 0.00020f) * cellHeightCompensation, 1.0f); // pow(x, 0.5)
       reflection += 0.0002f;
@@ -940,12 +967,22 @@ __device__ __forceinline__ float4 lighting_cell(const UT &u, const Geo &g, int x
       const float lightAbsorbed = sunlight * absorbtion;
       sunlight = fmaxf(0.0f, sunlight - lightReflected - lightAbsorbed);
       net_heating += lightAbsorbed * lightHeatingConst;
+      if (EMIT) { // sunlight reflected by clouds and precipitation REPLACES the scattering term (:78)
+        er = u.sun_col[0] * lightReflected / standardSunBrightness;
+        eg = u.sun_col[1] * lightReflected / standardSunBrightness;
+        eb = u.sun_col[2] * lightReflected / standardSunBrightness;
+      }
     }
     const int yu = (y + 1 >= Y) ? Y - 1 : y + 1; // light texture: CLAMP_TO_EDGE in T
     const int yd = (y == 0) ? 0 : y - 1;
     float IR_down = a.ir_down_at(yu);
     float IR_up = 0.0f; // unassigned for air above an INERT wall (:90) -> 0
     if (!AIR && wall.z == 1) {
+      if (EMIT && u.night_glow && (wall.x == WALLTYPE_RUNWAY || wall.x == WALLTYPE_URBAN || wall.x == WALLTYPE_INDUSTRIAL)) { // :98-101
+        er += 1.00f * 0.03f;
+        eg += 0.97f * 0.03f;
+        eb += 0.57f * 0.03f;
+      }
       switch (wall.x) {
       case WALLTYPE_RUNWAY:
       case WALLTYPE_URBAN:
@@ -982,9 +1019,21 @@ __device__ __forceinline__ float4 lighting_cell(const UT &u, const Geo &g, int x
       IR_up -= absorbedUp;
       IR_up += emitted;
     }
+    if (EMIT) { // glow of thick smoke = fire (:143-148)
+      const float smokeOpacity = clampf(1.0f - (1.0f / (water.w + 1.0f)), 0.0f, 1.0f);
+      const float fireIntensity = clampf((smokeOpacity - 0.8f) * 25.0f, 0.0f, 1.0f);
+      float fc[3];
+      hsv2rgb(fireIntensity * 0.008f, 0.98f, 5.0f, fc);
+      er += (fireIntensity * fc[0]) * 0.1f; // mix(vec3(0), fireCol, fireIntensity)
+      eg += (fireIntensity * fc[1]) * 0.1f;
+      eb += (fireIntensity * fc[2]) * 0.1f;
+      *emit = make_float4(er, eg, eb, 0.0f);
+    }
     net_heating *= u.IR_rate;
     return make_float4(sunlight, net_heating, IR_down, IR_up);
   }
+  if (EMIT && wall.x != WALLTYPE_WATER) // land: part of the light is reflected by the ground (:158-166)
+    *emit = make_float4(sunlight * 0.60f / standardSunBrightness, sunlight * 0.5f / standardSunBrightness, sunlight * 0.4f / standardSunBrightness, 0.0f);
   return make_float4((wall.x == WALLTYPE_WATER) ? sunlight * 0.90f : 0.0f, 0.0f, 0.0f, 0.0f);
 }
 

@@ -5,6 +5,7 @@
 // wx_fused.h compute exactly the same per-cell arithmetic (wx_cells.h) with less HBM traffic.
 #pragma once
 #include "wx_cells.h"
+#include <hip/hip_fp16.h>
 
 namespace wx {
 
@@ -161,6 +162,44 @@ __global__ __launch_bounds__(BX *BY) void k_lighting(Geo g, Uni u, const float4 
   if (x >= g.X || y >= g.Y) return;
   GLightAcc a{base_in, water_in, wall_in, light_in, g.X, g.Y, x, y};
   light_out[cidx(x, y, g.X)] = lighting_cell(u, g, x, y, a);
+}
+
+// ---- emittedLight: the lighting pass's second render target (lightingShader.frag:15, 60-78, 98-101, 143-166; RGBA16F) ----
+// Only the display shaders read it, so the iteration kernels do not write it: it is recomputed on demand for the rectangle a
+// consumer asks for, from what the last lighting pass read -- its source light texture (still intact: the pass wrote the other
+// one), the post-advection water (= current) and the wall texture (pressure passes it through unchanged).
+struct half4 {
+  __half x, y, z, w;
+};
+template <bool PLANAR> struct GEmitAcc {
+  const float4 *water_;
+  const char4 *wall_;
+  const float4 *light_;
+  const float *sun_;
+  int X, Y, x, y;
+  __device__ __forceinline__ float T(int) const { return 0.0f; } // (feeds only the light output, which is discarded)
+  __device__ __forceinline__ float4 water() const { return water_[cidx(x, y, X)]; }
+  __device__ __forceinline__ char4 wall() const { return wall_[cidx(x, y, X)]; }
+  __device__ __forceinline__ float sun_at(int dx, int j) const
+  {
+    const size_t i = cidx(wrapmod(x + dx, X), j, X);
+    return PLANAR ? sun_[i] : light_[i].x;
+  }
+  __device__ __forceinline__ float ir_down_at(int) const { return 0.0f; }
+  __device__ __forceinline__ float ir_up_at(int) const { return 0.0f; }
+};
+
+template <bool PLANAR>
+__global__ __launch_bounds__(BX *BY) void k_emitted(Geo g, Uni u, int x0, int y0, int w, int h, const float4 *__restrict__ water_in,
+                                                     const char4 *__restrict__ wall_in, const float4 *__restrict__ light_in,
+                                                     const float *__restrict__ sun_in, half4 *__restrict__ out)
+{
+  const int x = x0 + blockIdx.x * BX + threadIdx.x, y = y0 + blockIdx.y * BY + threadIdx.y;
+  if (x >= x0 + w || y >= y0 + h) return;
+  GEmitAcc<PLANAR> a{water_in, wall_in, light_in, sun_in, g.X, g.Y, x, y};
+  float4 e;
+  lighting_cell<false, true>(u, g, x, y, a, &e);
+  out[cidx(x, y, g.X)] = half4{__float2half_rn(e.x), __float2half_rn(e.y), __float2half_rn(e.z), __float2half_rn(e.w)};
 }
 
 // ---- device-side initialiser (wx_setup_columns): the 2-D part of setupShader.frag:63-89 ----

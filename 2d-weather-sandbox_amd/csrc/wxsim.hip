@@ -67,6 +67,10 @@ struct wx_sim {
   int halo = 0, n_drops = 0;
   bool uploaded = false, have_params = false;
   int even = 1;          // app.js `even`
+  // emittedLight on demand (k_emitted): did the most recent iteration run the lighting pass, and with which uniforms
+  bool emit_lit = false;
+  Uni emit_uni;
+  half4 *emitted = nullptr; // RGBA16F, allocated by the first read
   int drop_cur = 0;      // particle buffer holding the latest state
   // slab handles with particles (see SlabP in wx_kernels.h)
   int *keys = nullptr;   // per-droplet claim key of the current exchange period
@@ -304,6 +308,13 @@ void build_uni(wx_sim *s)
   } else {
     u.sun_dx0 = u.sun_fv = 0;
     u.sun_w00 = u.sun_w10 = u.sun_w01 = u.sun_w11 = 0.0f;
+  }
+  { // lightingShader.frag:58-59: how red the sunlight is; common.glsl:374-378
+    const float deg2rad = 0.0174533f;
+    const float scattering = clampf(map_range(fabsf(p.sunAngle), 75.0f * deg2rad, 90.0f * deg2rad, 0.0f, 1.0f), 0.0f, 1.0f);
+    const float val = 1.0f - scattering;
+    hsv2rgb(0.015f + val * 0.15f, fminf(2.0f - val * 2.0f, 1.0f), 1.0f, u.sun_col);
+    u.night_glow = fabsf(p.sunAngle) > 85.0f * deg2rad;
   }
 }
 
@@ -713,6 +724,7 @@ void wx_destroy(wx_sim *s)
   }
   hipFree(s->base[2]);
   hipFree(s->curl);
+  hipFree(s->emitted);
   hipFree(s->vort);
   hipFree(s->fb);
   hipFree(s->dep);
@@ -810,6 +822,7 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   s->period_j = 0;
   s->ran_fused = false;
   s->even = 1;
+  s->emit_lit = false; // (the reference re-creates the emittedLight texture with the others)
   s->drop_cur = 0;
   s->uploaded = true;
   return WX_OK;
@@ -986,6 +999,10 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
     }
     s->iter++;
   }
+  if (n_iter > 0) {
+    s->emit_lit = !dry && (mask & WX_PASS_LIGHTING) != 0;
+    s->emit_uni = s->uni;
+  }
   if (s->cow_pending && getenv("WX_COW_DEBUG")) {
     const size_t nt = (size_t)((s->X + 63) / 64) * ((s->Y + 15) / 16);
     std::vector<unsigned int> f(nt);
@@ -1035,6 +1052,31 @@ static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int
   }
 }
 
+// WX_FIELD_EMITTED: (re)compute the rectangle into the handle's RGBA16F buffer
+static int emitted_rect(wx_sim *s, int x, int y, int w, int h)
+{
+  if (!s->emitted) {
+    HIPCHK(s, hipMalloc((void **)&s->emitted, ncell(s) * sizeof(half4)));
+    HIPCHK(s, hipMemsetAsync(s->emitted, 0, ncell(s) * sizeof(half4), s->stream));
+  }
+  if (s->copy_in_flight) { // a streamed frame may still be reading the buffer
+    HIPCHK(s, hipStreamWaitEvent(s->stream, s->ev_copy_done, 0));
+    s->copy_in_flight = false;
+  }
+  const dim3 grid((w + BX - 1) / BX, (h + BY - 1) / BY), block(BX, BY);
+  if (!s->emit_lit) { // no lighting pass has drawn into the texture since it was created: zero
+    HIPCHK(s, hipMemset2DAsync(s->emitted + ((size_t)y * s->X + x), (size_t)s->X * sizeof(half4), 0, (size_t)w * sizeof(half4), h, s->stream));
+    return WX_OK;
+  }
+  const int src = s->even ? 1 : 0; // the last iteration read light[even_then ? 0 : 1] and flipped `even`
+  if (s->light_planar)
+    hipLaunchKernelGGL(k_emitted<true>, grid, block, 0, s->stream, s->geo, s->emit_uni, x, y, w, h, s->water[1], s->wall[0], nullptr, s->lp[src].x, s->emitted);
+  else
+    hipLaunchKernelGGL(k_emitted<false>, grid, block, 0, s->stream, s->geo, s->emit_uni, x, y, w, h, s->water[1], s->wall[0], s->light[src], nullptr, s->emitted);
+  HIPCHK(s, hipGetLastError());
+  return WX_OK;
+}
+
 int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, int dtype)
 {
   if (!s || !dst) return WX_E_INVALID;
@@ -1045,6 +1087,25 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
     return WX_OK;
   }
   wait_unpacked(s); // ghost columns written on the comm stream are part of what a readback sees
+  if (field == WX_FIELD_EMITTED) {
+    if (w <= 0 || h <= 0 || x < 0 || y < 0 || x + w > s->X || y + h > s->Y)
+      return fail(s, WX_E_RANGE, "wx_read_rect: rect (%d,%d %dx%d) outside %dx%d (no wrap)", x, y, w, h, s->X, s->Y);
+    if (dtype != WX_DTYPE_F16 && dtype != WX_DTYPE_F32) return fail(s, WX_E_INVALID, "wx_read_rect: emittedLight is RGBA16F: WX_DTYPE_F16 or WX_DTYPE_F32");
+    const int rc = emitted_rect(s, x, y, w, h);
+    if (rc != WX_OK) return rc;
+    const half4 *src = s->emitted + ((size_t)y * s->X + x);
+    if (dtype == WX_DTYPE_F16) {
+      HIPCHK(s, hipMemcpy2DAsync(dst, (size_t)w * 8, src, (size_t)s->X * 8, (size_t)w * 8, h, hipMemcpyDeviceToHost, s->stream));
+      HIPCHK(s, hipStreamSynchronize(s->stream));
+      return WX_OK;
+    }
+    std::vector<__half> tmp((size_t)w * h * 4); // like gl.readPixels(..., gl.FLOAT, ...) of the half-float attachment
+    HIPCHK(s, hipMemcpy2DAsync(tmp.data(), (size_t)w * 8, src, (size_t)s->X * 8, (size_t)w * 8, h, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    float *d = (float *)dst;
+    for (size_t i = 0; i < tmp.size(); i++) d[i] = __half2float(tmp[i]);
+    return WX_OK;
+  }
   const void *ptr;
   int ch, el;
   if (field_info(s, field, &ptr, &ch, &el)) return fail(s, WX_E_INVALID, "wx_read_rect: unknown field %d", field);
@@ -1083,7 +1144,7 @@ namespace {
 const int kStreamFields[6] = {WX_FIELD_BASE_DISP, WX_FIELD_WATER_CUR, WX_FIELD_WALL_DISP, WX_FIELD_LIGHT_0, WX_FIELD_CURL, WX_FIELD_PRECIP_FB};
 }
 
-size_t wx_stream_bytes(int w, int h) { return (w > 0 && h > 0) ? (size_t)w * h * (16 + 16 + 4 + 16 + 4 + 16) : 0; }
+size_t wx_stream_bytes(int w, int h) { return (w > 0 && h > 0) ? (size_t)w * h * (16 + 16 + 4 + 16 + 4 + 16 + 8) : 0; }
 
 void *wx_host_alloc(size_t bytes)
 {
@@ -1114,6 +1175,10 @@ int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst)
     if (field_info(s, kStreamFields[f], &ptr[f], &ch, &el)) return fail(s, WX_E_INVALID, "wx_stream_frame: field %d", kStreamFields[f]);
     texel[f] = (size_t)ch * el;
   }
+  { // the seventh block: emittedLight (RGBA16F) of the rectangle, computed now on the compute stream
+    const int rc = emitted_rect(s, x, y, w, h);
+    if (rc != WX_OK) return rc;
+  }
   // the copies start when everything enqueued so far on the compute stream has produced the fields ...
   HIPCHK(s, hipEventRecord(s->ev_fields_ready, s->stream));
   HIPCHK(s, hipStreamWaitEvent(s->copy_stream, s->ev_fields_ready, 0));
@@ -1123,6 +1188,7 @@ int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst)
                                (size_t)w * texel[f], h, hipMemcpyDeviceToHost, s->copy_stream));
     dst += (size_t)w * h * texel[f];
   }
+  HIPCHK(s, hipMemcpy2DAsync(dst, (size_t)w * 8, s->emitted + ((size_t)y * s->X + x), (size_t)s->X * 8, (size_t)w * 8, h, hipMemcpyDeviceToHost, s->copy_stream));
   // ... and the next wx_step (which overwrites them) waits for the copies on the device, not on the host
   HIPCHK(s, hipEventRecord(s->ev_copy_done, s->copy_stream));
   s->copy_in_flight = true;
@@ -1162,6 +1228,7 @@ void *wx_device_ptr(wx_sim *s, int field)
 {
   if (!s) return nullptr;
   if (field == WX_FIELD_LIGHTNING) return s->state->lightning;
+  if (field == WX_FIELD_EMITTED) return emitted_rect(s, 0, 0, s->X, s->Y) == WX_OK ? s->emitted : nullptr; // (whole grid, computed now)
   const void *ptr;
   int ch, el;
   if (field_info(s, field, &ptr, &ch, &el)) return nullptr;

@@ -20,10 +20,10 @@ LIB_PATH = os.environ.get("WXSIM_LIB") or os.path.join(CSRC, "libwxsim.so")  # W
 
 FIELD_IDS = {
     "BASE_CUR": 0, "BASE_DISP": 1, "WATER_0": 2, "WATER_CUR": 3, "WALL_CUR": 4, "WALL_DISP": 5,
-    "LIGHT_0": 6, "LIGHT_1": 7, "CURL": 8, "VORT": 9, "PRECIP_FB": 10, "PRECIP_DEP": 11, "LIGHTNING": 12,
+    "LIGHT_0": 6, "LIGHT_1": 7, "CURL": 8, "VORT": 9, "PRECIP_FB": 10, "PRECIP_DEP": 11, "LIGHTNING": 12, "EMITTED": 13,
 }
 FIELD_CHANNELS = {"CURL": 1, "VORT": 2, "PRECIP_DEP": 2}
-DTYPE_F32, DTYPE_I8, DTYPE_I32 = 0, 1, 2
+DTYPE_F32, DTYPE_I8, DTYPE_I32, DTYPE_F16 = 0, 1, 2, 3
 
 # every symbol include/wxsim.h declares
 EXPORTS = [
@@ -220,6 +220,9 @@ class Handle:
         if field.startswith("WALL"):
             out = np.zeros((max(h, 0), max(w, 0), ch), np.int32 if int32 else np.int8)
             dt = DTYPE_I32 if int32 else DTYPE_I8
+        elif field == "EMITTED":  # RGBA16F emittedLight, in its own format
+            out = np.zeros((max(h, 0), max(w, 0), 4), np.float16)
+            dt = DTYPE_F16
         else:
             out = np.zeros((max(h, 0), max(w, 0), ch), np.float32)
             dt = DTYPE_F32
@@ -254,7 +257,7 @@ class Handle:
 
     # ---- display streaming (wx_stream_frame): one pinned buffer per Handle, re-used while the viewport size is unchanged
     STREAM_FIELDS = (("BASE_DISP", np.float32, 4), ("WATER_CUR", np.float32, 4), ("WALL_DISP", np.int8, 4), ("LIGHT_0", np.float32, 4),
-                     ("CURL", np.float32, 1), ("PRECIP_FB", np.float32, 4))
+                     ("CURL", np.float32, 1), ("PRECIP_FB", np.float32, 4), ("EMITTED", np.float16, 4))
 
     def stream_frame(self, x: int = 0, y: int = 0, w: Optional[int] = None, h: Optional[int] = None):
         """Start the asynchronous copy of the display fields of a viewport; returns immediately."""

@@ -39,7 +39,7 @@ const GUI_DEFAULTS = { // app.js:347-407
 };
 
 const FIELD = {BASE_CUR: 0, BASE_DISP: 1, WATER_0: 2, WATER_CUR: 3, WALL_CUR: 4, WALL_DISP: 5, LIGHT_0: 6, LIGHT_1: 7, CURL: 8, VORT: 9,
-               PRECIP_FB: 10, PRECIP_DEP: 11, LIGHTNING: 12};
+               PRECIP_FB: 10, PRECIP_DEP: 11, LIGHTNING: 12, EMITTED: 13};
 
 function loadAddon()
 {
@@ -342,6 +342,7 @@ WeatherSim.prototype.streamFrame = function(x, y, w, h) {
     out.LIGHT_0 = f32(4);
     out.CURL = f32(1);
     out.PRECIP_FB = f32(4);
+    out.EMITTED = new Uint16Array(ab, off, 4 * n); // binary16 bits, as texImage2D(..., gl.RGBA16F, gl.RGBA, gl.HALF_FLOAT, u16) takes them
     return out;
   }};
 };

@@ -333,7 +333,7 @@ static napi_value ReadRect(napi_env env, napi_callback_info info)
     napi_throw_type_error(env, NULL, "readRect: dst must be a typed array");
     return NULL;
   }
-  int dtype = t == napi_float32_array ? WX_DTYPE_F32 : t == napi_int8_array ? WX_DTYPE_I8 : t == napi_int32_array ? WX_DTYPE_I32 : -1;
+  int dtype = t == napi_float32_array ? WX_DTYPE_F32 : t == napi_int8_array ? WX_DTYPE_I8 : t == napi_int32_array ? WX_DTYPE_I32 : t == napi_uint16_array ? WX_DTYPE_F16 /* raw binary16 */ : -1;
   int ch = (v[0] == WX_FIELD_CURL) ? 1 : (v[0] == WX_FIELD_VORT || v[0] == WX_FIELD_PRECIP_DEP) ? 2 : 4;
   if (dtype < 0 || len < (size_t)v[3] * v[4] * ch) {
     napi_throw_range_error(env, NULL, "readRect: destination too small or of unsupported type");

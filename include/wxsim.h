@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WX_ABI_VERSION 3
+#define WX_ABI_VERSION 4
 
 /* error codes */
 #define WX_OK 0
@@ -89,11 +89,15 @@ enum {
   WX_FIELD_PRECIP_FB = 10, /* RGBA32F precipitationFeedbackTexture */
   WX_FIELD_PRECIP_DEP = 11,/* RG32F precipitationDepositionTexture */
   WX_FIELD_LIGHTNING = 12, /* 1x1 RGBA32F lightningDataTexture */
-  WX_FIELD_COUNT = 13
+  /* RGBA16F emittedLight: the lighting pass's second render target (app.js:838, 5283, 5294; lightingShader.frag:15, 60-78,
+   * 98-101, 143-166), read only by the renderer's ambient-light pyramid (app.js:6096). Not stored per iteration: computed for
+   * the requested rectangle when read, from what the most recent lighting pass sampled (zero before the first one). */
+  WX_FIELD_EMITTED = 13,
+  WX_FIELD_COUNT = 14
 };
 
-/* destination element types of wx_read_rect */
-enum { WX_DTYPE_F32 = 0, WX_DTYPE_I8 = 1, WX_DTYPE_I32 = 2 };
+/* destination element types of wx_read_rect (WX_DTYPE_F16: IEEE binary16, WX_FIELD_EMITTED only) */
+enum { WX_DTYPE_F32 = 0, WX_DTYPE_I8 = 1, WX_DTYPE_I32 = 2, WX_DTYPE_F16 = 3 };
 
 typedef struct wx_sim wx_sim;
 
@@ -149,7 +153,8 @@ int wx_set_iter(wx_sim *s, int64_t iter);
 /* Replaces every gl.readPixels of SURVEY.md section 3.5 (app.js:1084-1092, 3931-3943, 3020-3065,
  * 1840-1906, 4215-4237, 4347-4357, 5958-5961, 5986-5988, 6584-6593). Rows bottom-up, no wrap
  * (WX_E_RANGE outside the local grid); float fields accept WX_DTYPE_F32, wall fields WX_DTYPE_I8 or
- * WX_DTYPE_I32 (both are used by the reference: app.js:6593 vs 3943). Synchronises the stream. */
+ * WX_DTYPE_I32 (both are used by the reference: app.js:6593 vs 3943), WX_FIELD_EMITTED WX_DTYPE_F16 (the texture's own
+ * format) or WX_DTYPE_F32 (what readPixels(..., gl.FLOAT) of a half-float attachment returns). Synchronises the stream. */
 int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, int dtype);
 
 /* Replaces gl.getBufferSubData on the transform-feedback buffers (app.js:5019, 5086, 6597):
@@ -157,8 +162,8 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
 int wx_read_particles(wx_sim *s, int first, int count, float *dst);
 
 /* Field streaming for a display consumer: what the reference's renderer binds every frame (app.js:6081-6219)
- * -- BASE_DISP, WATER_CUR, WALL_DISP (int8), LIGHT_0, CURL, PRECIP_FB of the viewport rect, in this order, each field
- * contiguous (w*h texels, rows bottom-up, no wrap) -- copied asynchronously into ONE host buffer of wx_stream_bytes(w, h)
+ * -- BASE_DISP, WATER_CUR, WALL_DISP (int8), LIGHT_0, CURL, PRECIP_FB, EMITTED (binary16) of the viewport rect, in this order,
+ * each field contiguous (w*h texels, rows bottom-up, no wrap) -- copied asynchronously into ONE host buffer of wx_stream_bytes(w, h)
  * bytes, ideally pinned (wx_host_alloc). wx_stream_frame returns at once: the copies run on the handle's own copy
  * stream after everything enqueued so far; later wx_step calls are ordered after them on the device, so the host never
  * blocks; wx_stream_wait blocks until the frame is complete in host memory. One frame in flight per handle. */

@@ -136,7 +136,7 @@ def run_fixture(name, X, Y, base, water, wall, drops, u, *, niter, dump_iters, p
     shapes = {"curl": (Y, X), "vort": (Y, X, 2), "precip_dep": (Y, X, 2), "drops": (-1, 5), "precip_drops": (-1, 5), "lightning": (4,)}
     for it, d in res["dumps"].items():
         for k, v in d.items():
-            if k not in keep and k not in keep_particles:
+            if k not in keep and k not in keep_particles and not (dump_emitted and k == "emitted"):
                 continue
             dt = np.int8 if "wall" in k else np.float32
             out[f"it{it}_{k}"] = _dec(v, dt).reshape(shapes.get(k, (Y, X, 4)))
@@ -426,6 +426,39 @@ def fx_randwalls64p():
                        dump_emitted=True)
 
 
+def _emitted_scene(seed):
+    """synth64's terrain (every wall type; irregular blocks would grow into the sky within 60 iterations) plus smoke plumes dense enough
+    to glow (lightingShader.frag:143-148: opacity > 0.8 <=> smoke > 4)."""
+    rng = np.random.default_rng(seed)
+    X, Y = 64, 64  # (Y >= 50: below that the top row passes boundaryShader.frag:192's `texCoord.y < 0.99` and the sky fills with wall)
+    gui, u, base, water, wall = synth_terrain(X, Y, rng)
+    air = wall[..., 1] != 0
+    for _ in range(12):  # smoke plumes, 0 .. 14 g/m3
+        cx, cy, r = rng.integers(0, X), rng.integers(4, Y - 4), rng.integers(2, 6)
+        yy, xx = np.mgrid[0:Y, 0:X]
+        d = np.hypot(xx - cx, yy - cy)
+        water[..., 3] = np.where(air & (d < r), np.maximum(water[..., 3], 14.0 * (1.0 - d / r)), water[..., 3]).astype(np.float32)
+    return X, Y, gui, u, base, water, wall
+
+
+def fx_emitted64():
+    """The lighting pass's second render target (emittedLight, RGBA16F): daylight at -30 degrees for 80 iterations (sunlight has
+    reached the ground: air scattering, cloud / precipitation reflection, ground reflection, smoke glow) and a sun 2 degrees above
+    the horizon for 6 iterations (red sunlight colour, urban / industrial / runway night glow). Dumped together with the light
+    textures one iteration earlier, so the pass can be checked on the reference's own inputs."""
+    X, Y, gui, u, base, water, wall = _emitted_scene(31337)
+    keep = ("base_cur", "water_cur", "wall_cur", "light_0", "light_1")
+    u_day = dict(u)
+    u_day["sunAngle"] = float(np.deg2rad(-30.0))
+    day = run_fixture("emitted64_day", X, Y, base, water, wall, None, u_day, niter=80, dump_iters=[1, 40, 79, 80], precip=False, iter0=7,
+                      keep=keep, points=True, dump_emitted=True)
+    u_night = dict(u)
+    u_night["sunAngle"] = float(np.deg2rad(88.0))
+    night = run_fixture("emitted64_night", X, Y, base, water, wall, None, u_night, niter=6, dump_iters=[5, 6], precip=False, iter0=7,
+                        keep=keep, points=True, dump_emitted=True)
+    return day, night
+
+
 def fx_lightning64():
     """Lightning: a cold, very dense cloud deck (cloud + precipitation > 2.5 below 0 C) and a large pool of inactive droplets,
     from iterNum = 40 (> the 30-iteration lock-out of a fresh lightning texture), so that precipitationShader.vert:121-140
@@ -524,6 +557,7 @@ FIXTURES = {
     "save100raw": fx_save100raw,
     "randwalls64p": fx_randwalls64p,
     "lightning64": fx_lightning64,
+    "emitted64": fx_emitted64,
     "airplane64": fx_airplane64,
     "setup256": fx_setup256,
 }

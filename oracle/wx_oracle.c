@@ -987,8 +987,22 @@ void wxo_advection(const wxo_params *p, const float *initial_T, const float *snd
 }
 
 /* ------------------------------------------------------------------------------------------
- * lightingShader.frag:38-170 (light output only; reflectedLight is display-only)
+ * lightingShader.frag:38-170. emit_out (optional, X*Y*4 floats): the second render target
+ * `reflectedLight` (:15), bound to the RGBA16F emittedLight texture (app.js:5283, 5294), as the
+ * unrounded fp32 values the shader computes; the attachment stores them as binary16. Its alpha is
+ * never written and the accumulating `+=` starts from the zero-initialised output variable.
  * ---------------------------------------------------------------------------------------- */
+/* common.glsl:367-372 */
+static inline void hsv2rgb(float h, float sv, float v, float rgb[3])
+{
+  const float K[3] = {1.0f, 2.0f / 3.0f, 1.0f / 3.0f};
+  for (int i = 0; i < 3; i++) {
+    const float t = h + K[i];
+    const float pch = fabsf((t - floorf(t)) * 6.0f - 3.0f);
+    rgb[i] = v * mixf(1.0f, clampf(pch - 1.0f, 0.0f, 1.0f), sv);
+  }
+}
+
 /* GL LINEAR filtering (GLES 3.0 spec 3.8.10), S=REPEAT, T=CLAMP_TO_EDGE, channel SUNLIGHT, of the
  * sample at (texel centre of (x,y)) + (ox, oy) texels. The filter-weight precision is implementation
  * defined in GL; here the weights are the exact fp32 fractions of the offsets, which also makes the
@@ -1006,14 +1020,23 @@ static inline float light_linear_sun(const float *light, int X, int Y, int x, in
   return (1.0f - a) * (1.0f - bb) * t00 + a * (1.0f - bb) * t10 + (1.0f - a) * bb * t01 + a * bb * t11;
 }
 
-void wxo_lighting(const wxo_params *p, const float *base_in, const float *water_in,
-                  const int8_t *wall_in, const float *light_in, float *light_out)
+void wxo_lighting_mrt(const wxo_params *p, const float *base_in, const float *water_in,
+                      const int8_t *wall_in, const float *light_in, float *light_out, float *emit_out)
 {
   const geo_t g = mkgeo(p);
   const int X = p->X, Y = p->Y;
   const float resY = (float)Y;
   const float cellHeightCompensation = 300.0f / resY;
   const float sin_a = sinf(p->sunAngle), cos_a = cosf(p->sunAngle);
+  /* :58-59 how red the sunlight is; sunColor() common.glsl:374-378 */
+  const float deg2rad = 0.0174533f, standardSunBrightness = 1250.0f; /* common.glsl:6, 11 */
+  const float scattering = clampf(map_range(fabsf(p->sunAngle), 75.0f * deg2rad, 90.0f * deg2rad, 0.0f, 1.0f), 0.0f, 1.0f);
+  float sunCol[3];
+  {
+    const float val = 1.0f - scattering;
+    hsv2rgb(0.015f + val * 0.15f, fminf(2.0f - val * 2.0f, 1.0f), 1.0f, sunCol);
+  }
+  const int night_glow = fabsf(p->sunAngle) > 85.0f * deg2rad;
 
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < Y; y++) {
@@ -1024,6 +1047,9 @@ void wxo_lighting(const wxo_params *p, const float *base_in, const float *water_
       float *lo = C4(light_out, x, y);
       const cc_t cc = cellcoord(&g, x, y);
       const float fy = cc.fy, tcy = cc.tcy;
+      float em[3] = {0.0f, 0.0f, 0.0f};
+      float *eo = emit_out ? C4(emit_out, x, y) : NULL;
+      if (eo) eo[0] = eo[1] = eo[2] = eo[3] = 0.0f;
       if (fy >= resY - 1.0f) {
         lo[0] = p->sunIntensity;
         lo[1] = 0.0f;
@@ -1042,6 +1068,7 @@ void wxo_lighting(const wxo_params *p, const float *base_in, const float *water_
       const int8_t *wall = C4(wall_in, x, y);
 
       if (wall[DISTANCE] != 0) {
+        for (int c = 0; c < 3; c++) em[c] = sunCol[c] * sunlight * (1.0f - tcy) * 2.0f / standardSunBrightness; /* :60 scattering in air */
         float net_heating = 0.0f;
         if (fy < resY - 2.0f) {
           float reflection =
@@ -1052,10 +1079,16 @@ void wxo_lighting(const wxo_params *p, const float *base_in, const float *water_
           const float lightAbsorbed = sunlight * absorbtion;
           sunlight = fmaxf(0.0f, sunlight - lightReflected - lightAbsorbed);
           net_heating += lightAbsorbed * lightHeatingConst;
+          for (int c = 0; c < 3; c++) em[c] = sunCol[c] * lightReflected / standardSunBrightness; /* :78 `=`: replaces the air term */
         }
         float IR_down = C4(light_in, x, yu)[IR_DOWN];
         float IR_up = 0.0f;
         if (wall[VERT_DISTANCE] == 1) {
+          if (night_glow && (wall[TYPE] == WALLTYPE_RUNWAY || wall[TYPE] == WALLTYPE_URBAN || wall[TYPE] == WALLTYPE_INDUSTRIAL)) { /* :98-101 */
+            em[0] += 1.00f * 0.03f;
+            em[1] += 0.97f * 0.03f;
+            em[2] += 0.57f * 0.03f;
+          }
           switch (wall[TYPE]) {
           case WALLTYPE_RUNWAY:
           case WALLTYPE_URBAN:
@@ -1092,12 +1125,24 @@ void wxo_lighting(const wxo_params *p, const float *base_in, const float *water_
           IR_up -= absorbedUp;
           IR_up += emitted;
         }
+        if (eo) { /* :143-148 thick smoke glows (fire) */
+          const float smokeOpacity = clampf(1.0f - (1.0f / (water[SMOKE] + 1.0f)), 0.0f, 1.0f);
+          const float fireIntensity = clampf((smokeOpacity - 0.8f) * 25.0f, 0.0f, 1.0f);
+          float fireCol[3];
+          hsv2rgb(fireIntensity * 0.008f, 0.98f, 5.0f, fireCol);
+          for (int c = 0; c < 3; c++) eo[c] = em[c] + mixf(0.0f, fireCol[c], fireIntensity) * 0.1f;
+        }
         net_heating *= p->IR_rate;
         lo[0] = sunlight;
         lo[1] = net_heating;
         lo[2] = IR_down;
         lo[3] = IR_up;
       } else {
+        if (eo && wall[TYPE] != WALLTYPE_WATER) { /* :158-166 land reflects part of the light */
+          eo[0] = sunlight * 0.60f / standardSunBrightness;
+          eo[1] = sunlight * 0.5f / standardSunBrightness;
+          eo[2] = sunlight * 0.4f / standardSunBrightness;
+        }
         lo[0] = (wall[TYPE] == WALLTYPE_WATER) ? sunlight * 0.90f : 0.0f;
         lo[1] = 0.0f;
         lo[2] = 0.0f;
@@ -1105,6 +1150,12 @@ void wxo_lighting(const wxo_params *p, const float *base_in, const float *water_
       }
     }
   }
+}
+
+void wxo_lighting(const wxo_params *p, const float *base_in, const float *water_in,
+                  const int8_t *wall_in, const float *light_in, float *light_out)
+{
+  wxo_lighting_mrt(p, base_in, water_in, wall_in, light_in, light_out, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1348,6 +1399,7 @@ struct wxo_sim {
   float *base[2], *water[2];
   int8_t *wall[2];
   float *light[2], *curl, *vort, *fb, *dep;
+  float *emitted; /* emittedLight, unrounded */
   float lightning[4];
   float *drops[2];
   int even;     /* app.js: `even` */
@@ -1370,6 +1422,7 @@ wxo_sim *wxo_create(int X, int Y, int n_drops)
     s->drops[i] = (float *)calloc((size_t)(n_drops > 0 ? n_drops : 1) * 5, 4);
   }
   s->curl = (float *)calloc(n, 4);
+  s->emitted = (float *)calloc(n, 16);
   s->vort = (float *)calloc(n * 2, 4);
   s->fb = (float *)calloc(n * 4, 4);
   s->dep = (float *)calloc(n * 2, 4);
@@ -1395,6 +1448,7 @@ void wxo_destroy(wxo_sim *s)
     free(s->drops[i]);
   }
   free(s->curl);
+  free(s->emitted);
   free(s->vort);
   free(s->fb);
   free(s->dep);
@@ -1417,6 +1471,7 @@ void wxo_upload(wxo_sim *s, const float *base, const float *water, const int8_t 
     if (drops && s->n_drops > 0) memcpy(s->drops[i], drops, (size_t)s->n_drops * 20);
   }
   memset(s->curl, 0, n * 4);
+  memset(s->emitted, 0, n * 16);
   memset(s->vort, 0, n * 8);
   memset(s->fb, 0, n * 16);
   memset(s->dep, 0, n * 8);
@@ -1484,7 +1539,7 @@ void wxo_step_ex(wxo_sim *s, int n_iter, unsigned mask)
     }
     /* 7 lighting (5903-5930) */
     const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
-    if (mask & 32u) wxo_lighting(&s->p, s->base[1], s->water[1], s->wall[1], s->light[src], s->light[dst]);
+    if (mask & 32u) wxo_lighting_mrt(&s->p, s->base[1], s->water[1], s->wall[1], s->light[src], s->light[dst], s->emitted);
     s->even = !s->even;
     /* 8 clear (5933-5934) */
     memset(s->fb, 0, n * 16);
@@ -1523,6 +1578,7 @@ const void *wxo_field(const wxo_sim *s, int field)
   case 11: return s->dep;
   case 12: return s->lightning;
   case 13: return s->drops[s->drop_cur];
+  case 14: return s->emitted;
   default: return NULL;
   }
 }

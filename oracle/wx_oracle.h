@@ -74,6 +74,9 @@ void wxo_pressure(const wxo_params *p, const float *base_in, const int8_t *wall_
                   int8_t *wall_out);
 void wxo_lighting(const wxo_params *p, const float *base_in, const float *water_in,
                   const int8_t *wall_in, const float *light_in, float *light_out);
+/* the same pass with its second render target (emittedLight; emit_out may be NULL) */
+void wxo_lighting_mrt(const wxo_params *p, const float *base_in, const float *water_in,
+                      const int8_t *wall_in, const float *light_in, float *light_out, float *emit_out);
 /* particles: drops are 5 floats each (pos.xy, mass.xy, density); fb RGBA32F, dep RG32F are += */
 void wxo_precipitation(const wxo_params *p, float iterNum, int n_drops, const float *drops_in,
                        const float *base_in, const float *water_in, const float *lightning_in,

@@ -49,6 +49,7 @@ FIELDS = {
     "LIGHT_0": (6, np.float32, 4), "LIGHT_1": (7, np.float32, 4),
     "CURL": (8, np.float32, 1), "VORT": (9, np.float32, 2),
     "PRECIP_FB": (10, np.float32, 4), "PRECIP_DEP": (11, np.float32, 2),
+    "EMITTED": (14, np.float32, 4),  # unrounded; the reference's attachment is RGBA16F: compare .astype(np.float16)
 }
 
 
@@ -81,6 +82,7 @@ def lib() -> C.CDLL:
         L.wxo_advection.argtypes = [PP, fp, C.c_void_p, C.c_void_p, C.c_void_p, fp, fp, i8p, fp, fp, i8p]
         L.wxo_pressure.argtypes = [PP, fp, i8p, fp, i8p]
         L.wxo_lighting.argtypes = [PP, fp, fp, i8p, fp, fp]
+        L.wxo_lighting_mrt.argtypes = [PP, fp, fp, i8p, fp, fp, C.c_void_p]
         L.wxo_precipitation.argtypes = [PP, C.c_float, C.c_int, fp, fp, fp, fp, fp, fp, fp]
         L.wxo_lightning_location.argtypes = [PP, C.c_float, fp, fp]
         L.wxo_hash.argtypes = [C.c_uint32]

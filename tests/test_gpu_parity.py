@@ -48,13 +48,16 @@ def _make_pair(pkg, oracle, E, X, Y, base, water, wall, u, drops=None, iter0=0):
     return h, o
 
 
-def _assert_grid_equal(h, o, fields=GRID_FIELDS):
+def _assert_grid_equal(h, o, fields=GRID_FIELDS, emitted=True):
     for f in fields:
         a, b = h.read_rect(f), o.field(f)
         assert np.array_equal(a, b), f"{f}: {np.count_nonzero(a != b)} of {a.size} values differ, max |d| = {np.abs(a.astype(np.float64) - b).max()}"
+    if emitted and (o.pass_mask & 32):  # the lighting pass's second render target (RGBA16F): the oracle's fp32 values, rounded once
+        a, b = h.read_rect("EMITTED"), o.field("EMITTED").astype(np.float16)
+        assert a.dtype == np.float16 and np.array_equal(a, b), f"EMITTED: {np.count_nonzero(a != b)} of {a.size} values differ"
 
 
-@pytest.mark.parametrize("name", ["save100qa", "synth64", "randwalls64", "sounding64", "save100raw", "randwalls64p"])
+@pytest.mark.parametrize("name", ["save100qa", "synth64", "randwalls64", "sounding64", "save100raw", "randwalls64p", "emitted64_day", "emitted64_night"])
 @pytest.mark.parametrize("quad_scale", [0, 1])
 def test_bit_exact_vs_oracle_on_golden_inputs(pkg, oracle, golden, E, name, quad_scale, fused):
     g, u = golden(name)
@@ -735,6 +738,38 @@ def test_display_field_streaming(pkg, golden, E):
     assert np.array_equal(full["WATER_CUR"], h.read_rect("WATER_CUR"))
     with pytest.raises(E.WxError):
         h.stream_frame(X - 4, 0, 8, 8)  # no wrap
+
+
+def test_emitted_light_field(pkg, oracle, golden, E, fused):
+    """WX_FIELD_EMITTED (the lighting pass's RGBA16F second render target, computed on demand): zero before the first lighting
+    pass, the reference's values after 80 iterations, rectangle reads == whole-grid reads, both dtypes, and -- like the
+    texture -- not affected by a uniform change that no lighting pass has drawn with yet."""
+    g, u = golden("emitted64_day")
+    u = dict(u, quad_scale=1, enablePrecipitation=0)
+    X, Y = int(g["X"]), int(g["Y"])
+    h, o = _make_pair(pkg, oracle, E, X, Y, g["in_base"], g["in_water"], g["in_wall"], u, iter0=int(g["iter0"]))
+    assert not h.read_rect("EMITTED").any()
+    h.step(80)
+    e = h.read_rect("EMITTED")
+    r = g["it80_emitted"]
+    assert e.dtype == np.float16 and e.shape == (Y, X, 4)
+    assert (np.abs(e.astype(np.float32) - r) <= 2e-5 + 2.0 ** -11 * np.abs(r)).all()  # the run's drift + one rounding to binary16
+    assert np.count_nonzero(e[..., :3].any(-1)) >= 0.9 * X * Y
+    assert np.array_equal(h.read_rect("EMITTED", 5, 7, 33, 21), e[7:28, 5:38])
+    f32 = np.zeros((Y, X, 4), np.float32)
+    h._chk(E.lib().wx_read_rect(h._h, E.FIELD_IDS["EMITTED"], 0, 0, X, Y, f32.ctypes.data, E.DTYPE_F32))
+    assert np.array_equal(f32, e.astype(np.float32))
+    with pytest.raises(E.WxError):
+        h._chk(E.lib().wx_read_rect(h._h, E.FIELD_IDS["EMITTED"], 0, 0, X, Y, f32.ctypes.data, E.DTYPE_I8))
+    night = dict(u, sunAngle=float(np.deg2rad(88.0)))
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), night), u["initial_T"])
+    assert np.array_equal(h.read_rect("EMITTED"), e)
+    h.step(1)
+    e2 = h.read_rect("EMITTED")
+    glow = (g["it80_wall_cur"][..., 2] == 1) & np.isin(g["it80_wall_cur"][..., 0], (4, 5, 6))
+    assert glow.sum() >= 10 and (e2[glow][:, 0] >= 0.03).all() and not (e2 == e).all()
+    h.upload(g["in_base"], g["in_water"], g["in_wall"])
+    assert not h.read_rect("EMITTED").any()
 
 
 def test_python_host_new_simulation_round_trip(pkg, tmp_path):

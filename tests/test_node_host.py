@@ -38,7 +38,7 @@ def test_addon_builds_loads_and_fails_loudly_without_gpu(pkg):
     js = ("const m=require('%s'); console.log(m.abiVersion());"
           "try{m.create(64,32,0); console.log('created')}catch(e){console.log('ERR '+e.message)}" % os.path.join(ROOT, "host", "wxsim_napi.node"))
     out = subprocess.check_output([NODE, "-e", js]).decode().split("\n")
-    assert out[0] == "3"
+    assert out[0] == "4"
     import torch
     if not torch.cuda.is_available():
         assert out[1].startswith("ERR") and "no CPU fallback" in out[1]
@@ -100,8 +100,10 @@ def test_node_new_simulation_and_streaming(pkg, tmp_path):
     js = ("const H=require('%s'), fs=require('fs');"
           "const sim=H.WeatherSim.newSimulation(%d,%d,{sunFixed:true,settings:{enablePrecipitation:false}});"
           "sim.frame(%d); const fr=sim.streamFrame(8,4,64,32); sim.frame(5); const v=fr.wait();"
-          "let s=0; for (const x of v.WATER_CUR) s+=x; let t=0; for (const x of v.BASE_DISP) t+=x;"
-          "console.log(JSON.stringify({iter:sim.iterNum(), water:s, base:t, wall0:v.WALL_DISP[0], n:v.CURL.length}));"
+          "let s=0; for (const x of v.WATER_CUR) s+=x; let t=0; for (const x of v.BASE_DISP) t+=x; let e=0; for (const x of v.EMITTED) e+=x;"
+          "const eh=new Uint16Array(4*3*2); sim.addon.readRect(sim.h, H.FIELD.EMITTED, 8, 4, 3, 2, eh);"
+          "const ef=new Float32Array(4*3*2); sim.addon.readRect(sim.h, H.FIELD.EMITTED, 8, 4, 3, 2, ef);"
+          "console.log(JSON.stringify({iter:sim.iterNum(), water:s, base:t, wall0:v.WALL_DISP[0], n:v.CURL.length, emitted:e, eh:Array.from(eh), ef:Array.from(ef)}));"
           "fs.writeFileSync('%s', H.encodeSave(sim.toSave())); sim.destroy();" % (os.path.join(ROOT, "host", "sim_host.js"), X, Y, n, out_file))
     info = json.loads(subprocess.check_output([NODE, "-e", js]).decode().strip().split("\n")[-1])
     assert info["iter"] == n + 5 and info["n"] == 64 * 32
@@ -116,7 +118,11 @@ def test_node_new_simulation_and_streaming(pkg, tmp_path):
     assert np.isclose(info["water"], float(fr["WATER_CUR"].astype(np.float64).sum()), rtol=1e-12)
     assert np.isclose(info["base"], float(fr["BASE_DISP"].astype(np.float64).sum()), rtol=1e-12)
     assert info["wall0"] == int(fr["WALL_DISP"].reshape(-1)[0])
+    # emittedLight: the streamed block holds binary16 bits (sum of the uint16 codes), readRect takes Uint16Array (bits) or Float32Array
+    assert info["emitted"] == int(h.read_rect("EMITTED", 8, 4, 64, 32).view(np.uint16).astype(np.int64).sum()) > 0
     h.step(5)
+    e = h.read_rect("EMITTED", 8, 4, 3, 2)
+    assert info["eh"] == e.view(np.uint16).ravel().tolist() and info["ef"] == e.astype(np.float32).ravel().tolist()
     got = pkg.codec.load(out_file)
     assert np.array_equal(got.base, h.read_rect("BASE_CUR")) and np.array_equal(got.water, h.read_rect("WATER_0"))
     assert np.array_equal(got.wall, h.read_rect("WALL_CUR"))

@@ -345,6 +345,35 @@ def test_randwalls64p_irregular_walls_through_the_whole_iteration(oracle, golden
     assert (g["it12_wall_cur"] != g["in_wall"]).any(-1).sum() > 300
 
 
+@pytest.mark.parametrize("name,N,its", [("emitted64_day", 80, (1, 40, 79, 80)), ("emitted64_night", 6, (5, 6))])
+def test_emitted_light_second_render_target(oracle, golden, name, N, its):
+    """lightingShader's second output (emittedLight): first the pass alone on the reference's own textures of iteration N
+    (post-advection water / wall and the light texture the pass sampled), then through the run. Day: white sunlight, air scattering in
+    the top rows, cloud / precipitation reflection, ground reflection, smoke glow; night: red sunlight (88 degrees), urban glow."""
+    g, u = golden(name)
+    u, p = _params(oracle, g, u)
+    X, Y = int(g["X"]), int(g["Y"])
+    lo, eo = _z((Y, X, 4)), _z((Y, X, 4))
+    src = np.ascontiguousarray(g[f"it{N - 1}_light_{0 if N % 2 else 1}"])  # iteration N reads light_0 when N is odd (`even` starts true)
+    oracle.lib().wxo_lighting_mrt(p, g[f"it{N}_base_cur"].ravel(), g[f"it{N}_water_cur"].ravel(), g[f"it{N}_wall_cur"].ravel(), src.ravel(),
+                                  lo.ravel(), eo.ctypes.data)
+    r = g[f"it{N}_emitted"]
+    assert (np.abs(eo - r) <= 1e-7 + 4e-6 * np.abs(r)).all(), np.abs(eo - r).max()
+    assert not r[..., 3].any() and not eo[..., 3].any()  # alpha is never written
+    wl, wa = g[f"it{N}_wall_cur"], g[f"it{N}_water_cur"]
+    air, lit = wl[..., 1] != 0, r[..., :3].any(-1)
+    assert (air & (wa[..., 3] > 5.0)).sum() >= 80  # glowing smoke
+    if name == "emitted64_day":
+        assert lit.sum() >= 0.9 * X * Y and (~air & (wl[..., 0] != 2) & lit).sum() >= 50  # sunlight everywhere, reflected by the ground
+        assert np.ptp(r[air & (wa[..., 3] == 0)][:, :3], axis=-1).max() <= 1e-7  # white light
+    else:
+        glow = air & (wl[..., 2] == 1) & np.isin(wl[..., 0], (4, 5, 6)) & (wa[..., 3] < 1.0)  # URBAN, RUNWAY, INDUSTRIAL
+        assert glow.sum() >= 10 and (r[glow][:, 0] >= 0.03).all()
+    for it, s in _run(oracle, g, u, its):
+        e, r = s.field("EMITTED"), g[f"it{it}_emitted"]
+        assert np.abs(e - r).max() <= 2e-5, it  # (values up to 0.5; the run's own drift, see the envelope test)
+
+
 def test_lightning64_strikes_rejections_and_lockout(oracle, golden):
     """precipitationShader.vert:121-140 + lightningLocationShader.frag:24-38 against the reference, iteration by iteration on the
     reference's own inputs (the strike decision hashes the BITS of temperature and water, so a free-running comparison would
