@@ -285,6 +285,10 @@ struct SplatGrid {
   unsigned char *fb_zero; // per 64x16 tile of the feedback texture: known to be all zero
   int AP, AH;    // pitch (>= X+1) and rows (>= Y+1) of the accumulation grid
   int TXn, TYn;  // tiles per row / column
+  // work lists of one iteration (k_splat_classify): work[4*par + {0,1,2}] = number of texture tiles to box-sum, texture tiles to
+  // zero, accumulation tiles to clear (par = iteration parity: the kernel that fills one set of counters resets the other);
+  // the lists follow at work[8 + k*TXn*TYn], k = 0, 1, 2
+  int *work;
 };
 constexpr int STX = 64, STY = 16; // splat tile
 
@@ -569,40 +573,55 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
 }
 
 // 12x12 box sum of the deposits -> precipitationFeedbackTexture (RGBA32F) + precipitationDepositionTexture (RG32F).
-// out(i,j) = sum of acc(q,r) for q in [i-5, i+6], r in [j-5, j+6] (anchor q = i0+6 covers pixels i0..i0+11).
+// out(i,j) = sum of acc(q,r) for q in [i-5, i+6], r in [j-5, j+6] (anchor q = i0+6 covers pixels i0..i0+11), columns first.
 // One workgroup per 64x16 output tile; tiles whose 3x3 neighbourhood holds no deposits only (re)write zeros, and
 // not even that when the texture tile is already known to be zero. Replaces the per-iteration clear of both
 // textures (app.js:5933-5934) and the blend-unit splats.
 // seam > 0 (slab handle whose local array contains the domain edge at a tile boundary): sums never cross it, anchors
 // right of it sit one column further right; then the (0,0) / (1,0) mailbox texels are not injected either.
-__global__ __launch_bounds__(256) void k_splat_box(int X, int Y, SplatGrid sg, const DevState *__restrict__ st, float4 *__restrict__ fb,
-                                                   float2 *__restrict__ dep, int seam, int mailbox)
+// Which tiles need work this iteration? One thread per tile: texture tiles whose 3x3 neighbourhood of accumulation tiles holds
+// deposits are box-summed, texture tiles that still hold the previous iteration's feedback are zeroed, accumulation tiles with
+// deposits are cleared afterwards. (One workgroup per tile with an early exit cost 0.2 ms at 16384 x 2048: 32768 workgroups, each
+// two dependent global round trips long, three per CU at a time because of the LDS the box sum needs.)
+__global__ __launch_bounds__(256) void k_splat_classify(int X, int Y, SplatGrid sg, int mailbox, int par)
 {
-  constexpr int WW = STX + 11, WH = STY + 11;
-  __shared__ float pl[5][WH][WW + 1];
-  __shared__ float hs[WH][STX + 1];
-  __shared__ int any_dirty;
+  const int T = sg.TXn * sg.TYn, t = blockIdx.x * blockDim.x + threadIdx.x;
+  int *cnt = sg.work + 4 * par;
+  if (t == 0) sg.work[4 * (par ^ 1)] = sg.work[4 * (par ^ 1) + 1] = sg.work[4 * (par ^ 1) + 2] = 0;
+  if (t >= T) return;
+  const int tby = t / sg.TXn, tbx = t - tby * sg.TXn;
+  if (sg.dirty[t]) sg.work[8 + 2 * T + atomicAdd(&cnt[2], 1)] = t;
+  if (tbx * STX >= X || tby * STY >= Y) return; // (the accumulation grid is one anchor wider / higher than the texture)
+  int a = 0;
+  for (int dy = -1; dy <= 1; dy++)
+    for (int dx = -1; dx <= 1; dx++) {
+      const int ax = tbx + dx, ay = tby + dy;
+      if (ax >= 0 && ay >= 0 && ax < sg.TXn && ay < sg.TYn) a |= sg.dirty[ay * sg.TXn + ax];
+    }
+  const bool corner = mailbox && t == 0;
+  if (a)
+    sg.work[8 + atomicAdd(&cnt[0], 1)] = t;
+  else if (!sg.fb_zero[t] || corner)
+    sg.work[8 + T + atomicAdd(&cnt[1], 1)] = t;
+}
+
+__global__ __launch_bounds__(256) void k_splat_box(int X, int Y, SplatGrid sg, const DevState *__restrict__ st, float4 *__restrict__ fb,
+                                                   float2 *__restrict__ dep, int seam, int mailbox, int par)
+{
+  constexpr int WW = STX + 11, WH = STY + 11, PW = 77; // (pitch 77: the 4 rows x 8 runs a half-wave reads in the horizontal pass hit 32 banks)
+  __shared__ float pl[5][WH][PW];
   const int tid = threadIdx.x;
-  const int tbx = blockIdx.x, tby = blockIdx.y;
-  const int x0 = tbx * STX, y0 = tby * STY;
-  if (tid == 0) {
-    int a = 0;
-    // deposits that reach this tile sit in accumulation tiles tbx-1..tbx+1 (window q in [x0-5, x0+69])
-    for (int dy = -1; dy <= 1; dy++)
-      for (int dx = -1; dx <= 1; dx++) {
-        const int ax = tbx + dx, ay = tby + dy;
-        if (ax >= 0 && ay >= 0 && ax < sg.TXn && ay < sg.TYn) a |= sg.dirty[ay * sg.TXn + ax];
-      }
-    any_dirty = a;
-  }
-  __syncthreads();
+  const int T = sg.TXn * sg.TYn, n_box = sg.work[4 * par], n_zero = sg.work[4 * par + 1];
   const int cx = tid & 63, cyg = tid >> 6;
+  for (int wi = blockIdx.x; wi < n_box + n_zero; wi += gridDim.x) {
+  const bool any_dirty = wi < n_box;
+  const int tile = any_dirty ? sg.work[8 + wi] : sg.work[8 + T + (wi - n_box)];
+  const int tby = tile / sg.TXn, tbx = tile - tby * sg.TXn;
+  const int x0 = tbx * STX, y0 = tby * STY;
   const bool corner = mailbox && (tbx == 0 && tby == 0);
-  const int tile = tby * sg.TXn + tbx;
   const bool right = seam > 0 && x0 >= seam;
   const int qmin = right ? seam : 0, qmax = (seam > 0 && !right) ? seam : X, qshift = right ? 1 : 0;
-  if (!any_dirty) {
-    if (sg.fb_zero[tile] && !corner) return; // texture tile still zero from an earlier iteration
+  if (!any_dirty) { // the texture tile holds the feedback of an earlier iteration (or the mailbox texels): zero it
     for (int k = 0; k < STY / 4; k++) {
       const int x = x0 + cx, y = y0 + cyg + 4 * k;
       if (x < X && y < Y) {
@@ -614,7 +633,7 @@ __global__ __launch_bounds__(256) void k_splat_box(int X, int Y, SplatGrid sg, c
       }
     }
     if (tid == 0) sg.fb_zero[tile] = corner ? 0 : 1;
-    return;
+    continue;
   }
   // stage the deposit window (zero outside the accumulation grid)
   for (int i = tid; i < WW * WH; i += 256) {
@@ -633,33 +652,59 @@ __global__ __launch_bounds__(256) void k_splat_box(int X, int Y, SplatGrid sg, c
     pl[4][ly][lx] = a2.y;
   }
   __syncthreads();
-  float res[5][STY / 4];
+  // A 12-sum as a tree whose nodes depend on the absolute index only -- pair sums p[i] = a[i] + a[i+1], quads q[i] = p[i] + p[i+2],
+  // s[i] = (q[i] + q[i+4]) + q[i+8] -- so that neighbouring outputs share their partial sums (4 additions per output instead of 11)
+  // and the result does not depend on where the tile or slab boundaries lie.
+  // vertical pass: one (channel, window column) per thread, the 16 sums written back in place
+  float vres[2][STY];
+#pragma unroll
+  for (int rnd = 0; rnd < 2; rnd++) {
+    const int task = tid + 256 * rnd;
+    if (task < 5 * WW) {
+      const int c = task / WW, lx = task - c * WW;
+      float a[WH];
+#pragma unroll
+      for (int i = 0; i < WH; i++) a[i] = pl[c][i][lx];
+#pragma unroll
+      for (int i = 0; i < WH - 1; i++) a[i] = a[i] + a[i + 1];
+#pragma unroll
+      for (int i = 0; i < WH - 3; i++) a[i] = a[i] + a[i + 2];
+#pragma unroll
+      for (int j = 0; j < STY; j++) vres[rnd][j] = (a[j] + a[j + 4]) + a[j + 8];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rnd = 0; rnd < 2; rnd++) {
+    const int task = tid + 256 * rnd;
+    if (task < 5 * WW) {
+      const int c = task / WW, lx = task - c * WW;
+#pragma unroll
+      for (int j = 0; j < STY; j++) pl[c][j][lx] = vres[rnd][j];
+    }
+  }
+  __syncthreads();
+  // horizontal pass: a run of 4 output cells of one row per thread, all five channels
+  const int run = (tid & 7) + 8 * ((tid >> 5) & 1), row = ((tid >> 3) & 3) + 4 * (tid >> 6);
+  float res[5][4];
 #pragma unroll
   for (int c = 0; c < 5; c++) {
-    // horizontal 12-sums for every window row, then vertical 12-sums (fixed summation order)
-    for (int i = tid; i < WH * STX; i += 256) {
-      const int ly = i >> 6, lx = i & 63;
-      float s = 0.f;
+    float a[15];
 #pragma unroll
-      for (int k = 0; k < 12; k++) s += pl[c][ly][lx + k];
-      hs[ly][lx] = s;
-    }
-    __syncthreads();
+    for (int k = 0; k < 15; k++) a[k] = pl[c][row][run * 4 + k];
 #pragma unroll
-    for (int k = 0; k < STY / 4; k++) {
-      const int ly = cyg + 4 * k;
-      float s = 0.f;
+    for (int k = 0; k < 14; k++) a[k] = a[k] + a[k + 1];
 #pragma unroll
-      for (int m = 0; m < 12; m++) s += hs[ly + m][cx];
-      res[c][k] = s;
-    }
-    __syncthreads();
+    for (int k = 0; k < 12; k++) a[k] = a[k] + a[k + 2];
+#pragma unroll
+    for (int m = 0; m < 4; m++) res[c][m] = (a[m] + a[m + 4]) + a[m + 8];
   }
+  const int y = y0 + row;
 #pragma unroll
-  for (int k = 0; k < STY / 4; k++) {
-    const int x = x0 + cx, y = y0 + cyg + 4 * k;
+  for (int m = 0; m < 4; m++) {
+    const int x = x0 + run * 4 + m;
     if (x < X && y < Y) {
-      float4 v = make_float4(res[0][k], res[1][k], res[2][k], 0.f);
+      float4 v = make_float4(res[0][m], res[1][m], res[2][m], 0.f);
       if (corner && y == 0 && x == 0) v.x += st->px_count;
       if (corner && y == 0 && x == 1) {
         v.x += st->px_light[0];
@@ -668,27 +713,31 @@ __global__ __launch_bounds__(256) void k_splat_box(int X, int Y, SplatGrid sg, c
         v.w += st->px_light[3];
       }
       fb[(size_t)y * X + x] = v;
-      dep[(size_t)y * X + x] = make_float2(res[3][k], res[4][k]);
+      dep[(size_t)y * X + x] = make_float2(res[3][m], res[4][m]);
     }
   }
   if (tid == 0) sg.fb_zero[tile] = 0;
+  __syncthreads(); // (the next tile re-uses the staging buffer)
+  }
 }
 
 // zero the accumulation tiles that hold deposits (after k_splat_box consumed them)
-__global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg)
+__global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg, int par)
 {
-  const int tile = blockIdx.y * sg.TXn + blockIdx.x;
-  if (!sg.dirty[tile]) return;
-  const int x0 = blockIdx.x * STX, y0 = blockIdx.y * STY;
-  for (int i = threadIdx.x; i < STX * STY; i += 256) {
-    const int q = x0 + (i & 63), r = y0 + (i >> 6);
-    if (q < sg.AP && r < sg.AH) {
-      sg.acc4[(size_t)r * sg.AP + q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      sg.acc2[(size_t)r * sg.AP + q] = make_float2(0.f, 0.f);
+  const int T = sg.TXn * sg.TYn, n = sg.work[4 * par + 2];
+  for (int wi = blockIdx.x; wi < n; wi += gridDim.x) {
+    const int tile = sg.work[8 + 2 * T + wi];
+    const int tby = tile / sg.TXn, tbx = tile - tby * sg.TXn;
+    const int x0 = tbx * STX, y0 = tby * STY;
+    for (int i = threadIdx.x; i < STX * STY; i += 256) {
+      const int q = x0 + (i & 63), r = y0 + (i >> 6);
+      if (q < sg.AP && r < sg.AH) {
+        sg.acc4[(size_t)r * sg.AP + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sg.acc2[(size_t)r * sg.AP + q] = make_float2(0.f, 0.f);
+      }
     }
+    if (threadIdx.x == 0) sg.dirty[tile] = 0;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) sg.dirty[tile] = 0;
 }
 
 // lightningLocationShader.frag:24-38 + the 600-iteration inactive count (app.js:5957-5966), one thread

@@ -491,6 +491,19 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     if (HAS_FB) asm volatile("" ::"v"(fb_cur.w));
     asm volatile("" : "+v"(w_raw)); // keeps the byte unpacking on this side of the prefetch
     const char4 w_cur = unpack_wall(w_raw);
+    // ---- row r enters the ring: P, T and wall (velocity leaves them unchanged); light row r-2 ----
+    // HAS_FB: ahead of the prefetch. Behind it (where the other variant has them: its loads are issued a few instructions earlier) the
+    // compiler puts an s_waitcnt vmcnt in front of these LDS writes that waits for the loads just issued -- a memory latency per step
+    // (5 % of the kernel, profiles/r02_particles_ring_first.txt).
+    auto ring_in = [&]() {
+      const int o = s0 * WRW + li;
+      (&rg.P[0][0])[o] = b_cur.z;
+      (&rg.T[0][0])[o] = b_cur.w;
+      (&rg.wl[0][0])[o] = w_cur;
+      rg.lx[(r - 2 + 8) & (WL - 1)][li] = lx_cur;
+      rg.lw[(r - 2 + 8) & (WL - 1)][li] = lzw_cur.y;
+    };
+    if (HAS_FB) ring_in();
     // ---- software prefetch: the loads of the next step are in flight while this one computes ----
     if (r < y_hi + 3) {
       {
@@ -540,15 +553,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       if (out.t_disp) st_row(out.t_disp + e, so4, st_ab.w);
     }
     st_valid = false;
-    // ---- row r enters the ring: P, T and wall (velocity leaves them unchanged); light row r-2 ----
-    {
-      const int o = s0 * WRW + li;
-      (&rg.P[0][0])[o] = b_cur.z;
-      (&rg.T[0][0])[o] = b_cur.w;
-      (&rg.wl[0][0])[o] = w_cur;
-      rg.lx[(r - 2 + 8) & (WL - 1)][li] = lx_cur;
-      rg.lw[(r - 2 + 8) & (WL - 1)][li] = lzw_cur.y;
-    }
+    if (!HAS_FB) ring_in();
     // ---- velocity of row r-1 ----
     float v0x = 0.f, v0y = 0.f;
     if (t >= 1) {

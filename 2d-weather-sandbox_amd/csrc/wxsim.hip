@@ -130,6 +130,7 @@ struct wx_sim {
   WetLaunch wet_shape{};       // cached launch shape for that value
   bool wet_shape_valid = false;
   SplatGrid sg{};              // particle splat accumulation (allocated when the handle has droplets)
+  int splat_par = 0;           // which set of work-list counters the next iteration fills (see SplatGrid::work)
   bool fb_dirty = false; // feedback/deposition hold non-zero data (particles ran last iteration)
   bool water_trivial = false; // the water texture is known to be 0 in air cells and only the wall marker in wall cells: set by wx_upload,
                               // cleared by every step that can put water there (anything but the water-free dry iteration)
@@ -684,6 +685,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
     if (rc == WX_OK) rc = dalloc(s, &sg.acc2, (size_t)sg.AP * sg.AH);
     if (rc == WX_OK) rc = dalloc(s, &sg.dirty, (size_t)sg.TXn * sg.TYn);
     if (rc == WX_OK) rc = dalloc(s, &sg.fb_zero, (size_t)sg.TXn * sg.TYn);
+    if (rc == WX_OK) rc = dalloc(s, &sg.work, 8 + 3 * (size_t)sg.TXn * sg.TYn);
     if (rc == WX_OK && halo > 0) rc = dalloc(s, &s->keys, (size_t)n_droplets);
     if (rc == WX_OK && halo > 0) {
       if (hipMemset(s->keys, 0, (size_t)n_droplets * 4) != hipSuccess) rc = WX_E_DEVICE;
@@ -761,6 +763,7 @@ void wx_destroy(wx_sim *s)
   hipFree(s->sg.acc2);
   hipFree(s->sg.dirty);
   hipFree(s->sg.fb_zero);
+  hipFree(s->sg.work);
   delete s;
 }
 
@@ -812,6 +815,8 @@ static int reset_after_upload(wx_sim *s, const float *drops)
     HIPCHK(s, hipMemsetAsync(s->sg.acc2, 0, (size_t)s->sg.AP * s->sg.AH * 8, s->stream));
     HIPCHK(s, hipMemsetAsync(s->sg.dirty, 0, (size_t)s->sg.TXn * s->sg.TYn, s->stream));
     HIPCHK(s, hipMemsetAsync(s->sg.fb_zero, 1, (size_t)s->sg.TXn * s->sg.TYn, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->sg.work, 0, 32, s->stream));
+    s->splat_par = 0;
   }
   HIPCHK(s, hipStreamSynchronize(s->stream)); // the caller keeps ownership of the host arrays
   s->fb_dirty = false;
@@ -977,8 +982,10 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       }
       {
         ProfScope ps(s, K_SPLAT);
-        hipLaunchKernelGGL(k_splat_box, dim3((s->X + STX - 1) / STX, (s->Y + STY - 1) / STY), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->state,
-                           s->fb, s->dep, s->seam, s->keys ? 0 : 1);
+        const int T = s->sg.TXn * s->sg.TYn, par = s->splat_par;
+        hipLaunchKernelGGL(k_splat_classify, dim3((T + 255) / 256), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->keys ? 0 : 1, par);
+        hipLaunchKernelGGL(k_splat_box, dim3(T < 2048 ? T : 2048), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->state, s->fb, s->dep, s->seam,
+                           s->keys ? 0 : 1, par);
       }
       {
         ProfScope ps(s, K_LIGHTNING);
@@ -986,7 +993,9 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       }
       {
         ProfScope ps(s, K_SPLAT);
-        hipLaunchKernelGGL(k_splat_clear, dim3(s->sg.TXn, s->sg.TYn), dim3(256), 0, s->stream, s->X, s->Y, s->sg);
+        const int T = s->sg.TXn * s->sg.TYn;
+        hipLaunchKernelGGL(k_splat_clear, dim3(T < 2048 ? T : 2048), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->splat_par);
+        s->splat_par ^= 1;
       }
       s->drop_cur = dst;
       s->fb_dirty = true;
