@@ -43,6 +43,9 @@ namespace wx {
 #define WX_WET_WPB 4 // wavefronts per workgroup: independent strips (no barrier between them); the dispatcher spreads the waves of
                      // ONE workgroup evenly over the four SIMDs of a CU, which it does not guarantee for single-wave workgroups
 #endif
+#ifndef WX_WET_PRIO_ROTATE
+#define WX_WET_PRIO_ROTATE 0
+#endif
 #ifndef WX_WET_SKIP_LOADS
 #define WX_WET_SKIP_LOADS 1 // no water / light loads in the first two warm-up steps; light_0.x only near walls
 #endif
@@ -80,6 +83,9 @@ struct WetOut {
   float4 *water0;    // optional (OPT_OUT): post-boundary water (waterTexture_0)
   float *curl;       // optional (OPT_OUT)
   float *t_disp;     // optional (runtime): post-advection temperature for the droplets
+#ifdef WX_WET_TIMING
+  unsigned long long *cycles; // (tuning builds) per wave: s_memtime at start / end
+#endif
 };
 
 // ---- exact out-of-line path: the post-boundary texel of an ARBITRARY cell recomputed from global memory (velocity, curl
@@ -469,6 +475,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   bool st_valid = false;
   int first_slow = 0x7fffffff; // index (row - (y_lo - 1)) of the first row with cells left to the exact path
 
+#ifdef WX_WET_TIMING
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   int r = y_lo - 4;
   { // prefetch of the first row
     const size_t e = (size_t)wrapmod(r, Y) * X;
@@ -478,7 +487,19 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   int s0 = (r + 12) % WD, sq3 = (r - 3 + 12) % WQ; // ring slots of row r (base / wall planes) and of row r-3 (water planes)
   // wrapped (REPEAT) row indices of rows r+1, r-1 .. r-4, advanced by one per step (a general modulo costs ~20 scalar instructions)
   int yw_p1 = wrapmod(r + 1, Y), yw_m1 = wrapmod(r - 1, Y), yw_m2 = wrapmod(r - 2, Y), yw_m3 = wrapmod(r - 3, Y), yw_m4 = wrapmod(r - 4, Y);
+#if WX_WET_PRIO_ROTATE
+  // wave slot within the SIMD (HW_ID.WAVE_ID): the waves that share a SIMD have different ones
+  const int prio_phase = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+#endif
   for (int t = 0; r <= y_hi + 3; r++, t++) {
+#if WX_WET_PRIO_ROTATE
+    { // the SIMD issues the OLDEST ready wave first: without this the first-dispatched waves run ~30 % faster than the last ones
+      const int pr = (t + prio_phase) % 3;
+      if (pr == 0) __builtin_amdgcn_s_setprio(0);
+      else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(2);
+    }
+#endif
     const float4 b_cur = pf_b, q_up = pf_q;       // base row r, water row r-2
     int w_raw = pf_w;
     const float lx_cur = pf_lx, l0x_cur = pf_l0x, l0y_cur = pf_l0y; // light row r-2
@@ -736,6 +757,12 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   }
   // ---- exact path for the recorded cells: cell (x, y) feeds the outputs (x, y), (x+1, y) [pressure: vx of the left neighbour]
   //      and (x, y+1) [pressure / lighting: vy, T and wall of the lower neighbour]; each lane redoes those of them this wave owns ----
+#ifdef WX_WET_TIMING
+  if (lane == 0) {
+    out.cycles[2 * (size_t)item] = t_begin;
+    out.cycles[2 * (size_t)item + 1] = __builtin_readcyclecounter();
+  }
+#endif
   if (first_slow != 0x7fffffff) {
     struct KArgs { // the kernel-argument segment holds the pointer structs the out-of-line function takes from memory
       const FullCtx *ctx;
@@ -762,8 +789,15 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 // workgroups to CUs as earlier ones retire; bottom segments are dispatched first), and rows below `air_from_row` -- the lowest
 // row above which every cell is free air, -1 if unknown -- count WX_WET_ALPHA times a free-air row when the segment borders
 // are placed. Measured at 16384x2048 (gpurun_out/r2j..r2l): 1 round 29-34, 2 rounds 36-37, 4 rounds 38-40, 6 rounds 38-40
-// Gcell-steps/s -- many short waves in scattered phases of their pipeline beat few long ones although each segment re-runs
-// 8 warm-up rows; weighting terrain rows (alpha 2-2.5) is worth +15 % with one round and nothing from two rounds on.
+// Gcell-steps/s -- many short waves beat few long ones although each segment re-runs 8 warm-up rows; weighting terrain rows
+// (alpha 2-2.5) is worth +15 % with one round and nothing from two rounds on.
+// Why (tuning build -DWX_WET_TIMING: s_memtime per wave, profiles/r02_wet_wave_timing.txt): the kernel is VALU-bound at 3 waves per
+// SIMD (524 VALU instructions per row step x 4 cycles x 3 waves = the ~6800 cycles a wave takes per row), and the SIMD issues its
+// OLDEST ready wave first. With one round of 9 long segments the first-dispatched waves run at 6000 cycles / row and the last at 8100;
+// when the old ones retire nothing refills their slots and the young ones finish at 1-2 waves per SIMD, which cannot hide their own
+// memory latency: 77 % of the SIMD-time is used, against 89 % with four rounds, and that costs more than the warm-up rows saved
+// (0.87-0.90 ms against 0.835-0.845). Rotating s_setprio per step (WX_WET_PRIO_ROTATE=1) equalises the rates but marches the waves
+// of a SIMD in lock-step into their memory waits (-5 %); giving older segments more rows (WX_WET_SKEW) shifts the rates with it.
 #ifndef WX_WET_ROUNDS
 #define WX_WET_ROUNDS 4
 #endif
@@ -796,16 +830,23 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
   if (const char *e = getenv("WX_WET_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
   if (const char *e = getenv("WX_WET_ALPHA")) alpha = atof(e) >= 1.0 ? atof(e) : alpha;
   if (const char *e = getenv("WX_WET_MINROWS")) minrows = atoi(e) > 0 ? atoi(e) : minrows;
-  int n_seg = (int)((long long)rounds * wet_capacity() / w.n_strips);
+  // workgroups per segment: 8 XCD column blocks x ceil(strips of the block / waves per workgroup); the device holds capacity / WPB
+  const int wg_per_seg = 8 * (((w.n_strips + 7) / 8 + WX_WET_WPB - 1) / WX_WET_WPB);
+  int n_seg = (int)((long long)rounds * (wet_capacity() / WX_WET_WPB) / wg_per_seg);
+  double skew = 0.0; // > 0: earlier-dispatched (lower) segments get more rows: the SIMD issues its OLDEST ready wave first
+  if (const char *e = getenv("WX_WET_SKEW")) skew = atof(e);
   if (const char *e = getenv("WX_WET_SEG")) n_seg = atoi(e) > 0 ? (Y + atoi(e) - 1) / atoi(e) : n_seg;
   n_seg = n_seg < 1 ? 1 : (n_seg > WMAXSEG ? WMAXSEG : n_seg);
   if (n_seg > (Y + minrows - 1) / minrows) n_seg = (Y + minrows - 1) / minrows; // (8 warm-up rows per segment are redundant work)
   const int A = (air_from_row < 0 || air_from_row > Y) ? 0 : air_from_row;           // unknown: uniform segments
-  const double total = alpha * A + (Y - A), per = total / n_seg;
-  // border s at the row where the accumulated cost reaches s * per
+  const double total = alpha * A + (Y - A);
+  // border s at the row where the accumulated cost reaches the share of segments 0 .. s-1 (weights 1 + skew/2 .. 1 - skew/2)
   w.segs.start[0] = 0;
+  double wsum = 0.0, wacc = 0.0;
+  for (int sg = 0; sg < n_seg; sg++) wsum += 1.0 + skew * (0.5 - (n_seg > 1 ? (double)sg / (n_seg - 1) : 0.5));
   for (int sg = 1; sg < n_seg; sg++) {
-    const double c = per * sg;
+    wacc += 1.0 + skew * (0.5 - (double)(sg - 1) / (n_seg - 1));
+    const double c = total * wacc / wsum;
     int y = c <= alpha * A ? (int)(c / alpha + 0.5) : A + (int)(c - alpha * A + 0.5);
     if (y <= w.segs.start[sg - 1]) y = w.segs.start[sg - 1] + 1;
     w.segs.start[sg] = y < Y ? y : Y;

@@ -523,6 +523,11 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
            LightPlanesC{s->lp[src].x, s->lp[src].y, s->lp[src].zw}, fb ? s->fb : nullptr, fb ? s->dep : nullptr, fb ? s->sg.fb_zero : nullptr,
            s->zero_row, s->sg.TXn};
   WetOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], s->water[0], s->curl, precip ? s->tdisp : nullptr};
+#ifdef WX_WET_TIMING
+  static unsigned long long *dbg_cycles = nullptr;
+  if (!dbg_cycles) hipMalloc((void **)&dbg_cycles, 16 * 8192 * WMAXSEG);
+  out.cycles = dbg_cycles;
+#endif
   if (s->air_from_row < 0) { // after an upload or a wall edit: where does the terrain end? (one small kernel + a 4-byte readback)
     int *d = &s->state->scratch_int, v = 0;
     hipMemsetAsync(d, 0, 4, s->stream);
@@ -569,6 +574,28 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
       if (!interior_first) launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream, nl, nr0 - nl);
     }
   }
+#ifdef WX_WET_TIMING
+  if (s->iter == 40) { // per segment: start offset and duration of its waves (s_memtime ticks, 100 MHz)
+    hipStreamSynchronize(s->stream);
+    const int ns = shape.n_strips, nseg = shape.segs.n_seg;
+    std::vector<unsigned long long> c(2 * (size_t)ns * nseg);
+    hipMemcpy(c.data(), dbg_cycles, c.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t i = 0; i < c.size(); i += 2) { t0 = c[i] < t0 ? c[i] : t0; t1 = c[i + 1] > t1 ? c[i + 1] : t1; }
+    fprintf(stderr, "[wx_wet timing] kernel span %llu ticks, %d strips x %d segments\n", t1 - t0, ns, nseg);
+    for (int sg = 0; sg < nseg; sg++) {
+      double st = 0, du = 0, dmin = 1e30, dmax = 0, en = 0;
+      for (int k = 0; k < ns; k++) {
+        const size_t i = 2 * ((size_t)sg * ns + k);
+        const double d = (double)(c[i + 1] - c[i]);
+        st += (double)(c[i] - t0); du += d; en += (double)(c[i + 1] - t0);
+        dmin = d < dmin ? d : dmin; dmax = d > dmax ? d : dmax;
+      }
+      fprintf(stderr, "  seg %3d rows %4d..%4d (%3d): start %7.0f end %7.0f  dur avg %6.0f min %6.0f max %6.0f  per row %5.1f\n", sg, shape.segs.start[sg], shape.segs.start[sg + 1],
+              shape.segs.start[sg + 1] - shape.segs.start[sg], st / ns, en / ns, du / ns, dmin, dmax, du / ns / (shape.segs.start[sg + 1] - shape.segs.start[sg] + 8));
+    }
+  }
+#endif
   std::swap(s->base[0], s->base[1]);
   std::swap(s->wall[0], s->wall[1]);
   std::swap(s->water[1], s->water[2]);
