@@ -798,6 +798,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 // memory latency: 77 % of the SIMD-time is used, against 89 % with four rounds, and that costs more than the warm-up rows saved
 // (0.87-0.90 ms against 0.835-0.845). Rotating s_setprio per step (WX_WET_PRIO_ROTATE=1) equalises the rates but marches the waves
 // of a SIMD in lock-step into their memory waits (-5 %); giving older segments more rows (WX_WET_SKEW) shifts the rates with it.
+// Halo columns are not the problem: an s_barrier per row step, which keeps the four strips of a workgroup on the same rows, lowers
+// FETCH_SIZE by 2 % and costs 6 % of time -- the neighbouring strips' lines already hit in L2; what the counters show above the
+// algorithmic bytes (reads 1.15x) is the 8 warm-up rows per segment.
 #ifndef WX_WET_ROUNDS
 #define WX_WET_ROUNDS 4
 #endif
