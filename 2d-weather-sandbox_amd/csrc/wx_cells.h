@@ -2,7 +2,7 @@
 //
 // One function per reference pass; each is written against an ACCESSOR (template parameter) that
 // yields neighbour texels, so the same arithmetic serves the per-pass kernels (global memory) and the
-// fused LDS-tiled kernels. Semantics: NEAREST + REPEAT sampling on both axes,
+// row-marching (wave-private LDS ring) and LDS-tiled kernels. Semantics: NEAREST + REPEAT sampling on both axes,
 // light texture clamped in y, fp32 evaluated left-to-right with NO contraction (-ffp-contract=off),
 // RGBA8I stores saturate, pow() with constant exponents is a fixed multiply chain / sqrt so that the
 // result is bit-reproducible (GLSL leaves pow's rounding undefined).

@@ -10,7 +10,7 @@
 // set: bit-identical results. Buffers are pointer-swapped by the host after each launch.
 #pragma once
 #include "wx_cells.h"
-#include "wx_fused.h"
+#include "wx_tile.h"
 #include "wx_wet.h" // FullCtx
 
 namespace wx {

@@ -1,8 +1,8 @@
 // wx_kernels.h -- per-pass HIP kernels (one launch per reference draw call) and utility kernels.
 //
 // These are the parity baseline: each kernel is one reference pass with one thread per cell, coalesced
-// float4 / char4 traffic and neighbour reads served by L1/L2. The fused LDS-tiled kernels in
-// wx_fused.h compute exactly the same per-cell arithmetic (wx_cells.h) with less HBM traffic.
+// float4 / char4 traffic and neighbour reads served by L1/L2. The row-marching kernels
+// (wx_wet.h, wx_march.h) compute exactly the same per-cell arithmetic (wx_cells.h) with a fraction of the HBM traffic.
 #pragma once
 #include "wx_cells.h"
 #include <hip/hip_fp16.h>

@@ -28,7 +28,7 @@
 // Same per-cell arithmetic as every other kernel set (wx_cells.h): bit-identical results.
 #pragma once
 #include "wx_cells.h"
-#include "wx_fused.h"
+#include "wx_tile.h"
 #include <cstddef>
 
 namespace wx {

@@ -5,7 +5,7 @@
 // There is NO CPU fallback: every entry point that computes needs a HIP device and fails with
 // WX_E_DEVICE otherwise.
 #include "../../include/wxsim.h"
-#include "wx_fused.h"
+#include "wx_tile.h"
 #include "wx_wet.h"
 #include "wx_dry.h"
 #include "wx_march.h"
@@ -41,17 +41,13 @@ enum KernelId {
   K_SPLAT, // box filter of the particle deposits + accumulation clear
   K_COPY,
   K_HALO,
-  K_FUSED_VCVB, // velocity + curl + vorticity + boundary
-  K_FUSED_APL,  // advection + pressure + lighting
-  K_FUSED_FULL, // the whole iteration in one kernel
   K_FUSED_DRY,  // velocity + advection + pressure (pass_mask WX_PASS_DRY)
   K_MARCH_DRY,  // the same as a row-marching wavefront kernel (wx_march.h)
   K_MARCH_WET,  // the whole iteration as one row-marching wavefront kernel (wx_wet.h)
   K_COUNT
 };
 const char *const kKernelNames[K_COUNT] = {"velocity", "curl", "vorticity", "boundary", "advection", "pressure", "lighting",
-                                           "precipitation", "lightning", "splat_box", "copy", "halo", "fused_vel_curl_vort_boundary",
-                                           "fused_advect_pressure_light", "fused_full_iteration", "fused_dry_vel_advect_pressure", "march_dry_vel_advect_pressure",
+                                           "precipitation", "lightning", "splat_box", "copy", "halo", "fused_dry_vel_advect_pressure", "march_dry_vel_advect_pressure",
                                            "march_wet_full_iteration"};
 
 struct ProfRec {
@@ -80,8 +76,8 @@ struct wx_sim {
   int64_t iter = 0;
   int dry_march = 1;     // water-free dry iteration: 1 = row-marching wavefront kernel (wx_march.h, default: 0.32 vs 0.38 ms at
                          // 16384x2048), 0 = LDS-tiled kernel (wx_dry.h); env WX_DRY_MARCH
-  int fused = 2;         // 2 (default): the whole iteration as one row-marching kernel (wx_wet.h); 1: two fused LDS-tiled kernels; 0: one kernel
-                         // per reference pass (env WX_FUSED)
+  int fused = 2;         // non-zero (default): the whole iteration as one row-marching kernel (wx_wet.h); 0: one kernel per reference
+                         // pass (env WX_FUSED; the independent cross-check of the parity tests)
   wx_params p{};
   Geo geo{};
   Uni uni{};
@@ -91,32 +87,22 @@ struct wx_sim {
   hipEvent_t ev_fields_ready = nullptr, ev_copy_done = nullptr;
   bool copy_in_flight = false;
   // device storage
-  float4 *base[3] = {nullptr, nullptr, nullptr}; // [2]: post-advection base of the fused path (= baseTexture_1)
-  float4 *water[3] = {nullptr, nullptr, nullptr}, *light[2] = {nullptr, nullptr}; // water[2]: spare of the copy-on-write / single-kernel ping-pong
-  bool ran_fused = false; // the last iteration used the fused ping-pong (field mapping differs)
-  char4 *wall[3] = {nullptr, nullptr, nullptr}; // [2]: third buffer of the copy-on-write scheme (wx_fused.h, FusedBIn)
+  float4 *base[3] = {nullptr, nullptr, nullptr}; // [2]: post-advection base of the single-kernel paths (= baseTexture_1)
+  float4 *water[3] = {nullptr, nullptr, nullptr}, *light[2] = {nullptr, nullptr}; // water[2]: spare of the single-kernel ping-pong
+  bool ran_fused = false; // the last iteration used the single-kernel ping-pong (field mapping differs)
+  char4 *wall[2] = {nullptr, nullptr};
   float *curl = nullptr;
   float2 *vort = nullptr, *dep = nullptr;
   float4 *fb = nullptr;
   float *drops[2] = {nullptr, nullptr};
   float *initial_T = nullptr, *snd_T = nullptr, *snd_W = nullptr, *snd_Vel = nullptr;
   DevState *state = nullptr;
-  // device copies of geometry/uniforms/pointers for the out-of-line advection path. The buffer roles of kernel B
-  // alternate between two configurations (pointer rotation), so two contexts are cached and matched by content.
-  SlowCtx *slow_ctx = nullptr;
-  SlowCtx slow_host[2];
-  bool slow_valid[2] = {false, false};
-  int slow_next = 0;
-  // light_0 / light_1 as planes (wx_fused.h, LightPlanes): the representation of the two-kernel path. `light_planar`
-  // says which copy is current; the other kernel sets, readback and streaming use the interleaved light[] buffers.
+  // light_0 / light_1 as planes (wx_tile.h, LightPlanes): the representation of the marching wet kernel. `light_planar`
+  // says which copy is current; the other kernels, readback and streaming use the interleaved light[] buffers.
   LightPlanes lp[3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; // [2]: spare of the marching kernel
   bool light_planar = false;
-  float *tdisp = nullptr;   // post-advection temperature for the droplets (two-kernel path, instead of the whole base_disp)
+  float *tdisp = nullptr;   // post-advection temperature for the droplets (marching wet kernel, instead of the whole base_disp)
   bool wall_veg_ok = false; // no negative vegetation byte anywhere (advection would clamp it: the one wall change it can make unasked)
-  // copy-on-write of kernel A's water / wall outputs
-  int cow = 1;                         // env WX_COW=0 disables it
-  unsigned int *cow_clean = nullptr;   // per 64x16 tile: kernel A left water[0] / wall[1] unwritten
-  bool cow_pending = false;            // water[0] has unwritten tiles whose values live in water[2]
   FullCtx *full_ctx = nullptr;
   float4 *zero_row = nullptr;              // X texels of zeros (marching wet kernel: rows of feedback tiles that are known to be zero)
   unsigned long long *slow_rows = nullptr; // marching wet kernel: per-wave row masks of the cells left to the exact path
@@ -406,10 +392,7 @@ int iterate_per_pass(wx_sim *s, unsigned mask)
   return WX_OK;
 }
 
-// The same iteration as two fused kernels (wx_fused.h); results are bit-identical to iterate_per_pass.
-// write_disp: also store the post-advection base (the reference's baseTexture_1, read by the particle pass and
-// by display-side consumers) -- needed only for the last iteration of a wx_step call or when particles run.
-// light_0 / light_1: switch between the interleaved textures and the planes of the two-kernel path
+// light_0 / light_1: switch between the interleaved textures and the planes of the marching wet kernel
 static void light_to_planes(wx_sim *s)
 {
   if (s->light_planar) return;
@@ -424,78 +407,6 @@ static void light_to_rgba(wx_sim *s)
     hipLaunchKernelGGL(k_light_from_planes, dim3(2048), dim3(256), 0, s->stream, ncell(s), src, s->light[i]);
   }
   s->light_planar = false;
-}
-
-// device-side SlowCtx matching kernel B's inputs of this iteration (two cached configurations)
-static const SlowCtx *slow_ctx_for(wx_sim *s, const FusedBIn &in)
-{
-  SlowCtx c;
-  memset(&c, 0, sizeof(c)); // padding bytes take part in the comparison
-  c.g = s->geo;
-  c.u = s->uni;
-  c.initial_T = s->initial_T;
-  c.snd_T = s->snd_T;
-  c.snd_W = s->snd_W;
-  c.snd_Vel = s->snd_Vel;
-  // field by field: a struct assignment would also copy the caller's (indeterminate) padding bytes into the key
-  c.in.base = in.base;
-  c.in.water = in.water;
-  c.in.wall = in.wall;
-  c.in.light = LightPlanesC{nullptr, nullptr, nullptr}; // alternates with the even / odd parity, not used by the out-of-line path
-  c.in.water_alt = in.water_alt;
-  c.in.wall_alt = in.wall_alt;
-  c.in.clean = in.clean;
-  c.in.txn = in.txn;
-  for (int i = 0; i < 2; i++)
-    if (s->slow_valid[i] && memcmp(&s->slow_host[i], &c, sizeof(c)) == 0) return s->slow_ctx + i;
-  const int i = s->slow_next;
-  s->slow_next ^= 1;
-  // an earlier launch may still read this slot: the (rare) rebuild waits for the stream
-  hipStreamSynchronize(s->stream);
-  memcpy(&s->slow_host[i], &c, sizeof(c));
-  hipMemcpy(s->slow_ctx + i, &s->slow_host[i], sizeof(c), hipMemcpyHostToDevice);
-  s->slow_valid[i] = true;
-  return s->slow_ctx + i;
-}
-
-// Before anything outside kernel B reads water[0] (waterTexture_0): fill the tiles kernel A left unwritten.
-static void cow_resolve(wx_sim *s)
-{
-  if (!s->cow_pending) return;
-  const dim3 grid((s->X + 63) / 64, (s->Y + 15) / 16);
-  hipLaunchKernelGGL(k_cow_resolve, grid, dim3(256), 0, s->stream, s->X, s->Y, s->cow_clean, s->water[2], s->water[0]);
-  s->cow_pending = false;
-}
-
-int iterate_fused(wx_sim *s, bool write_disp, bool precip)
-{
-  const Geo g = s->geo;
-  Uni u = s->uni;
-  u.iterNum = (float)s->iter;
-  u.iterI = (int)u.iterNum;
-  const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
-  light_to_planes(s);
-  unsigned int *clean = (s->cow && s->X >= 72 && s->Y >= 24) ? s->cow_clean : nullptr; // not for grids whose tile halo wraps twice
-  {
-    FusedAIn in{s->base[0], s->wall[0], s->water[1], LightPlanesC{s->lp[0].x, s->lp[0].y, s->lp[0].zw}, s->fb_dirty ? s->fb : nullptr,
-                s->fb_dirty ? s->dep : nullptr, s->sg.fb_zero, s->sg.TXn};
-    ProfScope ps(s, K_FUSED_VCVB);
-    launch_fused_a(g, u, s->initial_T, in, s->base[1], s->water[0], s->wall[1], s->curl, write_disp, clean, s->stream);
-  }
-  {
-    // B reads A's outputs (water[0], wall[1]) -- or, for tiles A left unwritten, A's inputs (water[1], wall[0]) -- and
-    // writes the third buffer of each; afterwards the pointers rotate back into their usual roles
-    FusedBIn in{s->base[1], s->water[0], s->wall[1], LightPlanesC{s->lp[src].x, s->lp[src].y, s->lp[src].zw}, s->water[1], s->wall[0], clean,
-                (s->X + 63) / 64};
-    const SlowCtx *ctx = slow_ctx_for(s, in);
-    ProfScope ps(s, K_FUSED_APL);
-    launch_fused_b(g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, ctx, s->base[0], s->base[2], s->water[2], s->wall[2], s->lp[dst],
-                   write_disp, precip ? s->tdisp : nullptr, s->stream);
-  }
-  std::swap(s->water[1], s->water[2]); // water[1] = post-advection water, water[2] = what A read (source of the clean tiles)
-  std::swap(s->wall[0], s->wall[2]);
-  s->cow_pending = clean != nullptr;
-  return WX_OK;
 }
 
 // the compute stream may not touch ghost columns before the comm stream has written them
@@ -669,8 +580,6 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   s->n_drops = n_droplets;
   if (const char *f = getenv("WX_FUSED")) s->fused = atoi(f);
   if (const char *f = getenv("WX_DRY_MARCH")) s->dry_march = atoi(f);
-  if (const char *f = getenv("WX_COW")) s->cow = atoi(f);
-  if (!kHaveFused) s->fused = 0;
   const size_t n = ncell(s);
   int rc = WX_OK;
   for (int i = 0; i < 2 && rc == WX_OK; i++) {
@@ -690,15 +599,12 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (rc == WX_OK) rc = dalloc(s, &s->snd_W, (size_t)Y + 8);
   if (rc == WX_OK) rc = dalloc(s, &s->snd_Vel, (size_t)Y + 8);
   if (rc == WX_OK) rc = dalloc(s, &s->state, 1);
-  if (rc == WX_OK) rc = dalloc(s, &s->slow_ctx, 2);
-  if (rc == WX_OK) rc = dalloc(s, &s->wall[2], n);
   if (rc == WX_OK && n_droplets > 0) rc = dalloc(s, &s->tdisp, n);
   for (int i = 0; i < 3 && rc == WX_OK; i++) {
     if ((rc = dalloc(s, &s->lp[i].x, n))) break;
     if ((rc = dalloc(s, &s->lp[i].y, n))) break;
     rc = dalloc(s, &s->lp[i].zw, n);
   }
-  if (rc == WX_OK) rc = dalloc(s, &s->cow_clean, (size_t)((s->X + 63) / 64) * ((Y + 15) / 16));
   if (rc == WX_OK) rc = dalloc(s, &s->full_ctx, 1);
   if (rc == WX_OK) rc = dalloc(s, &s->zero_row, (size_t)s->X);
   if (rc == WX_OK) rc = dalloc(s, &s->water[2], n);
@@ -773,15 +679,12 @@ void wx_destroy(wx_sim *s)
   }
   hipFree(s->state);
   hipFree(s->keys);
-  hipFree(s->slow_ctx);
-  hipFree(s->wall[2]);
   hipFree(s->tdisp);
   for (int i = 0; i < 3; i++) {
     hipFree(s->lp[i].x);
     hipFree(s->lp[i].y);
     hipFree(s->lp[i].zw);
   }
-  hipFree(s->cow_clean);
   hipFree(s->full_ctx);
   hipFree(s->zero_row);
   hipFree(s->slow_rows);
@@ -849,7 +752,6 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   s->fb_dirty = false;
   s->air_from_row = -1;
   s->ghost_check = false;
-  s->cow_pending = false;
   s->light_planar = false; // the interleaved light textures were just zeroed
   s->period_j = 0;
   s->ran_fused = false;
@@ -918,7 +820,6 @@ int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const f
   if (sounding_W) HIPCHK(s, hipMemcpyAsync(s->snd_W, sounding_W, nb, hipMemcpyHostToDevice, s->stream));
   if (sounding_Vel) HIPCHK(s, hipMemcpyAsync(s->snd_Vel, sounding_Vel, nb, hipMemcpyHostToDevice, s->stream));
   {
-    s->slow_valid[0] = s->slow_valid[1] = false; // uniforms changed: the contexts are rebuilt on the next fused iteration
     FullCtx fc{s->geo, s->uni, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel};
     HIPCHK(s, hipMemcpyAsync(s->full_ctx, &fc, sizeof(fc), hipMemcpyHostToDevice, s->stream));
   }
@@ -939,7 +840,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   const unsigned mask = s->p.pass_mask;
   const bool precip = (mask & WX_PASS_PRECIPITATION) && s->p.enablePrecipitation && s->n_drops > 0;
   const size_t n = ncell(s);
-  // the fused kernels implement the full grid-pass set; any other pass_mask runs the per-pass kernels
+  // the marching kernel implements the full grid-pass set; any other pass_mask (but the dry one) runs the per-pass kernels
   const bool fused = s->fused && (mask & 0x3Fu) == 0x3Fu;
   const bool dry = s->fused && (mask & 0x3Fu) == WX_PASS_DRY;
   if (s->copy_in_flight) { // a streamed frame still reads the display fields: order this step after it (device-side wait)
@@ -964,10 +865,9 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       return fail(s, WX_E_STATE, "wx_step: %d iterations asked, %d done since the last halo exchange; %d ghost columns allow %d per period with particles",
                   n_iter, s->period_j, s->halo, (s->halo - 6) / WX_SLAB_CONE);
   }
-  if (!(fused && s->fused == 1)) cow_resolve(s);    // the other kernel sets take water[0] as a fully written buffer
-  if (!(fused && s->fused >= 1)) light_to_rgba(s);  // ... and the per-pass / dry kernels the light textures interleaved
+  if (!fused) light_to_rgba(s); // the per-pass / dry kernels take the light textures interleaved
   // overlap needs the kernel that can be launched per strip range; everything else orders the exchange on the compute stream
-  const bool can_split = fused && s->fused >= 2 && !precip && s->comm_stream != nullptr && s->halo > 0;
+  const bool can_split = fused && !precip && s->comm_stream != nullptr && s->halo > 0;
   if (!can_split) wait_unpacked(s);
   s->edges_recorded = false;
   for (int it = 0; it < n_iter; it++) {
@@ -976,12 +876,10 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
     if (can_split && it == 0 && !(edge_mode & 2)) wait_unpacked(s);
     if (dry)
       iterate_dry(s, precip || it == n_iter - 1);
-    else if (fused && s->fused >= 2) {
+    else if (fused) {
       const int rc = iterate_march_wet(s, it == n_iter - 1, precip, edge_mode);
       if (rc != WX_OK) return rc;
     }
-    else if (fused)
-      iterate_fused(s, it == n_iter - 1, precip);
     else
       iterate_per_pass(s, mask);
     s->ran_fused = fused || dry;
@@ -990,7 +888,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
     // 8-10 clear feedback/deposition, precipitation, lightning location (app.js:5933-5983). The clear and the
     // blend-unit splats are replaced by: deposit at the sprite anchors -> 12x12 box sum that (re)writes both textures.
     if (precip) {
-      const bool two_kernel = fused && !dry; // fused / marching kernels: droplets sample base[0] (velocity) + tdisp (temperature)
+      const bool two_kernel = fused && !dry; // marching wet kernel: droplets sample base[0] (velocity) + tdisp (temperature)
       Uni u = s->uni;
       u.iterNum = (float)s->iter;
       u.iterI = (int)u.iterNum;
@@ -1039,15 +937,6 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
     s->emit_lit = !dry && (mask & WX_PASS_LIGHTING) != 0;
     s->emit_uni = s->uni;
   }
-  if (s->cow_pending && getenv("WX_COW_DEBUG")) {
-    const size_t nt = (size_t)((s->X + 63) / 64) * ((s->Y + 15) / 16);
-    std::vector<unsigned int> f(nt);
-    hipStreamSynchronize(s->stream);
-    hipMemcpy(f.data(), s->cow_clean, nt * 4, hipMemcpyDeviceToHost);
-    size_t c = 0;
-    for (unsigned int v : f) c += v != 0;
-    fprintf(stderr, "[wx_cow] iter %lld: %zu of %zu tiles clean\n", (long long)s->iter, c, nt);
-  }
   HIPCHK(s, hipGetLastError());
   return WX_OK;
 }
@@ -1073,10 +962,10 @@ static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int
   switch (field) {
   case WX_FIELD_BASE_CUR: *ptr = s->base[0]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_BASE_DISP: *ptr = s->ran_fused ? s->base[2] : s->base[1]; *channels = 4; *elem = 4; return 0;
-  case WX_FIELD_WATER_0: cow_resolve(s); *ptr = s->water[0]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_WATER_0: *ptr = s->water[0]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_WATER_CUR: *ptr = s->water[1]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_WALL_CUR: *ptr = s->wall[0]; *channels = 4; *elem = 1; return 0;
-  // wallTexture_1 (post-advection) == wallTexture_0 after the pressure pass-through; the fused path keeps one copy
+  // wallTexture_1 (post-advection) == wallTexture_0 after the pressure pass-through; the single-kernel paths keep one copy
   case WX_FIELD_WALL_DISP: *ptr = s->ran_fused ? s->wall[0] : s->wall[1]; *channels = 4; *elem = 1; return 0;
   case WX_FIELD_LIGHT_0: light_to_rgba(s); *ptr = s->light[0]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_LIGHT_1: light_to_rgba(s); *ptr = s->light[1]; *channels = 4; *elem = 4; return 0;

@@ -27,12 +27,6 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 ALGO_BYTES = {
     "velocity": 20 + 20, "curl": 16 + 4, "vorticity": 4 + 8, "boundary": 60 + 36, "advection": 36 + 36,
     "pressure": 20 + 20, "lighting": 52 + 16,
-    # A: R base16 wall4 water16 light16, W base16 water16 wall4 (+curl4 on the last iteration of a wx_step call; the water16 + wall4
-    # stores are skipped for tiles the boundary pass leaves unchanged -- still counted here, the pass semantically produces them);
-    # B: R base16 water16 wall4 light16,
-    # W base16 water16 wall4 light16 (+16 for the post-advection base on the last iteration of a wx_step call only)
-    # (A reads only the x and y planes of the light texture: base16 wall4 water16 light8)
-    "fused_vel_curl_vort_boundary": 44 + 36, "fused_advect_pressure_light": 52 + 52,
     # the whole iteration as one row-marching kernel: R base16 wall4 water16 light16 (source x, zw + light_0 y), W base16 wall4 water16
     # light16 -- every compulsory byte of the iteration exactly once
     "march_wet_full_iteration": 52 + 52,
@@ -88,7 +82,7 @@ def cpu_baseline(pkg, budget_s=12.0):
 
 
 KERNEL_SYMBOL = {  # profile name -> substring of the kernel symbol rocprofv3 reports
-    "fused_vel_curl_vort_boundary": "k_fused_a", "fused_advect_pressure_light": "k_fused_b", "march_wet_full_iteration": "k_march_wet",
+    "march_wet_full_iteration": "k_march_wet",
     "fused_dry_vel_advect_pressure": "k_fused_dry", "march_dry_vel_advect_pressure": "k_march_dry", "advection": "k_advection", "boundary": "k_boundary", "lighting": "k_lighting",
     "velocity": "k_velocity", "pressure": "k_pressure", "curl": "k_curl", "vorticity": "k_vorticity", "precipitation": "k_precipitation",
 }
