@@ -43,6 +43,9 @@ namespace wx {
 #define WX_WET_WPB 4 // wavefronts per workgroup: independent strips (no barrier between them); the dispatcher spreads the waves of
                      // ONE workgroup evenly over the four SIMDs of a CU, which it does not guarantee for single-wave workgroups
 #endif
+#ifndef WX_ABL_FORCE_AIR
+#define WX_ABL_FORCE_AIR 0 // (instruction-budget builds: every row takes the free-air instantiations; wrong near terrain)
+#endif
 #ifndef WX_WET_PRIO_ROTATE
 #define WX_WET_PRIO_ROTATE 0
 #endif
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #else
         // free air (no wall within one cell, terrain at least 8 rows below) in every lane that feeds something: the
         // branch-free instantiation. Most rows of most strips; the general one handles everything else.
-        if (WX_WET_AIR && __all(lane < 2 || lane > 60 || air_cell(w00, a.wall(-1, 0), wD, a.wall(1, 0), a.wall(0, 1))))
+        if (WX_ABL_FORCE_AIR || (WX_WET_AIR && __all(lane < 2 || lane > 60 || air_cell(w00, a.wall(-1, 0), wD, a.wall(1, 0), a.wall(0, 1)))))
           boundary_cell<true>(u, iterNum, iterI, g, initial_T, col, yb, a, bb, bq, bwl);
         else
           boundary_cell<false>(u, iterNum, iterI, g, initial_T, col, yb, a, bb, bq, bwl);
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       fast = false;
 #endif
       if (fast) {
-        if (WX_WET_AIR && (nowall1 & nowall2 & nowall3)) // (wave-uniform) plain instead of wall-aware interpolation, no wall branch
+        if (WX_ABL_FORCE_AIR || (WX_WET_AIR && (nowall1 & nowall2 & nowall3))) // (wave-uniform) plain instead of wall-aware interpolation, no wall branch
           advection_cell<false, true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
         else
           advection_cell<false, false>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #ifdef WX_ABL_NOLIGHT
         st_l = make_float4(la.sun_at(0, r - 4), la.ir_up_at(r - 5), lz1, ab.w);
 #else
-        if (WX_WET_AIR && __all(lane < WLO || lane >= WLO + WOUT || (awl.y != 0 && awl.z != 1)))
+        if (WX_ABL_FORCE_AIR || (WX_WET_AIR && __all(lane < WLO || lane >= WLO + WOUT || (awl.y != 0 && awl.z != 1))))
           st_l = lighting_cell<true>(u, g, col, r - 4, la);
         else
           st_l = lighting_cell<false>(u, g, col, r - 4, la);

@@ -308,7 +308,7 @@ def main():
             "metric": "Mcell-steps/s", "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{X}x{Y} dry-air grid, pressure+velocity+advection only (BASELINE configs[1])" if a.workload == "dry" else f"{X}x{Y} terrain grid, all six grid passes + lighting, ") if a.workload == "dry" else f"{X}x{Y} terrain grid, all six grid passes + lighting, " + (f"{a.particles} precipitation particles (BASELINE configs[4] on one GPU)" if a.particles else "particles off (BASELINE configs[2])"),
+            "config": {"workload": f"{X}x{Y} dry-air grid, pressure+velocity+advection only (BASELINE configs[1])" if a.workload == "dry" else f"{X}x{Y} terrain grid, all six grid passes + lighting, " + (f"{a.particles} precipitation particles (BASELINE configs[4]" + (" on one GPU)" if world == 1 else ")") if a.particles else ("particles off (BASELINE configs[3] grid)" if (X, Y) == (32768, 4096) else "particles off (BASELINE configs[2])")),
                        "grid": [X, Y], "decomposition": "none" if world == 1 else (f"{world} x-slabs, 64 ghost columns, ring halo exchange + droplet-pool reconciliation (2 all-reduces) every 9 iterations" if a.particles else f"{world} x-slabs, 48 ghost columns, ring halo exchange every 8 iterations (RCCL send/recv)"),
                        "iteration_algorithmic_bytes_per_cell": 36 if a.workload == "dry" else 72},
             "iteration_roofline_frac_A_wet": cells * a.steps * (36 if a.workload == "dry" else 72) / dt / 1e9 / (HBM_PEAK_GBS * world),

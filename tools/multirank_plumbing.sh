@@ -1,0 +1,9 @@
+#!/bin/bash
+# GPU box (one GPU): the N-rank bench path end to end with every rank on cuda:0 -- gloo transport (host-staged halos), then an attempt
+# with RCCL itself (it normally refuses two ranks on one device; if it does not, this is first contact with the nccl path).
+R=$GRAFT_REPO_ROOT; cd $R; export TMPDIR=/tmp
+run() { echo "== $*"; env WX_BENCH_SHARE_GPU=1 "$@" 2>&1 | tail -4 | cut -c1-900; }
+run WX_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 40 --warmup 8
+run WX_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 4 --steps 40 --warmup 8 --X 32768 --Y 4096
+run WX_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 36 --warmup 9 --particles 262144
+run WX_DIST_BACKEND=nccl timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29514 bench.py --gpus 2 --steps 40 --warmup 8
