@@ -131,8 +131,8 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
   int yw_p1 = wrapmod(r + 1, Y), yw_m2 = wrapmod(r - 2, Y); // wrapped rows r+1 and r-2, advanced by one per step
   {
     const size_t e = (size_t)wrapmod(r, Y) * X;
-    b_new = ld_row(in.base + e, lo16);
-    w_new = ld_row(wall_raw + e, lo4);
+    b_new = ld_row_v(in.base + e, lo16);
+    w_new = ld_row_v(wall_raw + e, lo4);
   }
   for (; r <= y_hi + 1; r++) {
     const int rc = r + 8; // non-negative ring counter
@@ -143,14 +143,14 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     // software prefetch: next row's loads are in flight while this row is processed
     if (r < y_hi + 1) {
       const size_t e = (size_t)yw_p1 * X;
-      b_new = ld_row(in.base + e, lo16);
-      w_new = ld_row(wall_raw + e, lo4);
+      b_new = ld_row_v(in.base + e, lo16);
+      w_new = ld_row_v(wall_raw + e, lo4);
     }
     if (st_valid && lane_out) { // row r-3
       const size_t e = (size_t)(r - 3) * X;
-      st_row(out.base + e, so16, st_p);
-      if (WRITE_WALL) st_row(out.wall + e, so4, st_w);
-      if (WRITE_DISP) st_row(out.base_disp + e, so16, st_ab);
+      st_row_v(out.base + e, so16, st_p);
+      if (WRITE_WALL) st_row_v(out.wall + e, so4, st_w);
+      if (WRITE_DISP) st_row_v(out.base_disp + e, so16, st_ab);
     }
     st_valid = false;
     // row r: P, T and wall enter the ring (velocity leaves them unchanged)
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
   }
   if (st_valid && lane_out) { // the last row
     const size_t e = (size_t)(y_hi - 1) * X;
-    st_row(out.base + e, so16, st_p);
-    if (WRITE_WALL) st_row(out.wall + e, so4, st_w);
-    if (WRITE_DISP) st_row(out.base_disp + e, so16, st_ab);
+    st_row_v(out.base + e, so16, st_p);
+    if (WRITE_WALL) st_row_v(out.wall + e, so4, st_w);
+    if (WRITE_DISP) st_row_v(out.base_disp + e, so16, st_ab);
   }
 }
 

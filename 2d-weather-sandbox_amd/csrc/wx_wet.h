@@ -358,18 +358,20 @@ __device__ __forceinline__ unsigned long long uniform_addr(const void *p)
   return ((unsigned long long)hi << 32) | lo;
 }
 #if defined(__HIP_DEVICE_COMPILE__)
-template <class T> __device__ __forceinline__ T ld_row(const T *row, unsigned byte_off)
+template <class T> __device__ __forceinline__ T ld_row(const T *row, unsigned &byte_off)
 {
   typedef const __attribute__((address_space(1))) char *GBytes; // (an integer round trip would otherwise yield a generic "flat" pointer)
   typedef const __attribute__((address_space(1))) T *GPtr;
-  asm("" : "+v"(byte_off)); // keeps the zero-extension next to the access: instruction selection folds it only within a block
+  // keeps the zero-extension next to the access (instruction selection folds it only within a block). The offset is taken by
+  // reference and redefined IN PLACE: on a by-value copy every access paid a v_mov of the loop-invariant original (15 per row step)
+  asm("" : "+v"(byte_off));
   return *(GPtr)((GBytes)uniform_addr(row) + byte_off);
 }
 template <int N> struct NativeVec;
 template <> struct NativeVec<4> { typedef unsigned type; };
 template <> struct NativeVec<8> { typedef unsigned type __attribute__((ext_vector_type(2))); };
 template <> struct NativeVec<16> { typedef unsigned type __attribute__((ext_vector_type(4))); };
-template <class T> __device__ __forceinline__ void st_row(T *row, unsigned byte_off, T v)
+template <class T> __device__ __forceinline__ void st_row(T *row, unsigned &byte_off, T v)
 {
   typedef __attribute__((address_space(1))) char *GBytes;
   asm("" : "+v"(byte_off));
@@ -385,9 +387,12 @@ template <class T> __device__ __forceinline__ void st_row(T *row, unsigned byte_
 #endif
 }
 #else // host pass of the single-source compile: same meaning, never executed
-template <class T> __device__ __forceinline__ T ld_row(const T *row, unsigned byte_off) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(row) + byte_off); }
-template <class T> __device__ __forceinline__ void st_row(T *row, unsigned byte_off, T v) { *reinterpret_cast<T *>(reinterpret_cast<char *>(row) + byte_off) = v; }
+template <class T> __device__ __forceinline__ T ld_row(const T *row, unsigned &byte_off) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(row) + byte_off); }
+template <class T> __device__ __forceinline__ void st_row(T *row, unsigned &byte_off, T v) { *reinterpret_cast<T *>(reinterpret_cast<char *>(row) + byte_off) = v; }
 #endif
+// by-value forms (a private copy of the offset per access): what the dry marching kernel uses -- there the in-place form is 2 % slower
+template <class T> __device__ __forceinline__ T ld_row_v(const T *row, unsigned byte_off) { return ld_row(row, byte_off); }
+template <class T> __device__ __forceinline__ void st_row_v(T *row, unsigned byte_off, T v) { st_row(row, byte_off, v); }
 __device__ __forceinline__ int ring_back(int s, int k, int n) // slot of the row k steps behind the one in slot s (ring of n)
 {
   const int v = s - k;
@@ -443,8 +448,8 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   const int c_out = strip * WOUT + lane - WLO; // output column of this lane (may be >= X in the last strip, < 0 in the first)
   const int col = wrapmod(c_out, X);           // column this lane loads / computes
   const bool lane_out = lane >= WLO && lane < WLO + WOUT && c_out < X;
-  const unsigned lo4 = (unsigned)col * 4u, lo8 = (unsigned)col * 8u, lo16 = (unsigned)col * 16u; // byte offsets of the loaded column
-  const unsigned so4 = lane_out ? (unsigned)c_out * 4u : 0u, so8 = so4 * 2u, so16 = so4 * 4u;    // ... of the stored column
+  unsigned lo4 = (unsigned)col * 4u, lo8 = (unsigned)col * 8u, lo16 = (unsigned)col * 16u; // byte offsets of the loaded column
+  unsigned so4 = lane_out ? (unsigned)c_out * 4u : 0u, so8 = so4 * 2u, so16 = so4 * 4u;    // ... of the stored column
   const int y_lo = segs.start[seg], y_hi = segs.start[seg + 1];
   const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
   unsigned long long *__restrict__ my_slow = slow_rows + (size_t)item * segs.slow_stride;
@@ -516,9 +521,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     asm volatile("" : "+v"(w_raw)); // keeps the byte unpacking on this side of the prefetch
     const char4 w_cur = unpack_wall(w_raw);
     // ---- row r enters the ring: P, T and wall (velocity leaves them unchanged); light row r-2 ----
-    // HAS_FB: ahead of the prefetch. Behind it (where the other variant has them: its loads are issued a few instructions earlier) the
-    // compiler puts an s_waitcnt vmcnt in front of these LDS writes that waits for the loads just issued -- a memory latency per step
-    // (5 % of the kernel, profiles/r02_particles_ring_first.txt).
+    // Ahead of the prefetch: behind it (and behind the deferred stores) the compiler puts an s_waitcnt vmcnt in front of these LDS
+    // writes that waits for the loads just issued -- a memory latency per step (5 % of the feedback instantiation,
+    // profiles/r02_particles_ring_first.txt; the other one shows the same wait as soon as the stores lose their address copies).
     auto ring_in = [&]() {
       const int o = s0 * WRW + li;
       (&rg.P[0][0])[o] = b_cur.z;
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       rg.lx[(r - 2 + 8) & (WL - 1)][li] = lx_cur;
       rg.lw[(r - 2 + 8) & (WL - 1)][li] = lzw_cur.y;
     };
-    if (HAS_FB) ring_in();
+    ring_in();
     // ---- software prefetch: the loads of the next step are in flight while this one computes ----
     if (r < y_hi + 3) {
       {
@@ -577,7 +582,6 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       if (out.t_disp) st_row(out.t_disp + e, so4, st_ab.w);
     }
     st_valid = false;
-    if (!HAS_FB) ring_in();
     // ---- velocity of row r-1 ----
     float v0x = 0.f, v0y = 0.f;
     if (t >= 1) {

@@ -485,7 +485,8 @@ def test_slab_handles_equal_whole_domain(pkg, E, fused, nslab, halo):
         for h in slabs:
             h.sync()
     whole.step(n_iter)
-    for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1"):
+    # (EMITTED is computed on demand from the last lighting pass's inputs incl. one ghost column per side: valid after the exchange)
+    for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1", "EMITTED"):
         ref = whole.read_rect(f)
         for r, h in enumerate(slabs):
             assert np.array_equal(h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]), (f, r)
