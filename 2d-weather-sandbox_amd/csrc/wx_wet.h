@@ -46,6 +46,9 @@ namespace wx {
 #ifndef WX_ABL_FORCE_AIR
 #define WX_ABL_FORCE_AIR 0 // (instruction-budget builds: every row takes the free-air instantiations; wrong near terrain)
 #endif
+#ifndef WX_WET_ARGS_MEM
+#define WX_WET_ARGS_MEM 1
+#endif
 #ifndef WX_WET_PRIO_ROTATE
 #define WX_WET_PRIO_ROTATE 0
 #endif
@@ -413,10 +416,28 @@ struct WetSegs {
   int start[WMAXSEG + 1];
 };
 template <bool OPT_OUT, bool HAS_FB>
-__global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out,
+__global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in_arg, WetOut out_arg,
                                                                     unsigned long long *__restrict__ slow_rows, int n_strips, int strip_lo,
                                                                     int n_strips_all, WetSegs segs)
 {
+  struct KArgs { // layout of the kernel-argument segment up to the pointer structs
+    const FullCtx *ctx;
+    float iterNum;
+    WetIn in;
+    WetOut out;
+  };
+#if WX_WET_ARGS_MEM && defined(__HIP_DEVICE_COMPILE__)
+  // The ~22 plane pointers are read from the kernel-argument segment (constant address space) where they are used: separate
+  // two-dword scalar loads that the register allocator can re-issue, instead of 44 SGPRs preloaded in wide loads that it can only
+  // spill -- and an SGPR spill / restore is a v_writelane / v_readlane, i.e. a VECTOR instruction in a VALU-bound loop.
+  typedef const __attribute__((address_space(4))) char *KBytes;
+  const KBytes ka_c = (KBytes)__builtin_amdgcn_kernarg_segment_ptr();
+  const __attribute__((address_space(4))) WetIn &in = *(const __attribute__((address_space(4))) WetIn *)(ka_c + offsetof(KArgs, in));
+  const __attribute__((address_space(4))) WetOut &out = *(const __attribute__((address_space(4))) WetOut *)(ka_c + offsetof(KArgs, out));
+#else
+  const WetIn &in = in_arg;
+  const WetOut &out = out_arg;
+#endif
   __shared__ WetRing rings[WX_WET_WPB];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   WetRing &rg = rings[wave];
@@ -451,7 +472,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   unsigned lo4 = (unsigned)col * 4u, lo8 = (unsigned)col * 8u, lo16 = (unsigned)col * 16u; // byte offsets of the loaded column
   unsigned so4 = lane_out ? (unsigned)c_out * 4u : 0u, so8 = so4 * 2u, so16 = so4 * 4u;    // ... of the stored column
   const int y_lo = segs.start[seg], y_hi = segs.start[seg + 1];
-  const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
+#define WX_WALL_RAW (reinterpret_cast<const int *>(in.wall))
   unsigned long long *__restrict__ my_slow = slow_rows + (size_t)item * segs.slow_stride;
 
   // ---- registers carried from step to step ----
@@ -490,7 +511,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   { // prefetch of the first row
     const size_t e = (size_t)wrapmod(r, Y) * X;
     pf_b = ld_row(in.base + e, lo16);
-    pf_w = ld_row(wall_raw + e, lo4);
+    pf_w = ld_row(WX_WALL_RAW + e, lo4);
   }
   int s0 = (r + 12) % WD, sq3 = (r - 3 + 12) % WQ; // ring slots of row r (base / wall planes) and of row r-3 (water planes)
   // wrapped (REPEAT) row indices of rows r+1, r-1 .. r-4, advanced by one per step (a general modulo costs ~20 scalar instructions)
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       {
         const size_t e = (size_t)yw_p1 * X;
         pf_b = ld_row(in.base + e, lo16);
-        pf_w = ld_row(wall_raw + e, lo4);
+        pf_w = ld_row(WX_WALL_RAW + e, lo4);
       }
       if (!WX_WET_SKIP_LOADS || t >= 2) { // (the first warm-up steps of a segment only feed velocity / curl: no water, no light yet)
         const int rl = r - 1;
@@ -771,12 +792,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   }
 #endif
   if (first_slow != 0x7fffffff) {
-    struct KArgs { // the kernel-argument segment holds the pointer structs the out-of-line function takes from memory
-      const FullCtx *ctx;
-      float iterNum;
-      WetIn in;
-      WetOut out;
-    };
+    // (the kernel-argument segment holds the pointer structs the out-of-line function takes from memory)
     const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
     const WetIn *in_mem = reinterpret_cast<const WetIn *>(ka + offsetof(KArgs, in));
     const WetOut *out_mem = reinterpret_cast<const WetOut *>(ka + offsetof(KArgs, out));
@@ -791,6 +807,8 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     }
   }
 }
+
+#undef WX_WALL_RAW
 
 // Segmentation. The grid is cut into about WX_WET_ROUNDS times as many waves as the device holds at once (the hardware deals
 // workgroups to CUs as earlier ones retire; bottom segments are dispatched first), and rows below `air_from_row` -- the lowest
