@@ -30,6 +30,7 @@
 #include "wx_cells.h"
 #include "wx_tile.h"
 #include <cstddef>
+#include <cstdlib>
 
 namespace wx {
 
@@ -48,6 +49,12 @@ namespace wx {
 #endif
 #ifndef WX_WET_ARGS_MEM
 #define WX_WET_ARGS_MEM 1
+#endif
+#ifndef WX_WET_TAIL
+#define WX_WET_TAIL 1
+#endif
+#ifndef WX_WET_ALPHA_DEFAULT
+#define WX_WET_ALPHA_DEFAULT 1.0 // cost of a row below air_from_row relative to a free-air row when the segment borders are placed
 #endif
 #ifndef WX_WET_PRIO_ROTATE
 #define WX_WET_PRIO_ROTATE 0
@@ -848,15 +855,20 @@ inline int wet_capacity()
   }
   return capacity;
 }
+inline double wet_alpha()
+{
+  double alpha = WX_WET_ALPHA_DEFAULT;
+  if (const char *e = getenv("WX_WET_ALPHA")) alpha = atof(e) >= 1.0 ? atof(e) : alpha;
+  return alpha;
+}
 inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
 {
   WetLaunch w;
   const int Y = g.Y;
   w.n_strips = (g.X + WOUT - 1) / WOUT;
   int rounds = WX_WET_ROUNDS, minrows = 32;
-  double alpha = 2.0;
+  const double alpha = wet_alpha();
   if (const char *e = getenv("WX_WET_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
-  if (const char *e = getenv("WX_WET_ALPHA")) alpha = atof(e) >= 1.0 ? atof(e) : alpha;
   if (const char *e = getenv("WX_WET_MINROWS")) minrows = atoi(e) > 0 ? atoi(e) : minrows;
   // workgroups per segment: 8 XCD column blocks x ceil(strips of the block / waves per workgroup); the device holds capacity / WPB
   const int wg_per_seg = 8 * (((w.n_strips + 7) / 8 + WX_WET_WPB - 1) / WX_WET_WPB);
@@ -868,12 +880,43 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
   if (n_seg > (Y + minrows - 1) / minrows) n_seg = (Y + minrows - 1) / minrows; // (8 warm-up rows per segment are redundant work)
   const int A = (air_from_row < 0 || air_from_row > Y) ? 0 : air_from_row;           // unknown: uniform segments
   const double total = alpha * A + (Y - A);
-  // border s at the row where the accumulated cost reaches the share of segments 0 .. s-1 (weights 1 + skew/2 .. 1 - skew/2)
+  // weights of the segments in dispatch order (bottom first): 1 + skew/2 .. 1 - skew/2, or an explicit list
+  // WX_WET_SPEC="29x1,5x0.5,5x0.25" (count x weight, ...; the counts give the number of segments): short segments LAST shorten the
+  // drain phase of the launch, in which finished waves are not replaced
+  double wt[WMAXSEG];
+  for (int sg = 0; sg < n_seg; sg++) wt[sg] = 1.0 + skew * (0.5 - (n_seg > 1 ? (double)sg / (n_seg - 1) : 0.5));
+  if (WX_WET_TAIL && skew == 0.0 && !getenv("WX_WET_SEG") && !getenv("WX_WET_NOTAIL")) {
+    // default shape: (rounds - 1) rounds of full segments, then about half a round each of segments of weight 1/2, 1/4 and 1/8.
+    // The launch ends with a drain phase in which finished waves are not replaced; short segments at the end of the dispatch order
+    // make it short: -5 % kernel time against equal segments (interleaved A/B, profiles/r02_wet_tail_shape.txt)
+    const double per_round = (double)(wet_capacity() / WX_WET_WPB) / wg_per_seg;
+    const int n_full = (int)((rounds - 1) * per_round + 0.5), c = (int)(per_round / 2.0 + 0.5) > 1 ? (int)(per_round / 2.0 + 0.5) : 1;
+    const int n_tail = 3 * c - 1, n = n_full + n_tail;
+    const double units = n_full + c * 0.5 + c * 0.25 + (c - 1) * 0.125;
+    if (n_full >= 1 && n <= WMAXSEG && Y / units >= minrows) { // (a unit segment keeps at least `minrows` rows; else equal segments)
+      n_seg = n;
+      for (int sg = 0; sg < n; sg++) wt[sg] = sg < n_full ? 1.0 : (sg < n_full + c ? 0.5 : (sg < n_full + 2 * c ? 0.25 : 0.125));
+    }
+  }
+  if (const char *e = getenv("WX_WET_SPEC")) {
+    int n = 0;
+    for (const char *q = e; *q && n < WMAXSEG;) {
+      char *end = nullptr;
+      const long cnt = strtol(q, &end, 10);
+      if (end == q || *end != 'x') break;
+      const double wv = strtod(end + 1, &end);
+      for (long k = 0; k < cnt && n < WMAXSEG; k++) wt[n++] = wv > 0.0 ? wv : 1.0;
+      q = *end == ',' ? end + 1 : end;
+      if (*q == 0) break;
+    }
+    if (n > 0 && n <= (Y + 7) / 8) n_seg = n;
+  }
+  // border s at the row where the accumulated cost reaches the share of segments 0 .. s-1
   w.segs.start[0] = 0;
   double wsum = 0.0, wacc = 0.0;
-  for (int sg = 0; sg < n_seg; sg++) wsum += 1.0 + skew * (0.5 - (n_seg > 1 ? (double)sg / (n_seg - 1) : 0.5));
+  for (int sg = 0; sg < n_seg; sg++) wsum += wt[sg];
   for (int sg = 1; sg < n_seg; sg++) {
-    wacc += 1.0 + skew * (0.5 - (double)(sg - 1) / (n_seg - 1));
+    wacc += wt[sg - 1];
     const double c = total * wacc / wsum;
     int y = c <= alpha * A ? (int)(c / alpha + 0.5) : A + (int)(c - alpha * A + 0.5);
     if (y <= w.segs.start[sg - 1]) y = w.segs.start[sg - 1] + 1;

@@ -439,6 +439,10 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
   if (!dbg_cycles) hipMalloc((void **)&dbg_cycles, 16 * 8192 * WMAXSEG);
   out.cycles = dbg_cycles;
 #endif
+  if (s->air_from_row < 0 && wet_alpha() == 1.0) { // rows cost the same with or without terrain (the default): nothing to measure
+    s->air_from_row = 0;
+    s->wet_shape_valid = false;
+  }
   if (s->air_from_row < 0) { // after an upload or a wall edit: where does the terrain end? (one small kernel + a 4-byte readback)
     int *d = &s->state->scratch_int, v = 0;
     hipMemsetAsync(d, 0, 4, s->stream);
