@@ -50,6 +50,9 @@ namespace wx {
 #ifndef WX_WET_ARGS_MEM
 #define WX_WET_ARGS_MEM 1
 #endif
+#ifndef WX_WET_BANDS
+#define WX_WET_BANDS 1
+#endif
 #ifndef WX_WET_TAIL
 #define WX_WET_TAIL 1
 #endif
@@ -420,6 +423,7 @@ __device__ __forceinline__ int ring_back(int s, int k, int n) // slot of the row
 constexpr int WMAXSEG = 128;
 struct WetSegs {
   int n_seg, slow_stride; // slow_stride: entries per wave in slow_rows (tallest segment + 1)
+  int bands;              // experimental (WX_WET_BANDS=1): XCD k takes the row band [k*Y/8, (k+1)*Y/8) of ALL strips; start[] is relative to it
   int start[WMAXSEG + 1];
 };
 template <bool OPT_OUT, bool HAS_FB>
@@ -468,17 +472,20 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   // (a contiguous range of segment-major items would hand all the terrain segments to XCD 0). Bottom segments first.
   // A workgroup = WX_WET_WPB neighbouring strips of one segment, one wavefront each.
   const int n_seg = segs.n_seg, k = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int sk0 = (k * n_strips) >> 3, nk = (((k + 1) * n_strips) >> 3) - sk0, gk = (nk + WX_WET_WPB - 1) / WX_WET_WPB;
+  const bool bands = segs.bands != 0;
+  const int sk0 = bands ? 0 : (k * n_strips) >> 3, nk = bands ? n_strips : (((k + 1) * n_strips) >> 3) - sk0, gk = (nk + WX_WET_WPB - 1) / WX_WET_WPB;
   if (j >= gk * n_seg) return;
   const int seg = j / gk, sloc = (j - seg * gk) * WX_WET_WPB + wave;
   if (sloc >= nk) return;
-  const int strip = strip_lo + sk0 + sloc, item = seg * n_strips_all + strip;
+  const int strip = strip_lo + sk0 + sloc, item = ((bands ? k * n_seg : 0) + seg) * n_strips_all + strip;
+  const int band_lo = bands ? (int)(((long long)k * g.Y) >> 3) : 0, band_hi = bands ? (int)(((long long)(k + 1) * g.Y) >> 3) : g.Y;
   const int c_out = strip * WOUT + lane - WLO; // output column of this lane (may be >= X in the last strip, < 0 in the first)
   const int col = wrapmod(c_out, X);           // column this lane loads / computes
   const bool lane_out = lane >= WLO && lane < WLO + WOUT && c_out < X;
   unsigned lo4 = (unsigned)col * 4u, lo8 = (unsigned)col * 8u, lo16 = (unsigned)col * 16u; // byte offsets of the loaded column
   unsigned so4 = lane_out ? (unsigned)c_out * 4u : 0u, so8 = so4 * 2u, so16 = so4 * 4u;    // ... of the stored column
-  const int y_lo = segs.start[seg], y_hi = segs.start[seg + 1];
+  const int y_lo = band_lo + segs.start[seg], y_hi = min(band_lo + segs.start[seg + 1], band_hi);
+  if (y_lo >= y_hi) return;
 #define WX_WALL_RAW (reinterpret_cast<const int *>(in.wall))
   unsigned long long *__restrict__ my_slow = slow_rows + (size_t)item * segs.slow_stride;
 
@@ -864,14 +871,21 @@ inline double wet_alpha()
 inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
 {
   WetLaunch w;
-  const int Y = g.Y;
+  // Wide grids (a segment over all strips fills at least half of an XCD's workgroup slots): XCD k takes the row band
+  // [k*Y/8, (k+1)*Y/8) of ALL strips instead of a column block of every segment -- each XCD then streams one contiguous eighth of
+  // every plane: -3..-8 % kernel time at 16384x2048 and 32768x4096 (profiles/r02_wet_tail_shape.txt). Narrow grids (slabs) keep the
+  // column blocks, whose segments can be cut much finer.
+  bool bands = WX_WET_BANDS && (g.X + WOUT - 1) / WOUT >= 48 * WX_WET_WPB && g.Y >= 8 * 64;
+  if (const char *e = getenv("WX_WET_BANDS")) bands = atoi(e) != 0 && g.Y >= 8 * 64;
+  const int Y = bands ? (g.Y + 7) / 8 : g.Y; // (bands: the shape of ONE band; the kernel clips it to the band's own height)
+  w.segs.bands = bands ? 1 : 0;
   w.n_strips = (g.X + WOUT - 1) / WOUT;
-  int rounds = WX_WET_ROUNDS, minrows = 32;
+  int rounds = WX_WET_ROUNDS, minrows = 24; // (narrow slabs: 2144x2048 runs 17 % faster with 30-row unit segments + tail than with equal 32-row ones)
   const double alpha = wet_alpha();
   if (const char *e = getenv("WX_WET_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
   if (const char *e = getenv("WX_WET_MINROWS")) minrows = atoi(e) > 0 ? atoi(e) : minrows;
   // workgroups per segment: 8 XCD column blocks x ceil(strips of the block / waves per workgroup); the device holds capacity / WPB
-  const int wg_per_seg = 8 * (((w.n_strips + 7) / 8 + WX_WET_WPB - 1) / WX_WET_WPB);
+  const int wg_per_seg = bands ? 8 * ((w.n_strips + WX_WET_WPB - 1) / WX_WET_WPB) : 8 * (((w.n_strips + 7) / 8 + WX_WET_WPB - 1) / WX_WET_WPB);
   int n_seg = (int)((long long)rounds * (wet_capacity() / WX_WET_WPB) / wg_per_seg);
   double skew = 0.0; // > 0: earlier-dispatched (lower) segments get more rows: the SIMD issues its OLDEST ready wave first
   if (const char *e = getenv("WX_WET_SKEW")) skew = atof(e);
@@ -890,12 +904,22 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
     // The launch ends with a drain phase in which finished waves are not replaced; short segments at the end of the dispatch order
     // make it short: -5 % kernel time against equal segments (interleaved A/B, profiles/r02_wet_tail_shape.txt)
     const double per_round = (double)(wet_capacity() / WX_WET_WPB) / wg_per_seg;
-    const int n_full = (int)((rounds - 1) * per_round + 0.5), c = (int)(per_round / 2.0 + 0.5) > 1 ? (int)(per_round / 2.0 + 0.5) : 1;
-    const int n_tail = 3 * c - 1, n = n_full + n_tail;
-    const double units = n_full + c * 0.5 + c * 0.25 + (c - 1) * 0.125;
-    if (n_full >= 1 && n <= WMAXSEG && Y / units >= minrows) { // (a unit segment keeps at least `minrows` rows; else equal segments)
-      n_seg = n;
-      for (int sg = 0; sg < n; sg++) wt[sg] = sg < n_full ? 1.0 : (sg < n_full + c ? 0.5 : (sg < n_full + 2 * c ? 0.25 : 0.125));
+    // (a band segment is a large part of a round already: one segment per tail level there)
+    const int c = bands ? 1 : ((int)(per_round / 2.0 + 0.5) > 1 ? (int)(per_round / 2.0 + 0.5) : 1);
+    for (int rr = rounds; rr >= 2; rr--) { // (fewer rounds if a unit segment would fall below `minrows` rows; else equal segments)
+      int n_full = (int)((rr - 1) * per_round + 0.5);
+      if (bands) { // unit segments of about 64 rows
+        const int by_rows = (int)(Y / 64.0 + 0.5) - 1;
+        n_full = n_full > by_rows ? n_full : by_rows;
+      }
+      const int n8 = bands ? (n_full >= 6 ? 1 : 0) : c - 1; // segments of weight 1/8
+      const int n = n_full + 2 * c + n8;
+      const double units = n_full + c * 0.5 + c * 0.25 + n8 * 0.125;
+      if (n_full >= 1 && n <= WMAXSEG && Y / units >= minrows) {
+        n_seg = n;
+        for (int sg = 0; sg < n; sg++) wt[sg] = sg < n_full ? 1.0 : (sg < n_full + c ? 0.5 : (sg < n_full + 2 * c ? 0.25 : 0.125));
+        break;
+      }
     }
   }
   if (const char *e = getenv("WX_WET_SPEC")) {
@@ -929,7 +953,7 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
   int tallest = 1;
   for (int sg = 0; sg < n_seg; sg++) tallest = w.segs.start[sg + 1] - w.segs.start[sg] > tallest ? w.segs.start[sg + 1] - w.segs.start[sg] : tallest;
   w.segs.slow_stride = tallest + 1;
-  w.slow_entries = (size_t)w.n_strips * n_seg * w.segs.slow_stride;
+  w.slow_entries = (size_t)w.n_strips * n_seg * w.segs.slow_stride * (bands ? 8 : 1);
   return w;
 }
 
@@ -939,7 +963,7 @@ inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *c
   const int ns = strip_count < 0 ? w.n_strips : strip_count;
   if (ns <= 0) return;
   // 8 XCDs x (workgroups of the largest column block) x segments; surplus workgroups / waves exit at once
-  const dim3 grid(8 * (((ns + 7) / 8 + WX_WET_WPB - 1) / WX_WET_WPB) * w.segs.n_seg);
+  const dim3 grid(8 * (((w.segs.bands ? ns : (ns + 7) / 8) + WX_WET_WPB - 1) / WX_WET_WPB) * w.segs.n_seg);
   static bool dbg = getenv("WX_MARCH_DEBUG") != nullptr;
   if (dbg) {
     fprintf(stderr, "[wx_wet] strips=%d segs=%d waves=%d first/last segment rows=%d/%d\n", w.n_strips, w.segs.n_seg, w.n_strips * w.segs.n_seg,
