@@ -18,11 +18,11 @@
 #include "wx_dry.h"
 #include "wx_wet.h" // ld_row / st_row (scalar-base addressing), wave_from_left (DPP shift)
 
-// WX_MARCH_TAIL=1: column-block XCD mapping + short segments at the end of the dispatch order (what helps the wet kernel by 5-10 %).
-// Measured here (32768x4096, same call): the tail itself +0.3..1 %, but the column-block mapping costs 4-5 % against the contiguous
-// item ranges below (0.959-0.983 vs 0.920-0.933 ms) -- with 14 rounds of 32-row segments the drain phase is short anyway. Off.
-#ifndef WX_MARCH_TAIL
-#define WX_MARCH_TAIL 0
+#ifndef WX_MARCH_BANDS
+#define WX_MARCH_BANDS 1
+#endif
+#ifndef WX_MARCH_BAND_SEG
+#define WX_MARCH_BAND_SEG 24 // (32768x4096, interleaved: 24-row band segments + tail 0.941-0.943 ms, 32-row 0.953, equal 32-row segments 0.954)
 #endif
 namespace wx {
 
@@ -84,7 +84,7 @@ __device__ __forceinline__ MDryFp make_fp(const MDryAcc &a, int dx0, int dy0) { 
 // so the pass-through store is dropped and the wall buffers are not swapped: 36 B/cell, SURVEY's A_dry.
 template <bool WRITE_DISP, bool WRITE_WALL>
 __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u_arg, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows,
-                                                                     int n_full, int n_half)
+                                                                     int n_full, int n_half, int band_h, int n_seg)
 {
   __shared__ MarchRing rg;
 #if WX_MARCH_UNI_MEM
@@ -98,21 +98,12 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
   const CFloatP initial_T = as_constant(ctx->initial_T), snd_T = as_constant(ctx->snd_T), snd_W = as_constant(ctx->snd_W), snd_Vel = as_constant(ctx->snd_Vel);
   const int X = g.X, Y = g.Y;
   const int lane = threadIdx.x;
-#if WX_MARCH_TAIL
-  // XCD k (workgroup id % 8, MI355X_MICROARCH.md) takes the column block of strips [k*S/8, (k+1)*S/8) of EVERY segment, bottom segments
-  // first: neighbouring strips share an L2 (as below), and every XCD walks through the segments in the same order, so that the short
-  // segments at the end of the list (see launch_march_dry) shorten the drain phase of the launch on every XCD.
-  const int k = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int sk0 = (k * n_strips) >> 3, nk = (((k + 1) * n_strips) >> 3) - sk0, nk_max = (n_strips + 7) >> 3;
-  const int seg = j / nk_max, sloc = j - seg * nk_max;
-  if (sloc >= nk) return;
-  const int strip = sk0 + sloc;
-#elif WX_MARCH_XCD
+#if WX_MARCH_XCD
   // XCD-aware placement: workgroup id lands on XCD id % 8 (MI355X_MICROARCH.md). The (segment, strip) items are numbered
   // segment-major and XCD k takes the contiguous range [k*T/8, (k+1)*T/8): neighbouring strips run on the same XCD, so the
   // 128-byte lines they share (2 halo columns each side; 60-column strips are not line aligned) are fetched into ONE L2
   // instead of two. Measured FETCH_SIZE: 1.22x -> 1.00x of the bytes the strips need; 32768x4096: 1.39 -> 1.11 ms.
-  const int total = n_strips * ((Y + seg_rows - 1) / seg_rows), k = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int total = n_strips * n_seg, k = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int first = (int)(((long long)k * total) >> 3), count = (int)(((long long)(k + 1) * total) >> 3) - first;
   if (j >= count) return;
   const int item = first + j, seg = item / n_strips, strip = item - seg * n_strips;
@@ -122,15 +113,20 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
   const int c_out = strip * MOUT + lane - 2;         // output column of this lane (may be >= X in the last strip)
   const int col = wrapmod(c_out, X);                 // column this lane loads / computes
   const bool lane_out = lane >= 2 && lane <= 61 && c_out < X;
-#if WX_MARCH_TAIL
-  // n_full segments of seg_rows rows, then n_half of seg_rows / 2 and n_half of seg_rows / 4 (clipped at the top of the grid)
-  const int t1 = seg - n_full, t2 = t1 - n_half, h2 = seg_rows >> 1, h4 = seg_rows >> 2;
-  const int y_lo = t1 < 0 ? seg * seg_rows : (t2 < 0 ? n_full * seg_rows + t1 * h2 : n_full * seg_rows + n_half * h2 + t2 * h4);
-  const int y_hi = min(y_lo + (t1 < 0 ? seg_rows : (t2 < 0 ? h2 : h4)), Y);
-  if (y_lo >= Y) return;
-#else
-  const int y_lo = seg * seg_rows, y_hi = min(y_lo + seg_rows, Y);
-#endif
+  // band_h > 0: the rows are cut into eight bands (one per XCD with the contiguous item ranges above), each band into n_full segments
+  // of seg_rows rows followed by n_half of seg_rows / 2 and n_half of seg_rows / 4 -- short segments at the END of every XCD's work
+  // shorten the drain phase of the launch (cf. wet_launch_shape)
+  int y_lo, y_hi;
+  if (band_h > 0) {
+    const int nb = n_full + 2 * n_half, bnd = seg / nb, sl = seg - bnd * nb;
+    const int t1 = sl - n_full, t2 = t1 - n_half, h2 = seg_rows >> 1, h4 = seg_rows >> 2, y0 = bnd * band_h;
+    y_lo = y0 + (t1 < 0 ? sl * seg_rows : (t2 < 0 ? n_full * seg_rows + t1 * h2 : n_full * seg_rows + n_half * h2 + t2 * h4));
+    y_hi = min(y_lo + (t1 < 0 ? seg_rows : (t2 < 0 ? h2 : h4)), y0 + band_h);
+    if (y_lo >= y_hi) return;
+  } else {
+    y_lo = seg * seg_rows;
+    y_hi = min(y_lo + seg_rows, Y);
+  }
   const unsigned lo4 = (unsigned)col * 4u, lo16 = (unsigned)col * 16u;                      // byte offsets of the loaded column
   const unsigned so4 = lane_out ? (unsigned)c_out * 4u : 0u, so16 = so4 * 4u;              // ... of the stored column
 
@@ -279,29 +275,27 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
                              hipStream_t stream)
 {
   const int n_strips = (g.X + MOUT - 1) / MOUT;
-  const int seg_rows = march_seg_rows(n_strips, g.Y);
-  int n_seg = (g.Y + seg_rows - 1) / seg_rows, n_full = n_seg, n_half = 0;
-#if WX_MARCH_TAIL
-  {
-    // short segments at the end of the dispatch order: about half a round each of half and quarter segments (the launch ends with a
-    // drain phase in which finished waves are not replaced, cf. wet_launch_shape)
-    const int c = (march_capacity() / n_strips + 1) / 2, tail_rows = c * (seg_rows / 2) + c * (seg_rows / 4);
-    if (!getenv("WX_MARCH_NOTAIL") && c >= 1 && seg_rows >= 16 && g.Y >= tail_rows + 4 * seg_rows) {
-      n_full = (g.Y - tail_rows + seg_rows - 1) / seg_rows;
-      n_half = c;
-      n_seg = n_full + 2 * c;
+  int seg_rows = march_seg_rows(n_strips, g.Y);
+  int n_seg = (g.Y + seg_rows - 1) / seg_rows, n_full = n_seg, n_half = 0, band_h = 0;
+  if (WX_MARCH_XCD && WX_MARCH_BANDS && !getenv("WX_MARCH_NOTAIL") && !getenv("WX_MARCH_SEG") && g.Y % 8 == 0) {
+    int R = WX_MARCH_BAND_SEG;
+    if (const char *e = getenv("WX_MARCH_BAND_SEG")) R = atoi(e) >= 16 ? atoi(e) : R;
+    const int bh = g.Y / 8, tail = R / 2 + R / 4;
+    if (bh >= 3 * R) { // tall enough for at least two full segments and the tail per band
+      band_h = bh;
+      seg_rows = R;
+      n_half = 1;
+      n_full = (bh - tail + R - 1) / R;
+      n_seg = 8 * (n_full + 2 * n_half);
     }
   }
-  const dim3 grid(8 * ((n_strips + 7) / 8) * n_seg);
-#else
   const dim3 grid(WX_MARCH_XCD ? 8 * ((n_strips * n_seg + 7) / 8) : n_strips * n_seg);
-#endif
   static bool dbg = getenv("WX_MARCH_DEBUG") != nullptr;
   if (dbg) {
-    fprintf(stderr, "[wx_march] strips=%d seg_rows=%d segs=%d (%d full + 2 x %d short) waves=%d\n", n_strips, seg_rows, n_seg, n_full, n_half, n_strips * n_seg);
+    fprintf(stderr, "[wx_march] strips=%d seg_rows=%d segs=%d (bands of %d rows: %d full + 2 x %d short each) waves=%d\n", n_strips, seg_rows, n_seg, band_h, n_full, n_half, n_strips * n_seg);
     dbg = false;
   }
-#define WX_LAUNCH_M(D, W) hipLaunchKernelGGL((k_march_dry<D, W>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half)
+#define WX_LAUNCH_M(D, W) hipLaunchKernelGGL((k_march_dry<D, W>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg)
   if (write_disp) {
     if (write_wall) WX_LAUNCH_M(true, true); else WX_LAUNCH_M(true, false);
   } else {
