@@ -609,6 +609,7 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
     const float velAtVx_x = c00.x, velAtVx_y = (cD.y + cR.y + c00.y + cRD.y) / 4.0f;
     const float velAtVy_x = (cL.x + cU.x + cLU.x + c00.x) / 4.0f, velAtVy_y = c00.y;
 
+    Taps tP; // footprint of the P / T / water sample
     {
       const Taps t = mktaps(cc, y, fx - velAtVx_x, fy - velAtVx_y);
       const auto f = make_fp(a, t.dx0, t.dy0);
@@ -622,6 +623,7 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
     {
       // bilerpWall at velAtP (common.glsl:216-254): P, T and water.xyw share one footprint
       const Taps t = mktaps(cc, y, fx - velAtP_x, fy - velAtP_y);
+      tP = t;
       const auto f = make_fp(a, t.dx0, t.dy0);
       float mAB = t.fx, mCD = t.fx, mY = t.fy;
       if (!NO_WALL) {
@@ -657,8 +659,11 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
       if (tcy > u.globalEffectsStartAlt && tcy < u.globalEffectsEndAlt) b.w += u.globalHeating;
     } else {
     {
-      // precipitation visualisation channel, +0.05 in y (:103)
-      const Taps t = mktaps(cc, y, fx - velAtP_x + 0.0f, fy - velAtP_y + 0.05f);
+      // precipitation visualisation channel, +0.05 in y (:103). Its x position is (fx - velAtP_x) + 0.0: the same number as above
+      // except -0 -> +0, and both give the same stx = -0.5 -- so the x half of the footprint is the one already computed
+      Taps t = mktaps(cc, y, fx - velAtP_x, fy - velAtP_y + 0.05f);
+      t.dx0 = tP.dx0;
+      t.fx = tP.fx;
       const auto f = make_fp(a, t.dx0, t.dy0);
       float mAB = t.fx, mCD = t.fx, mY = t.fy;
       if (!NO_WALL) {

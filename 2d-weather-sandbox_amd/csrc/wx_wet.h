@@ -63,7 +63,7 @@ namespace wx {
 #define WX_WET_PRIO_ROTATE 0
 #endif
 #ifndef WX_WET_SKIP_LOADS
-#define WX_WET_SKIP_LOADS 1 // no water / light loads in the first two warm-up steps; light_0.x only near walls
+#define WX_WET_SKIP_LOADS 1 // 1: no water / light loads in the first two warm-up steps; light_0.x only near walls. 2: only the latter. 0: neither
 #endif
 #ifndef WX_WET_NT_STORES
 #define WX_WET_NT_STORES 0
@@ -555,6 +555,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     if (HAS_FB) asm volatile("" ::"v"(fb_cur.w));
     asm volatile("" : "+v"(w_raw)); // keeps the byte unpacking on this side of the prefetch
     const char4 w_cur = unpack_wall(w_raw);
+#ifdef WX_STAGE_MARKS
+    asm volatile("; @@ring");
+#endif
     // ---- row r enters the ring: P, T and wall (velocity leaves them unchanged); light row r-2 ----
     // Ahead of the prefetch: behind it (and behind the deferred stores) the compiler puts an s_waitcnt vmcnt in front of these LDS
     // writes that waits for the loads just issued -- a memory latency per step (5 % of the feedback instantiation,
@@ -568,6 +571,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       rg.lw[(r - 2 + 8) & (WL - 1)][li] = lzw_cur.y;
     };
     ring_in();
+#ifdef WX_STAGE_MARKS
+    asm volatile("; @@prefetch");
+#endif
     // ---- software prefetch: the loads of the next step are in flight while this one computes ----
     if (r < y_hi + 3) {
       {
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         pf_b = ld_row(in.base + e, lo16);
         pf_w = ld_row(WX_WALL_RAW + e, lo4);
       }
-      if (!WX_WET_SKIP_LOADS || t >= 2) { // (the first warm-up steps of a segment only feed velocity / curl: no water, no light yet)
+      if (WX_WET_SKIP_LOADS != 1 || t >= 2) { // (the first warm-up steps of a segment only feed velocity / curl: no water, no light yet)
         const int rl = r - 1;
         const size_t ew = (size_t)yw_m1 * X;
         pf_q = ld_row(in.water + ew, lo16);
@@ -604,6 +610,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         pf_flag = in.fb_zero != nullptr ? in.fb_zero[(yw_m1 >> 4) * in.fb_txn + (col >> 6)] : 0; // row r-1, voted on next step
       }
     }
+#ifdef WX_STAGE_MARKS
+    asm volatile("; @@stores");
+#endif
     // ---- the stores of the previous step's row (r-5), issued behind the prefetch ----
     if (st_valid && lane_out) {
       const size_t e = (size_t)(r - 5) * X;
@@ -617,6 +626,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       if (out.t_disp) st_row(out.t_disp + e, so4, st_ab.w);
     }
     st_valid = false;
+#ifdef WX_STAGE_MARKS
+    asm volatile("; @@velocity");
+#endif
     // ---- velocity of row r-1 ----
     float v0x = 0.f, v0y = 0.f;
     if (t >= 1) {
@@ -627,6 +639,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       (&rg.vx[0][0])[o] = v0x;
       (&rg.vy[0][0])[o] = v0y;
     }
+#ifdef WX_STAGE_MARKS
+    asm volatile("; @@curlvort");
+#endif
     // ---- curl of row r-2, vortForce of row r-3 (registers + wave shifts only) ----
     float c0 = 0.f;
     if (t >= 2) {
@@ -648,6 +663,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     }
     wave_fence();
 
+#ifdef WX_STAGE_MARKS
+    asm volatile("; @@boundary");
+#endif
     // ---- boundary of row yb = r-3, written back in place ----
     if (t >= 4) {
       const int ob0 = ring_back(s0, 3, WD) * WRW, ob1 = ring_back(s0, 2, WD) * WRW;
@@ -700,6 +718,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     }
     wave_fence();
 
+#ifdef WX_STAGE_MARKS
+    asm volatile("; @@advection");
+#endif
     // ---- advection of row ya = r-4 ----
     if (t >= 7) {
       const int ya = yw_m4;
@@ -736,6 +757,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         aw = a.water_off(0, 0);
         awl = a.wall(0, 0);
       }
+#ifdef WX_STAGE_MARKS
+    asm volatile("; @@presslight");
+#endif
       // ---- pressure + lighting of row ya: kept in registers, stored at the top of the next step ----
       const float vx_l = wave_from_left(ab.x);
       if (t >= 8) {
@@ -758,6 +782,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       adv_T_prev = ab.w;
       adv_w_prev = awl;
     }
+#ifdef WX_STAGE_MARKS
+    asm volatile("; @@rotate");
+#endif
     // ---- rotate the carried rows ----
     b_prev = b_cur;
     w_prev = w_raw;

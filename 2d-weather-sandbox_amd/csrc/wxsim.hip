@@ -492,7 +492,7 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
 #ifdef WX_WET_TIMING
   if (s->iter == 40) { // per segment: start offset and duration of its waves (s_memtime ticks, 100 MHz)
     hipStreamSynchronize(s->stream);
-    const int ns = shape.n_strips, nseg = shape.segs.n_seg;
+    const int ns = shape.n_strips, nseg = shape.segs.n_seg * (shape.segs.bands ? 8 : 1), per_band = shape.segs.n_seg;
     std::vector<unsigned long long> c(2 * (size_t)ns * nseg);
     hipMemcpy(c.data(), dbg_cycles, c.size() * 8, hipMemcpyDeviceToHost);
     unsigned long long t0 = ~0ull, t1 = 0;
@@ -506,8 +506,9 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
         st += (double)(c[i] - t0); du += d; en += (double)(c[i + 1] - t0);
         dmin = d < dmin ? d : dmin; dmax = d > dmax ? d : dmax;
       }
-      fprintf(stderr, "  seg %3d rows %4d..%4d (%3d): start %7.0f end %7.0f  dur avg %6.0f min %6.0f max %6.0f  per row %5.1f\n", sg, shape.segs.start[sg], shape.segs.start[sg + 1],
-              shape.segs.start[sg + 1] - shape.segs.start[sg], st / ns, en / ns, du / ns, dmin, dmax, du / ns / (shape.segs.start[sg + 1] - shape.segs.start[sg] + 8));
+      const int sl = sg % per_band; // (row bands: the table is relative to the band of XCD sg / per_band)
+      fprintf(stderr, "  seg %3d rows %4d..%4d (%3d): start %7.0f end %7.0f  dur avg %6.0f min %6.0f max %6.0f  per row %5.1f\n", sg, shape.segs.start[sl], shape.segs.start[sl + 1],
+              shape.segs.start[sl + 1] - shape.segs.start[sl], st / ns, en / ns, du / ns, dmin, dmax, du / ns / (shape.segs.start[sl + 1] - shape.segs.start[sl] + 8));
     }
   }
 #endif
