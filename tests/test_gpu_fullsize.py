@@ -98,6 +98,19 @@ def test_config2_wet_16384x2048_vs_oracle(pkg, oracle, E):
     _run_pair(pkg, oracle, E, X, Y, _wet_state(pkg, X, Y, 31), _uniforms(pkg, Y), (1, 4), FIELDS_WET)
 
 
+@pytest.mark.parametrize("X,Y,bands", [(10781, 523, "1"), (10781, 523, "0"), (11000, 800, "1"), (2150, 1030, None)])
+def test_wet_launch_shapes_on_ragged_grids_vs_oracle(pkg, oracle, E, monkeypatch, X, Y, bands):
+    """The launch shapes of the marching wet kernel on grids that divide into nothing: row bands per XCD (wide grids; heights not
+    divisible by 8, last strip ragged), column blocks with the short tail, and a narrow slab-like grid -- with long back-traces
+    (|v| > 0.9: the recorded-mask exact tail crosses segment and band borders). Bit-exact against the oracle."""
+    if bands is not None:
+        monkeypatch.setenv("WX_WET_BANDS", bands)
+    state = _wet_state(pkg, X, Y, 40 + X % 7)
+    rng = np.random.Generator(np.random.Philox(5))
+    state[0][Y // 4:, :, 0] += rng.normal(0, 0.3, (Y - Y // 4, X)).astype(np.float32)
+    _run_pair(pkg, oracle, E, X, Y, state, _uniforms(pkg, Y), (1, 3, 5), FIELDS_WET)
+
+
 def test_config3_grid_32768x4096_dry_vs_oracle(pkg, oracle, E):
     """The north-star size on one GPU, dry stencil (initial_T[Y+1] with Y = 4096, indices beyond 2^27 cells)."""
     X, Y = 32768, 4096
