@@ -53,6 +53,9 @@ namespace wx {
 #ifndef WX_WET_BANDS
 #define WX_WET_BANDS 1
 #endif
+#ifndef WX_WET_FB_COND
+#define WX_WET_FB_COND 0 // 1: load feedback rows only where a tile holds feedback (measured: 1.012-1.021 vs 0.974-0.977 ms with the always-issued loads from a row of zeros)
+#endif
 #ifndef WX_WET_TAIL
 #define WX_WET_TAIL 1
 #endif
@@ -600,14 +603,34 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         // does any of the (up to three) 64x16 tiles under this strip hold feedback in row r-2? The flag byte was loaded one step
         // ago (pf_flag), so the vote costs no wait of its own
         fb_have = __any(pf_flag == 0);
+#if defined(WX_ABL_FB_NOFLAG) || defined(WX_ABL_FB_NOLOAD)
+        fb_have = false; // (timing experiments only: wrong results)
+#endif
+#ifdef WX_ABL_FB_NOLOAD
+        pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);
+        pf_dep = make_float2(0.f, 0.f);
+#else
         {
           // always the same two loads -- from the textures' row, or from a row of zeros (L2 resident) where the tiles are known
           // to be zero: a conditional load would make the number of loads per step, which the waits are built on, vary
           const size_t e = (size_t)yw_m2 * X;
+#if WX_WET_FB_COND
+          if (fb_have) {
+            pf_fb = ld_row(in.fb + e, lo16);
+            pf_dep = ld_row(in.dep + e, lo8);
+          } else {
+            pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);
+            pf_dep = make_float2(0.f, 0.f);
+          }
+#else
           pf_fb = ld_row(fb_have ? in.fb + e : in.zero_row, lo16);
           pf_dep = ld_row(fb_have ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
+#endif
         }
+#endif
+#if !defined(WX_ABL_FB_NOFLAG) && !defined(WX_ABL_FB_NOLOAD)
         pf_flag = in.fb_zero != nullptr ? in.fb_zero[(yw_m1 >> 4) * in.fb_txn + (col >> 6)] : 0; // row r-1, voted on next step
+#endif
       }
     }
 #ifdef WX_STAGE_MARKS
@@ -623,7 +646,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       st_row(out.light.y + e, so4, st_l.y);
       st_row(out.light.zw + e, so8, make_float2(st_l.z, st_l.w));
       if (OPT_OUT) st_row(out.base_disp + e, so16, st_ab);
+#ifndef WX_ABL_NO_TDISP
       if (out.t_disp) st_row(out.t_disp + e, so4, st_ab.w);
+#endif
     }
     st_valid = false;
 #ifdef WX_STAGE_MARKS
