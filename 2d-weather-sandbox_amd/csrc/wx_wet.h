@@ -928,7 +928,7 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
   // every plane: -3..-8 % kernel time at 16384x2048 and 32768x4096 (profiles/r02_wet_tail_shape.txt). Narrow grids (slabs) keep the
   // column blocks, whose segments can be cut much finer.
   bool bands = WX_WET_BANDS && (g.X + WOUT - 1) / WOUT >= 48 * WX_WET_WPB && g.Y >= 8 * 64;
-  if (const char *e = getenv("WX_WET_BANDS")) bands = atoi(e) != 0 && g.Y >= 8 * 64;
+  if (const char *e = getenv("WX_WET_BANDS")) bands = atoi(e) >= 2 ? g.Y >= 16 : (atoi(e) != 0 && g.Y >= 8 * 64); // (2: tests force it on small grids)
   const int Y = bands ? (g.Y + 7) / 8 : g.Y; // (bands: the shape of ONE band; the kernel clips it to the band's own height)
   w.segs.bands = bands ? 1 : 0;
   w.n_strips = (g.X + WOUT - 1) / WOUT;

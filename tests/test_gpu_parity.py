@@ -492,8 +492,8 @@ def test_slab_handles_equal_whole_domain(pkg, E, fused, nslab, halo):
             assert np.array_equal(h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]), (f, r)
 
 
-@pytest.mark.parametrize("nslab,halo,X", [(2, 12, 1024), (4, 24, 4096), (2, 6, 128)])
-def test_slab_overlapped_exchange_equals_whole_domain(pkg, E, monkeypatch, nslab, halo, X):
+@pytest.mark.parametrize("nslab,halo,X,bands", [(2, 12, 1024, None), (4, 24, 4096, None), (2, 6, 128, None), (2, 12, 1024, "2")])
+def test_slab_overlapped_exchange_equals_whole_domain(pkg, E, monkeypatch, nslab, halo, X, bands):
     """The exchange / compute overlap (wx_set_comm_stream + wx_step_overlap): N slab handles on one GPU, each with its own compute
     stream and its own comm stream, nothing synchronised on the host between the steps -- the edge strips of the last iteration
     run first, pack + copy + unpack proceed on the comm streams while the interior strips compute, the edge strips of the next
@@ -501,6 +501,8 @@ def test_slab_overlapped_exchange_equals_whole_domain(pkg, E, monkeypatch, nslab
     interior strips, the third case, degrades to the in-order exchange through the same calls.)"""
     import torch
     monkeypatch.setenv("WX_FUSED", "2")
+    if bands:  # the row-band launch shape of wide slabs (e.g. two ranks on 32768 columns), forced onto this small grid
+        monkeypatch.setenv("WX_WET_BANDS", bands)
     Y = 64
     per, n_iter = halo // 6, 10 * (halo // 6) + 1
     base, water, wall = pkg.synth.terrain_grid(X, Y)
