@@ -923,11 +923,10 @@ inline double wet_alpha()
 inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
 {
   WetLaunch w;
-  // Wide grids (a segment over all strips fills at least half of an XCD's workgroup slots): XCD k takes the row band
-  // [k*Y/8, (k+1)*Y/8) of ALL strips instead of a column block of every segment -- each XCD then streams one contiguous eighth of
-  // every plane: -3..-8 % kernel time at 16384x2048 and 32768x4096 (profiles/r02_wet_tail_shape.txt). Narrow grids (slabs) keep the
-  // column blocks, whose segments can be cut much finer.
-  bool bands = WX_WET_BANDS && (g.X + WOUT - 1) / WOUT >= 48 * WX_WET_WPB && g.Y >= 8 * 64;
+  // Grids at least 512 rows high: XCD k takes the row band [k*Y/8, (k+1)*Y/8) of ALL strips instead of a column block of every
+  // segment -- each XCD then streams one contiguous eighth of every plane: -3..-8 % kernel time at 16384x2048 and 32768x4096,
+  // -5 % on a 4192x4096 slab, -9 % on a 2144x2048 one (profiles/r02_wet_tail_shape.txt).
+  bool bands = WX_WET_BANDS && g.Y >= 8 * 64;
   if (const char *e = getenv("WX_WET_BANDS")) bands = atoi(e) >= 2 ? g.Y >= 16 : (atoi(e) != 0 && g.Y >= 8 * 64); // (2: tests force it on small grids)
   const int Y = bands ? (g.Y + 7) / 8 : g.Y; // (bands: the shape of ONE band; the kernel clips it to the band's own height)
   w.segs.bands = bands ? 1 : 0;
@@ -958,8 +957,11 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
     const double per_round = (double)(wet_capacity() / WX_WET_WPB) / wg_per_seg;
     // (a band segment is a large part of a round already: one segment per tail level there)
     const int c = bands ? 1 : ((int)(per_round / 2.0 + 0.5) > 1 ? (int)(per_round / 2.0 + 0.5) : 1);
-    for (int rr = rounds; rr >= 2; rr--) { // (fewer rounds if a unit segment would fall below `minrows` rows; else equal segments)
-      int n_full = (int)((rr - 1) * per_round + 0.5);
+    const double rr_list[6] = {(double)rounds, 3.0, 2.0, 1.75, 1.5, 1.25};
+    for (int ri = 0; ri < 6; ri++) { // (fewer rounds if a unit segment would fall below `minrows` rows; else equal segments)
+      const double rr = rr_list[ri];
+      if (rr > rounds) continue;
+      int n_full = (int)((rr - 1.0) * per_round + 0.5);
       if (bands) { // unit segments of about 64 rows
         const int by_rows = (int)(Y / 64.0 + 0.5) - 1;
         n_full = n_full > by_rows ? n_full : by_rows;
