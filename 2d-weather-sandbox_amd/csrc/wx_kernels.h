@@ -605,90 +605,77 @@ __global__ __launch_bounds__(256) void k_splat_classify(int X, int Y, SplatGrid 
     sg.work[8 + T + atomicAdd(&cnt[1], 1)] = t;
 }
 
-__global__ __launch_bounds__(256) void k_splat_box(int X, int Y, SplatGrid sg, const DevState *__restrict__ st, float4 *__restrict__ fb,
-                                                   float2 *__restrict__ dep, int seam, int mailbox, int par)
+// One (tile, texture) work item: KIND 0 = the feedback texture from the three used channels of acc4, KIND 1 = the deposition texture
+// from acc2. Splitting a tile by texture brings the staging buffer from 41 to 25 KB (6 instead of 3 workgroups per CU: the kernel
+// is latency-bound between its load, sum and store phases) and doubles the number of independent items.
+template <int KIND>
+__device__ __forceinline__ void splat_box_tile(float (*pl)[STY + 11][77], int X, int Y, const SplatGrid &sg, const DevState *__restrict__ st,
+                                               float4 *__restrict__ fb, float2 *__restrict__ dep, int x0, int y0, int qmin, int qmax, int qshift, bool corner)
 {
-  constexpr int WW = STX + 11, WH = STY + 11, PW = 77; // (pitch 77: the 4 rows x 8 runs a half-wave reads in the horizontal pass hit 32 banks)
-  __shared__ float pl[5][WH][PW];
+  constexpr int WW = STX + 11, WH = STY + 11, NCH = KIND == 0 ? 3 : 2;
   const int tid = threadIdx.x;
-  const int T = sg.TXn * sg.TYn, n_box = sg.work[4 * par], n_zero = sg.work[4 * par + 1];
-  const int cx = tid & 63, cyg = tid >> 6;
-  for (int wi = blockIdx.x; wi < n_box + n_zero; wi += gridDim.x) {
-  const bool any_dirty = wi < n_box;
-  const int tile = any_dirty ? sg.work[8 + wi] : sg.work[8 + T + (wi - n_box)];
-  const int tby = tile / sg.TXn, tbx = tile - tby * sg.TXn;
-  const int x0 = tbx * STX, y0 = tby * STY;
-  const bool corner = mailbox && (tbx == 0 && tby == 0);
-  const bool right = seam > 0 && x0 >= seam;
-  const int qmin = right ? seam : 0, qmax = (seam > 0 && !right) ? seam : X, qshift = right ? 1 : 0;
-  if (!any_dirty) { // the texture tile holds the feedback of an earlier iteration (or the mailbox texels): zero it
-    for (int k = 0; k < STY / 4; k++) {
-      const int x = x0 + cx, y = y0 + cyg + 4 * k;
-      if (x < X && y < Y) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (corner && y == 0 && x == 0) v.x = st->px_count;
-        if (corner && y == 0 && x == 1) v = make_float4(st->px_light[0], st->px_light[1], st->px_light[2], st->px_light[3]);
-        fb[(size_t)y * X + x] = v;
-        dep[(size_t)y * X + x] = make_float2(0.f, 0.f);
+  // stage the deposit window (zero outside the accumulation grid). All loads of a thread are issued before the first LDS write:
+  // as a rolled loop this was load -> wait -> write eight times in a row, i.e. eight memory latencies per tile.
+  constexpr int NST = (WW * WH + 255) / 256;
+  float4 v4[KIND == 0 ? NST : 1];
+  float2 v2[KIND == 0 ? 1 : NST];
+#pragma unroll
+  for (int k = 0; k < NST; k++) {
+    const int i = tid + 256 * k, ly = i / WW, lx = i - ly * WW;
+    const int q = x0 - 5 + lx, r = y0 - 5 + ly;
+    const bool inside = i < WW * WH && q >= qmin && r >= 0 && q <= qmax && r <= Y;
+    if (KIND == 0) {
+      v4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (inside) v4[k] = sg.acc4[(size_t)r * sg.AP + q + qshift];
+    } else {
+      v2[k] = make_float2(0.f, 0.f);
+      if (inside) v2[k] = sg.acc2[(size_t)r * sg.AP + q + qshift];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NST; k++) {
+    const int i = tid + 256 * k, ly = i / WW, lx = i - ly * WW;
+    if (i < WW * WH) {
+      if (KIND == 0) {
+        pl[0][ly][lx] = v4[k].x;
+        pl[1][ly][lx] = v4[k].y;
+        pl[2][ly][lx] = v4[k].z;
+      } else {
+        pl[0][ly][lx] = v2[k].x;
+        pl[1][ly][lx] = v2[k].y;
       }
     }
-    if (tid == 0) sg.fb_zero[tile] = corner ? 0 : 1;
-    continue;
-  }
-  // stage the deposit window (zero outside the accumulation grid)
-  for (int i = tid; i < WW * WH; i += 256) {
-    const int ly = i / WW, lx = i - ly * WW;
-    const int q = x0 - 5 + lx, r = y0 - 5 + ly;
-    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float2 a2 = make_float2(0.f, 0.f);
-    if (q >= qmin && r >= 0 && q <= qmax && r <= Y) {
-      a4 = sg.acc4[(size_t)r * sg.AP + q + qshift];
-      a2 = sg.acc2[(size_t)r * sg.AP + q + qshift];
-    }
-    pl[0][ly][lx] = a4.x;
-    pl[1][ly][lx] = a4.y;
-    pl[2][ly][lx] = a4.z;
-    pl[3][ly][lx] = a2.x;
-    pl[4][ly][lx] = a2.y;
   }
   __syncthreads();
   // A 12-sum as a tree whose nodes depend on the absolute index only -- pair sums p[i] = a[i] + a[i+1], quads q[i] = p[i] + p[i+2],
   // s[i] = (q[i] + q[i+4]) + q[i+8] -- so that neighbouring outputs share their partial sums (4 additions per output instead of 11)
   // and the result does not depend on where the tile or slab boundaries lie.
   // vertical pass: one (channel, window column) per thread, the 16 sums written back in place
-  float vres[2][STY];
+  float vres[STY];
+  const bool vtask = tid < NCH * WW;
+  const int vc = tid / WW, vx = tid - vc * WW;
+  if (vtask) {
+    float a[WH];
 #pragma unroll
-  for (int rnd = 0; rnd < 2; rnd++) {
-    const int task = tid + 256 * rnd;
-    if (task < 5 * WW) {
-      const int c = task / WW, lx = task - c * WW;
-      float a[WH];
+    for (int i = 0; i < WH; i++) a[i] = pl[vc][i][vx];
 #pragma unroll
-      for (int i = 0; i < WH; i++) a[i] = pl[c][i][lx];
+    for (int i = 0; i < WH - 1; i++) a[i] = a[i] + a[i + 1];
 #pragma unroll
-      for (int i = 0; i < WH - 1; i++) a[i] = a[i] + a[i + 1];
+    for (int i = 0; i < WH - 3; i++) a[i] = a[i] + a[i + 2];
 #pragma unroll
-      for (int i = 0; i < WH - 3; i++) a[i] = a[i] + a[i + 2];
-#pragma unroll
-      for (int j = 0; j < STY; j++) vres[rnd][j] = (a[j] + a[j + 4]) + a[j + 8];
-    }
+    for (int j = 0; j < STY; j++) vres[j] = (a[j] + a[j + 4]) + a[j + 8];
   }
   __syncthreads();
+  if (vtask) {
 #pragma unroll
-  for (int rnd = 0; rnd < 2; rnd++) {
-    const int task = tid + 256 * rnd;
-    if (task < 5 * WW) {
-      const int c = task / WW, lx = task - c * WW;
-#pragma unroll
-      for (int j = 0; j < STY; j++) pl[c][j][lx] = vres[rnd][j];
-    }
+    for (int j = 0; j < STY; j++) pl[vc][j][vx] = vres[j];
   }
   __syncthreads();
-  // horizontal pass: a run of 4 output cells of one row per thread, all five channels
+  // horizontal pass: a run of 4 output cells of one row per thread, all channels of the texture
   const int run = (tid & 7) + 8 * ((tid >> 5) & 1), row = ((tid >> 3) & 3) + 4 * (tid >> 6);
-  float res[5][4];
+  float res[NCH][4];
 #pragma unroll
-  for (int c = 0; c < 5; c++) {
+  for (int c = 0; c < NCH; c++) {
     float a[15];
 #pragma unroll
     for (int k = 0; k < 15; k++) a[k] = pl[c][row][run * 4 + k];
@@ -704,20 +691,61 @@ __global__ __launch_bounds__(256) void k_splat_box(int X, int Y, SplatGrid sg, c
   for (int m = 0; m < 4; m++) {
     const int x = x0 + run * 4 + m;
     if (x < X && y < Y) {
-      float4 v = make_float4(res[0][m], res[1][m], res[2][m], 0.f);
-      if (corner && y == 0 && x == 0) v.x += st->px_count;
-      if (corner && y == 0 && x == 1) {
-        v.x += st->px_light[0];
-        v.y += st->px_light[1];
-        v.z += st->px_light[2];
-        v.w += st->px_light[3];
+      if (KIND == 0) {
+        float4 v = make_float4(res[0][m], res[1][m], res[2][m], 0.f);
+        if (corner && y == 0 && x == 0) v.x += st->px_count;
+        if (corner && y == 0 && x == 1) {
+          v.x += st->px_light[0];
+          v.y += st->px_light[1];
+          v.z += st->px_light[2];
+          v.w += st->px_light[3];
+        }
+        fb[(size_t)y * X + x] = v;
+      } else {
+        dep[(size_t)y * X + x] = make_float2(res[0][m], res[1][m]);
       }
-      fb[(size_t)y * X + x] = v;
-      dep[(size_t)y * X + x] = make_float2(res[3][m], res[4][m]);
     }
   }
-  if (tid == 0) sg.fb_zero[tile] = 0;
-  __syncthreads(); // (the next tile re-uses the staging buffer)
+  __syncthreads(); // (the next item re-uses the staging buffer)
+}
+
+__global__ __launch_bounds__(256, 4) void k_splat_box(int X, int Y, SplatGrid sg, const DevState *__restrict__ st, float4 *__restrict__ fb,
+                                                   float2 *__restrict__ dep, int seam, int mailbox, int par)
+{
+  constexpr int WH = STY + 11, PW = 77; // (pitch 77: the 4 rows x 8 runs a half-wave reads in the horizontal pass hit 32 banks)
+  __shared__ float pl[3][WH][PW];
+  const int tid = threadIdx.x;
+  const int T = sg.TXn * sg.TYn, n_box = sg.work[4 * par], n_zero = sg.work[4 * par + 1];
+  const int cx = tid & 63, cyg = tid >> 6;
+  // items: (tile, texture) for the tiles to box-sum, then the tiles to zero
+  for (int wi = blockIdx.x; wi < 2 * n_box + n_zero; wi += gridDim.x) {
+    const bool any_dirty = wi < 2 * n_box;
+    const int tile = any_dirty ? sg.work[8 + (wi >> 1)] : sg.work[8 + T + (wi - 2 * n_box)];
+    const int tby = tile / sg.TXn, tbx = tile - tby * sg.TXn;
+    const int x0 = tbx * STX, y0 = tby * STY;
+    const bool corner = mailbox && (tbx == 0 && tby == 0);
+    const bool right = seam > 0 && x0 >= seam;
+    const int qmin = right ? seam : 0, qmax = (seam > 0 && !right) ? seam : X, qshift = right ? 1 : 0;
+    if (!any_dirty) { // the texture tile holds the feedback of an earlier iteration (or the mailbox texels): zero it
+      for (int k = 0; k < STY / 4; k++) {
+        const int x = x0 + cx, y = y0 + cyg + 4 * k;
+        if (x < X && y < Y) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (corner && y == 0 && x == 0) v.x = st->px_count;
+          if (corner && y == 0 && x == 1) v = make_float4(st->px_light[0], st->px_light[1], st->px_light[2], st->px_light[3]);
+          fb[(size_t)y * X + x] = v;
+          dep[(size_t)y * X + x] = make_float2(0.f, 0.f);
+        }
+      }
+      if (tid == 0) sg.fb_zero[tile] = corner ? 0 : 1;
+      continue;
+    }
+    if ((wi & 1) == 0) {
+      splat_box_tile<0>(pl, X, Y, sg, st, fb, dep, x0, y0, qmin, qmax, qshift, corner);
+      if (tid == 0) sg.fb_zero[tile] = 0;
+    } else {
+      splat_box_tile<1>(pl, X, Y, sg, st, fb, dep, x0, y0, qmin, qmax, qshift, corner);
+    }
   }
 }
 
