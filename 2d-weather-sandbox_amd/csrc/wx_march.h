@@ -16,7 +16,8 @@
 #pragma once
 #include "wx_cells.h"
 #include "wx_dry.h"
-#include "wx_wet.h" // ld_row / st_row (scalar-base addressing), wave_from_left (DPP shift)
+#include "wx_wet.h"
+#include <vector> // ld_row / st_row (scalar-base addressing), wave_from_left (DPP shift)
 
 #ifndef WX_MARCH_BANDS
 #define WX_MARCH_BANDS 1
@@ -84,8 +85,15 @@ __device__ __forceinline__ MDryFp make_fp(const MDryAcc &a, int dx0, int dy0) { 
 // so the pass-through store is dropped and the wall buffers are not swapped: 36 B/cell, SURVEY's A_dry.
 template <bool WRITE_DISP, bool WRITE_WALL>
 __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u_arg, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows,
-                                                                     int n_full, int n_half, int band_h, int n_seg)
+                                                                     int n_full, int n_half, int band_h, int n_seg
+#ifdef WX_MARCH_TIMING
+                                                                     , unsigned long long *cycles
+#endif
+)
 {
+#ifdef WX_MARCH_TIMING
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   __shared__ MarchRing rg;
 #if WX_MARCH_UNI_MEM
   // uniforms and the per-row profiles through the constant address space: scalar loads the compiler may re-issue anywhere
@@ -238,6 +246,12 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     if (WRITE_WALL) st_row_v(out.wall + e, so4, st_w);
     if (WRITE_DISP) st_row_v(out.base_disp + e, so16, st_ab);
   }
+#ifdef WX_MARCH_TIMING
+  if (lane == 0) {
+    cycles[2 * ((size_t)seg * n_strips + strip)] = t_begin;
+    cycles[2 * ((size_t)seg * n_strips + strip) + 1] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 // Segment height: the grid is cut so that the number of waves is just under a whole multiple of what the device holds
@@ -295,13 +309,41 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
     fprintf(stderr, "[wx_march] strips=%d seg_rows=%d segs=%d (bands of %d rows: %d full + 2 x %d short each) waves=%d\n", n_strips, seg_rows, n_seg, band_h, n_full, n_half, n_strips * n_seg);
     dbg = false;
   }
+#ifdef WX_MARCH_TIMING
+  static unsigned long long *cyc = nullptr;
+  static int calls = 0;
+  if (!cyc) hipMalloc((void **)&cyc, 16 * (size_t)n_strips * n_seg);
+#define WX_LAUNCH_M(D, W) hipLaunchKernelGGL((k_march_dry<D, W>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, cyc)
+#else
 #define WX_LAUNCH_M(D, W) hipLaunchKernelGGL((k_march_dry<D, W>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg)
+#endif
   if (write_disp) {
     if (write_wall) WX_LAUNCH_M(true, true); else WX_LAUNCH_M(true, false);
   } else {
     if (write_wall) WX_LAUNCH_M(false, true); else WX_LAUNCH_M(false, false);
   }
 #undef WX_LAUNCH_M
+#ifdef WX_MARCH_TIMING
+  if (++calls == 40) { // per segment: start / end relative to the first wave of its XCD band, duration (shader clock cycles)
+    hipStreamSynchronize(stream);
+    std::vector<unsigned long long> c(2 * (size_t)n_strips * n_seg);
+    hipMemcpy(c.data(), cyc, c.size() * 8, hipMemcpyDeviceToHost);
+    const int per = band_h > 0 ? n_seg / 8 : n_seg;
+    for (int sg = 0; sg < n_seg; sg++) {
+      if (band_h > 0 && sg / per != 0 && sg / per != 7) continue; // (first and last XCD only)
+      unsigned long long t0 = ~0ull;
+      for (int q = (sg / per) * per; q < (sg / per + 1) * per; q++)
+        for (int k = 0; k < n_strips; k++) t0 = c[2 * ((size_t)q * n_strips + k)] < t0 ? c[2 * ((size_t)q * n_strips + k)] : t0;
+      double st = 0, en = 0, du = 0, dmax = 0;
+      for (int k = 0; k < n_strips; k++) {
+        const size_t i = 2 * ((size_t)sg * n_strips + k);
+        st += (double)(c[i] - t0); en += (double)(c[i + 1] - t0); du += (double)(c[i + 1] - c[i]);
+        dmax = (double)(c[i + 1] - c[i]) > dmax ? (double)(c[i + 1] - c[i]) : dmax;
+      }
+      fprintf(stderr, "  dry seg %3d: start %8.0f end %8.0f dur avg %7.0f max %7.0f\n", sg, st / n_strips, en / n_strips, du / n_strips, dmax);
+    }
+  }
+#endif
 }
 
 } // namespace wx
