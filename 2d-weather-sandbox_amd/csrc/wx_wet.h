@@ -1,6 +1,6 @@
 // wx_wet.h -- the WHOLE wet iteration (reference draws 1-7, app.js:5832-5930: velocity -> curl -> vorticity -> boundary ->
-// advection -> pressure -> lighting) as ONE row-MARCHING kernel (gfx950). One wavefront = one workgroup owns a 64-column
-// strip and walks up the rows of its segment; per step (newest input row r) it
+// advection -> pressure -> lighting) as ONE row-MARCHING kernel (gfx950). One wavefront owns a 64-column strip (a workgroup
+// = four neighbouring strips, no barrier between them) and walks up the rows of its segment; per step (newest input row r) it
 //
 //   loads row r+1 (prefetch)  |  velocity(r-1)  |  curl(r-2)  |  vortForce(r-3)  |  boundary(r-3)  |  advection(r-4)  |
 //   pressure(r-4) + lighting(r-4) -> stores row r-4
@@ -8,7 +8,7 @@
 // * every intermediate texture of the reference (velocity output, curl, vortForce, post-boundary base / water / wall,
 //   advection output) lives in registers or in a wave-PRIVATE LDS ring of the last six rows; nothing but the iteration's
 //   inputs and outputs touches HBM: base 16 R + 16 W, water 16 R + 16 W, wall 4 R + 4 W, light 16 R + 16 W = 104 B/cell
-//   (two-kernel form: 184 B/cell; reference pass structure: ~380 B/cell);
+//   (round 1's two-kernel form: 184 B/cell; reference pass structure: ~380 B/cell);
 // * vertical neighbours are the wave's own earlier rows (ring or carried registers), horizontal neighbours of values that
 //   were just computed come from whole-wave DPP shifts (v_mov_b32_dpp wave_shr / wave_shl: one VALU instruction, no LDS
 //   round trip), data-dependent taps (advection's back-trace, the sun ray) from the ring;
@@ -25,7 +25,10 @@
 //   row r+1, water and light row r-1, feedback row r-2), and the stores of a row are issued at the top of the NEXT step, right
 //   behind the prefetch: the only vmcnt wait of the common path (top of the step) then covers operations that have had a
 //   whole step to complete -- gfx9 counts loads and stores in one in-order counter.
-// Same per-cell arithmetic as every other kernel set (wx_cells.h): bit-identical results.
+// * launch shape (wet_launch_shape): the rows are cut into eight bands, one per XCD, each band into a few full segments followed
+//   by segments of 1/2, 1/4 (and 1/8) the height -- short segments at the END of the dispatch order shorten the drain phase of
+//   the launch; grids lower than 512 rows use column blocks per XCD instead.
+// Same per-cell arithmetic as the per-pass kernels (wx_cells.h): bit-identical results.
 #pragma once
 #include "wx_cells.h"
 #include "wx_tile.h"
