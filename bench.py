@@ -104,7 +104,10 @@ def pmc_traffic(a, kernel, X=None, Y=None, workload=None):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             d = tempfile.mkdtemp(prefix="wxpmc_", dir="/tmp")
-            cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "2",
+            # one whole frame of warm-up, one measured: the averaged launches have the timed region's mix of plain iterations and the
+            # one per frame that also writes the display fields
+            nfr = max(1, int(a.frame))
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", str(nfr), "--warmup", str(nfr),
                    "--X", str(X or a.X), "--Y", str(Y or a.Y), "--workload", workload or a.workload, "--no-cpu-baseline", "--no-pmc",
                    "--no-north-star", "--frame", str(a.frame)]
             env = dict(os.environ, TMPDIR="/tmp")
@@ -113,7 +116,7 @@ def pmc_traffic(a, kernel, X=None, Y=None, workload=None):
             c = sqlite3.connect(dbs[0])
             rows = c.execute("select k.kernel_name, d.event_id, d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol k "
                              "on d.kernel_id = k.id order by d.start").fetchall()
-            ev = [e for n, e, _ in rows if sym in n][2:]  # skip the warm-up launches
+            ev = [e for n, e, _ in rows if sym in n][nfr:]  # skip the warm-up launches
             per = []
             for e in ev:
                 v = c.execute("select sum(value) from rocpd_pmc_event where event_id = ?", (e,)).fetchone()[0]
