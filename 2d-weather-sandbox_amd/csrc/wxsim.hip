@@ -703,11 +703,21 @@ void wx_destroy(wx_sim *s)
 }
 
 static int reset_after_upload(wx_sim *s, const float *drops);
+// a halo unpack still running on the comm stream would overwrite freshly uploaded ghost columns: drain it first
+static int drain_comm(wx_sim *s)
+{
+  if (s->comm_stream) {
+    HIPCHK(s, hipStreamSynchronize(s->comm_stream));
+    s->unpack_pending = s->edges_recorded = false;
+  }
+  return WX_OK;
+}
 
 int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wall, const float *drops)
 {
   if (!s) return WX_E_INVALID;
   if (!base || !water || !wall) return fail(s, WX_E_INVALID, "wx_upload: NULL grid array");
+  if (int rc = drain_comm(s)) return rc;
   const size_t n = ncell(s);
   {
     bool trivial = true;
@@ -775,6 +785,7 @@ int wx_setup_columns(wx_sim *s, const int32_t *wall_rows, const uint8_t *sea_col
   if (!s) return WX_E_INVALID;
   if (!wall_rows || !sea_column || !veg_noise || !snow || !T_air || !total_water || !cloud_water)
     return fail(s, WX_E_INVALID, "wx_setup_columns: NULL descriptor array");
+  if (int rc = drain_comm(s)) return rc;
   const int X = s->X, Y = s->Y;
   for (int x = 0; x < X; x++)
     if (wall_rows[x] < 0 || wall_rows[x] > Y) return fail(s, WX_E_RANGE, "wx_setup_columns: wall_rows[%d] = %d outside 0..%d", x, wall_rows[x], Y);
@@ -854,6 +865,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   }
   if (dry && s->water_trivial && s->ghost_check) { // a neighbour's ghost columns arrived since the last look: do they carry water?
     int flag = 0;
+    wait_unpacked(s); // k_halo_unpack sets the flag on the comm stream: order the readback behind it
     HIPCHK(s, hipMemcpyAsync(&flag, &s->state->ghost_nontrivial, 4, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(s, hipStreamSynchronize(s->stream));
     s->ghost_check = false;
@@ -870,10 +882,10 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       return fail(s, WX_E_STATE, "wx_step: %d iterations asked, %d done since the last halo exchange; %d ghost columns allow %d per period with particles",
                   n_iter, s->period_j, s->halo, (s->halo - 6) / WX_SLAB_CONE);
   }
-  if (!fused) light_to_rgba(s); // the per-pass / dry kernels take the light textures interleaved
   // overlap needs the kernel that can be launched per strip range; everything else orders the exchange on the compute stream
   const bool can_split = fused && !precip && s->comm_stream != nullptr && s->halo > 0;
   if (!can_split) wait_unpacked(s);
+  if (!fused) light_to_rgba(s); // the per-pass / dry kernels take the light textures interleaved (behind the unpack: it reads ghost columns)
   s->edges_recorded = false;
   for (int it = 0; it < n_iter; it++) {
     int edge_mode = 0;
@@ -1098,6 +1110,7 @@ int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst)
     HIPCHK(s, hipEventCreateWithFlags(&s->ev_fields_ready, hipEventDisableTiming));
     HIPCHK(s, hipEventCreateWithFlags(&s->ev_copy_done, hipEventDisableTiming));
   }
+  wait_unpacked(s); // ghost columns written on the comm stream are part of what a frame shows
   const void *ptr[6];
   size_t texel[6];
   for (int f = 0; f < 6; f++) { // (may enqueue a layout conversion of the light texture on the compute stream)
@@ -1158,6 +1171,7 @@ void *wx_device_ptr(wx_sim *s, int field)
 {
   if (!s) return nullptr;
   if (field == WX_FIELD_LIGHTNING) return s->state->lightning;
+  wait_unpacked(s); // whatever the caller enqueues on the compute stream next sees the unpacked ghost columns
   if (field == WX_FIELD_EMITTED) return emitted_rect(s, 0, 0, s->X, s->Y) == WX_OK ? s->emitted : nullptr; // (whole grid, computed now)
   const void *ptr;
   int ch, el;

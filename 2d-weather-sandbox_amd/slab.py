@@ -203,18 +203,21 @@ class SlabSim:
         rank's lightning state the latest strike any rank registered. Two all-reduces: MAX over the claim keys (+ the
         strike key), SUM over the winners' states (+ the winning strike). Device tensors only: no host round trip.
 
-        Strike key = start iteration * 1024 + (1023 - rank): the latest strike wins; two ranks that registered different strikes
-        in the same iteration are told apart by the rank, so exactly one of them contributes (no averaging of two bolts)."""
+        Strike key = start iteration << 10 | (1023 - rank), reduced in its OWN int64 tensor (the iteration is never wrapped: an
+        int32 key would wrap after 2^20 iterations and an old strike would then beat every new one): the latest strike wins; two
+        ranks that registered different strikes in the same iteration are told apart by the rank, so exactly one of them
+        contributes (no averaging of two bolts)."""
         e, n = self.engine, self.engine.n_droplets
         e.particle_keys(self.keys)
         live = hasattr(e, "lightning_tensor")
         light = e.lightning_tensor() if live else torch.from_numpy(np.asarray(e.lightning(), np.float32).copy()).to(self.keys.device)
-        it = light[2].to(torch.int64) % (1 << 20)
-        my_key = torch.where(light[2] > 0, it * 1024 + (1023 - self.rank), torch.zeros_like(it)).to(torch.int32)
-        self.keys[n:n + 1] = my_key
+        it = light[2].to(torch.int64)
+        my_key = torch.where(light[2] > 0, it * 1024 + (1023 - self.rank), torch.zeros_like(it)).reshape(1)
+        win_key = my_key.clone()
         dist.all_reduce(self.keys, op=dist.ReduceOp.MAX)
+        dist.all_reduce(win_key, op=dist.ReduceOp.MAX)
         e.particle_contribute(self.keys, self.state)
-        mine = ((my_key > 0) & (my_key == self.keys[n])).to(torch.float32)
+        mine = ((my_key > 0) & (my_key == win_key)).to(torch.float32)[0]
         self.state[5 * n] = mine
         self.state[5 * n + 1:] = light * mine
         dist.all_reduce(self.state, op=dist.ReduceOp.SUM)
@@ -248,6 +251,15 @@ class SlabSim:
 
     def sync(self):
         self.engine.sync()
+
+    def upload(self, base, water, wall, drops=None):
+        """Re-upload this rank's slab (local arrays incl. ghost columns): the ghost columns are fresh again, so the exchange
+        period starts over and the next step does not run the interior-first split against an exchange that never happened."""
+        self.engine.upload(base, water, wall, drops)
+        self._since_exchange = 0
+        self._exchanged = False
+        if self.particles and hasattr(self.engine, "period_begin"):
+            self.engine.period_begin()
 
     # ---- construction on the HIP engine ----
     @classmethod

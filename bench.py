@@ -51,7 +51,9 @@ def parse():
     ap.add_argument("--particles", type=int, default=0, help="also run the particle pass with N droplets (BASELINE configs[4]; N=1 GPU only)")
     ap.add_argument("--frame", type=int, default=10, help="iterations per wx_step call (the reference's IterPerFrame, app.js:398)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 32768 x 4096 dry north-star measurement (N=1)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.frame = max(1, a.frame)  # (0 or a negative value would never advance run_frames)
+    return a
 
 
 def cpu_baseline(pkg, budget_s=12.0):
