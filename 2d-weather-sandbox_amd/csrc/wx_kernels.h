@@ -292,6 +292,18 @@ struct SplatGrid {
 };
 constexpr int STX = 64, STY = 16; // splat tile
 
+// Deterministic splat order (wx_set_option(WX_OPT_SPLAT_ORDER, 1); tests): instead of fp32 atomics in arrival order every droplet
+// RECORDS its deposit -- key = anchor index (r * AP + q), DET_KEY_LIGHT for a lightning request, DET_KEY_NONE for nothing -- the
+// records are radix-sorted by key (stable: equal keys stay in droplet-index order) and k_splat_runs adds each run sequentially,
+// i.e. every anchor receives ((d_i0 + d_i1) + d_i2) ... with i0 < i1 < i2 the droplets that hit it. The box sum that follows is
+// order-free already (index-anchored trees), so the feedback / deposition textures become a pure function of the droplet pool.
+struct DetSplat {
+  int *key;   // per droplet (NULL: atomics)
+  float *val; // per droplet 5 floats: (mass, heat, vapor | rain, snow), or the four lightning-request channels
+};
+constexpr int DET_KEY_NONE = 0x7fffffff;
+__device__ __forceinline__ int det_key_light(const SplatGrid &sg) { return sg.AP * sg.AH; }
+
 // common.glsl:103-111
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x)
 {
@@ -342,13 +354,14 @@ __device__ __forceinline__ void atomic_add_f(float *p, float v)
 __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops, const float *__restrict__ drops_in,
                                                         const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
                                                         DevState *__restrict__ st, float *__restrict__ drops_out, SplatGrid sg, SlabP sp,
-                                                        const float *__restrict__ t_in)
+                                                        const float *__restrict__ t_in, DetSplat det)
 {
   // t_in != nullptr (two-kernel path): base_in is the POST-pressure base texture, whose velocity components equal the
   // post-advection ones the reference samples (pressure_cell only touches P and T), and t_in holds the post-advection
   // temperature -- kernel B then stores 4 instead of 16 extra bytes per cell for the droplets.
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = i < n_drops;
+  if (live && det.key) det.key[i] = DET_KEY_NONE; // (overwritten below if this droplet deposits something)
   const int Y = g.Y;
   const float resX = (float)g.Xg, resY = (float)Y;
   const float initalMass = 0.15f;
@@ -546,6 +559,11 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
   if (size <= 1.0f) {
     // the only 1-px sprite that reaches this point is a lightning request, drawn at pixel (1,0)
     // (precipitationShader.vert:135-139)
+    if (det.key) {
+      det.key[i] = det_key_light(sg);
+      for (int c = 0; c < 4; c++) det.val[5 * (size_t)i + c] = feedback[c];
+      return;
+    }
     atomic_add_f(&st->px_light[0], feedback[0]);
     atomic_add_f(&st->px_light[1], feedback[1]);
     atomic_add_f(&st->px_light[2], feedback[2]);
@@ -562,6 +580,15 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
     q -= g.xoff;
   if (q < 0 || q >= sg.AP) return; // the sprite lies outside this slab
   const size_t ai = (size_t)r * sg.AP + q;
+  if (det.key) {
+    det.key[i] = (int)ai;
+    det.val[5 * (size_t)i + 0] = feedback[0];
+    det.val[5 * (size_t)i + 1] = feedback[1];
+    det.val[5 * (size_t)i + 2] = feedback[2];
+    det.val[5 * (size_t)i + 3] = deposition[0];
+    det.val[5 * (size_t)i + 4] = deposition[1];
+    return;
+  }
   float *f = reinterpret_cast<float *>(sg.acc4 + ai);
   atomic_add_f(f + 0, feedback[0]);
   atomic_add_f(f + 1, feedback[1]);
@@ -569,6 +596,30 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
   float *d = reinterpret_cast<float *>(sg.acc2 + ai);
   atomic_add_f(d + 0, deposition[0]);
   atomic_add_f(d + 1, deposition[1]);
+  sg.dirty[(r / STY) * sg.TXn + (q / STX)] = 1;
+}
+
+// deterministic splat order: one thread per sorted record; the first record of a run of equal keys adds the run in order
+__global__ __launch_bounds__(256) void k_splat_runs(int n, const int *__restrict__ key_sorted, const int *__restrict__ idx_sorted,
+                                                     const float *__restrict__ val, SplatGrid sg, DevState *__restrict__ st)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int k = key_sorted[t];
+  if (k == DET_KEY_NONE || (t > 0 && key_sorted[t - 1] == k)) return;
+  float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool light = k == det_key_light(sg);
+  for (int u = t; u < n && key_sorted[u] == k; u++) {
+    const float *v = val + 5 * (size_t)idx_sorted[u];
+    for (int c = 0; c < (light ? 4 : 5); c++) a[c] += v[c];
+  }
+  if (light) {
+    for (int c = 0; c < 4; c++) st->px_light[c] += a[c];
+    return;
+  }
+  sg.acc4[k] = make_float4(a[0], a[1], a[2], 0.f);
+  sg.acc2[k] = make_float2(a[3], a[4]);
+  const int r = k / sg.AP, q = k - r * sg.AP;
   sg.dirty[(r / STY) * sg.TXn + (q / STX)] = 1;
 }
 

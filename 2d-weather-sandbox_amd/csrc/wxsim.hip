@@ -12,6 +12,7 @@
 #include "wx_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <cstdarg>
@@ -118,6 +119,13 @@ struct wx_sim {
   SplatGrid sg{};              // particle splat accumulation (allocated when the handle has droplets)
   int splat_par = 0;           // which set of work-list counters the next iteration fills (see SplatGrid::work)
   bool fb_dirty = false; // feedback/deposition hold non-zero data (particles ran last iteration)
+  // wx_set_option
+  int splat_order = 0;        // WX_OPT_SPLAT_ORDER: 1 = deterministic (records sorted by anchor, summed in droplet-index order)
+  int check_launches = 0;     // WX_OPT_CHECK_LAUNCHES: synchronise and check after every kernel launch of wx_step (debugging)
+  int *det_key[2] = {nullptr, nullptr}, *det_idx[2] = {nullptr, nullptr}; // deposit records: keys / droplet indices, unsorted and sorted
+  float *det_val = nullptr;
+  void *det_tmp = nullptr;
+  size_t det_tmp_bytes = 0;
   bool water_trivial = false; // the water texture is known to be 0 in air cells and only the wall marker in wall cells: set by wx_upload,
                               // cleared by every step that can put water there (anything but the water-free dry iteration)
   bool ghost_check = false;   // ghost columns were unpacked while water_trivial: DevState::ghost_nontrivial must be read before relying on it
@@ -153,6 +161,15 @@ int fail(wx_sim *s, int code, const char *fmt, ...)
   } while (0)
 
 size_t ncell(const wx_sim *s) { return (size_t)s->X * s->Y; }
+
+// after every kernel launch of the iteration loop: the launch itself is always checked (hipGetLastError is a thread-local read);
+// with WX_OPT_CHECK_LAUNCHES the stream is also synchronised, so that an asynchronous fault is reported with the kernel's name
+#define LAUNCH_CHECK(s, what)                                                                                         \
+  do {                                                                                                                \
+    hipError_t e_ = hipGetLastError();                                                                                \
+    if (e_ == hipSuccess && (s)->check_launches) e_ = hipStreamSynchronize((s)->stream);                              \
+    if (e_ != hipSuccess) return fail((s), WX_E_DEVICE, "wx_step: %s (iteration %lld): %s", what, (long long)(s)->iter, hipGetErrorString(e_)); \
+  } while (0)
 
 hipEvent_t get_event(wx_sim *s)
 {
@@ -316,12 +333,14 @@ int copy_field(wx_sim *s, const float4 *src, float4 *dst)
 {
   ProfScope ps(s, K_COPY);
   hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, s->stream, src, dst, ncell(s));
+  LAUNCH_CHECK(s, "copy");
   return WX_OK;
 }
 int copy_wall(wx_sim *s, const char4 *src, char4 *dst)
 {
   ProfScope ps(s, K_COPY);
   hipLaunchKernelGGL(k_copy4, dim3(2048), dim3(256), 0, s->stream, src, dst, ncell(s));
+  LAUNCH_CHECK(s, "copy");
   return WX_OK;
 }
 
@@ -338,19 +357,22 @@ int iterate_per_pass(wx_sim *s, unsigned mask)
   if (mask & WX_PASS_VELOCITY) {
     ProfScope ps(s, K_VELOCITY);
     hipLaunchKernelGGL(k_velocity, grid, block, 0, s->stream, g, u, s->base[0], s->wall[0], s->base[1], s->wall[1]);
+    LAUNCH_CHECK(s, "velocity");
   } else {
-    copy_field(s, s->base[0], s->base[1]);
-    copy_wall(s, s->wall[0], s->wall[1]);
+    if (int rc_ = copy_field(s, s->base[0], s->base[1])) return rc_;
+    if (int rc_ = copy_wall(s, s->wall[0], s->wall[1])) return rc_;
   }
   // 2, 3 curl + vorticity
   if (mask & WX_PASS_VORTICITY) {
     {
       ProfScope ps(s, K_CURL);
       hipLaunchKernelGGL(k_curl, grid, block, 0, s->stream, g, s->base[1], s->curl);
+      LAUNCH_CHECK(s, "curl");
     }
     {
       ProfScope ps(s, K_VORTICITY);
       hipLaunchKernelGGL(k_vorticity, grid, block, 0, s->stream, g, s->curl, s->vort);
+      LAUNCH_CHECK(s, "vorticity");
     }
   }
   // 4 boundary: base_1, water_1, vort, wall_1, light_0 (always _0), feedback, deposition -> base_0, water_0, wall_0
@@ -359,10 +381,11 @@ int iterate_per_pass(wx_sim *s, unsigned mask)
                 s->fb_dirty ? s->dep : nullptr};
     ProfScope ps(s, K_BOUNDARY);
     hipLaunchKernelGGL(k_boundary, grid, block, 0, s->stream, g, u, s->initial_T, in, s->base[0], s->water[0], s->wall[0]);
+    LAUNCH_CHECK(s, "boundary");
   } else {
-    copy_field(s, s->base[1], s->base[0]);
-    copy_field(s, s->water[1], s->water[0]);
-    copy_wall(s, s->wall[1], s->wall[0]);
+    if (int rc_ = copy_field(s, s->base[1], s->base[0])) return rc_;
+    if (int rc_ = copy_field(s, s->water[1], s->water[0])) return rc_;
+    if (int rc_ = copy_wall(s, s->wall[1], s->wall[0])) return rc_;
   }
   // 5 advection: _0 -> _1
   if (mask & WX_PASS_ADVECTION) {
@@ -370,24 +393,27 @@ int iterate_per_pass(wx_sim *s, unsigned mask)
     ProfScope ps(s, K_ADVECTION);
     hipLaunchKernelGGL(k_advection, grid, block, 0, s->stream, g, u, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel, in, s->base[1],
                        s->water[1], s->wall[1]);
+    LAUNCH_CHECK(s, "advection");
   } else {
-    copy_field(s, s->base[0], s->base[1]);
-    copy_field(s, s->water[0], s->water[1]);
-    copy_wall(s, s->wall[0], s->wall[1]);
+    if (int rc_ = copy_field(s, s->base[0], s->base[1])) return rc_;
+    if (int rc_ = copy_field(s, s->water[0], s->water[1])) return rc_;
+    if (int rc_ = copy_wall(s, s->wall[0], s->wall[1])) return rc_;
   }
   // 6 pressure: base_1, wall_1 -> base_0, wall_0
   if (mask & WX_PASS_PRESSURE) {
     ProfScope ps(s, K_PRESSURE);
     hipLaunchKernelGGL(k_pressure, grid, block, 0, s->stream, g, s->base[1], s->wall[1], s->base[0], s->wall[0]);
+    LAUNCH_CHECK(s, "pressure");
   } else {
-    copy_field(s, s->base[1], s->base[0]);
-    copy_wall(s, s->wall[1], s->wall[0]);
+    if (int rc_ = copy_field(s, s->base[1], s->base[0])) return rc_;
+    if (int rc_ = copy_wall(s, s->wall[1], s->wall[0])) return rc_;
   }
   // 7 lighting: base_1 (pre-pressure!), water_1, wall_1, light_src -> light_dst ; even = !even
   const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
   if (mask & WX_PASS_LIGHTING) {
     ProfScope ps(s, K_LIGHTING);
     hipLaunchKernelGGL(k_lighting, grid, block, 0, s->stream, g, u, s->base[1], s->water[1], s->wall[1], s->light[src], s->light[dst]);
+    LAUNCH_CHECK(s, "lighting");
   }
   return WX_OK;
 }
@@ -436,7 +462,7 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
   WetOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], s->water[0], s->curl, precip ? s->tdisp : nullptr};
 #ifdef WX_WET_TIMING
   static unsigned long long *dbg_cycles = nullptr;
-  if (!dbg_cycles) hipMalloc((void **)&dbg_cycles, 16 * 8192 * WMAXSEG);
+  if (!dbg_cycles && hipMalloc((void **)&dbg_cycles, 16 * 8192 * WMAXSEG) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_step: timing buffer");
   out.cycles = dbg_cycles;
 #endif
   if (s->air_from_row < 0 && wet_alpha() == 1.0) { // rows cost the same with or without terrain (the default): nothing to measure
@@ -488,6 +514,7 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
       }
       if (!interior_first) launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream, nl, nr0 - nl);
     }
+    LAUNCH_CHECK(s, "march_wet");
   }
 #ifdef WX_WET_TIMING
   if (s->iter == 40) { // per segment: start offset and duration of its waves (s_memtime ticks, 100 MHz)
@@ -532,10 +559,12 @@ int iterate_dry(wx_sim *s, bool write_disp)
   if (!water && s->dry_march && s->X >= 64) {
     ProfScope ps(s, K_MARCH_DRY);
     launch_march_dry(s->geo, s->uni, s->full_ctx, in, out, write_disp, !wall_const, s->stream);
+    LAUNCH_CHECK(s, "march_dry");
     wall_written = !wall_const;
   } else {
     ProfScope ps(s, K_FUSED_DRY);
     launch_fused_dry(s->geo, s->uni, s->full_ctx, in, out, water, write_disp, s->stream);
+    LAUNCH_CHECK(s, "fused_dry");
   }
   std::swap(s->base[0], s->base[1]);
   if (wall_written) std::swap(s->wall[0], s->wall[1]);
@@ -699,6 +728,12 @@ void wx_destroy(wx_sim *s)
   hipFree(s->sg.dirty);
   hipFree(s->sg.fb_zero);
   hipFree(s->sg.work);
+  for (int i = 0; i < 2; i++) {
+    hipFree(s->det_key[i]);
+    hipFree(s->det_idx[i]);
+  }
+  hipFree(s->det_val);
+  hipFree(s->det_tmp);
   delete s;
 }
 
@@ -891,14 +926,14 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
     int edge_mode = 0;
     if (can_split) edge_mode = ((flags & WX_OVERLAP_EDGES_LAST) && it == 0 ? 2 : 0) | ((flags & WX_OVERLAP_EDGES_FIRST) && it == n_iter - 1 ? 1 : 0);
     if (can_split && it == 0 && !(edge_mode & 2)) wait_unpacked(s);
+    int rc;
     if (dry)
-      iterate_dry(s, precip || it == n_iter - 1);
-    else if (fused) {
-      const int rc = iterate_march_wet(s, it == n_iter - 1, precip, edge_mode);
-      if (rc != WX_OK) return rc;
-    }
+      rc = iterate_dry(s, precip || it == n_iter - 1);
+    else if (fused)
+      rc = iterate_march_wet(s, it == n_iter - 1, precip, edge_mode);
     else
-      iterate_per_pass(s, mask);
+      rc = iterate_per_pass(s, mask);
+    if (rc != WX_OK) return rc;
     s->ran_fused = fused || dry;
     const int src = s->even ? 0 : 1, dst = s->even ? 1 : 0;
     s->even = !s->even;
@@ -920,7 +955,16 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
         }
         hipLaunchKernelGGL(k_precipitation, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, u, s->n_drops, s->drops[src],
                            two_kernel ? s->base[0] : ((fused || dry) ? s->base[2] : s->base[1]), s->water[1], s->state, s->drops[dst], s->sg, sp,
-                           two_kernel ? s->tdisp : nullptr);
+                           two_kernel ? s->tdisp : nullptr, DetSplat{s->splat_order ? s->det_key[0] : nullptr, s->det_val});
+        LAUNCH_CHECK(s, "precipitation");
+      }
+      if (s->splat_order) { // deterministic order: sort the deposit records by anchor (stable), add each run in droplet-index order
+        ProfScope ps(s, K_SPLAT);
+        HIPCHK(s, hipcub::DeviceRadixSort::SortPairs(s->det_tmp, s->det_tmp_bytes, s->det_key[0], s->det_key[1], s->det_idx[0], s->det_idx[1], s->n_drops, 0, 31,
+                                                     s->stream));
+        hipLaunchKernelGGL(k_splat_runs, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->det_key[1], s->det_idx[1], s->det_val, s->sg,
+                           s->state);
+        LAUNCH_CHECK(s, "splat_runs");
       }
       {
         ProfScope ps(s, K_SPLAT);
@@ -928,15 +972,18 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
         hipLaunchKernelGGL(k_splat_classify, dim3((T + 255) / 256), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->keys ? 0 : 1, par);
         hipLaunchKernelGGL(k_splat_box, dim3(T < 2048 ? T : 2048), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->state, s->fb, s->dep, s->seam,
                            s->keys ? 0 : 1, par);
+        LAUNCH_CHECK(s, "splat_classify / splat_box");
       }
       {
         ProfScope ps(s, K_LIGHTNING);
         hipLaunchKernelGGL(k_lightning, dim3(1), dim3(64), 0, s->stream, u.iterNum, (int)(s->iter % 600 == 0), s->fb, s->state, s->keys ? 0 : 1);
+        LAUNCH_CHECK(s, "lightning");
       }
       {
         ProfScope ps(s, K_SPLAT);
         const int T = s->sg.TXn * s->sg.TYn;
         hipLaunchKernelGGL(k_splat_clear, dim3(T < 2048 ? T : 2048), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->splat_par);
+        LAUNCH_CHECK(s, "splat_clear");
         s->splat_par ^= 1;
       }
       s->drop_cur = dst;
@@ -956,6 +1003,37 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   }
   HIPCHK(s, hipGetLastError());
   return WX_OK;
+}
+
+int wx_set_option(wx_sim *s, int option, int value)
+{
+  if (!s) return WX_E_INVALID;
+  switch (option) {
+  case WX_OPT_SPLAT_ORDER: {
+    if (value != 0 && value != 1) return fail(s, WX_E_INVALID, "wx_set_option: WX_OPT_SPLAT_ORDER takes 0 (atomics) or 1 (deterministic)");
+    if (value && s->n_drops > 0 && !s->det_val) { // the deposit records and the sort's scratch space, once
+      const size_t n = (size_t)s->n_drops;
+      for (int i = 0; i < 2; i++) {
+        if (int rc = dalloc(s, &s->det_key[i], n)) return rc;
+        if (int rc = dalloc(s, &s->det_idx[i], n)) return rc;
+      }
+      if (int rc = dalloc(s, &s->det_val, 5 * n)) return rc;
+      std::vector<int> iota(n);
+      for (size_t i = 0; i < n; i++) iota[i] = (int)i;
+      HIPCHK(s, hipMemcpy(s->det_idx[0], iota.data(), n * 4, hipMemcpyHostToDevice));
+      HIPCHK(s, hipcub::DeviceRadixSort::SortPairs(nullptr, s->det_tmp_bytes, s->det_key[0], s->det_key[1], s->det_idx[0], s->det_idx[1], s->n_drops, 0, 31,
+                                                   s->stream));
+      HIPCHK(s, hipMalloc(&s->det_tmp, s->det_tmp_bytes ? s->det_tmp_bytes : 16));
+    }
+    s->splat_order = value;
+    return WX_OK;
+  }
+  case WX_OPT_CHECK_LAUNCHES:
+    s->check_launches = value != 0;
+    return WX_OK;
+  default:
+    return fail(s, WX_E_INVALID, "wx_set_option: unknown option %d", option);
+  }
 }
 
 int wx_sync(wx_sim *s)

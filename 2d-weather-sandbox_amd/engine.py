@@ -33,6 +33,7 @@ EXPORTS = [
     "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_particles_keys",
     "wx_particles_contribute", "wx_particles_adopt", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns",
     "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait", "wx_set_comm_stream", "wx_step_overlap",
+    "wx_set_option",
 ]
 
 
@@ -79,6 +80,7 @@ def lib() -> C.CDLL:
     L.wx_step_overlap.argtypes = [vp, i32, C.c_uint]
     L.wx_set_comm_stream.argtypes = [vp, vp]
     L.wx_sync.argtypes = [vp]
+    L.wx_set_option.argtypes = [vp, i32, i32]
     L.wx_get_iter.argtypes = [vp]
     L.wx_get_iter.restype = i64
     L.wx_set_iter.argtypes = [vp, i64]
@@ -199,6 +201,13 @@ class Handle:
 
     def sync(self):
         self._chk(lib().wx_sync(self._h))
+
+    OPT_SPLAT_ORDER, OPT_CHECK_LAUNCHES = 1, 2
+
+    def set_option(self, option: int, value: int):
+        """wx_set_option: OPT_SPLAT_ORDER 1 = deterministic particle splats (sorted, droplet-index order); OPT_CHECK_LAUNCHES 1 =
+        synchronise and check after every kernel launch."""
+        self._chk(lib().wx_set_option(self._h, int(option), int(value)))
 
     @property
     def iter(self) -> int:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WX_ABI_VERSION 4
+#define WX_ABI_VERSION 5
 
 /* error codes */
 #define WX_OK 0
@@ -145,6 +145,18 @@ int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const f
  * refreshed on the device without a host round trip. */
 int wx_step(wx_sim *s, int n_iter);
 int wx_sync(wx_sim *s);
+
+/* Engine options (no reference counterpart).
+ * WX_OPT_SPLAT_ORDER: how the additive particle splats (gl.blendFunc(ONE, ONE) point sprites, app.js:5940-5953) are summed.
+ *   0 (default): fp32 atomics in arrival order -- like the reference's blend unit the result depends on the order;
+ *   1: deterministic -- every droplet records its deposit, the records are sorted by anchor texel (stable radix sort) and each
+ *      texel's deposits are added in droplet-index order, so the feedback / deposition textures (and everything downstream)
+ *      are a pure function of the state. Slower; meant for tests that compare coupled particle runs bit for bit.
+ * WX_OPT_CHECK_LAUNCHES: 1 = synchronise after every kernel launch of wx_step and report a fault with the kernel's name
+ *   (debugging; the launch status itself is always checked). */
+#define WX_OPT_SPLAT_ORDER 1
+#define WX_OPT_CHECK_LAUNCHES 2
+int wx_set_option(wx_sim *s, int option, int value);
 
 /* iterNum global (app.js:440) */
 int64_t wx_get_iter(const wx_sim *s);

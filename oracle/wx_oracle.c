@@ -1169,8 +1169,15 @@ static inline const float *texfetch4(const float *tex, int X, int Y, float u, fl
   return C4(tex, ix, iy);
 }
 
+/* accumulators of splat_order 1: one deposit per sprite at its anchor (i0 + 6, j0 + 6) of an (X+1) x (Y+1) grid, the 1-px
+ * sprites (inactive count into texel (0,0), lightning request into texel (1,0)) in their own slots */
+typedef struct {
+  float *acc; /* 5 floats per anchor: mass, heat, vapor | rain, snow */
+  float count, light[4];
+} anchors_t;
+
 static void splat(const wxo_params *p, float gposx, float gposy, float size, const float *feedback,
-                  const float *deposition, float *fb, float *dep)
+                  const float *deposition, float *fb, float *dep, anchors_t *an)
 {
   const int X = p->X, Y = p->Y;
   if (!(gposx >= -1.0f && gposx <= 1.0f && gposy >= -1.0f && gposy <= 1.0f)) return; /* clipped */
@@ -1192,6 +1199,25 @@ static void splat(const wxo_params *p, float gposx, float gposy, float size, con
     j0 = (int)ceilf(yw - h - 0.5f);
     j1 = j0 + (int)size - 1;
   }
+  if (an) {
+    if (size <= 1.0f) { /* the only 1-px sprites: texel (0,0) counts inactive droplets, texel (1,0) takes lightning requests */
+      if (j0 != 0 || i0 < 0 || i0 > 1) return;
+      if (i0 == 0)
+        an->count += feedback[0];
+      else
+        for (int c = 0; c < 4; c++) an->light[c] += feedback[c];
+      return;
+    }
+    const int q = i0 + 6, r = j0 + 6;
+    if (q < 0 || q > X || r < 0 || r > Y) return;
+    float *a = an->acc + 5 * ((size_t)r * (X + 1) + q);
+    a[0] += feedback[0];
+    a[1] += feedback[1];
+    a[2] += feedback[2];
+    a[3] += deposition[0];
+    a[4] += deposition[1];
+    return;
+  }
   for (int j = j0; j <= j1; j++) {
     if (j < 0 || j >= Y) continue;
     for (int i = i0; i <= i1; i++) {
@@ -1208,6 +1234,58 @@ static void splat(const wxo_params *p, float gposx, float gposy, float size, con
   }
 }
 
+/* 12 consecutive values with the index-anchored tree of the HIP engine (csrc/wx_kernels.h splat_box_tile): pairs
+ * p[i] = a[i] + a[i+1], quads q[i] = p[i] + p[i+2], s = (q[0] + q[4]) + q[8]; values outside the grid are 0 */
+static inline float tree12(const float *a) /* a[0..11] */
+{
+  const float q0 = (a[0] + a[1]) + (a[2] + a[3]);
+  const float q4 = (a[4] + a[5]) + (a[6] + a[7]);
+  const float q8 = (a[8] + a[9]) + (a[10] + a[11]);
+  return (q0 + q4) + q8;
+}
+
+/* splat_order 1: out(i, j) = sum of the anchors q in [i-5, i+6], r in [j-5, j+6]; columns (vertical sums) first, then rows.
+ * The textures were cleared before (app.js:5933-5934), so they are written, then the 1-px sprites are added. */
+static void box_sum_anchors(const wxo_params *p, const anchors_t *an, float *fb, float *dep)
+{
+  const int X = p->X, Y = p->Y, AP = X + 1;
+  float *V = (float *)calloc((size_t)AP * Y * 5, 4); /* vertical 12-sums: V[j][q][c] */
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < Y; j++)
+    for (int q = 0; q <= X; q++)
+      for (int c = 0; c < 5; c++) {
+        float a[12];
+        for (int k = 0; k < 12; k++) {
+          const int r = j - 5 + k;
+          a[k] = (r >= 0 && r <= Y) ? an->acc[5 * ((size_t)r * AP + q) + c] : 0.0f;
+        }
+        V[5 * ((size_t)j * AP + q) + c] = tree12(a);
+      }
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < Y; j++)
+    for (int i = 0; i < X; i++) {
+      float o[5];
+      for (int c = 0; c < 5; c++) {
+        float a[12];
+        for (int k = 0; k < 12; k++) {
+          const int q = i - 5 + k;
+          a[k] = (q >= 0 && q <= X) ? V[5 * ((size_t)j * AP + q) + c] : 0.0f;
+        }
+        o[c] = tree12(a);
+      }
+      float *f = C4(fb, i, j);
+      f[0] = o[0];
+      f[1] = o[1];
+      f[2] = o[2];
+      f[3] = 0.0f;
+      dep[2 * ((size_t)j * X + i)] = o[3];
+      dep[2 * ((size_t)j * X + i) + 1] = o[4];
+    }
+  free(V);
+  C4(fb, 0, 0)[0] += an->count;
+  for (int c = 0; c < 4; c++) C4(fb, 1, 0)[c] += an->light[c];
+}
+
 void wxo_precipitation(const wxo_params *p, float iterNum, int n_drops, const float *drops_in,
                        const float *base_in, const float *water_in, const float *lightning_in,
                        float *drops_out, float *fb, float *dep)
@@ -1216,6 +1294,11 @@ void wxo_precipitation(const wxo_params *p, float iterNum, int n_drops, const fl
   const int X = p->X, Y = p->Y;
   const float resX = (float)X, resY = (float)Y;
   const float initalMass = 0.15f;
+  anchors_t an_store = {NULL, 0.0f, {0.0f, 0.0f, 0.0f, 0.0f}}, *an = NULL;
+  if (p->splat_order == 1) {
+    an_store.acc = (float *)calloc((size_t)(X + 1) * (Y + 1) * 5, 4);
+    an = &an_store;
+  }
 
   for (int i = 0; i < n_drops; i++) {
     const float dropPosition[2] = {drops_in[5 * i], drops_in[5 * i + 1]};
@@ -1376,7 +1459,11 @@ void wxo_precipitation(const wxo_params *p, float iterNum, int n_drops, const fl
     drops_out[5 * i + 2] = newMass[0];
     drops_out[5 * i + 3] = newMass[1];
     drops_out[5 * i + 4] = fmaxf(newDensity, 0.0f);
-    splat(p, gpos[0], gpos[1], size, feedback, deposition, fb, dep);
+    splat(p, gpos[0], gpos[1], size, feedback, deposition, fb, dep, an);
+  }
+  if (an) {
+    box_sum_anchors(p, an, fb, dep);
+    free(an->acc);
   }
 }
 

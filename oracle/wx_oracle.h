@@ -53,6 +53,12 @@ typedef struct wxo_params {
   const float *varyings;
   /* particle splats: 0 = exact window coordinates; n>0 = snap to 1/2^n pixel first (SwiftShader: 4) */
   int32_t subpixel_bits;
+  /* particle splats: 0 = every covered texel receives the droplets' values in droplet-index order (what an in-order blend
+   * unit does; the pinned mode); 1 = the summation tree of the HIP engine's deterministic mode (WX_OPT_SPLAT_ORDER 1): per
+   * sprite ANCHOR texel the deposits are added in droplet-index order, then a 12x12 box sum with index-anchored trees
+   * (pairs, quads, (q0 + q4) + q8; columns first) -- the same real sum, a different fp32 association; validated against
+   * mode 0 to rounding in tests/test_oracle_golden.py */
+  int32_t splat_order;
 } wxo_params;
 
 typedef struct wxo_sim wxo_sim;

@@ -39,6 +39,7 @@ class OracleParams(C.Structure):
         ("enablePrecipitation", C.c_int32),
         ("varyings", C.c_void_p),
         ("subpixel_bits", C.c_int32),
+        ("splat_order", C.c_int32),
     ]
 
 

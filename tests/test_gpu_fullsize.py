@@ -111,6 +111,109 @@ def test_wet_launch_shapes_on_ragged_grids_vs_oracle(pkg, oracle, E, monkeypatch
     _run_pair(pkg, oracle, E, X, Y, state, _uniforms(pkg, Y), (1, 3, 5), FIELDS_WET)
 
 
+def _storm_population(N, X, Y, seed):
+    """BASELINE configs[4]'s droplet pool with a developed storm in it (instead of the survey's 2000 warm-up iterations): 40 % of
+    the droplets active -- rain and snow inside and below the cloud deck of synth.add_cloud_deck, some about to evaporate
+    (mass < 0.04), some about to hit the ground -- the rest inactive seeds of initRainDrops (app.js:4901-4913)."""
+    from weather_sandbox_amd import synth
+    rng = np.random.Generator(np.random.Philox(seed))
+    drops = synth.init_rain_drops(N)
+    na = (N * 2) // 5
+    drops[:na, 0] = rng.uniform(-1, 1, na).astype(np.float32)
+    drops[:na, 1] = rng.uniform(-0.98, 0.05, na).astype(np.float32)  # ground .. top of the deck (rows Y/4 .. Y/2 = -0.5 .. 0)
+    drops[:na, 2] = rng.uniform(0.02, 1.2, na).astype(np.float32)
+    drops[:na, 3] = np.where(rng.random(na) < 0.3, rng.uniform(0.05, 0.6, na), 0).astype(np.float32)
+    drops[:na, 4] = np.where(drops[:na, 3] > 0, np.float32(0.6), np.float32(1.0))
+    return drops, N - na
+
+
+@pytest.fixture(scope="module")
+def config4(pkg):
+    """BASELINE configs[4]: 16384 x 2048 terrain grid with a cloud deck + 1 048 576 droplets (shared by the tests below)."""
+    X, Y, N = 16384, 2048, 1 << 20
+    base, water, wall = _wet_state(pkg, X, Y, 51)
+    pkg.synth.add_cloud_deck(water, wall)
+    drops, n_inactive = _storm_population(N, X, Y, 52)
+    u = _uniforms(pkg, Y)
+    u["enablePrecipitation"] = 1
+    u["inactiveDroplets"] = float(n_inactive)
+    return X, Y, N, base, water, wall, drops, u
+
+
+def _particle_pair(pkg, oracle, E, cfg, det):
+    X, Y, N, base, water, wall, drops, u = cfg
+    u = dict(u, splat_order=1 if det else 0)
+    h = E.Handle(X, Y, N)
+    h.upload(base, water, wall, drops)
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    if det:
+        h.set_option(h.OPT_SPLAT_ORDER, 1)
+    o = oracle.OracleSim(X, Y, N)
+    o.upload(base, water, wall, drops)
+    o.set_params(u)
+    h.iter = o.iter = 1  # (iteration 0 would refresh the inactiveDroplets uniform from texel (0,0): covered by the small tests)
+    return h, o
+
+
+def test_config4_particles_16384x2048_1M_vs_oracle(pkg, oracle, E, config4):
+    """BASELINE configs[4] at size on one GPU, default (atomic) splat order, against the oracle: what is size dependent in the
+    particle path -- work lists over 32 768 splat tiles, the parity-double-buffered counters, the persistent box-sum / clear
+    loops capped at 2048 workgroups, the fb_zero tile flags the marching kernel trusts, 1 M random gathers. Iteration 1: droplet
+    state and inactive count exact, feedback / deposition to fp32 summation order (atomics vs droplet-index order), grid fields
+    bit-exact (they have not seen this iteration's feedback yet). Three more: same droplets active, wall masks bit-exact, fields to
+    the feedback's rounding."""
+    h, o = _particle_pair(pkg, oracle, E, config4, det=False)
+    N = config4[2]
+    h.step(1)
+    o.step(1)
+    d, od = h.read_particles(), o.field("DROPS")
+    assert np.array_equal(d, od)
+    was_inactive = config4[6][:, 2] < 0
+    spawned, retired = int((was_inactive & (d[:, 2] >= 0)).sum()), int((~was_inactive & (d[:, 2] < 0)).sum())
+    assert spawned > 50 and retired > 1000  # spawns and deposits / evaporations happened
+    del d, od
+    fb, ofb = h.read_rect("PRECIP_FB"), o.field("PRECIP_FB")
+    # texel (0,0): +1 per droplet that was inactive and stayed so (precipitationShader.vert:158-159)
+    assert round(float(fb[0, 0, 0])) == round(float(ofb[0, 0, 0])) == int(was_inactive.sum()) - spawned
+    assert np.abs(fb - ofb).max() <= 1e-6 * np.abs(ofb[1:]).max()
+    assert (np.abs(ofb[..., 0]) > 0).mean() > 0.2  # the storm covers a good part of the domain
+    del fb, ofb
+    dep, odep = h.read_rect("PRECIP_DEP"), o.field("PRECIP_DEP")
+    assert odep.max() > 0 and np.abs(dep - odep).max() <= 1e-6 * odep.max()
+    del dep, odep
+    _assert_equal(h, o, FIELDS_WET)
+    h.step(3)
+    o.step(3)
+    d, od = h.read_particles(), o.field("DROPS")
+    assert np.array_equal(d[:, 2] >= 0, od[:, 2] >= 0), "same droplets active"
+    assert np.abs(d - od).max() <= 1e-5
+    del d, od
+    _assert_equal(h, o, ["WALL_CUR"])
+    for f, tol in (("BASE_CUR", 1e-3), ("WATER_CUR", 1e-4)):
+        a, b = h.read_rect(f), o.field(f)
+        assert np.abs(a - b).max() <= tol, f
+        del a, b
+    h.close()
+    o.close()
+    gc.collect()
+
+
+def test_config4_particles_deterministic_order_bit_exact(pkg, oracle, E, config4):
+    """The same configuration with the deterministic splat order on both sides (WX_OPT_SPLAT_ORDER 1 / the oracle's splat_order 1:
+    per-anchor sums in droplet-index order + index-anchored box trees): the coupled particle <-> grid run is compared BIT FOR BIT --
+    droplet pool, feedback, deposition and every grid field, four iterations."""
+    h, o = _particle_pair(pkg, oracle, E, config4, det=True)
+    for n in (1, 3):
+        h.step(n)
+        o.step(n)
+        assert np.array_equal(h.read_particles(), o.field("DROPS"))
+        _assert_equal(h, o, ["PRECIP_FB", "PRECIP_DEP"] + FIELDS_WET)
+    assert np.array_equal(h.read_rect("LIGHTNING"), o.field("LIGHTNING"))
+    h.close()
+    o.close()
+    gc.collect()
+
+
 def test_config3_grid_32768x4096_dry_vs_oracle(pkg, oracle, E):
     """The north-star size on one GPU, dry stencil (initial_T[Y+1] with Y = 4096, indices beyond 2^27 cells)."""
     X, Y = 32768, 4096

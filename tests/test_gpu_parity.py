@@ -307,6 +307,40 @@ def test_particles_vs_oracle(pkg, oracle, golden, E, fused):
     assert np.abs(h.read_rect("BASE_CUR")[..., 3] - o.field("BASE_CUR")[..., 3]).max() <= 1e-3
 
 
+def test_particles_deterministic_order_coupled_run_bit_exact(pkg, oracle, golden, E, fused):
+    """WX_OPT_SPLAT_ORDER 1 (deposit records sorted by anchor texel, each texel's deposits added in droplet-index order, order-free
+    box trees) against the oracle's matching summation tree (splat_order 1): the COUPLED run -- droplets feed the grid through the
+    feedback textures, the grid feeds the droplets -- stays bit for bit equal, iteration after iteration."""
+    g, u = golden("precip64")
+    u = dict(u, quad_scale=0, enablePrecipitation=1, splat_order=1)
+    X, Y = int(g["X"]), int(g["Y"])
+    h, o = _make_pair(pkg, oracle, E, X, Y, g["in_base"], g["in_water"], g["in_wall"], u, drops=g["in_drops"])
+    h.set_option(h.OPT_SPLAT_ORDER, 1)
+    for n in (1, 3, 8):
+        h.step(n)
+        o.step(n)
+        assert np.array_equal(h.read_particles(), o.field("DROPS"))
+        assert np.array_equal(h.read_rect("PRECIP_FB"), o.field("PRECIP_FB"))
+        assert np.array_equal(h.read_rect("PRECIP_DEP"), o.field("PRECIP_DEP"))
+        assert np.array_equal(h.read_rect("LIGHTNING"), o.field("LIGHTNING"))
+        _assert_grid_equal(h, o)
+    assert np.abs(h.read_rect("PRECIP_FB")).max() > 0 and np.abs(h.read_rect("PRECIP_DEP")).max() > 0
+    # two runs of the deterministic mode are identical; the atomic mode agrees with it to summation order
+    h2 = E.Handle(X, Y, len(g["in_drops"]))
+    h2.upload(g["in_base"], g["in_water"], g["in_wall"], g["in_drops"])
+    h2.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    h2.step(12)
+    assert np.abs(h2.read_particles() - h.read_particles()).max() <= 1e-5
+    with pytest.raises(E.WxError):
+        h.set_option(99, 1)
+    h.set_option(h.OPT_CHECK_LAUNCHES, 1)  # synchronise-and-check after every launch: same results
+    h.step(1)
+    o.step(1)
+    assert np.array_equal(h.read_particles(), o.field("DROPS"))
+    h.close()
+    h2.close()
+
+
 def test_read_rect_contract(pkg, golden, E):
     g, u = golden("synth64")
     X, Y = int(g["X"]), int(g["Y"])
