@@ -85,7 +85,7 @@ __device__ __forceinline__ MDryFp make_fp(const MDryAcc &a, int dx0, int dy0) { 
 // so the pass-through store is dropped and the wall buffers are not swapped: 36 B/cell, SURVEY's A_dry.
 template <bool WRITE_DISP, bool WRITE_WALL>
 __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u_arg, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows,
-                                                                     int n_full, int n_half, int band_h, int n_seg
+                                                                     int n_full, int n_half, int band_h, int n_seg, int strip_lo
 #ifdef WX_MARCH_TIMING
                                                                      , unsigned long long *cycles
 #endif
@@ -114,9 +114,9 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
   const int total = n_strips * n_seg, k = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int first = (int)(((long long)k * total) >> 3), count = (int)(((long long)(k + 1) * total) >> 3) - first;
   if (j >= count) return;
-  const int item = first + j, seg = item / n_strips, strip = item - seg * n_strips;
+  const int item = first + j, seg = item / n_strips, strip = strip_lo + item - seg * n_strips;
 #else
-  const int strip = blockIdx.x % n_strips, seg = blockIdx.x / n_strips;
+  const int strip = strip_lo + blockIdx.x % n_strips, seg = blockIdx.x / n_strips;
 #endif
   const int c_out = strip * MOUT + lane - 2;         // output column of this lane (may be >= X in the last strip)
   const int col = wrapmod(c_out, X);                 // column this lane loads / computes
@@ -285,11 +285,17 @@ inline int march_seg_rows(int n_strips, int Y)
   return maxseg < Y ? maxseg : Y;
 }
 
+inline int march_dry_strips(const Geo &g) { return (g.X + MOUT - 1) / MOUT; }
+
+// A launch covers the strips [strip_lo, strip_lo + strip_count) (strip_count < 0: all of them): the whole width normally, the edge
+// strips and the interior separately where a slab overlaps its halo exchange with compute (cf. launch_march_wet). The row
+// segmentation is the one of the whole width, so that every strip is cut the same way whichever launch computes it.
 inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, const DryIn &in, const DryOut &out, bool write_disp, bool write_wall,
-                             hipStream_t stream)
+                             hipStream_t stream, int strip_lo = 0, int strip_count = -1)
 {
-  const int n_strips = (g.X + MOUT - 1) / MOUT;
-  int seg_rows = march_seg_rows(n_strips, g.Y);
+  const int n_strips_all = march_dry_strips(g), n_strips = strip_count < 0 ? n_strips_all : strip_count;
+  if (n_strips <= 0) return;
+  int seg_rows = march_seg_rows(n_strips_all, g.Y);
   int n_seg = (g.Y + seg_rows - 1) / seg_rows, n_full = n_seg, n_half = 0, band_h = 0;
   if (WX_MARCH_XCD && WX_MARCH_BANDS && !getenv("WX_MARCH_NOTAIL") && !getenv("WX_MARCH_SEG") && g.Y % 8 == 0) {
     int R = WX_MARCH_BAND_SEG;
@@ -312,10 +318,10 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
 #ifdef WX_MARCH_TIMING
   static unsigned long long *cyc = nullptr;
   static int calls = 0;
-  if (!cyc) hipMalloc((void **)&cyc, 16 * (size_t)n_strips * n_seg);
-#define WX_LAUNCH_M(D, W) hipLaunchKernelGGL((k_march_dry<D, W>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, cyc)
+  if (!cyc && hipMalloc((void **)&cyc, 16 * (size_t)n_strips_all * n_seg) != hipSuccess) return;
+#define WX_LAUNCH_M(D, W) hipLaunchKernelGGL((k_march_dry<D, W>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, cyc)
 #else
-#define WX_LAUNCH_M(D, W) hipLaunchKernelGGL((k_march_dry<D, W>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg)
+#define WX_LAUNCH_M(D, W) hipLaunchKernelGGL((k_march_dry<D, W>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo)
 #endif
   if (write_disp) {
     if (write_wall) WX_LAUNCH_M(true, true); else WX_LAUNCH_M(true, false);

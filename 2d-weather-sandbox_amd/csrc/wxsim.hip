@@ -128,7 +128,9 @@ struct wx_sim {
   size_t det_tmp_bytes = 0;
   bool water_trivial = false; // the water texture is known to be 0 in air cells and only the wall marker in wall cells: set by wx_upload,
                               // cleared by every step that can put water there (anything but the water-free dry iteration)
-  bool ghost_check = false;   // ghost columns were unpacked while water_trivial: DevState::ghost_nontrivial must be read before relying on it
+  bool ghost_check = false;   // ghost columns were unpacked while water_trivial: DevState::ghost_nontrivial is validated by the next blocking call
+  bool local_water_free = false; // what the last upload established for THIS handle's cells (wx_water_free)
+  bool slab_dry_agreed = false;  // the host asserted that every slab of the domain was uploaded water-free (wx_slab_assert_water_free)
   // profiling
   bool profiling = false;
   std::vector<ProfRec> prof;
@@ -546,19 +548,49 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
   return WX_OK;
 }
 
-// BASELINE configs[1] (pass_mask == WX_PASS_DRY): velocity + advection + pressure in one kernel (wx_dry.h).
+// BASELINE configs[1] (pass_mask == WX_PASS_DRY): velocity + advection + pressure in one kernel.
 // The masked-off boundary pass makes water_0 a copy of water_1, so advection's water input is water[1].
-int iterate_dry(wx_sim *s, bool write_disp)
+// Does the dry iteration carry water (brush / airplane / sounding forcing can create it, an upload can hold it)?
+static bool dry_has_water(const wx_sim *s)
 {
-  const bool water = !(s->water_trivial && s->p.userInputType < 0 && s->p.airplaneValues[3] == 0.0f && s->p.soundingForcing == 0.0f);
+  return !(s->water_trivial && s->p.userInputType < 0 && s->p.airplaneValues[3] == 0.0f && s->p.soundingForcing == 0.0f);
+}
+// ... and does it run the row-marching kernel (wx_march.h: the water-free state, strips of 60 columns), which can be launched
+// per strip range, or the tiled one (wx_dry.h)?
+static bool dry_marches(const wx_sim *s) { return !dry_has_water(s) && s->dry_march && s->X >= 64; }
+
+// edge_mode: as iterate_march_wet (marching kernel only)
+int iterate_dry(wx_sim *s, bool write_disp, int edge_mode = 0)
+{
+  const bool water = dry_has_water(s);
   DryIn in{s->base[0], s->wall[0], s->water[1]};
   DryOut out{s->base[1], s->wall[1], s->water[2], s->base[2]};
   // advection changes the wall texture only through the brush, an airplane crash or by clamping a negative vegetation byte
   const bool wall_const = s->wall_veg_ok && s->p.userInputType < 0 && !(s->p.airplaneValues[3] > 0.9f);
   bool wall_written = true;
-  if (!water && s->dry_march && s->X >= 64) {
+  if (dry_marches(s)) {
     ProfScope ps(s, K_MARCH_DRY);
-    launch_march_dry(s->geo, s->uni, s->full_ctx, in, out, write_disp, !wall_const, s->stream);
+    const int n_strips = march_dry_strips(s->geo);
+    // edge strips: every output column wx_halo_pack reads ([halo, 2*halo) and its mirror) and every strip that reads ghost columns
+    const int nl = s->halo > 0 ? (2 * s->halo - 1) / MOUT + 1 : 0, nr0 = s->halo > 0 ? (s->X - 2 * s->halo) / MOUT : n_strips;
+    auto launch = [&](int lo, int cnt) { launch_march_dry(s->geo, s->uni, s->full_ctx, in, out, write_disp, !wall_const, s->stream, lo, cnt); };
+    if (edge_mode == 0 || s->halo == 0 || nl >= nr0) {
+      if (edge_mode & 2) wait_unpacked(s);
+      launch(0, -1);
+    } else {
+      const bool interior_first = (edge_mode & 2) && s->unpack_pending;
+      if (interior_first) { // ghosts still in flight: everything that does not read them goes first
+        launch(nl, nr0 - nl);
+        wait_unpacked(s);
+      }
+      launch(0, nl);
+      launch(nr0, n_strips - nr0);
+      if (edge_mode & 1) { // the columns the neighbours need are final: let the comm stream pack them while the interior computes
+        hipEventRecord(s->ev_edges, s->stream);
+        s->edges_recorded = true;
+      }
+      if (!interior_first) launch(nl, nr0 - nl);
+    }
     LAUNCH_CHECK(s, "march_dry");
     wall_written = !wall_const;
   } else {
@@ -762,7 +794,9 @@ int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wa
       const float x_expected = wl[1] == 0 ? (wl[0] == 2 ? 1002.0f : 1001.0f) : 0.0f;
       trivial = (w[0] == x_expected) && w[1] == 0.0f && w[2] == 0.0f && w[3] == 0.0f && wl[3] >= 0;
     }
-    s->water_trivial = trivial;
+    s->local_water_free = trivial;
+    // a slab may rely on it only once the host has established it for the neighbours too (their ghost columns flow in)
+    s->water_trivial = trivial && (s->halo == 0 || s->slab_dry_agreed);
     bool veg_ok = true;
     for (size_t i = 0; i < n && veg_ok; i++) veg_ok = wall[4 * i + 3] >= 0;
     s->wall_veg_ok = veg_ok;
@@ -852,7 +886,7 @@ int wx_setup_columns(wx_sim *s, const int32_t *wall_rows, const uint8_t *sea_col
   hipError_t e = hipStreamSynchronize(s->stream); // sea32 and the caller's arrays may go away now
   hipFree(scratch);
   if (e != hipSuccess) return fail(s, WX_E_DEVICE, "wx_setup_columns: %s", hipGetErrorString(e));
-  s->water_trivial = false;
+  s->water_trivial = s->local_water_free = false;
   s->wall_veg_ok = true; // k_setup_columns clamps the vegetation to 0..127
   return reset_after_upload(s, drops);
 }
@@ -898,14 +932,6 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
     HIPCHK(s, hipStreamWaitEvent(s->stream, s->ev_copy_done, 0));
     s->copy_in_flight = false;
   }
-  if (dry && s->water_trivial && s->ghost_check) { // a neighbour's ghost columns arrived since the last look: do they carry water?
-    int flag = 0;
-    wait_unpacked(s); // k_halo_unpack sets the flag on the comm stream: order the readback behind it
-    HIPCHK(s, hipMemcpyAsync(&flag, &s->state->ghost_nontrivial, 4, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(s, hipStreamSynchronize(s->stream));
-    s->ghost_check = false;
-    if (flag) s->water_trivial = s->wall_veg_ok = false;
-  }
   // the vegetation byte stays known non-negative only while nothing but the brush-free dry iteration touches the wall texture
   if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] > 0.9f) s->wall_veg_ok = false;
   // ... and the water texture stays known trivial only through water-free dry iterations (iterate_dry's `water == false` case)
@@ -918,9 +944,12 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
                   n_iter, s->period_j, s->halo, (s->halo - 6) / WX_SLAB_CONE);
   }
   // overlap needs the kernel that can be launched per strip range; everything else orders the exchange on the compute stream
-  const bool can_split = fused && !precip && s->comm_stream != nullptr && s->halo > 0;
+  const bool can_split = (fused || (dry && dry_marches(s))) && !precip && s->comm_stream != nullptr && s->halo > 0;
   if (!can_split) wait_unpacked(s);
-  if (!fused) light_to_rgba(s); // the per-pass / dry kernels take the light textures interleaved (behind the unpack: it reads ghost columns)
+  if (!fused && s->light_planar) { // the per-pass / dry kernels take the light textures interleaved (the conversion reads ghost columns)
+    wait_unpacked(s);
+    light_to_rgba(s);
+  }
   s->edges_recorded = false;
   for (int it = 0; it < n_iter; it++) {
     int edge_mode = 0;
@@ -928,7 +957,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
     if (can_split && it == 0 && !(edge_mode & 2)) wait_unpacked(s);
     int rc;
     if (dry)
-      rc = iterate_dry(s, precip || it == n_iter - 1);
+      rc = iterate_dry(s, precip || it == n_iter - 1, edge_mode);
     else if (fused)
       rc = iterate_march_wet(s, it == n_iter - 1, precip, edge_mode);
     else
@@ -1036,12 +1065,40 @@ int wx_set_option(wx_sim *s, int option, int value)
   }
 }
 
+// Ghost columns were unpacked while the handle relied on the host's assertion that the whole domain is water-free: k_halo_unpack
+// checked every ghost texel on the device; a blocking call is where the verdict is collected (never a silent divergence).
+static int validate_ghost_flag(wx_sim *s)
+{
+  if (!s->ghost_check) return WX_OK;
+  int flag = 0;
+  wait_unpacked(s);
+  HIPCHK(s, hipMemcpyAsync(&flag, &s->state->ghost_nontrivial, 4, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(s, hipStreamSynchronize(s->stream));
+  s->ghost_check = false;
+  if (flag) {
+    s->water_trivial = s->wall_veg_ok = false;
+    return fail(s, WX_E_STATE, "a neighbour's ghost columns carry water (or a negative vegetation byte) although wx_slab_assert_water_free(1) was "
+                               "called: the water-free dry iteration that ran since is invalid");
+  }
+  return WX_OK;
+}
+
+int wx_water_free(const wx_sim *s) { return s && s->local_water_free ? 1 : 0; }
+
+int wx_slab_assert_water_free(wx_sim *s, int agreed)
+{
+  if (!s) return WX_E_INVALID;
+  s->slab_dry_agreed = agreed != 0;
+  s->water_trivial = s->local_water_free && (s->halo == 0 || s->slab_dry_agreed);
+  return WX_OK;
+}
+
 int wx_sync(wx_sim *s)
 {
   if (!s) return WX_E_INVALID;
   if (s->comm_stream) HIPCHK(s, hipStreamSynchronize(s->comm_stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
-  return WX_OK;
+  return validate_ghost_flag(s);
 }
 
 int64_t wx_get_iter(const wx_sim *s) { return s ? s->iter : -1; }
@@ -1107,6 +1164,7 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
     return WX_OK;
   }
   wait_unpacked(s); // ghost columns written on the comm stream are part of what a readback sees
+  if (int rc = validate_ghost_flag(s)) return rc;
   if (field == WX_FIELD_EMITTED) {
     if (w <= 0 || h <= 0 || x < 0 || y < 0 || x + w > s->X || y + h > s->Y)
       return fail(s, WX_E_RANGE, "wx_read_rect: rect (%d,%d %dx%d) outside %dx%d (no wrap)", x, y, w, h, s->X, s->Y);

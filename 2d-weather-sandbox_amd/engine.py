@@ -33,7 +33,7 @@ EXPORTS = [
     "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_particles_keys",
     "wx_particles_contribute", "wx_particles_adopt", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns",
     "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait", "wx_set_comm_stream", "wx_step_overlap",
-    "wx_set_option",
+    "wx_set_option", "wx_water_free", "wx_slab_assert_water_free",
 ]
 
 
@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
     L.wx_set_comm_stream.argtypes = [vp, vp]
     L.wx_sync.argtypes = [vp]
     L.wx_set_option.argtypes = [vp, i32, i32]
+    L.wx_water_free.argtypes = [vp]
+    L.wx_slab_assert_water_free.argtypes = [vp, i32]
     L.wx_get_iter.argtypes = [vp]
     L.wx_get_iter.restype = i64
     L.wx_set_iter.argtypes = [vp, i64]
@@ -201,6 +203,14 @@ class Handle:
 
     def sync(self):
         self._chk(lib().wx_sync(self._h))
+
+    def water_free(self) -> bool:
+        """Did the last upload find this handle's cells water-free (wx_water_free)?"""
+        return bool(lib().wx_water_free(self._h))
+
+    def slab_assert_water_free(self, agreed: bool):
+        """The host's assertion that EVERY slab of the domain was uploaded water-free (wx_slab_assert_water_free)."""
+        self._chk(lib().wx_slab_assert_water_free(self._h, 1 if agreed else 0))
 
     OPT_SPLAT_ORDER, OPT_CHECK_LAUNCHES = 1, 2
 

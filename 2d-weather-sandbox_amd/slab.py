@@ -89,6 +89,12 @@ class HipSlabEngine:
     def upload(self, base, water, wall, drops=None):
         self.h.upload(base, water, wall, drops)
 
+    def water_free(self) -> bool:
+        return self.h.water_free()
+
+    def assert_water_free(self, agreed: bool):
+        self.h.slab_assert_water_free(agreed)
+
     # particle pool reconciliation (device tensors in, device tensors out)
     def new_particle_buffers(self):
         """(claim keys, droplet states): one extra int / five extra floats at the end carry the lightning state."""
@@ -158,6 +164,19 @@ class SlabSim:
             if self._stage:
                 self._hsend = [torch.empty_like(b, device="cpu") for b in self.send]
                 self._hrecv = [torch.empty_like(b, device="cpu") for b in self.recv]
+            self.agree_water_free()
+
+    def agree_water_free(self):
+        """The water-free dry iteration (36 B/cell) is only valid on a slab if NO slab of the domain carries water (ghost columns
+        flow in from the neighbours): all-reduce(MIN) of what each rank's upload found, once per upload -- so that no step ever
+        has to look at the ghost columns on the host (the device validates them at every unpack, wx_slab_assert_water_free)."""
+        e = self.engine
+        if self.world == 1 or not hasattr(e, "water_free"):
+            return
+        dev = self.send[0].device if (self.send[0].is_cuda and not self._stage) else torch.device("cpu")
+        t = torch.tensor([1 if e.water_free() else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        e.assert_water_free(bool(int(t.item())))
 
     @property
     def handle(self):
@@ -256,6 +275,7 @@ class SlabSim:
         """Re-upload this rank's slab (local arrays incl. ghost columns): the ghost columns are fresh again, so the exchange
         period starts over and the next step does not run the interior-first split against an exchange that never happened."""
         self.engine.upload(base, water, wall, drops)
+        self.agree_water_free()
         self._since_exchange = 0
         self._exchanged = False
         if self.particles and hasattr(self.engine, "period_begin"):
@@ -270,6 +290,16 @@ class SlabSim:
         x0, xo = slab_columns(X, rank, world)
         eng = HipSlabEngine(X, Y, x0, xo, halo, device, 0 if drops is None else len(drops), rank)
         eng.h.setup_columns(pkg.synth.terrain_columns(X, Y, cols=(x0 - halo, xo + 2 * halo), cloud_deck=cloud_deck), drops)
+        eng.set_params(u)
+        return cls(eng, rank, world, halo)
+
+    @classmethod
+    def from_dry_generator(cls, pkg, X: int, Y: int, u: Dict[str, Any], rank: int, world: int, device: torch.device,
+                           halo: int = DEFAULT_HALO, flow_sigma: float = 0.0) -> "SlabSim":
+        """BASELINE configs[1]'s dry-air state (synth.dry_grid: every value a function of the GLOBAL column), this rank's slab only."""
+        x0, xo = slab_columns(X, rank, world)
+        eng = HipSlabEngine(X, Y, x0, xo, halo, device, 0, rank)
+        eng.upload(*pkg.synth.dry_grid(X, Y, cols=(x0 - halo, xo + 2 * halo), flow_sigma=flow_sigma))
         eng.set_params(u)
         return cls(eng, rank, world, halo)
 

@@ -130,17 +130,38 @@ def terrain_grid(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: float
     return base, water, wall
 
 
-def dry_grid(X: int, Y: int, gui=None, seed: int = 1234, noise_K: float = 0.05):
-    """BASELINE config 2: inert floor row, dry still air, T = initial_T[y] + N(0, noise_K)."""
+_DRY_BLOCK = 256  # columns per random-number block of dry_grid
+
+
+def dry_grid(X: int, Y: int, gui=None, seed: int = 1234, noise_K: float = 0.05, cols=None, flow_sigma: float = 0.0):
+    """BASELINE config 2: inert floor row, dry air, T = initial_T[y] + N(0, noise_K); still (``flow_sigma`` 0) or with a
+    developed velocity field v ~ N(0, flow_sigma) cells / iteration (what the parity tests seed: back-traces that leave the lane's
+    own cell). The random numbers are drawn per block of 256 GLOBAL columns (Philox keyed by seed and block), so
+    ``cols=(start, count)`` -- the columns ``(start + i) mod X`` of the X-wide domain, a slab with its ghost columns -- tiles the
+    whole-domain result without generating it."""
     gui = params.merge_settings(None) if gui is None else gui
     sim_h = float(gui["simHeight"])
     dry_lapse = sim_h * float(gui["dryLapseRate"]) / 1000.0
     T0 = params.initial_temperature_profile(Y, sim_h, dry_lapse)
-    rng = np.random.Generator(np.random.Philox(seed))
-    base = np.zeros((Y, X, 4), np.float32)
-    water = np.zeros((Y, X, 4), np.float32)
-    wall = np.zeros((Y, X, 4), np.int8)
-    base[..., 3] = T0[:Y][:, None] + rng.normal(0.0, noise_K, (Y, X)).astype(np.float32)
+    gcol = np.arange(X) if cols is None else (cols[0] + np.arange(cols[1])) % X
+    n = len(gcol)
+    base = np.zeros((Y, n, 4), np.float32)
+    water = np.zeros((Y, n, 4), np.float32)
+    wall = np.zeros((Y, n, 4), np.int8)
+    base[..., 3] = T0[:Y][:, None]
+    blk = gcol // _DRY_BLOCK
+    for b in np.unique(blk):
+        rng = np.random.Generator(np.random.Philox(key=[seed, int(b)]))
+        w = min(_DRY_BLOCK, X - int(b) * _DRY_BLOCK)
+        noise = [rng.standard_normal((Y, w), dtype=np.float32) for _ in range(3 if flow_sigma else 1)]  # (T first: same with or without flow)
+        sel = np.nonzero(blk == b)[0]
+        loc = gcol[sel] - int(b) * _DRY_BLOCK
+        if len(sel) == sel[-1] - sel[0] + 1 and len(loc) == loc[-1] - loc[0] + 1:  # (the usual case: one contiguous run -> slices)
+            sel, loc = slice(sel[0], sel[-1] + 1), slice(loc[0], loc[-1] + 1)
+        base[:, sel, 3] += noise[0][:, loc] * np.float32(noise_K)
+        if flow_sigma:
+            base[1:, sel, 0] += noise[1][1:, loc] * np.float32(flow_sigma)
+            base[1:, sel, 1] += noise[2][1:, loc] * np.float32(flow_sigma)
     yy = np.arange(Y)[:, None]
     wall[..., 1] = np.clip(yy, 0, 127)
     wall[..., 2] = np.clip(yy, -127, 127)

@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: Mcell-steps/s of the simulation iteration on MI355X.
 
-`python bench.py --gpus N --steps K --warmup W`. A "step" is ONE simulation iteration (all grid passes +
-lighting; BASELINE.json configs[2]) over the 16384 x 2048 synthetic terrain grid, issued the way the reference's
-frame loop issues them: frames of IterPerFrame = 10 iterations (app.js:398), i.e. the display-only outputs (curl,
-post-boundary water, post-advection base) are produced once per 10 iterations. For N > 1 the same grid is cut into
-N column slabs (strong scaling) with a ring halo exchange over RCCL.
-Prints one JSON line on rank 0 (contract in the task description): throughput with inputs resident in HBM,
-plus `roofline` (dominant kernel, HIP-event timed on the engine's stream), `cpu_baseline` (the CPU oracle timed on
-this box's host cores, N=1 only) and `north_star_dry` (N=1 only): BASELINE.json's north-star stencil -- the fused
-pressure + velocity + advection kernel on a 32768 x 4096 dry grid -- measured in the same process with its own roofline.
+`python bench.py --gpus N --steps K --warmup W`. A "step" is ONE simulation iteration (all grid passes + lighting; BASELINE.json
+configs[2]) over the 16384 x 2048 synthetic terrain grid, issued the way the reference's frame loop issues them: frames of
+IterPerFrame = 10 iterations (app.js:398), i.e. the display-only outputs (curl, post-boundary water, post-advection base) are
+produced once per 10 iterations (`--frame 1` = every iteration, round 1's definition; both are in the N = 1 line). The fluid MOVES:
+a seeded velocity field (sigma = 0.2 cells / iteration, `--flow`) is added on the device before the warm-up, so back-traces leave
+the lane's own cell; the figure for the still start state is reported next to it (`at_rest`).
+For N > 1 the same grid is cut into N column slabs (strong scaling) with a ring halo exchange over RCCL, overlapped with compute
+on a side stream; `--workload dry --X 32768 --Y 4096` runs BASELINE's north-star stencil the same way. `--verify` makes an N-rank run
+self-validating: every rank checksums its owned columns and rank 0 compares them with an undecomposed run of the same state.
+Prints one JSON line on rank 0 (contract in the task description): throughput with inputs resident in HBM, plus `roofline`
+(dominant kernel, HIP-event timed on the engine's stream), `cpu_baseline` (the CPU oracle timed on this box's host cores, N = 1 only),
+`hbm_ceiling` (tools/ubench_hbm: read / write / copy streams with the kernels' own access pattern) and `north_star_dry` (N = 1 only):
+BASELINE.json's north-star stencil -- the fused pressure + velocity + advection kernel on a 32768 x 4096 dry grid -- measured in
+the same process with its own roofline, at rest and on the moving fluid.
 """
 import argparse
+import datetime
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured float4-copy ceiling
 
 # Algorithmic (compulsory) bytes per cell and launch for each kernel -- DESIGN.md section 4.
 # fp32 RGBA texel = 16 B, wall RGBA8I = 4 B, curl 4 B, vortForce 8 B.
@@ -35,6 +42,7 @@ ALGO_BYTES = {
     "fused_dry_vel_advect_pressure": 36,
     "march_dry_vel_advect_pressure": 36,
 }
+VERIFY_FIELDS = ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1")
 
 
 def parse():
@@ -45,12 +53,15 @@ def parse():
     ap.add_argument("--X", type=int, default=16384)
     ap.add_argument("--Y", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the two short rocprofv3 --pmc passes that fill roofline.traffic")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the short rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--workload", choices=["wet", "dry"], default="wet",
                     help="wet: BASELINE configs[2] (default, the metric's config); dry: configs[1] pressure+velocity+advection only")
-    ap.add_argument("--particles", type=int, default=0, help="also run the particle pass with N droplets (BASELINE configs[4]; N=1 GPU only)")
+    ap.add_argument("--particles", type=int, default=0, help="also run the particle pass with N droplets (BASELINE configs[4])")
     ap.add_argument("--frame", type=int, default=10, help="iterations per wx_step call (the reference's IterPerFrame, app.js:398)")
+    ap.add_argument("--flow", type=float, default=0.2, help="std of the seeded velocity field, cells / iteration (0: fluid at rest)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 32768 x 4096 dry north-star measurement (N=1)")
+    ap.add_argument("--no-extras", action="store_true", help="skip at_rest / frame-1 / hbm_ceiling side measurements (N=1)")
+    ap.add_argument("--verify", action="store_true", help="N > 1: checksum every rank's owned columns against an undecomposed run on rank 0")
     a = ap.parse_args()
     a.frame = max(1, a.frame)  # (0 or a negative value would never advance run_frames)
     return a
@@ -83,6 +94,19 @@ def cpu_baseline(pkg, budget_s=12.0):
             "sample": f"CPU oracle (C/OpenMP restatement, not the reference itself), {X}x{Y} terrain grid, {n} iterations, {dt:.1f} s"}
 
 
+def hbm_ceiling(X, Y):
+    """tools/ubench_hbm (built by __graft_entry__.build()): float4 read / write / copy streams and the wet kernel's stream mix with the
+    kernels' own access pattern -- the practical ceiling the roofline fractions are to be read against."""
+    exe = os.path.join(ROOT, "tools", "ubench_hbm")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, str(X), str(Y), "64", "15"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120, check=True).stdout.decode()
+        return json.loads(out.strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
 KERNEL_SYMBOL = {  # profile name -> substring of the kernel symbol rocprofv3 reports
     "march_wet_full_iteration": "k_march_wet",
     "fused_dry_vel_advect_pressure": "k_fused_dry", "march_dry_vel_advect_pressure": "k_march_dry", "advection": "k_advection", "boundary": "k_boundary", "lighting": "k_lighting",
@@ -96,24 +120,23 @@ def pmc_traffic(a, kernel, X=None, Y=None, workload=None):
     wide coalesced read stream). Re-runs this script for a few steps under rocprofv3; returns None on any problem."""
     import shutil
     import sqlite3
-    import subprocess
     import tempfile
     exe = shutil.which("rocprofv3")
     sym = KERNEL_SYMBOL.get(kernel)
     if not exe or not sym:
-        return None, None
+        return None, None, None
     vals = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT"):
             d = tempfile.mkdtemp(prefix="wxpmc_", dir="/tmp")
             # one whole frame of warm-up, one measured: the averaged launches have the timed region's mix of plain iterations and the
             # one per frame that also writes the display fields
             nfr = max(1, int(a.frame))
             cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", str(nfr), "--warmup", str(nfr),
                    "--X", str(X or a.X), "--Y", str(Y or a.Y), "--workload", workload or a.workload, "--no-cpu-baseline", "--no-pmc",
-                   "--no-north-star", "--frame", str(a.frame)]
+                   "--no-north-star", "--no-extras", "--frame", str(a.frame), "--flow", str(a.flow)]
             env = dict(os.environ, TMPDIR="/tmp")
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
             c = sqlite3.connect(dbs[0])
             rows = c.execute("select k.kernel_name, d.event_id, d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol k "
@@ -126,16 +149,43 @@ def pmc_traffic(a, kernel, X=None, Y=None, workload=None):
                     per.append(v)
             vals[counter] = sum(per) / len(per)
             shutil.rmtree(d, ignore_errors=True)
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, vals["SQ_INSTS_VALU"]
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, vals["SQ_INSTS_VALU"], vals["SQ_LDS_BANK_CONFLICT"]
     except Exception:
-        return None, None
+        return None, None, None
+
+
+def run_frames(step, n, frame):
+    """n iterations as frames of `frame` iterations, like the reference's draw() loop."""
+    done = 0
+    while done < n:
+        k = min(frame, n - done)
+        step(k)
+        done += k
+
+
+def timed_run(h, steps, frame, profile=True):
+    """(seconds, profile dict) of `steps` iterations on a single handle, synchronised on both sides."""
+    import torch
+    if profile:
+        h.profile(True)
+    h.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_frames(h.step, steps, frame)
+    h.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = h.profile_read() if profile else {}
+    if profile:
+        h.profile(False)
+    return dt, prof
 
 
 def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
     """BASELINE.json north_star: the fused pressure + velocity + advection stencil on a 32768 x 4096 dry grid (configs[1]'s
-    passes at configs[3]'s size) on one GPU, same process, own roofline. A_dry = 36 B/cell-step."""
-    import numpy as np
-    import torch
+    passes at configs[3]'s size) on one GPU, same process, own roofline. A_dry = 36 B/cell-step. Measured on the still
+    start state of SURVEY's C2 (`at_rest`) and -- the claim -- on a moving fluid (seeded sigma = --flow velocities)."""
+    from weather_sandbox_amd import devtools
     gui = pkg.params.merge_settings(None)
     u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, pass_mask=pkg.params.PASS_DRY)
     u["enablePrecipitation"] = 0
@@ -144,40 +194,64 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
     h.upload(base, water, wall)
     del base, water, wall
     h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
-    for _ in range(warmup // a.frame):
-        h.step(a.frame)
-    h.sync()
-    runs = []
-    for _ in range(3):  # three timed runs: the slowest one is the claim
-        h.profile(True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps // a.frame):
-            h.step(a.frame)
-        h.sync()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        prof = h.profile_read()
-        h.profile(False)
-        runs.append((dt, prof))
-    h.close()
-    dt, prof = max(runs, key=lambda r: r[0])
-    name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
-    avg_ms = ms / cnt
-    achieved = ALGO_BYTES[name] * X * Y / (avg_ms * 1e-3) / 1e9
     n = (steps // a.frame) * a.frame
+
+    def measure(label):
+        run_frames(h.step, warmup, a.frame)
+        runs = [timed_run(h, n, a.frame) for _ in range(3)]  # three timed runs: the slowest one is the claim
+        dt, prof = max(runs, key=lambda r: r[0])
+        name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
+        avg_ms = ms / cnt
+        achieved = ALGO_BYTES[name] * X * Y / (avg_ms * 1e-3) / 1e9
+        return {"state": label, "value": X * Y * n / dt / 1e6, "ms_per_step": dt / n * 1e3, "runs_Mcell_steps_per_s": [X * Y * n / r[0] / 1e6 for r in runs],
+                "flow": devtools.flow_stats(h),
+                "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "algo_bytes_per_cell": ALGO_BYTES[name], "avg_launch_ms": avg_ms, "launches": cnt, "traffic": None}}
+
+    rest = measure("at rest (SURVEY 8d C2: v = 0, P = 0)")
+    moving = None
+    if a.flow > 0:
+        devtools.seed_flow(h, a.flow)
+        moving = measure(f"moving fluid: seeded velocities, std {a.flow} cells/iteration")
+    h.close()
+    main_ = moving or rest
     res = {"workload": f"{X}x{Y} dry-air grid, pressure+velocity+advection only (BASELINE north_star / configs[1] passes), frames of {a.frame}",
-           "value": X * Y * n / dt / 1e6, "unit": "Mcell-steps/s", "steps": n, "ms_per_step": dt / n * 1e3,
-           "runs_Mcell_steps_per_s": [X * Y * n / r[0] / 1e6 for r in runs], "claim": "slowest of three runs",
-           "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "algo_bytes_per_cell": ALGO_BYTES[name], "avg_launch_ms": avg_ms, "launches": cnt, "traffic": None}}
+           "value": main_["value"], "unit": "Mcell-steps/s", "steps": n, "ms_per_step": main_["ms_per_step"],
+           "runs_Mcell_steps_per_s": main_["runs_Mcell_steps_per_s"], "claim": "slowest of three runs, " + main_["state"], "flow": main_["flow"],
+           "roofline": main_["roofline"]}
+    if moving:
+        res["at_rest"] = {k: rest[k] for k in ("value", "ms_per_step", "runs_Mcell_steps_per_s", "flow")}
+        res["at_rest"]["roofline_frac"] = rest["roofline"]["frac"]
     if not a.no_pmc:
-        traffic, valu = pmc_traffic(a, name, X, Y, "dry")
+        traffic, valu, conflicts = pmc_traffic(a, res["roofline"]["kernel"], X, Y, "dry")
         res["roofline"]["traffic"] = traffic
         res["roofline"]["traffic_unit"] = "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, KiB counters)"
         if valu:
-            res["roofline"]["valu"] = {"wave_insts_per_launch": valu, "busy_frac": valu * 4.0 / (1024 * 2.4e9 * avg_ms * 1e-3)}
+            res["roofline"]["valu"] = {"wave_insts_per_launch": valu, "busy_frac": valu * 4.0 / (1024 * 2.4e9 * res["roofline"]["avg_launch_ms"] * 1e-3)}
+        if conflicts is not None:
+            res["roofline"]["lds_bank_conflict_cycles_per_launch"] = conflicts
     return res
+
+
+def p2p_selftest(dist, torch, rank, world, device):
+    """First contact with the transport: every rank sends its rank number to both ring neighbours and checks what arrives, with a
+    bounded wait -- so that a broken RCCL path fails here, readably, instead of hanging in the timed region."""
+    left, right = (rank - 1) % world, (rank + 1) % world
+    send = torch.full((256,), float(rank), device=device)
+    recv = [torch.full((256,), -1.0, device=device) for _ in range(2)]
+    if world == 2:
+        ops = [dist.P2POp(dist.isend, send, left), dist.P2POp(dist.isend, send.clone(), right),
+               dist.P2POp(dist.irecv, recv[1], right), dist.P2POp(dist.irecv, recv[0], left)]
+    else:
+        ops = [dist.P2POp(dist.isend, send, left), dist.P2POp(dist.irecv, recv[1], right),
+               dist.P2POp(dist.isend, send.clone(), right), dist.P2POp(dist.irecv, recv[0], left)]
+    for r in dist.batch_isend_irecv(ops):
+        r.wait()
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    got = (float(recv[0][0]), float(recv[1][0]))
+    if got != (float(left), float(right)):
+        raise RuntimeError(f"rank {rank}: P2P self-test received {got} from ranks ({left}, {right})")
 
 
 def main():
@@ -186,6 +260,7 @@ def main():
     import torch
     import wxpkg
     pkg = wxpkg.load_package()
+    from weather_sandbox_amd import devtools
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -194,62 +269,74 @@ def main():
     if os.environ.get("WX_BENCH_SHARE_GPU"):  # plumbing test on a 1-GPU box: all ranks on cuda:0, gloo transport
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("WX_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        tmo = datetime.timedelta(seconds=int(os.environ.get("WX_DIST_TIMEOUT_S", "180")))  # a stuck transfer ends the run with an error, not a hang
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+        ranks_seen = dist.get_world_size()
+        try:
+            p2p_selftest(dist, torch, rank, world, device if backend == "nccl" else torch.device("cpu"))
+        except Exception as e:  # readable first-contact failure
+            print(json.dumps({"error": f"P2P self-test failed on rank {rank} ({backend}): {e}", "ranks_seen": ranks_seen}), flush=True)
+            raise
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert not (a.workload == "dry" and a.particles), "the dry workload has no particle pass"
 
     X, Y = a.X, a.Y
     gui = pkg.params.merge_settings(None)
     gui["sunAngle"] = 50.0  # fixed sun ('MANUAL_ANGLE'), day side
-    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
-    u["enablePrecipitation"] = 0
-
     if a.workload == "dry":
-        assert world == 1 and not a.particles
         u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, pass_mask=pkg.params.PASS_DRY)
-        u["enablePrecipitation"] = 0
-    if world == 1:
+    else:
+        u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 1 if a.particles else 0  # (+ a cloud deck so that droplets spawn, grow and fall during the run)
+
+    def make_whole():
         h = pkg.engine.Handle(X, Y, a.particles)
         if a.workload == "dry":
-            base, water, wall = pkg.synth.dry_grid(X, Y)
-            h.upload(base, water, wall)
-            del base, water, wall
+            h.upload(*pkg.synth.dry_grid(X, Y))
         else:  # device-side initialiser: 1-D terrain / sounding descriptors instead of 1.2 GB of host arrays
-            if a.particles:
-                u["enablePrecipitation"] = 1  # + a cloud deck so that droplets spawn, grow and fall during the run
             h.setup_columns(pkg.synth.terrain_columns(X, Y, cloud_deck=bool(a.particles)),
                             pkg.synth.init_rain_drops(a.particles) if a.particles else None)
         h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
-        stepper = h
-        step = lambda n: h.step(n)
-        sync = lambda: (h.sync(), torch.cuda.synchronize())
-        barrier = lambda: None
+        return h
+
+    x0_owned = 0
+    if world == 1:
+        h = make_whole()
+        stepper, drv = h, None
+        step, sync, barrier = h.step, (lambda: (h.sync(), torch.cuda.synchronize())), (lambda: None)
     else:
         from weather_sandbox_amd import slab
-        if a.particles:  # the whole droplet pool on every rank; halo 64: sprite clipping needs tile-aligned slab edges
-            u["enablePrecipitation"] = 1
-            drv = slab.SlabSim.from_generator(pkg, X, Y, u, rank, world, torch.device("cuda", local_rank), halo=64,
+        if a.workload == "dry":
+            drv = slab.SlabSim.from_dry_generator(pkg, X, Y, u, rank, world, device)
+        elif a.particles:  # the whole droplet pool on every rank; halo 64: sprite clipping needs tile-aligned slab edges
+            drv = slab.SlabSim.from_generator(pkg, X, Y, u, rank, world, device, halo=64,
                                               drops=pkg.synth.init_rain_drops(a.particles), cloud_deck=True)
         else:
-            drv = slab.SlabSim.from_generator(pkg, X, Y, u, rank, world, torch.device("cuda", local_rank))
+            drv = slab.SlabSim.from_generator(pkg, X, Y, u, rank, world, device)
         stepper = drv.handle
-        step = drv.step
-        sync = lambda: (drv.sync(), torch.cuda.synchronize())
-        barrier = dist.barrier
+        x0_owned = slab.slab_columns(X, rank, world)[0]
+        step, sync, barrier = drv.step, (lambda: (drv.sync(), torch.cuda.synchronize())), dist.barrier
 
-    def run_frames(n):  # n iterations as frames of --frame iterations, like the reference's draw() loop
-        done = 0
-        while done < n:
-            k = min(a.frame, n - done)
-            step(k)
-            done += k
+    at_rest = None
+    if world == 1 and a.flow > 0 and not a.no_extras and not a.particles:  # the still start state first (round 2's definition)
+        run_frames(step, a.warmup, a.frame)
+        dt0, _ = timed_run(stepper, a.steps, a.frame, profile=False)
+        at_rest = {"value": X * Y * a.steps / dt0 / 1e6, "ms_per_step": dt0 / a.steps * 1e3, "flow": devtools.flow_stats(stepper),
+                   "state": "still start state (what round 2 timed)"}
+    if a.flow > 0:  # a moving fluid: identical on slabs and on the undecomposed grid (function of the global cell index)
+        devtools.seed_flow(stepper, a.flow, Xg=X, x0=x0_owned)
+    flow0 = devtools.flow_stats(stepper)
 
-    run_frames(a.warmup)
+    run_frames(step, a.warmup, a.frame)
     sync()
     barrier()
     # per-kernel HIP events (4 event records per iteration) are cheap next to a 1 ms iteration on one GPU; on N GPUs an
@@ -259,21 +346,47 @@ def main():
         stepper.profile(True)
     sync()
     t0 = time.perf_counter()
-    run_frames(a.steps)
+    run_frames(step, a.steps, a.frame)
     sync()
     barrier()
     dt = time.perf_counter() - t0
+    extra_iters = 0
     if not profile_inline:
         stepper.profile(True)
         step(16)
+        extra_iters = 16
         sync()
     prof = stepper.profile_read()
     stepper.profile(False)
     prof_steps = a.steps if profile_inline else 16
+    flow1 = devtools.flow_stats(stepper)
+    verify = "n/a (single rank)" if world == 1 else "not requested"
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64) if dist.get_backend() == "nccl" else torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if a.verify and not a.particles:
+            # every rank: checksums of its owned columns; rank 0: the same state undecomposed, same number of iterations
+            cs = torch.from_numpy(devtools.checksum(stepper, VERIFY_FIELDS, Xg=X, x0=x0_owned))
+            if dist.get_backend() == "nccl":
+                cs = cs.to(device)
+            gathered = [torch.zeros_like(cs) for _ in range(world)]
+            dist.all_gather(gathered, cs)
+            if rank == 0:
+                whole = make_whole()
+                if a.flow > 0:
+                    devtools.seed_flow(whole, a.flow, Xg=X, x0=0)
+                whole.step(a.warmup + a.steps + extra_iters)
+                bad = []
+                xo = X // world
+                for r in range(world):
+                    ref = devtools.checksum(whole, VERIFY_FIELDS, Xg=X, x0=0, cols=slice(r * xo, (r + 1) * xo))
+                    got = gathered[r].cpu().numpy()
+                    bad += [f"rank {r} {f}" for k, f in enumerate(VERIFY_FIELDS) if not np.array_equal(ref[k], got[k])]
+                whole.close()
+                verify = "ok" if not bad else "MISMATCH: " + ", ".join(bad)
+        elif a.verify:
+            verify = "not available with particles (replicated pool: compare with tests/test_slab_gpu_ranks.py)"
 
     if rank == 0:
         cells = X * Y
@@ -285,14 +398,15 @@ def main():
             name, (ms, cnt) = dom
             avg_ms = ms / cnt
             achieved = ALGO_BYTES.get(name, 0) * local_cells / (avg_ms * 1e-3) / 1e9
-            traffic, valu = (None, None) if (a.no_pmc or world > 1) else pmc_traffic(a, name)
+            traffic, valu, conflicts = (None, None, None) if (a.no_pmc or world > 1) else pmc_traffic(a, name)
             roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, KiB counters)",
                     "algorithmic_bytes_per_launch": ALGO_BYTES.get(name, 0) * local_cells, "avg_launch_ms": avg_ms, "launches": cnt,
                     "algo_bytes_per_cell": ALGO_BYTES.get(name, 0),
                     "kernels_ms_per_step": {k: v[0] / prof_steps for k, v in prof.items()}}
-            if world == 1:
-                # practical ceiling: a plain device-to-device copy of 1 GiB, read + write bytes counted
+            if world == 1 and not a.no_extras:
+                # the runtime's own device-to-device copy of 1 GiB, read + write bytes counted (kept for comparison with round 2; the
+                # ceiling that matters is hbm_ceiling below: the kernels' own access pattern)
                 src = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
                 dst = torch.empty_like(src)
                 dst.copy_(src)
@@ -305,27 +419,59 @@ def main():
                 roof["measured_copy_GBps"] = 2.0 * (1 << 30) * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
                 del src, dst
             if valu:
-                # the second limiter: a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
+                # the second limiter: SQ_ACTIVE_INST_VALU charges a wave64 VALU instruction 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
                 roof["valu"] = {"wave_insts_per_launch": valu, "busy_frac": valu * 4.0 / (1024 * 2.4e9 * avg_ms * 1e-3),
-                                "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time); 4 cycles is what SQ_ACTIVE_INST_VALU "
-                                        "charges per instruction, an all-v_mul_f32 micro-benchmark issues one per 3.05 cycles (profiles/r02_ubench_valu.txt)"}
+                                "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x launch time); an all-v_mul_f32 micro-benchmark "
+                                        "issues one per 3.05 cycles (profiles/r02_ubench_valu.txt)"}
+            if conflicts is not None:
+                roof["lds_bank_conflict_cycles_per_launch"] = conflicts
+        if a.workload == "dry":
+            wl = f"{X}x{Y} dry-air grid, pressure+velocity+advection only (BASELINE configs[1] passes" + (", north-star size)" if (X, Y) == (32768, 4096) else ")")
+        else:
+            wl = f"{X}x{Y} terrain grid, all six grid passes + lighting, "
+            if a.particles:
+                wl += f"{a.particles} precipitation particles (BASELINE configs[4]" + (" on one GPU)" if world == 1 else ")")
+            else:
+                wl += "particles off (BASELINE configs[3] grid)" if (X, Y) == (32768, 4096) else "particles off (BASELINE configs[2])"
+        wl += f"; frames of {a.frame} iterations; " + (f"moving fluid (seeded velocities, std {a.flow} cells/iteration)" if a.flow > 0 else "fluid at rest")
+        if world == 1:
+            deco = "none"
+        elif a.particles:
+            deco = f"{world} x-slabs, 64 ghost columns, ring halo exchange + droplet-pool reconciliation every 9 iterations"
+        else:
+            deco = f"{world} x-slabs, 48 ghost columns, ring halo exchange every 8 iterations (RCCL send/recv on a side stream, overlapped with compute)"
+        A = 36 if a.workload == "dry" else 72
         out = {
             "metric": "Mcell-steps/s", "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{X}x{Y} dry-air grid, pressure+velocity+advection only (BASELINE configs[1])" if a.workload == "dry" else f"{X}x{Y} terrain grid, all six grid passes + lighting, " + (f"{a.particles} precipitation particles (BASELINE configs[4]" + (" on one GPU)" if world == 1 else ")") if a.particles else ("particles off (BASELINE configs[3] grid)" if (X, Y) == (32768, 4096) else "particles off (BASELINE configs[2])")),
-                       "grid": [X, Y], "decomposition": "none" if world == 1 else (f"{world} x-slabs, 64 ghost columns, ring halo exchange + droplet-pool reconciliation (2 all-reduces) every 9 iterations" if a.particles else f"{world} x-slabs, 48 ghost columns, ring halo exchange every 8 iterations (RCCL send/recv)"),
-                       "iteration_algorithmic_bytes_per_cell": 36 if a.workload == "dry" else 72},
-            "iteration_roofline_frac_A_wet": cells * a.steps * (36 if a.workload == "dry" else 72) / dt / 1e9 / (HBM_PEAK_GBS * world),
+            "config": {"workload": wl, "grid": [X, Y], "decomposition": deco, "iteration_algorithmic_bytes_per_cell": A,
+                       "frame": a.frame, "flow_std": a.flow},
+            "ranks_seen": ranks_seen, "verify": verify,
+            "flow": {"start_of_warmup": flow0, "end_of_timed_region": flow1},
+            "iteration_roofline_frac_A_wet": cells * a.steps * A / dt / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roof,
         }
+        if at_rest:
+            out["at_rest"] = at_rest
+        if world == 1 and not a.no_extras and a.frame != 1 and not a.particles:
+            dt1, _ = timed_run(stepper, a.steps, 1, profile=False)  # round 1's definition: the display fields after EVERY iteration
+            out["frame_1"] = {"value": cells * a.steps / dt1 / 1e6, "ms_per_step": dt1 / a.steps * 1e3}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg)
+        if world == 1 and not a.no_extras:
+            stepper.close()
+            ceil = hbm_ceiling(16384, 2048)
+            if ceil:
+                out["hbm_ceiling"] = ceil
+                if roof and roof.get("traffic"):
+                    roof["frac_of_copy_ceiling_real_traffic"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / ceil["copy_GBps"]
         if world == 1 and not a.no_north_star and a.workload == "wet" and not a.particles:
             stepper.close()
             out["north_star_dry"] = north_star_dry(a, pkg)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

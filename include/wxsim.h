@@ -205,9 +205,19 @@ int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf);
  *   wx_step_overlap(s, n, WX_OVERLAP_EDGES_LAST): in the FIRST iteration the interior strips are launched first; the compute
  *     stream then waits for the event wx_halo_unpack recorded on the comm stream and launches the edge strips, the only ones
  *     that read ghost columns.
- * Both flags may be combined. The split needs the row-marching wet kernel (default kernel set, all grid passes on, particles
- * off) and a slab wide enough to have interior strips; otherwise the call degrades to the in-order exchange: wx_halo_pack waits
+ * Both flags may be combined. The split needs a row-marching kernel (default kernel set; all grid passes on, or the water-free
+ * dry iteration; particles off) and a slab wide enough to have interior strips; otherwise the call degrades to the in-order exchange: wx_halo_pack waits
  * for everything enqueued on the compute stream, the next wx_step waits for the unpack. wx_step(s, n) == wx_step_overlap(s, n, 0). */
+/* The water-free dry iteration on slabs. pass_mask == WX_PASS_DRY runs a kernel that does not touch the water texture at all
+ * (36 B/cell) while the handle KNOWS it is trivial (0 in air, only the wall marker in walls: established by wx_upload, dropped by
+ * anything that can create water). A slab also receives its neighbours' ghost columns, so it relies on that only after the host
+ * has established it for every slab: wx_water_free(s) reports what the last wx_upload found for THIS handle, the host combines
+ * the answers of all ranks (slab.py: all-reduce MIN) and passes the result to wx_slab_assert_water_free on every handle. The
+ * assertion is validated on the device at every wx_halo_unpack; a violation is reported by the next blocking call (wx_sync,
+ * wx_read_rect) as WX_E_STATE. Without the assertion a slab handle runs the water-carrying dry kernel. */
+int wx_water_free(const wx_sim *s);
+int wx_slab_assert_water_free(wx_sim *s, int agreed);
+
 #define WX_OVERLAP_EDGES_FIRST 1u
 #define WX_OVERLAP_EDGES_LAST 2u
 int wx_set_comm_stream(wx_sim *s, void *hip_stream); /* NULL: pack / unpack on the compute stream again */

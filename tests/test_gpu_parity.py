@@ -526,6 +526,44 @@ def test_slab_handles_equal_whole_domain(pkg, E, fused, nslab, halo):
             assert np.array_equal(h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]), (f, r)
 
 
+def _run_overlapped(E, slabs, comm, bufs, per, n_iter):
+    """n_iter iterations on N slab handles of one GPU with the halo exchange on per-handle comm streams (device-to-device copies
+    stand in for send / recv), edge / interior split launches, no host synchronisation between the steps."""
+    import torch
+    nslab = len(slabs)
+    done, exchanged = 0, False
+    while done < n_iter:
+        k = min(per, n_iter - done)
+        flags = (E.Handle.OVERLAP_EDGES_LAST if exchanged else 0) | (E.Handle.OVERLAP_EDGES_FIRST if k == per else 0)
+        for h in slabs:
+            h.step(k, flags)
+        done += k
+        if k < per:
+            break
+        packed = []
+        for r, h in enumerate(slabs):  # pack on each handle's comm stream (the library waits for the edge-strip event only)
+            h.halo_pack(0, bufs[r][0].data_ptr())
+            h.halo_pack(1, bufs[r][1].data_ptr())
+            ev = torch.cuda.Event()
+            ev.record(comm[r])
+            packed.append(ev)
+        for r, h in enumerate(slabs):  # "recv": a handle's unpack may start once BOTH neighbours have packed
+            comm[r].wait_event(packed[(r - 1) % nslab])
+            comm[r].wait_event(packed[(r + 1) % nslab])
+            h.halo_unpack(0, bufs[(r - 1) % nslab][1].data_ptr())
+            h.halo_unpack(1, bufs[(r + 1) % nslab][0].data_ptr())
+        # a neighbour's NEXT pack overwrites the buffers this handle's unpack reads: fence the comm streams among themselves
+        unpacked = []
+        for r in range(nslab):
+            ev = torch.cuda.Event()
+            ev.record(comm[r])
+            unpacked.append(ev)
+        for r in range(nslab):
+            comm[r].wait_event(unpacked[(r - 1) % nslab])
+            comm[r].wait_event(unpacked[(r + 1) % nslab])
+        exchanged = True
+
+
 @pytest.mark.parametrize("nslab,halo,X,bands", [(2, 12, 1024, None), (4, 24, 4096, None), (2, 6, 128, None), (2, 12, 1024, "2")])
 def test_slab_overlapped_exchange_equals_whole_domain(pkg, E, monkeypatch, nslab, halo, X, bands):
     """The exchange / compute overlap (wx_set_comm_stream + wx_step_overlap): N slab handles on one GPU, each with its own compute
@@ -562,37 +600,7 @@ def test_slab_overlapped_exchange_equals_whole_domain(pkg, E, monkeypatch, nslab
         h.set_comm_stream(comm[r].cuda_stream)
         slabs.append(h)
         bufs.append([torch.empty(h.halo_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2)])
-    done, exchanged = 0, False
-    while done < n_iter:
-        k = min(per, n_iter - done)
-        flags = (E.Handle.OVERLAP_EDGES_LAST if exchanged else 0) | (E.Handle.OVERLAP_EDGES_FIRST if k == per else 0)
-        for h in slabs:
-            h.step(k, flags)
-        done += k
-        if k < per:
-            break
-        packed = []
-        for r, h in enumerate(slabs):  # pack on each handle's comm stream (the library waits for the edge-strip event only)
-            h.halo_pack(0, bufs[r][0].data_ptr())
-            h.halo_pack(1, bufs[r][1].data_ptr())
-            ev = torch.cuda.Event()
-            ev.record(comm[r])
-            packed.append(ev)
-        for r, h in enumerate(slabs):  # "recv": a handle's unpack may start once BOTH neighbours have packed
-            comm[r].wait_event(packed[(r - 1) % nslab])
-            comm[r].wait_event(packed[(r + 1) % nslab])
-            h.halo_unpack(0, bufs[(r - 1) % nslab][1].data_ptr())
-            h.halo_unpack(1, bufs[(r + 1) % nslab][0].data_ptr())
-        # a neighbour's NEXT pack overwrites the buffers this handle's unpack reads: fence the comm streams among themselves
-        unpacked = []
-        for r in range(nslab):
-            ev = torch.cuda.Event()
-            ev.record(comm[r])
-            unpacked.append(ev)
-        for r in range(nslab):
-            comm[r].wait_event(unpacked[(r - 1) % nslab])
-            comm[r].wait_event(unpacked[(r + 1) % nslab])
-        exchanged = True
+    _run_overlapped(E, slabs, comm, bufs, per, n_iter)
     whole = E.Handle(X, Y, 0)
     whole.upload(base, water, wall)
     whole.set_params(p, u["initial_T"])
@@ -601,6 +609,95 @@ def test_slab_overlapped_exchange_equals_whole_domain(pkg, E, monkeypatch, nslab
         ref = whole.read_rect(f)
         for r, h in enumerate(slabs):
             assert np.array_equal(h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]), (f, r)
+    for h in slabs:
+        h.close()
+
+
+def _dry_uniforms(pkg, Y):
+    u = pkg.params.uniforms_from_gui(pkg.params.merge_settings(None), Y, quad_scale=0, pass_mask=pkg.params.PASS_DRY)
+    u["enablePrecipitation"] = 0
+    return u
+
+
+def _dry_slabs(pkg, E, X, Y, nslab, halo, base, water, wall, u, assert_free):
+    import torch
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    xo = X // nslab
+    slabs, bufs, main, comm = [], [], [], []
+    for r in range(nslab):
+        h = E.Handle(xo, Y, 0, X_global=X, x0=r * xo, halo=halo)
+        idx = (r * xo - halo + np.arange(xo + 2 * halo)) % X
+        h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]))
+        h.set_params(p, u["initial_T"])
+        main.append(torch.cuda.Stream())
+        comm.append(torch.cuda.Stream())
+        h.set_stream(main[r].cuda_stream)
+        h.set_comm_stream(comm[r].cuda_stream)
+        slabs.append(h)
+        bufs.append([torch.empty(h.halo_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2)])
+    free = [h.water_free() for h in slabs]
+    agreed = all(free) if assert_free is None else assert_free  # (slab.py: all-reduce MIN over the ranks)
+    for h in slabs:
+        h.slab_assert_water_free(agreed)
+    return slabs, comm, bufs, free
+
+
+@pytest.mark.parametrize("nslab,halo,X,wet_rank", [(2, 12, 1024, None), (4, 24, 4096, None), (2, 12, 1024, 1), (4, 12, 2048, 2)])
+def test_dry_slab_overlapped_exchange_equals_whole_domain(pkg, E, nslab, halo, X, wet_rank):
+    """BASELINE's north-star stencil (pass_mask DRY) on slabs with the exchange overlapped: the water-free row-marching kernel takes
+    strip ranges like the wet one (edge strips / interior). It may only run when NO slab carries water -- the hosts agree on that
+    once per upload (wx_water_free -> all-reduce MIN -> wx_slab_assert_water_free), so no step ever reads a flag back. With water in
+    ONE rank's slab (wet_rank) every handle falls back to the water-carrying kernel; both ways the owned columns equal the
+    undecomposed handle bit for bit over ten exchange periods."""
+    Y = 96
+    per, n_iter = halo // 6, 10 * (halo // 6) + 1
+    base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=0.2)
+    rng = np.random.Generator(np.random.Philox(77))
+    base[1:, :, 2] += rng.normal(0, 1e-3, (Y - 1, X)).astype(np.float32)
+    xo = X // nslab
+    if wet_rank is not None:  # a humid blob inside ONE rank's slab (outside its neighbour's ghost columns), drifting towards the edge
+        x0 = wet_rank * xo + halo + 2
+        water[20:60, x0:x0 + 40, 0] = 0.004
+        base[20:60, x0 - 20:x0 + 60, 0] = -0.7
+    u = _dry_uniforms(pkg, Y)
+    slabs, comm, bufs, free = _dry_slabs(pkg, E, X, Y, nslab, halo, base, water, wall, u, None)
+    assert free == [r != wet_rank for r in range(nslab)]
+    for h in slabs:
+        h.profile(True)
+    _run_overlapped(E, slabs, comm, bufs, per, n_iter)
+    for h in slabs:
+        names = set(h.profile_read())
+        assert ("march_dry_vel_advect_pressure" in names) == (wet_rank is None), names
+    whole = E.Handle(X, Y, 0)
+    whole.upload(base, water, wall)
+    whole.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    whole.step(n_iter)
+    assert np.abs(whole.read_rect("BASE_CUR")[..., :2]).max() < 1.0  # precondition of the 6-column cone
+    for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR"):
+        ref = whole.read_rect(f)
+        for r, h in enumerate(slabs):
+            assert np.array_equal(h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]), (f, r)
+    for h in slabs:
+        h.close()
+    whole.close()
+
+
+def test_dry_slab_wrong_water_free_assertion_is_reported(pkg, E):
+    """A host that asserts "every slab is water-free" although a neighbour's slab carries water gets WX_E_STATE from the next
+    blocking call after the ghost columns arrived (validated on the device by wx_halo_unpack) -- never a silent divergence."""
+    X, Y, nslab, halo = 1024, 64, 2, 12
+    base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=0.05)
+    x0 = X // 2 + halo + 1  # inside rank 1's slab, just outside rank 0's ghost columns, drifting left at 0.8 cells / iteration
+    water[20:40, x0:x0 + 30, 0] = 0.004
+    base[20:40, x0 - 20:x0 + 40, 0] = -0.8
+    u = _dry_uniforms(pkg, Y)
+    slabs, comm, bufs, free = _dry_slabs(pkg, E, X, Y, nslab, halo, base, water, wall, u, True)  # wrong on purpose
+    assert free == [True, False]
+    _run_overlapped(E, slabs, comm, bufs, halo // 6, 3 * (halo // 6))
+    with pytest.raises(E.WxError) as ei:
+        slabs[0].sync()
+    assert ei.value.code == -5 and "ghost columns carry water" in str(ei.value)
+    slabs[1].sync()  # (its own slab is not water-free: it never relied on the assertion)
     for h in slabs:
         h.close()
 

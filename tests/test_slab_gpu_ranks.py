@@ -98,3 +98,30 @@ def test_slab_sim_two_ranks(pkg, tmp_path, particles):
                 a[0, :2], b[0, :2] = 0, 0  # the reference's mailbox texels are not kept on slabs
             d = np.abs(a - b).max(-1)
             assert d.max() <= (1e-6 * max(1.0, np.abs(b).max()) if particles else 0.0), (f, r, d.max(), np.nonzero((d > 1e-6).any(0))[0][:20])
+
+
+@pytest.mark.parametrize("workload,grid", [("wet", (2048, 256)), ("dry", (4096, 512))])
+def test_bench_verify_two_ranks(workload, grid):
+    """bench.py --gpus 2 --verify end to end (two ranks on the one GPU of the box, gloo transport): P2P self-test, slabs of the wet
+    grid / of the north-star dry stencil with the overlapped exchange, then every rank's owned-column checksums against the
+    undecomposed run on rank 0 -- the line a multi-GPU node will print says "verify": "ok" only if the decomposed result is bit
+    for bit the single-GPU one."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, WX_BENCH_SHARE_GPU="1", WX_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8", "--X", str(grid[0]),
+           "--Y", str(grid[1]), "--workload", workload, "--verify", "--no-pmc"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["verify"] == "ok", d["verify"]
+    assert d["ranks_seen"] == 2 and d["n_gpus"] == 2 and d["value"] > 0
+    assert d["flow"]["end_of_timed_region"]["rms_v"] > 0.01  # the fluid moved
+    if workload == "dry":
+        assert d["roofline"]["kernel"] == "march_dry_vel_advect_pressure"  # the water-free marching kernel ran on the slabs
