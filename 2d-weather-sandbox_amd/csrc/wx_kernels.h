@@ -270,8 +270,9 @@ struct DevState {
   float px_count;         // this iteration's 1-px blends into texel (0,0): +1 per still-inactive droplet
   float px_light[4];      // this iteration's 1-px blends into texel (1,0): lightning requests
   int scratch_int;        // small device-side result slot (terrain scan of the marching wet kernel)
-  int ghost_nontrivial;   // set by k_halo_unpack when a neighbour's ghost columns carry water (or a negative vegetation byte):
-                          // the host then stops treating the water texture as identically zero (wx_step, dry iteration)
+  int ghost_nontrivial;   // set by k_halo_unpack when a neighbour's ghost columns carry water (or a negative vegetation byte)
+                          // although the host asserted a water-free domain (wx_slab_assert_water_free): reported by the next blocking call
+  int fix_overflow;       // set by k_wet_fix when more output cells needed the exact path than its list holds (the entry count)
 };
 
 // Splat accumulation: a 12x12 point sprite anchored at pixel (i0,j0) adds the same value to pixels

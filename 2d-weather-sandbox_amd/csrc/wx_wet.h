@@ -17,10 +17,13 @@
 // * no vertical halo is re-loaded or re-computed, there are no workgroup barriers (the wave's LDS queue is in order;
 //   wavefront-scope fences keep the compiler from reordering across stages); 56 of the 64 lanes produce output
 //   (cone of the seven chained stencils: 4 columns per side for |v| < 0.9 cell/iteration);
-// * cells whose back-trace is longer than that (never in a physical run: the shaders document velocities as -1 .. 1) are
-//   only RECORDED by the marching loop (one lane mask per row); after its last row the wave recomputes the three output
-//   cells each of them feeds with the exact out-of-line path (post-boundary texels rebuilt from global memory) and
-//   overwrites them. The hot loop therefore contains no call and no scratch access;
+// * cells whose back-trace is longer than that (|v| >= 0.9 cell/iteration: the core of a strong updraft) are only RECORDED by the
+//   marching loop: the (up to three) OUTPUT cells each of them feeds -- its own, the right neighbour's pressure, the upper
+//   neighbour's pressure / lighting -- are appended to a device list, and a second small kernel (k_wet_fix, one wavefront per list
+//   entry, spread over the whole chip) recomputes them exactly and overwrites the placeholders: 64 lanes rebuild an 8 x 8 patch
+//   of post-boundary texels around the cell from the iteration's inputs, three lanes advect from that patch. The hot loop contains
+//   no call and no scratch access, and a storm core costs microseconds (round 2: the recording wave redid such cells serially from
+//   global memory after its loop, ~1 ms PER CELL -- one fast cell tripled the iteration time);
 // * global loads are issued one step ahead of their use (software prefetch), each with the lag its consumer has (base / wall
 //   row r+1, water and light row r-1, feedback row r-2), and the stores of a row are issued at the top of the NEXT step, right
 //   behind the prefetch: the only vmcnt wait of the common path (top of the step) then covers operations that have had a
@@ -108,6 +111,14 @@ struct WetOut {
 #ifdef WX_WET_TIMING
   unsigned long long *cycles; // (tuning builds) per wave: s_memtime at start / end
 #endif
+};
+
+// Output cells left to the exact path (see k_wet_fix): appended by the marching kernel, consumed by the fix kernel of the same
+// launch group. count keeps counting past cap (the host reports the overflow as an error: the state has blown up).
+struct WetFixList {
+  int *count;
+  int2 *cells;
+  int cap;
 };
 
 // ---- exact out-of-line path: the post-boundary texel of an ARBITRARY cell recomputed from global memory (velocity, curl
@@ -422,19 +433,19 @@ __device__ __forceinline__ int ring_back(int s, int k, int n) // slot of the row
 // width normally; the edge strips and the interior separately where a slab overlaps its halo exchange with compute.
 // OPT_OUT: also store what only display-side consumers see (curl, post-boundary water, post-advection base): last iteration of a
 // wx_step call. HAS_FB: the precipitation feedback / deposition textures may be non-zero.
-// slow_rows: per wave (seg_rows + 1) 64-bit lane masks, one per advected row, of the cells left to the exact path.
+// fix: the list the output cells fed by a back-trace longer than 0.9 cells are appended to (k_wet_fix recomputes them).
 // The rows are cut into segments of (possibly) different heights: start[s] .. start[s+1]. Rows near terrain take the general,
 // branchy instantiations and cost about twice as much as free air, so the host makes the bottom segments shorter
 // (wet_launch_shape) and all waves of a launch finish together.
 constexpr int WMAXSEG = 128;
 struct WetSegs {
-  int n_seg, slow_stride; // slow_stride: entries per wave in slow_rows (tallest segment + 1)
+  int n_seg;
   int bands;              // experimental (WX_WET_BANDS=1): XCD k takes the row band [k*Y/8, (k+1)*Y/8) of ALL strips; start[] is relative to it
   int start[WMAXSEG + 1];
 };
 template <bool OPT_OUT, bool HAS_FB>
 __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in_arg, WetOut out_arg,
-                                                                    unsigned long long *__restrict__ slow_rows, int n_strips, int strip_lo,
+                                                                    WetFixList fix, int n_strips, int strip_lo,
                                                                     int n_strips_all, WetSegs segs)
 {
   struct KArgs { // layout of the kernel-argument segment up to the pointer structs
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   const int y_lo = band_lo + segs.start[seg], y_hi = min(band_lo + segs.start[seg + 1], band_hi);
   if (y_lo >= y_hi) return;
 #define WX_WALL_RAW (reinterpret_cast<const int *>(in.wall))
-  unsigned long long *__restrict__ my_slow = slow_rows + (size_t)item * segs.slow_stride;
+  (void)item;
 
   // ---- registers carried from step to step ----
   float4 pf_b, pf_q = make_float4(0.f, 0.f, 0.f, 0.f);                // prefetched: base row r, water row r-2
@@ -522,7 +533,6 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   float4 st_p = make_float4(0.f, 0.f, 0.f, 0.f), st_q = st_p, st_l = st_p, st_ab = st_p;
   char4 st_w = make_char4(0, 0, 0, 0);
   bool st_valid = false;
-  int first_slow = 0x7fffffff; // index (row - (y_lo - 1)) of the first row with cells left to the exact path
 
 #ifdef WX_WET_TIMING
   const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -763,14 +773,23 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         const float m = fmaxf(fmaxf(fmaxf(fabsf(vxp[o0]), fabsf(vxp[o0 - 1])), fmaxf(fabsf(vxp[op]), fabsf(vxp[op - 1]))),
                               fmaxf(fmaxf(fabsf(vyp[o0]), fabsf(vyp[om])), fmaxf(fabsf(vyp[o0 + 1]), fabsf(vyp[om + 1]))));
         fast = m < 0.9f || lane < 3 || lane > 59; // (lanes outside 3 .. 59 feed nothing)
-        // rows with such cells are recorded (from the first one on, every row: the array is not cleared between launches)
-        const unsigned long long mask = __ballot(!fast);
-        const int idx = t - 7; // == (r - 4) - (y_lo - 1)
-        if (mask != 0ull && first_slow == 0x7fffffff) first_slow = idx;
-      }
-      if (first_slow != 0x7fffffff) {
-        const unsigned long long mask = __ballot(!fast);
-        if (lane == 0) __hip_atomic_store(&my_slow[t - 7], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!fast) {
+          // This cell (column c_out, unwrapped row yu) keeps a placeholder; the OUTPUT cells it feeds that this wave owns -- its own,
+          // the right neighbour's (pressure: vx of the left cell), the upper neighbour's (pressure / lighting: vy, T, wall of the lower
+          // cell) -- go to the fix list. Rare path: one returning atomic per such lane.
+          const int yu = r - 4; // == y_lo - 1 + (t - 7)
+          const bool row_mine = yu >= y_lo, up_mine = yu + 1 < y_hi;
+          const bool oA = lane_out && row_mine, oB = lane + 1 >= WLO && lane + 1 < WLO + WOUT && c_out + 1 < X && row_mine, oC = lane_out && up_mine;
+          const int n_add = (int)oA + (int)oB + (int)oC;
+          if (n_add) {
+            int at = atomicAdd(fix.count, n_add);
+            if (at + n_add <= fix.cap) {
+              if (oA) fix.cells[at++] = make_int2(c_out, yu);
+              if (oB) fix.cells[at++] = make_int2(c_out + 1, yu);
+              if (oC) fix.cells[at++] = make_int2(c_out, yu + 1);
+            }
+          }
+        }
       }
 #ifdef WX_ABL_NOADV
       fast = false;
@@ -852,32 +871,117 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     if (OPT_OUT) st_row(out.base_disp + e, so16, st_ab);
     if (out.t_disp) st_row(out.t_disp + e, so4, st_ab.w);
   }
-  // ---- exact path for the recorded cells: cell (x, y) feeds the outputs (x, y), (x+1, y) [pressure: vx of the left neighbour]
-  //      and (x, y+1) [pressure / lighting: vy, T and wall of the lower neighbour]; each lane redoes those of them this wave owns ----
 #ifdef WX_WET_TIMING
   if (lane == 0) {
     out.cycles[2 * (size_t)item] = t_begin;
     out.cycles[2 * (size_t)item + 1] = __builtin_readcyclecounter();
   }
 #endif
-  if (first_slow != 0x7fffffff) {
-    // (the kernel-argument segment holds the pointer structs the out-of-line function takes from memory)
-    const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
-    const WetIn *in_mem = reinterpret_cast<const WetIn *>(ka + offsetof(KArgs, in));
-    const WetOut *out_mem = reinterpret_cast<const WetOut *>(ka + offsetof(KArgs, out));
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); // own stores (placeholder rows) before the corrections, masks before their read-back
-    for (int idx = first_slow; idx <= y_hi - y_lo; idx++) {
-      const unsigned long long mask = __hip_atomic_load(&my_slow[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!((mask >> lane) & 1ull)) continue;
-      const int yu = y_lo - 1 + idx; // unwrapped row of the recorded cell
-      if (lane_out && idx >= 1) wet_output_cell_exact(ctx, in_mem, out_mem, iterNum, OPT_OUT, c_out, yu);
-      if (lane + 1 >= WLO && lane + 1 < WLO + WOUT && c_out + 1 < X && idx >= 1) wet_output_cell_exact(ctx, in_mem, out_mem, iterNum, OPT_OUT, c_out + 1, yu);
-      if (lane_out && yu + 1 < y_hi) wet_output_cell_exact(ctx, in_mem, out_mem, iterNum, OPT_OUT, c_out, yu + 1);
-    }
-  }
 }
 
 #undef WX_WALL_RAW
+
+// ---- k_wet_fix: the output cells on the fix list, recomputed exactly -- one wavefront per cell ----
+// Output (X0, Y0) = pressure + lighting of the advected cells (X0, Y0), (X0 - 1, Y0) [vx of the left neighbour] and (X0, Y0 - 1)
+// [vy, T, wall of the lower one]. The 64 lanes rebuild the 8 x 8 patch [X0 - 4, X0 + 3] x [Y0 - 4, Y0 + 3] of POST-BOUNDARY texels from
+// the iteration's inputs (velocity, curl and vortForce evaluated on the fly, wet_boundary_texel_global), three lanes advect the three
+// cells from that patch with the very same advection_cell -- it covers every back-trace shorter than two cells -- and lane 0
+// finishes and stores the cell. Should a footprint leave the patch (|v| >= 2: the state has blown up) the fully general path from
+// global memory (wet_output_cell_exact) takes over. Recomputing an output is idempotent (always from the iteration's inputs), so
+// duplicates on the list and the order of the entries do not matter.
+constexpr int WPATCH = 8, WPATCH_C = 4;
+struct WetPatch {
+  float vx[WPATCH * WPATCH], vy[WPATCH * WPATCH], P[WPATCH * WPATCH], T[WPATCH * WPATCH];
+  float qx[WPATCH * WPATCH], qy[WPATCH * WPATCH], qz[WPATCH * WPATCH], qw[WPATCH * WPATCH];
+  char4 wl[WPATCH * WPATCH];
+};
+struct WetPatchAcc {
+  const WetPatch &p;
+  int cx, cy; // patch coordinates of the own cell
+  bool *bad;  // set when a texel outside the patch is asked for
+  __device__ __forceinline__ int at(int dx, int dy) const
+  {
+    const int x = cx + dx, y = cy + dy;
+    if (x < 0 || x >= WPATCH || y < 0 || y >= WPATCH) {
+      *bad = true;
+      return 0;
+    }
+    return y * WPATCH + x;
+  }
+  __device__ __forceinline__ float4 base(int dx, int dy) const
+  {
+    const int i = at(dx, dy);
+    return make_float4(p.vx[i], p.vy[i], p.P[i], p.T[i]);
+  }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return p.wl[at(dx, dy)]; }
+  __device__ __forceinline__ float4 base_off(int dx, int dy) const { return base(dx, dy); }
+  __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return wall(dx, dy); }
+  __device__ __forceinline__ float4 water_off(int dx, int dy) const
+  {
+    const int i = at(dx, dy);
+    return make_float4(p.qx[i], p.qy[i], p.qz[i], p.qw[i]);
+  }
+};
+
+template <bool OPT_OUT>
+__global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out, const int *__restrict__ count,
+                                                 const int2 *__restrict__ cells, int cap, int *__restrict__ overflow)
+{
+  __shared__ WetPatch patches[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  WetPatch &pt = patches[wave];
+  const int total = *count, n = total < cap ? total : cap;
+  if (total > cap && blockIdx.x == 0 && threadIdx.x == 0) *overflow = total;
+  const int X = ctx->g.X, Y = ctx->g.Y;
+  const WetSlowArgs sa{ctx, in, iterNum};
+  for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+    const int2 c = cells[i];
+    { // one post-boundary texel of the patch per lane
+      const BOut t = wet_boundary_texel_global(&sa, wrapmod(c.x - WPATCH_C + (lane & (WPATCH - 1)), X), wrapmod(c.y - WPATCH_C + (lane >> 3), Y));
+      pt.vx[lane] = t.b.x;
+      pt.vy[lane] = t.b.y;
+      pt.P[lane] = t.b.z;
+      pt.T[lane] = t.b.w;
+      pt.qx[lane] = t.w.x;
+      pt.qy[lane] = t.w.y;
+      pt.qz[lane] = t.w.z;
+      pt.qw[lane] = t.w.w;
+      pt.wl[lane] = t.wl;
+    }
+    wave_fence();
+    AdvOut o;
+    o.b = o.w = make_float4(0.f, 0.f, 0.f, 0.f);
+    o.wl = make_char4(0, 0, 0, 0);
+    bool bad = false;
+    if (lane < 3) { // lane 0: the cell itself, lane 1: its left neighbour, lane 2: the cell below
+      const int ox = lane == 1 ? -1 : 0, oy = lane == 2 ? -1 : 0;
+      const WetPatchAcc a{pt, WPATCH_C + ox, WPATCH_C + oy, &bad};
+      advection_cell(ctx->u, ctx->g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, wrapmod(c.x + ox, X), wrapmod(c.y + oy, Y), a, o.b, o.w, o.wl);
+    }
+    const bool any_bad = __any(bad);
+    const float vx_l = __shfl(o.b.x, 1), vy_d = __shfl(o.b.y, 2), T_d = __shfl(o.b.w, 2);
+    const int wl_d = __shfl(*reinterpret_cast<const int *>(&o.wl), 2);
+    if (lane == 0) {
+      if (any_bad) {
+        wet_output_cell_exact(ctx, &in, &out, iterNum, OPT_OUT, c.x, c.y);
+      } else {
+        const char4 wD = unpack_wall(wl_d);
+        const size_t gi = fidx(c.x, c.y, X);
+        out.base[gi] = pressure_cell(o.b, vx_l, vy_d, T_d, wD.x, wD.y);
+        out.water[gi] = o.w;
+        out.wall[gi] = o.wl;
+        GWetLightAcc la{in.lsrc, o.w, o.wl, o.b.w, T_d, X, c.x};
+        const float4 l = lighting_cell(ctx->u, ctx->g, c.x, c.y, la);
+        out.light.x[gi] = l.x;
+        out.light.y[gi] = l.y;
+        out.light.zw[gi] = make_float2(l.z, l.w);
+        if (OPT_OUT) out.base_disp[gi] = o.b;
+        if (out.t_disp) out.t_disp[gi] = o.b.w;
+      }
+    }
+    wave_fence(); // the patch is rewritten by the next entry
+  }
+}
 
 // Segmentation. The grid is cut into about WX_WET_ROUNDS times as many waves as the device holds at once (the hardware deals
 // workgroups to CUs as earlier ones retire; bottom segments are dispatched first), and rows below `air_from_row` -- the lowest
@@ -901,7 +1005,6 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 struct WetLaunch {
   int n_strips;
   WetSegs segs;
-  size_t slow_entries; // 64-bit masks the launch may write
 };
 inline int wet_capacity()
 {
@@ -1007,14 +1110,10 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
   while (n_seg > 1 && w.segs.start[n_seg - 1] >= Y) n_seg--; // (tiny grids: drop empty segments)
   w.segs.start[n_seg] = Y;
   w.segs.n_seg = n_seg;
-  int tallest = 1;
-  for (int sg = 0; sg < n_seg; sg++) tallest = w.segs.start[sg + 1] - w.segs.start[sg] > tallest ? w.segs.start[sg + 1] - w.segs.start[sg] : tallest;
-  w.segs.slow_stride = tallest + 1;
-  w.slow_entries = (size_t)w.n_strips * n_seg * w.segs.slow_stride * (bands ? 8 : 1);
   return w;
 }
 
-inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, unsigned long long *slow_rows,
+inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, const WetFixList &fix,
                              bool opt_out, hipStream_t stream, int strip_lo = 0, int strip_count = -1)
 {
   const int ns = strip_count < 0 ? w.n_strips : strip_count;
@@ -1029,13 +1128,24 @@ inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *c
   }
   const bool has_fb = in.fb != nullptr;
 #define WX_LAUNCH_W(O, F) \
-  hipLaunchKernelGGL((k_march_wet<O, F>), grid, dim3(64 * WX_WET_WPB), 0, stream, ctx, iterNum, in, out, slow_rows, ns, strip_lo, w.n_strips, w.segs)
+  hipLaunchKernelGGL((k_march_wet<O, F>), grid, dim3(64 * WX_WET_WPB), 0, stream, ctx, iterNum, in, out, fix, ns, strip_lo, w.n_strips, w.segs)
   if (opt_out) {
     if (has_fb) WX_LAUNCH_W(true, true); else WX_LAUNCH_W(true, false);
   } else {
     if (has_fb) WX_LAUNCH_W(false, true); else WX_LAUNCH_W(false, false);
   }
 #undef WX_LAUNCH_W
+}
+
+// the fix pass of a launch group: every list entry recomputed exactly, spread over the chip (exits at once while the list is empty)
+inline void launch_wet_fix(float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, const WetFixList &fix, int *overflow, bool opt_out,
+                           hipStream_t stream)
+{
+  const dim3 grid(512), block(256);
+  if (opt_out)
+    hipLaunchKernelGGL((k_wet_fix<true>), grid, block, 0, stream, ctx, iterNum, in, out, fix.count, fix.cells, fix.cap, overflow);
+  else
+    hipLaunchKernelGGL((k_wet_fix<false>), grid, block, 0, stream, ctx, iterNum, in, out, fix.count, fix.cells, fix.cap, overflow);
 }
 
 // lowest row above which every cell is free air in the sense of air_cell(): 1 + the highest row holding a wall cell, a cell next

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -106,8 +107,11 @@ struct wx_sim {
   bool wall_veg_ok = false; // no negative vegetation byte anywhere (advection would clamp it: the one wall change it can make unasked)
   FullCtx *full_ctx = nullptr;
   float4 *zero_row = nullptr;              // X texels of zeros (marching wet kernel: rows of feedback tiles that are known to be zero)
-  unsigned long long *slow_rows = nullptr; // marching wet kernel: per-wave row masks of the cells left to the exact path
-  size_t slow_cap = 0;
+  // marching wet kernel: output cells fed by a back-trace longer than 0.9 cells, recomputed exactly by k_wet_fix (wx_wet.h)
+  int *fix_count = nullptr;
+  int2 *fix_cells = nullptr;
+  int fix_cap = 0;
+  bool fix_check = false; // a marching iteration ran since the overflow flag was last looked at
   // overlap of the halo exchange with compute (wx_set_comm_stream / wx_step_overlap)
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_edges = nullptr, ev_unpacked = nullptr; // edge strips of the last iteration done (compute stream) / ghosts written (comm stream)
@@ -486,36 +490,43 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
     if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] air_from_row=%d of %d\n", s->air_from_row, s->Y);
   }
   const WetLaunch &shape = s->wet_shape;
-  if (shape.slow_entries > s->slow_cap) { // (once per handle; the kernel writes a row's mask before it reads it: no clearing)
-    hipStreamSynchronize(s->stream);
-    hipFree(s->slow_rows);
-    s->slow_rows = nullptr;
-    s->slow_cap = 0;
-    if (hipMalloc((void **)&s->slow_rows, shape.slow_entries * 8) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_step: %zu bytes for the marching kernel's row masks", shape.slow_entries * 8);
-    s->slow_cap = shape.slow_entries;
+  if (!s->fix_cells) { // (once per handle) room for a quarter of the grid's cells, at most 8 M entries
+    size_t cap = std::min<size_t>(std::max<size_t>(ncell(s) / 4, 1u << 16), 1u << 23);
+    if (const char *e = getenv("WX_WET_FIX_CAP")) cap = atoi(e) > 0 ? (size_t)atoi(e) : cap; // (tests: provoke the overflow report)
+    if (hipMalloc((void **)&s->fix_count, 4) != hipSuccess || hipMalloc((void **)&s->fix_cells, cap * sizeof(int2)) != hipSuccess)
+      return fail(s, WX_E_NOMEM, "wx_step: %zu bytes for the exact-path cell list", cap * sizeof(int2));
+    s->fix_cap = (int)cap;
   }
   {
     ProfScope ps(s, K_MARCH_WET);
+    const WetFixList fix{s->fix_count, s->fix_cells, s->fix_cap};
+    // one launch group: empty list -> marching kernel over a strip range (or two) -> the fix pass over what it recorded
+    auto group = [&](int lo0, int cnt0, int lo1 = 0, int cnt1 = 0) {
+      hipMemsetAsync(s->fix_count, 0, 4, s->stream);
+      launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, fix, opt_out, s->stream, lo0, cnt0);
+      if (cnt1 > 0) launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, fix, opt_out, s->stream, lo1, cnt1);
+      launch_wet_fix((float)s->iter, s->full_ctx, in, out, fix, &s->state->fix_overflow, opt_out, s->stream);
+    };
     // edge strips: every output column wx_halo_pack reads ([halo, 2*halo) and its mirror) and every strip that reads ghost columns
+    // (a wave records -- and the fix pass rewrites -- only output cells of its own strip: the groups never write each other's columns)
     const int nl = s->halo > 0 ? (2 * s->halo - 1) / WOUT + 1 : 0, nr0 = s->halo > 0 ? (s->X - 2 * s->halo) / WOUT : shape.n_strips;
-    const float itn = (float)s->iter;
     if (edge_mode == 0 || s->halo == 0 || nl >= nr0) {
       if (edge_mode & 2) wait_unpacked(s);
-      launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream);
+      group(0, -1);
     } else {
       const bool interior_first = (edge_mode & 2) && s->unpack_pending;
       if (interior_first) { // ghosts still in flight: everything that does not read them goes first
-        launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream, nl, nr0 - nl);
+        group(nl, nr0 - nl);
         wait_unpacked(s);
       }
-      launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream, 0, nl);
-      launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream, nr0, shape.n_strips - nr0);
+      group(0, nl, nr0, shape.n_strips - nr0);
       if (edge_mode & 1) { // the columns the neighbours need are final: let the comm stream pack them while the interior computes
         hipEventRecord(s->ev_edges, s->stream);
         s->edges_recorded = true;
       }
-      if (!interior_first) launch_march_wet(shape, itn, s->full_ctx, in, out, s->slow_rows, opt_out, s->stream, nl, nr0 - nl);
+      if (!interior_first) group(nl, nr0 - nl);
     }
+    s->fix_check = true;
     LAUNCH_CHECK(s, "march_wet");
   }
 #ifdef WX_WET_TIMING
@@ -753,7 +764,8 @@ void wx_destroy(wx_sim *s)
   }
   hipFree(s->full_ctx);
   hipFree(s->zero_row);
-  hipFree(s->slow_rows);
+  hipFree(s->fix_count);
+  hipFree(s->fix_cells);
   hipFree(s->water[2]);
   hipFree(s->sg.acc4);
   hipFree(s->sg.acc2);
@@ -823,7 +835,7 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 16, s->stream));
   HIPCHK(s, hipMemsetAsync(s->dep, 0, n * 8, s->stream));
   HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
-  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 28, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial
+  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 32, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow
   if (s->sg.acc4) {
     HIPCHK(s, hipMemsetAsync(s->sg.acc4, 0, (size_t)s->sg.AP * s->sg.AH * 16, s->stream));
     HIPCHK(s, hipMemsetAsync(s->sg.acc2, 0, (size_t)s->sg.AP * s->sg.AH * 8, s->stream));
@@ -1069,6 +1081,17 @@ int wx_set_option(wx_sim *s, int option, int value)
 // checked every ghost texel on the device; a blocking call is where the verdict is collected (never a silent divergence).
 static int validate_ghost_flag(wx_sim *s)
 {
+  if (s->fix_check) { // did a marching iteration find more cells with |v| >= 0.9 than the exact-path list holds?
+    int over = 0;
+    HIPCHK(s, hipMemcpyAsync(&over, &s->state->fix_overflow, 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    s->fix_check = false;
+    if (over) {
+      HIPCHK(s, hipMemsetAsync(&s->state->fix_overflow, 0, 4, s->stream));
+      return fail(s, WX_E_STATE, "%d output cells of one iteration were fed by velocities >= 0.9 cells/iteration; the exact path holds %d: the state has "
+                                 "left the simulation's range (velocities are documented as -1 .. 1) and the results since are invalid", over, s->fix_cap);
+    }
+  }
   if (!s->ghost_check) return WX_OK;
   int flag = 0;
   wait_unpacked(s);

@@ -1,9 +1,9 @@
 """Device-side helpers for benchmarks and self-verification (PyTorch is plumbing here: it wraps the engine's own device buffers).
 
 * ``field_tensor``  -- a live torch view of a field's current device storage (``wx_device_ptr``), no copy;
-* ``seed_flow``     -- adds a seeded velocity perturbation to the air cells on the device, a pure function of the GLOBAL cell
-  index (slabs of a decomposed domain and the undecomposed handle get bit-identical values): turns the still start state of a
-  synthetic grid into a moving fluid without a 1.2 GB host upload;
+* ``seed_flow``     -- adds a seeded velocity field (smooth divergence-free eddies, or white noise) to the air cells on the device,
+  a pure function of the GLOBAL cell coordinates (slabs of a decomposed domain and the undecomposed handle get bit-identical
+  values): turns the still start state of a synthetic grid into a moving fluid without a 1.2 GB host upload;
 * ``flow_stats``    -- rms / max |v| and the share of cells whose back-trace leaves the lane's own cell;
 * ``checksum``      -- position-weighted integer checksum of the owned columns of a field, again keyed by the global cell index:
   N slab handles and the undecomposed handle produce the same numbers iff the fields are bit-identical.
@@ -55,22 +55,54 @@ def _global_index(h: Handle, Xg: int, x0: int, halo: int, cols: slice, device) -
     return gy * Xg + gx[None, :]
 
 
-def seed_flow(h: Handle, sigma: float, seed: int = 1, Xg: Optional[int] = None, x0: int = 0) -> None:
-    """base_0.xy += U(-a, a) with a = sigma * sqrt(3) (standard deviation ``sigma`` cells / iteration) in every air cell above row 0,
-    clipped to |v| <= 0.9 -- the range the slab decomposition's 6-column cone assumes. In place on the device, on the current
-    torch stream; the handle must be idle (``h.sync()``)."""
+def seed_flow(h: Handle, sigma: float, seed: int = 1, Xg: Optional[int] = None, x0: int = 0, kind: str = "eddies") -> None:
+    """Adds a velocity field with standard deviation ``sigma`` cells / iteration to base_0.xy of every air cell above row 0, clipped
+    to |v| <= 0.9 (the range the slab decomposition's 6-column cone assumes). In place on the device; the handle must be idle.
+
+    ``kind="eddies"`` (default): a developed flow -- the discrete curl of a stream function made of a dozen seeded Fourier modes
+    (eddies of 50 .. 400 cells, zero at the floor and the top), i.e. smooth and divergence-free ON THE STAGGERED GRID
+    (vx = psi(x, y) - psi(x, y-1) on the right face, vy = -(psi(x, y) - psi(x-1, y)) on the top face, pressureShader.frag:16-43's
+    divergence of it is zero), so the pressure pass does not radiate it away: it keeps moving through a benchmark run.
+    ``kind="noise"``: independent U(-a, a) per cell and component -- every lane's back-trace footprint differs from its neighbour's:
+    the worst case for the kernels' ring reads (and a field the pressure pass kills within a few hundred iterations)."""
     Xg = h.X if Xg is None else Xg
     h.sync()
     dev = torch.device("cuda", torch.cuda.current_device())
     base = field_tensor(h, "BASE_CUR")
     air = field_tensor(h, "WALL_CUR")[..., 1] != 0
     air[0, :] = False
-    idx = _global_index(h, Xg, x0, h.halo, slice(None), dev)
-    a = float(sigma) * 3.0 ** 0.5
-    for c in (0, 1):
-        u = (_hash32(_hash32(idx * 2 + c) + seed * 0x9E3779B1) >> 8).to(torch.float32) * (1.0 / (1 << 24))  # [0, 1), exact in fp32
-        v = ((u - 0.5) * (2.0 * a)).clamp_(-0.9, 0.9)
-        base[..., c] += torch.where(air, v, torch.zeros_like(v))
+    if kind == "noise":
+        idx = _global_index(h, Xg, x0, h.halo, slice(None), dev)
+        a = float(sigma) * 3.0 ** 0.5
+        for c in (0, 1):
+            u = (_hash32(_hash32(idx * 2 + c) + seed * 0x9E3779B1) >> 8).to(torch.float32) * (1.0 / (1 << 24))  # [0, 1), exact in fp32
+            v = ((u - 0.5) * (2.0 * a)).clamp_(-0.9, 0.9)
+            base[..., c] += torch.where(air, v, torch.zeros_like(v))
+    else:
+        rng = np.random.Generator(np.random.Philox(seed))
+        Y = h.Y
+        gx = ((torch.arange(h.X, device=dev, dtype=torch.int64) + (x0 - h.halo)) % Xg).to(torch.float64)  # global column
+        gy = torch.arange(Y, device=dev, dtype=torch.float64)
+
+        def psi(xs, ys):  # stream function at the cell corners (xs + 1/2, ys + 1/2); float64, a pure function of the global coordinates
+            out = torch.zeros((len(ys), len(xs)), device=dev, dtype=torch.float64)
+            r = np.random.Generator(np.random.Philox(seed))
+            for _ in range(12):
+                lam = float(r.uniform(50.0, 400.0))
+                m = max(1, round(Xg / lam))  # whole periods around the periodic domain
+                n = max(1, round(2.0 * Y / float(r.uniform(50.0, 400.0))))  # half periods between floor and top
+                ph = float(r.uniform(0.0, 2.0 * np.pi))
+                amp = 1.0 / np.hypot(2.0 * np.pi * m / Xg, np.pi * n / Y)  # every mode contributes the same velocity amplitude
+                out += amp * torch.sin(2.0 * np.pi * m * (xs + 0.5) / Xg + ph)[None, :] * torch.sin(np.pi * n * (ys + 0.5) / Y)[:, None]
+            return out
+
+        p11, p10, p01 = psi(gx, gy), psi(gx, gy - 1.0), psi(gx - 1.0, gy)
+        vx, vy = p11 - p10, -(p11 - p01)
+        del rng
+        scale = float(sigma) / (12 ** 0.5 * 0.5)  # 12 modes of velocity amplitude ~1 per component and rms 1/2 each
+        for c, v in ((0, vx), (1, vy)):
+            v = (v * scale).clamp_(-0.9, 0.9).to(torch.float32)
+            base[..., c] += torch.where(air, v, torch.zeros_like(v))
     torch.cuda.synchronize()
 
 
@@ -82,8 +114,10 @@ def flow_stats(h: Handle) -> Dict[str, float]:
     air = field_tensor(h, "WALL_CUR")[:, cols, 1] != 0
     v = torch.sqrt(b[..., 0] ** 2 + b[..., 1] ** 2)[air]
     if v.numel() == 0:
-        return {"rms_v": 0.0, "max_v": 0.0, "frac_v_gt_0.05": 0.0}
-    return {"rms_v": float(torch.sqrt((v.double() ** 2).mean())), "max_v": float(v.max()), "frac_v_gt_0.05": float((v > 0.05).double().mean())}
+        return {"rms_v": 0.0, "max_v": 0.0, "frac_v_gt_0.05": 0.0, "cells_component_ge_0.9": 0}
+    big = (torch.maximum(b[..., 0].abs(), b[..., 1].abs()) >= 0.9) & air  # cells whose back-trace may leave the 3x3 neighbourhood (exact path)
+    return {"rms_v": float(torch.sqrt((v.double() ** 2).mean())), "max_v": float(v.max()), "frac_v_gt_0.05": float((v > 0.05).double().mean()),
+            "cells_component_ge_0.9": int(big.sum())}
 
 
 def checksum(h: Handle, fields: Sequence[str], Xg: Optional[int] = None, x0: int = 0, cols: Optional[slice] = None) -> np.ndarray:

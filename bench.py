@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--particles", type=int, default=0, help="also run the particle pass with N droplets (BASELINE configs[4])")
     ap.add_argument("--frame", type=int, default=10, help="iterations per wx_step call (the reference's IterPerFrame, app.js:398)")
     ap.add_argument("--flow", type=float, default=0.2, help="std of the seeded velocity field, cells / iteration (0: fluid at rest)")
+    ap.add_argument("--flow-kind", choices=["eddies", "noise"], default="eddies",
+                    help="eddies: smooth divergence-free eddies of 50..400 cells (a developed flow; default); noise: white noise per cell (worst case for the ring reads)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 32768 x 4096 dry north-star measurement (N=1)")
     ap.add_argument("--no-extras", action="store_true", help="skip at_rest / frame-1 / hbm_ceiling side measurements (N=1)")
     ap.add_argument("--verify", action="store_true", help="N > 1: checksum every rank's owned columns against an undecomposed run on rank 0")
@@ -134,7 +136,7 @@ def pmc_traffic(a, kernel, X=None, Y=None, workload=None):
             nfr = max(1, int(a.frame))
             cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", str(nfr), "--warmup", str(nfr),
                    "--X", str(X or a.X), "--Y", str(Y or a.Y), "--workload", workload or a.workload, "--no-cpu-baseline", "--no-pmc",
-                   "--no-north-star", "--no-extras", "--frame", str(a.frame), "--flow", str(a.flow)]
+                   "--no-north-star", "--no-extras", "--frame", str(a.frame), "--flow", str(a.flow), "--flow-kind", a.flow_kind]
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
@@ -209,10 +211,13 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
                              "algo_bytes_per_cell": ALGO_BYTES[name], "avg_launch_ms": avg_ms, "launches": cnt, "traffic": None}}
 
     rest = measure("at rest (SURVEY 8d C2: v = 0, P = 0)")
-    moving = None
+    moving = noise = None
     if a.flow > 0:
-        devtools.seed_flow(h, a.flow)
-        moving = measure(f"moving fluid: seeded velocities, std {a.flow} cells/iteration")
+        devtools.seed_flow(h, a.flow, kind=a.flow_kind)
+        moving = measure(f"moving fluid: seeded {a.flow_kind}, std {a.flow} cells/iteration")
+        if a.flow_kind != "noise" and not a.no_extras:  # the worst case for the ring reads: every lane's footprint differs from its neighbour's
+            devtools.seed_flow(h, a.flow, kind="noise", seed=2)
+            noise = measure(f"white-noise velocities on top, std {a.flow} cells/iteration (worst case)")
     h.close()
     main_ = moving or rest
     res = {"workload": f"{X}x{Y} dry-air grid, pressure+velocity+advection only (BASELINE north_star / configs[1] passes), frames of {a.frame}",
@@ -222,6 +227,9 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
     if moving:
         res["at_rest"] = {k: rest[k] for k in ("value", "ms_per_step", "runs_Mcell_steps_per_s", "flow")}
         res["at_rest"]["roofline_frac"] = rest["roofline"]["frac"]
+    if noise:
+        res["white_noise_worst_case"] = {k: noise[k] for k in ("value", "ms_per_step", "runs_Mcell_steps_per_s", "flow")}
+        res["white_noise_worst_case"]["roofline_frac"] = noise["roofline"]["frac"]
     if not a.no_pmc:
         traffic, valu, conflicts = pmc_traffic(a, res["roofline"]["kernel"], X, Y, "dry")
         res["roofline"]["traffic"] = traffic
@@ -333,7 +341,7 @@ def main():
         at_rest = {"value": X * Y * a.steps / dt0 / 1e6, "ms_per_step": dt0 / a.steps * 1e3, "flow": devtools.flow_stats(stepper),
                    "state": "still start state (what round 2 timed)"}
     if a.flow > 0:  # a moving fluid: identical on slabs and on the undecomposed grid (function of the global cell index)
-        devtools.seed_flow(stepper, a.flow, Xg=X, x0=x0_owned)
+        devtools.seed_flow(stepper, a.flow, Xg=X, x0=x0_owned, kind=a.flow_kind)
     flow0 = devtools.flow_stats(stepper)
 
     run_frames(step, a.warmup, a.frame)
@@ -375,7 +383,7 @@ def main():
             if rank == 0:
                 whole = make_whole()
                 if a.flow > 0:
-                    devtools.seed_flow(whole, a.flow, Xg=X, x0=0)
+                    devtools.seed_flow(whole, a.flow, Xg=X, x0=0, kind=a.flow_kind)
                 whole.step(a.warmup + a.steps + extra_iters)
                 bad = []
                 xo = X // world
@@ -433,7 +441,7 @@ def main():
                 wl += f"{a.particles} precipitation particles (BASELINE configs[4]" + (" on one GPU)" if world == 1 else ")")
             else:
                 wl += "particles off (BASELINE configs[3] grid)" if (X, Y) == (32768, 4096) else "particles off (BASELINE configs[2])"
-        wl += f"; frames of {a.frame} iterations; " + (f"moving fluid (seeded velocities, std {a.flow} cells/iteration)" if a.flow > 0 else "fluid at rest")
+        wl += f"; frames of {a.frame} iterations; " + (f"moving fluid (seeded {a.flow_kind}, std {a.flow} cells/iteration)" if a.flow > 0 else "fluid at rest")
         if world == 1:
             deco = "none"
         elif a.particles:
@@ -446,7 +454,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "grid": [X, Y], "decomposition": deco, "iteration_algorithmic_bytes_per_cell": A,
-                       "frame": a.frame, "flow_std": a.flow},
+                       "frame": a.frame, "flow_std": a.flow, "flow_kind": a.flow_kind},
             "ranks_seen": ranks_seen, "verify": verify,
             "flow": {"start_of_warmup": flow0, "end_of_timed_region": flow1},
             "iteration_roofline_frac_A_wet": cells * a.steps * A / dt / 1e9 / (HBM_PEAK_GBS * world),

@@ -282,6 +282,63 @@ def test_dry_water_free_flag_is_dropped_when_water_appears(pkg, oracle, E, monke
         h.close()
 
 
+@pytest.mark.parametrize("X,Y,bands", [(700, 200, None), (1100, 260, "2"), (130, 50, None)])
+def test_fast_cells_exact_path_vs_oracle(pkg, oracle, E, monkeypatch, X, Y, bands):
+    """Cells whose back-trace leaves the 3 x 3 neighbourhood (|v| >= 0.9 cells / iteration) go through the fix pass of the marching
+    wet kernel (k_wet_fix: an 8 x 8 post-boundary patch per output cell): an updraft core of contiguous fast cells (up to 1.8),
+    scattered single ones, cores that straddle strip / segment / band borders and the periodic seam, next to terrain -- and a few
+    cells beyond 2 cells / iteration, whose footprints leave the patch (fully general fallback). Bit-exact against the oracle."""
+    monkeypatch.setenv("WX_FUSED", "2")
+    if bands:
+        monkeypatch.setenv("WX_WET_BANDS", bands)
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    rng = np.random.Generator(np.random.Philox(91))
+    air = wall[..., 1] != 0
+    base[..., 0] += np.where(air, rng.normal(0, 0.15, (Y, X)), 0).astype(np.float32)
+    base[..., 1] += np.where(air, rng.normal(0, 0.1, (Y, X)), 0).astype(np.float32)
+    yy, xx = np.mgrid[0:Y, 0:X]
+    for cx, cy, rx, ry, vx, vy in [(50, Y // 2, 9, 14, 0.3, 1.6), (56 * 3 + 2, Y // 3, 7, 7, -1.4, 0.8), (X - 3, Y // 2, 8, 6, 1.2, -1.3),
+                                   (X // 2, Y - 20, 12, 10, 0.9, 1.1), (X // 3, 30, 6, 20, -1.0, 1.7)]:
+        blob = np.exp(-(((xx - cx + X // 2) % X - X // 2) / rx) ** 2 - ((yy - cy) / ry) ** 2)
+        base[..., 0] += np.where(air, vx * blob, 0).astype(np.float32)
+        base[..., 1] += np.where(air, vy * blob, 0).astype(np.float32)
+    for k in range(12):  # single cells far beyond the patch's reach
+        x, y = int(rng.integers(0, X)), int(rng.integers(Y // 2, Y - 2))
+        base[y, x, :2] = (2.6, -2.2) if k % 2 else (-3.1, 2.4)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 30.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+    h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
+    assert (np.abs(base[..., :2]).max(-1) >= 0.9).sum() > 300
+    for n in (1, 2, 4):
+        h.step(n)
+        o.step(n)
+        _assert_grid_equal(h, o)
+    h.sync()
+    h.close()
+
+
+def test_exact_path_overflow_is_reported(pkg, E, monkeypatch):
+    """More fast cells in one iteration than the exact-path list holds: WX_E_STATE from the next blocking call, not silence."""
+    monkeypatch.setenv("WX_FUSED", "2")
+    monkeypatch.setenv("WX_WET_FIX_CAP", "64")
+    X, Y = 256, 96
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    base[40:80, :, 1] = 1.5
+    gui = pkg.params.merge_settings(None)
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+    h = E.Handle(X, Y, 0)
+    h.upload(base, water, wall)
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    h.step(1)
+    with pytest.raises(E.WxError) as ei:
+        h.sync()
+    assert ei.value.code == -5 and "0.9" in str(ei.value)
+    h.close()
+
+
 def test_particles_vs_oracle(pkg, oracle, golden, E, fused):
     g, u = golden("precip64")
     u = dict(u, quad_scale=0, enablePrecipitation=1)

@@ -1,6 +1,6 @@
 """The launch shape of the row-marching wet kernel (csrc/wx_wet.h: wet_launch_shape) as pure host logic: a small hipcc-built
 harness prints the segment tables for a list of grids; every row of every band must be covered exactly once by non-empty segments,
-short segments come last, and the mask buffer is large enough. No GPU needed (the capacity falls back to 256 CUs x 12 waves)."""
+and short segments come last. No GPU needed (the capacity falls back to 256 CUs x 12 waves)."""
 import json
 import os
 import shutil
@@ -50,9 +50,6 @@ def test_segment_tables_cover_every_row_once(harness, env):
             for k in range(8):  # every band [k*Y/8, (k+1)*Y/8) is covered by the clipped table
                 lo, hi = k * Y // 8, (k + 1) * Y // 8
                 assert 0 < hi - lo <= height
-        tallest = max(b - a for a, b in zip(st, st[1:]))
-        assert sh["slow_stride"] == tallest + 1
-        assert sh["slow_entries"] == sh["n_strips"] * n * sh["slow_stride"] * (8 if sh["bands"] else 1)
 
 
 def test_default_shape_has_a_short_tail_on_the_metric_grid(harness):
