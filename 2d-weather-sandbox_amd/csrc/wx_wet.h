@@ -37,6 +37,7 @@
 #include "wx_tile.h"
 #include <cstddef>
 #include <cstdlib>
+#include <algorithm>
 
 namespace wx {
 
@@ -780,7 +781,10 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
           const int yu = r - 4; // == y_lo - 1 + (t - 7)
           const bool row_mine = yu >= y_lo, up_mine = yu + 1 < y_hi;
           const bool oA = lane_out && row_mine, oB = lane + 1 >= WLO && lane + 1 < WLO + WOUT && c_out + 1 < X && row_mine, oC = lane_out && up_mine;
-          const int n_add = (int)oA + (int)oB + (int)oC;
+          int n_add = (int)oA + (int)oB + (int)oC;
+#ifdef WX_ABL_NOFIX // (timing-only ablation builds produce garbage velocities: keep them from flooding the exact path)
+          n_add = 0;
+#endif
           if (n_add) {
             int at = atomicAdd(fix.count, n_add);
             if (at + n_add <= fix.cap) {
@@ -924,7 +928,7 @@ struct WetPatchAcc {
 };
 
 template <bool OPT_OUT>
-__global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out, const int *__restrict__ count,
+__global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out, int *__restrict__ count,
                                                  const int2 *__restrict__ cells, int cap, int *__restrict__ overflow)
 {
   __shared__ WetPatch patches[4];
@@ -981,6 +985,13 @@ __global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx
     }
     wave_fence(); // the patch is rewritten by the next entry
   }
+  // the list is empty again for the next launch group: reset by the LAST workgroup to get here (every workgroup has read the count
+  // by then) -- count[1] is the arrival ticket -- which saves a memset in the stream per iteration
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(count + 1, 1) == (int)gridDim.x - 1) {
+    count[1] = 0;
+    __hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // Segmentation. The grid is cut into about WX_WET_ROUNDS times as many waves as the device holds at once (the hardware deals
@@ -1012,10 +1023,22 @@ inline int wet_capacity()
   if (!capacity) {
     int dev = 0, ncu = 0, nb = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_wet<false, false>, 64 * WX_WET_WPB, 0) != hipSuccess || ncu <= 0 || nb <= 0)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_wet<false, false>, 64 * WX_WET_WPB, 0) != hipSuccess || ncu <= 0 || nb <= 0) {
       capacity = 256 * 4 * WX_WET_MINWAVES;
-    else
+    } else {
+      // the occupancy API can answer one workgroup per CU too many (MI355X_MICROARCH.md, "Residency"): bound it by what the kernel's own
+      // register and LDS footprint admit -- 512 registers per lane and SIMD in granules of 8, 160 KiB of LDS per CU; a workgroup is
+      // WX_WET_WPB waves, one per SIMD
+      hipFuncAttributes fa;
+      int by_regs = nb, by_lds = nb;
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_march_wet<false, false>)) == hipSuccess) {
+        if (fa.numRegs > 0) by_regs = (512 / (((fa.numRegs + 7) / 8) * 8)) * 4 / WX_WET_WPB;
+        if (fa.sharedSizeBytes > 0) by_lds = (int)(163840 / fa.sharedSizeBytes);
+        if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] numRegs=%d lds=%zu: blocks/CU by registers %d, by LDS %d, occupancy API %d\n", fa.numRegs, fa.sharedSizeBytes, by_regs, by_lds, nb);
+      }
+      nb = std::max(1, std::min(nb, std::min(by_regs, by_lds)));
       capacity = ncu * nb * WX_WET_WPB;
+    }
     if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] CUs=%d blocks/CU=%d capacity=%d\n", ncu, nb, capacity);
   }
   return capacity;
@@ -1067,7 +1090,7 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
     for (int ri = 0; ri < 6; ri++) { // (fewer rounds if a unit segment would fall below `minrows` rows; else equal segments)
       const double rr = rr_list[ri];
       if (rr > rounds) continue;
-      int n_full = (int)((rr - 1.0) * per_round + 0.5);
+      int n_full = (int)((rr - 1.0) * per_round + 0.1); // (16384x2048: 3.9 -> 3 full segments of 68 rows per band: 0.770-0.772 against 0.789-0.826 ms with 4 of 54, two boxes)
       if (bands) { // unit segments of about 64 rows
         const int by_rows = (int)(Y / 64.0 + 0.5) - 1;
         n_full = n_full > by_rows ? n_full : by_rows;

@@ -33,7 +33,7 @@ EXPORTS = [
     "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_particles_keys",
     "wx_particles_contribute", "wx_particles_adopt", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns",
     "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait", "wx_set_comm_stream", "wx_step_overlap",
-    "wx_set_option", "wx_water_free", "wx_slab_assert_water_free",
+    "wx_set_option", "wx_water_free", "wx_slab_assert_water_free", "wx_tune_placement",
 ]
 
 
@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
     L.wx_sync.argtypes = [vp]
     L.wx_set_option.argtypes = [vp, i32, i32]
     L.wx_water_free.argtypes = [vp]
+    L.wx_tune_placement.argtypes = [vp, i32, i32, vp, vp]
     L.wx_slab_assert_water_free.argtypes = [vp, i32]
     L.wx_get_iter.argtypes = [vp]
     L.wx_get_iter.restype = i64
@@ -203,6 +204,13 @@ class Handle:
 
     def sync(self):
         self._chk(lib().wx_sync(self._h))
+
+    def tune_placement(self, tries: int = 6, iters_per_try: int = 30):
+        """wx_tune_placement: try ``tries`` further device allocations for the handle's planes, keep the fastest; returns
+        (ms per iteration of the first candidate, of the winner). The state is unchanged."""
+        a, b = C.c_float(0), C.c_float(0)
+        self._chk(lib().wx_tune_placement(self._h, int(tries), int(iters_per_try), C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
 
     def water_free(self) -> bool:
         """Did the last upload find this handle's cells water-free (wx_water_free)?"""

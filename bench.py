@@ -63,6 +63,7 @@ def parse():
                     help="eddies: smooth divergence-free eddies of 50..400 cells (a developed flow; default); noise: white noise per cell (worst case for the ring reads)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 32768 x 4096 dry north-star measurement (N=1)")
     ap.add_argument("--no-extras", action="store_true", help="skip at_rest / frame-1 / hbm_ceiling side measurements (N=1)")
+    ap.add_argument("--tune", type=int, default=6, help="wx_tune_placement: further device allocations to try for the handle's planes (0: keep the first)")
     ap.add_argument("--verify", action="store_true", help="N > 1: checksum every rank's owned columns against an undecomposed run on rank 0")
     a = ap.parse_args()
     a.frame = max(1, a.frame)  # (0 or a negative value would never advance run_frames)
@@ -136,7 +137,7 @@ def pmc_traffic(a, kernel, X=None, Y=None, workload=None):
             nfr = max(1, int(a.frame))
             cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", str(nfr), "--warmup", str(nfr),
                    "--X", str(X or a.X), "--Y", str(Y or a.Y), "--workload", workload or a.workload, "--no-cpu-baseline", "--no-pmc",
-                   "--no-north-star", "--no-extras", "--frame", str(a.frame), "--flow", str(a.flow), "--flow-kind", a.flow_kind]
+                   "--no-north-star", "--no-extras", "--frame", str(a.frame), "--flow", str(a.flow), "--flow-kind", a.flow_kind, "--tune", "0"]
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
@@ -197,6 +198,10 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
     del base, water, wall
     h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
     n = (steps // a.frame) * a.frame
+    placement = None
+    if a.tune > 0:
+        ms0, ms1 = h.tune_placement(a.tune, 30)
+        placement = {"tries": a.tune, "ms_per_iteration_first_allocation": ms0, "ms_per_iteration_kept": ms1}
 
     def measure(label):
         run_frames(h.step, warmup, a.frame)
@@ -223,7 +228,7 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
     res = {"workload": f"{X}x{Y} dry-air grid, pressure+velocity+advection only (BASELINE north_star / configs[1] passes), frames of {a.frame}",
            "value": main_["value"], "unit": "Mcell-steps/s", "steps": n, "ms_per_step": main_["ms_per_step"],
            "runs_Mcell_steps_per_s": main_["runs_Mcell_steps_per_s"], "claim": "slowest of three runs, " + main_["state"], "flow": main_["flow"],
-           "roofline": main_["roofline"]}
+           "roofline": main_["roofline"], "placement": placement}
     if moving:
         res["at_rest"] = {k: rest[k] for k in ("value", "ms_per_step", "runs_Mcell_steps_per_s", "flow")}
         res["at_rest"]["roofline_frac"] = rest["roofline"]["frac"]
@@ -343,6 +348,12 @@ def main():
     if a.flow > 0:  # a moving fluid: identical on slabs and on the undecomposed grid (function of the global cell index)
         devtools.seed_flow(stepper, a.flow, Xg=X, x0=x0_owned, kind=a.flow_kind)
     flow0 = devtools.flow_stats(stepper)
+    placement = None
+    if a.tune > 0 and not (world > 1 and a.particles):
+        # where the planes lie in physical memory is worth several % (profiles/r03_alloc_probe.txt): let the engine try a
+        # few allocations with its own iteration and keep the fastest -- set-up work, like the allocation itself; the state is unchanged
+        ms0, ms1 = stepper.tune_placement(a.tune, 30)
+        placement = {"tries": a.tune, "ms_per_iteration_first_allocation": ms0, "ms_per_iteration_kept": ms1}
 
     run_frames(step, a.warmup, a.frame)
     sync()
@@ -455,7 +466,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "grid": [X, Y], "decomposition": deco, "iteration_algorithmic_bytes_per_cell": A,
                        "frame": a.frame, "flow_std": a.flow, "flow_kind": a.flow_kind},
-            "ranks_seen": ranks_seen, "verify": verify,
+            "ranks_seen": ranks_seen, "verify": verify, "placement": placement,
             "flow": {"start_of_warmup": flow0, "end_of_timed_region": flow1},
             "iteration_roofline_frac_A_wet": cells * a.steps * A / dt / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roof,

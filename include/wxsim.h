@@ -185,6 +185,17 @@ void wx_host_free(void *p);
 int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst);
 int wx_stream_wait(wx_sim *s);
 
+/* Placement tuning (no reference counterpart). Where a handle's planes lie in physical device memory decides how the ~13 streams of
+ * the marching kernels spread over the HBM channels: the same binary runs the same iteration in 0.72 .. 0.84 ms depending on the
+ * allocation (profiles/r03_alloc_probe.txt). wx_tune_placement times the handle's own iteration (current parameters and
+ * pass mask; 2 untimed + iters_per_try timed iterations) on the allocation it has and on up to `tries` further ones that receive a
+ * copy of the state, keeps the fastest as the handle's storage and restores the state from a backup taken at the start: state,
+ * iteration counter and all fields are unchanged;
+ * device pointers obtained from wx_device_ptr before the call are invalid afterwards. ms_before / ms_after (may be NULL): the
+ * iteration time on the allocation the handle had and on the winner. Needs three times the handle's memory while it runs (more is used
+ * if free: rejected candidates are kept until the end so that the allocator does not hand the same memory out again). */
+int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before, float *ms_after);
+
 /* ---- plumbing for hosts that own device memory / streams (PyTorch, multi-GPU halo exchange) ---- */
 int wx_set_stream(wx_sim *s, void *hip_stream);     /* NULL = legacy default stream */
 void *wx_device_ptr(wx_sim *s, int field);          /* device address of a field's current storage */

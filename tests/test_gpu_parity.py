@@ -398,6 +398,56 @@ def test_particles_deterministic_order_coupled_run_bit_exact(pkg, oracle, golden
     h2.close()
 
 
+@pytest.mark.parametrize("mode", ["wet", "dry", "particles"])
+def test_tune_placement_leaves_the_state_untouched(pkg, oracle, E, mode):
+    """wx_tune_placement re-allocates the handle's planes (several candidate arenas, each timed with the handle's own iteration on a
+    COPY of the state) and moves in with the fastest: every field, the droplet pool and the iteration counter are what they were, and
+    the run continues bit for bit like an untuned handle / the oracle."""
+    X, Y = 700, 200
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    rng = np.random.Generator(np.random.Philox(17))
+    air = wall[..., 1] != 0
+    base[..., 0] += np.where(air, rng.normal(0, 0.2, (Y, X)), 0).astype(np.float32)
+    drops = None
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 40.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, **({"pass_mask": pkg.params.PASS_DRY} if mode == "dry" else {}))
+    u["enablePrecipitation"] = 0
+    if mode == "dry":
+        base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=0.2)
+    if mode == "particles":
+        pkg.synth.add_cloud_deck(water, wall)
+        drops = pkg.synth.init_rain_drops(3000)
+        drops[:1000, 0] = rng.uniform(-1, 1, 1000).astype(np.float32)
+        drops[:1000, 1] = rng.uniform(-0.6, 0.2, 1000).astype(np.float32)
+        drops[:1000, 2] = rng.uniform(0.1, 1.0, 1000).astype(np.float32)
+        drops[:1000, 3] = 0.0
+        drops[:1000, 4] = 1.0
+        u.update(enablePrecipitation=1, inactiveDroplets=2000.0, splat_order=1)
+    h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u, drops=drops, iter0=3)
+    if mode == "particles":
+        h.set_option(h.OPT_SPLAT_ORDER, 1)
+    fields = ["BASE_CUR", "WATER_CUR", "WALL_CUR"] + ([] if mode == "dry" else ["LIGHT_0", "LIGHT_1", "BASE_DISP", "WATER_0"])
+    h.step(3)
+    o.step(3)
+    before = {f: h.read_rect(f) for f in fields + ["CURL", "PRECIP_FB"]}
+    ms0, ms1 = h.tune_placement(tries=3, iters_per_try=3)
+    assert ms1 <= ms0 and ms1 > 0
+    assert h.iter == 6
+    for f, a in before.items():
+        assert np.array_equal(h.read_rect(f), a), f
+    if drops is not None:
+        assert np.array_equal(h.read_particles(), o.field("DROPS"))
+    _assert_grid_equal(h, o, fields, emitted=mode != "dry")
+    h.step(5)
+    o.step(5)
+    _assert_grid_equal(h, o, fields, emitted=mode != "dry")
+    if drops is not None:
+        assert np.array_equal(h.read_particles(), o.field("DROPS"))
+        assert np.array_equal(h.read_rect("PRECIP_FB"), o.field("PRECIP_FB"))
+    h.close()
+
+
 def test_read_rect_contract(pkg, golden, E):
     g, u = golden("synth64")
     X, Y = int(g["X"]), int(g["Y"])

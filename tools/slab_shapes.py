@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Projected 1 -> 8 GPU scaling from slab-shaped runs on ONE GPU: what one rank of an N = 8 job computes per iteration (its X/8 owned
+columns + 2 x halo ghost columns, the kernel set and launch shape it would use, no exchange: ghost columns just go stale) against the
+whole grid on the same GPU, interleaved. T(whole) / T(slab) is the speed-up an 8-GPU run reaches when the exchange is hidden behind
+the interior strips (bench.py --gpus 8 measures the real thing). Usage: python tools/slab_shapes.py [halo] [reps]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import wxpkg  # noqa: E402
+
+pkg = wxpkg.load_package()
+from weather_sandbox_amd import devtools  # noqa: E402
+
+HALO = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+N, STEPS = 8, 200
+
+
+def make(X, Y, workload, slab):
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 50.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, **({"pass_mask": pkg.params.PASS_DRY} if workload == "dry" else {}))
+    u["enablePrecipitation"] = 0
+    xo = X // N
+    if slab:
+        h = pkg.engine.Handle(xo, Y, 0, X_global=X, x0=3 * xo, halo=HALO)
+        cols = (3 * xo - HALO, xo + 2 * HALO)
+    else:
+        h = pkg.engine.Handle(X, Y, 0)
+        cols = None
+    if workload == "dry":
+        h.upload(*pkg.synth.dry_grid(X, Y, cols=cols))
+        if slab:
+            h.slab_assert_water_free(True)
+    else:
+        h.setup_columns(pkg.synth.terrain_columns(X, Y, cols=cols))
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    devtools.seed_flow(h, 0.2, Xg=X, x0=3 * xo if slab else 0)
+    h.step(20)
+    h.sync()
+    return h
+
+
+def timed(h):
+    h.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(STEPS // 10):
+        h.step(10)
+    h.sync()
+    return (time.perf_counter() - t0) / STEPS * 1e3
+
+
+print(f"slab = X/8 owned columns + 2 x {HALO} ghost columns; ms per iteration, {REPS} interleaved repetitions of {STEPS} iterations (frames of 10)")
+for (X, Y) in ((16384, 2048), (32768, 4096)):
+    for workload in ("wet", "dry"):
+        whole, slab = make(X, Y, workload, False), make(X, Y, workload, True)
+        tw, ts = [], []
+        for _ in range(REPS):
+            tw.append(timed(whole))
+            ts.append(timed(slab))
+        whole.close()
+        slab.close()
+        r = [a / b for a, b in zip(tw, ts)]
+        print(f"{X}x{Y} {workload:3s}  whole {' '.join(f'{t:.4f}' for t in tw)}   slab {X // N + 2 * HALO}x{Y} {' '.join(f'{t:.4f}' for t in ts)}   "
+              f"T(whole)/T(slab) {' '.join(f'{v:.2f}' for v in r)}", flush=True)
