@@ -83,8 +83,59 @@ def load(path: str) -> SaveFile:
         return decode(f.read())
 
 
+def js_number(x) -> str:
+    """A number as JavaScript's Number::toString prints it -- what JSON.stringify(guiControls) writes into a save (app.js:6610):
+    shortest round-trip digits, no ".0" on integers, decimal notation for 1e-7 < |x| < 1e21 (Python: 1e-05, JS: 0.00001),
+    exponents as e-7 / e+21. Non-finite values become null, like JSON.stringify does."""
+    if isinstance(x, bool):
+        return "true" if x else "false"
+    if isinstance(x, int):
+        return str(x)
+    x = float(x)
+    if x != x or x in (float("inf"), float("-inf")):
+        return "null"
+    if x == 0:
+        return "0"
+    sign = "-" if x < 0 else ""
+    r = repr(abs(x))  # shortest round-trip digits, as ECMAScript requires
+    mant, _, exp = r.partition("e")
+    ip, _, fp = mant.partition(".")
+    digits = (ip + fp).lstrip("0")
+    n = len(ip.lstrip("0")) if ip.strip("0") else -(len(fp) - len(fp.lstrip("0")))  # value = 0.digits * 10^n
+    n += int(exp) if exp else 0
+    digits = digits.rstrip("0") or "0"
+    k = len(digits)
+    if k <= n <= 21:
+        return sign + digits + "0" * (n - k)
+    if 0 < n <= 21:
+        return sign + digits[:n] + "." + digits[n:]
+    if -6 < n <= 0:
+        return sign + "0." + "0" * (-n) + digits
+    e = n - 1
+    return sign + digits[0] + ("." + digits[1:] if k > 1 else "") + "e" + ("+" if e > 0 else "-") + str(abs(e))
+
+
+def js_json(obj) -> str:
+    """JSON.stringify(obj) (no indentation): key order as inserted, numbers by js_number, non-ASCII characters unescaped."""
+    if obj is None:
+        return "null"
+    if isinstance(obj, (bool, int, float)):
+        return js_number(obj)
+    if isinstance(obj, str):
+        return json.dumps(obj, ensure_ascii=False)
+    if isinstance(obj, (list, tuple)):
+        return "[" + ",".join(js_json(v) for v in obj) + "]"
+    if isinstance(obj, dict):
+        return "{" + ",".join(json.dumps(str(k), ensure_ascii=False) + ":" + js_json(v) for k, v in obj.items()) + "}"
+    if isinstance(obj, np.generic):
+        return js_json(obj.item())
+    raise TypeError(f"not JSON serialisable: {type(obj)}")
+
+
 def encode(sf: SaveFile, level: int = 6) -> bytes:
-    """Byte layout of prepareDownload() (app.js:6610-6621)."""
+    """Byte layout of prepareDownload() (app.js:6610-6621); the settings block is formatted like JSON.stringify does, so that
+    decode -> encode reproduces the payload of a file the reference wrote byte for byte (the deflate stream itself differs:
+    pako and zlib choose different matches)."""
     parts = [
         struct.pack("<H", sf.X),
         struct.pack("<H", sf.Y),
@@ -94,7 +145,7 @@ def encode(sf: SaveFile, level: int = 6) -> bytes:
         np.ascontiguousarray(sf.droplets, np.float32).tobytes(),
         struct.pack("<H", len(sf.stations)),
         np.asarray([c for xy in sf.stations for c in xy], np.int16).tobytes(),
-        json.dumps(sf.settings if sf.settings is not None else {}, separators=(",", ":")).encode("utf-8"),
+        js_json(sf.settings if sf.settings is not None else {}).encode("utf-8"),
     ]
     return struct.pack("<I", SAVE_FILE_VERSION_ID) + zlib.compress(b"".join(parts), level)
 

@@ -1313,7 +1313,7 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
       for (size_t i = 0; i < rejects.size(); i++)
         if (rejects[i] == original) rejects[i] = best;
       best = original;
-      best_ms = ms_o;
+      best_ms = first_ms = ms_o;
     } else {
       best_ms = ms_b;
       first_ms = ms_o;

@@ -25,6 +25,32 @@ def test_roundtrip(pkg, golden):
     assert sf2.stations == sf.stations and sf2.settings == sf.settings
 
 
+def test_js_number_formatting(pkg):
+    """codec.js_number == JavaScript's Number::toString (checked against `node -e` when this list was written)."""
+    f = pkg.codec.js_number
+    cases = {0.00001: "0.00001", 1e-7: "1e-7", 1.5e-7: "1.5e-7", 0.000001: "0.000001", 5.0: "5", -0.0: "0", 0.1: "0.1", 100: "100", 1e21: "1e+21",
+             1e20: "100000000000000000000", 123456789.125: "123456789.125", -2.5: "-2.5", 67.45275198770811: "67.45275198770811",
+             0.007: "0.007", 1.2e-10: "1.2e-10", 12000.0: "12000", 0.25: "0.25", True: "true", 3: "3", float("nan"): "null"}
+    for x, want in cases.items():
+        assert f(x) == want, (x, f(x), want)
+    assert pkg.codec.js_json({"a": [1.0, 0.00001, "x"], "b": None, "c": {"d": False, "e": 1e-7}}) == '{"a":[1,0.00001,"x"],"b":null,"c":{"d":false,"e":1e-7}}'
+
+
+REF_SAVE = "/root/reference/saves/100 X 100 Test.weathersandbox"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(REF_SAVE), reason="the reference tree is only present in the build container")
+def test_reencoding_the_reference_save_is_byte_identical(pkg):
+    """decode -> encode of the reference's own save: the deflated PAYLOAD (dimensions, three textures, droplets, stations and the
+    guiControls JSON written by JSON.stringify, app.js:6610-6621) comes out byte for byte; only the deflate stream differs."""
+    import zlib
+    blob = open(REF_SAVE, "rb").read()
+    sf = pkg.codec.decode(blob)
+    again = pkg.codec.encode(sf)
+    assert again[:4] == blob[:4]
+    assert zlib.decompress(again[4:]) == zlib.decompress(blob[4:])
+
+
 def test_rejects_wrong_version(pkg):
     with pytest.raises(ValueError):
         pkg.codec.decode(b"\x01\x02\x03\x04" + b"garbage")

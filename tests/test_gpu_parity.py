@@ -135,6 +135,9 @@ def test_lightning_vs_reference(pkg, golden, E):
     iter0, niter = int(g["iter0"]), int(g["niter"])
     u = dict(u, quad_scale=1, enablePrecipitation=1, pass_mask=pkg.params.PASS_PRECIPITATION)
     h = E.Handle(X, Y, n)
+    # several strike requests of one iteration are SUMMED in texel (1,0): with fp32 atomics the order -- and the last bit -- varies from
+    # run to run; the deterministic splat order adds them in droplet-index order, the order the reference's blend unit draws them in
+    h.set_option(h.OPT_SPLAT_ORDER, 1)
     drops, light = g["in_drops"].copy(), np.zeros(4, np.float32)
     p = pkg.params.fill_struct(pkg.params.WxParams(), u)
     flipped = accepted = 0
