@@ -245,21 +245,35 @@ __global__ void k_copy4(const char4 *__restrict__ src, char4 *__restrict__ dst, 
 // (app.js:5940-5953). One thread per droplet; splats are fp32 atomic adds (order-nondeterministic,
 // exactly like the reference's blend unit).
 //
-// Column slabs (no reference counterpart): every rank holds the WHOLE droplet pool. In iteration j of an exchange
-// period a rank processes the droplets whose sample column lies where its grid is still valid (owned columns +
-// halo - 6j ghost columns) -- droplets in the overlap are processed redundantly, and identically, by both neighbours,
-// exactly like ghost cells -- and leaves the others untouched. A droplet processed inside the OWNED columns gets the
-// key (j+1)*2048 + (active after the step ? 1024 : 0) + (1023 - rank); at the end of the period an all-reduce(MAX) of the keys names, per droplet, the rank
-// that tracked it last, whose copy every rank adopts (slab.py). Sprites never wrap around the domain edge (the
-// reference clips them at the framebuffer): if the edge ("seam") runs through the local array, anchors right of it are
-// stored one column further right and the box sum never crosses it.
+// Column slabs (no reference counterpart). The pool is PARTITIONED: an active droplet is tracked by the rank whose owned
+// columns contain it (plus, as a ghost copy, by a neighbour while it is within `halo` columns of the common edge); every other rank
+// only knows "active elsewhere" (remote flag) and skips it after reading one byte. Inactive droplets are static records -- their
+// state does not change until they spawn -- that every rank holds; the spawn probe (precipitationShader.vert:82-84) hashes to a
+// position anywhere in the domain, so every rank tests every inactive record against its own columns (8 bytes + two integer hashes
+// per record and iteration) and acts on the ones that land where its grid is valid (owned columns + halo - 6j ghost columns in
+// iteration j of an exchange period: droplets in the overlap are processed redundantly, and identically, by both neighbours, like
+// ghost cells). Nothing is communicated inside a period. At the halo exchange:
+//   * every rank packs the droplets whose active / inactive status FLIPPED while it processed them (flips: one bit per iteration of
+//     the period) and that it had in its owned columns at some point: (index, flip history, final record) -- a few hundred per period --
+//     and the ranks all-gather these events (slab.py). Per droplet the report with the earliest first flip wins, then the one that saw
+//     the most flips, then the lower rank: a rank that spawned a droplet from a stale inactive record after another rank had already
+//     spawned it (it could not know) loses and drops its phantom; among equal histories the rank that processed the droplet last
+//     wins. Everybody takes the winners' records;
+//   * then every rank demotes the active droplets that are no longer in its owned columns and sends the ones within `halo` columns of
+//     an edge to that neighbour (same batch of send / recv as the grid halos), which keeps them as ghost copies.
+// The pool is updated IN PLACE on slab handles (a droplet is only ever touched by its own thread). Sprites never wrap around the
+// domain edge (the reference clips them at the framebuffer): if the edge ("seam") runs through the local array, anchors right of it
+// are stored one column further right and the box sum never crosses it.
 // ------------------------------------------------------------------------------------------------
 struct SlabP {
   int lo, hi;         // local columns [lo, hi): sample positions this rank processes in this iteration
   int own_lo, own_hi; // owned local columns
   int seam;           // local column of global column 0 if it lies strictly inside the local array, else 0
-  int keyval;         // claim key of this iteration; 0 = whole-domain handle (no keys)
-  int *keys;
+  int stamp;          // iteration of the exchange period (0-based) + 1; 0 = whole-domain handle
+  const unsigned char *remote; // per droplet: tracked by another rank
+  unsigned short *flips;       // per droplet: bit j set = active / inactive status flipped in iteration j of this period (as seen here)
+  unsigned char *owned_once;   // per droplet: low 4 bits = last iteration (+1) of this period in which this rank processed it; bit 7 =
+                               // processed inside the OWNED columns at least once (this rank reports its flips)
 };
 #ifndef WX_PRECIP_COUNT_MODE
 #define WX_PRECIP_COUNT_MODE 1
@@ -273,6 +287,7 @@ struct DevState {
   int ghost_nontrivial;   // set by k_halo_unpack when a neighbour's ghost columns carry water (or a negative vegetation byte)
                           // although the host asserted a water-free domain (wx_slab_assert_water_free): reported by the next blocking call
   int fix_overflow;       // set by k_wet_fix when more output cells needed the exact path than its list holds (the entry count)
+  int pool_overflow;      // set when an exchange buffer of the partitioned droplet pool received more entries than it holds
 };
 
 // Splat accumulation: a 12x12 point sprite anchored at pixel (i0,j0) adds the same value to pixels
@@ -371,16 +386,17 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
   float feedback[4] = {0.f, 0.f, 0.f, 0.f}, deposition[2] = {0.f, 0.f};
   float size = 1.0f, gposx = -2.0f, gposy = -2.0f; // default: clipped
 
-  if (live && sp.keyval) { // slab handle: is the sample position (spawn probe / own position) in my valid columns?
-    const float dpx = drops_in[5 * (size_t)i], dpy = drops_in[5 * (size_t)i + 1], m0 = drops_in[5 * (size_t)i + 2];
-    (void)dpy;
-    const float tcx = m0 < 0.0f ? random2d(m0, dpx + u.iterNum * 0.3754f) : dpx / 2.0f + 0.5f;
-    const int lc = local_col(g, tcx);
-    if (lc < sp.lo || lc >= sp.hi) { // no: another rank tracks this droplet
-      for (int c = 0; c < 5; c++) drops_out[5 * (size_t)i + c] = drops_in[5 * (size_t)i + c];
-      live = false;
+  if (live && sp.stamp) { // slab handle: is the droplet mine to look at, and is its sample position (spawn probe / own position) in my valid columns?
+    if (sp.remote[i]) {
+      live = false; // active on another rank
     } else {
-      claim = lc >= sp.own_lo && lc < sp.own_hi;
+      const float dpx = drops_in[5 * (size_t)i], m0 = drops_in[5 * (size_t)i + 2];
+      const float tcx = m0 < 0.0f ? random2d(m0, dpx + u.iterNum * 0.3754f) : dpx / 2.0f + 0.5f;
+      const int lc = local_col(g, tcx);
+      if (lc < sp.lo || lc >= sp.hi)
+        live = false; // not where my grid is valid: a static inactive record, or a ghost copy the neighbour tracks (the pool is in place)
+      else
+        claim = lc >= sp.own_lo && lc < sp.own_hi;
     }
   }
 
@@ -531,9 +547,10 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
     drops_out[5 * (size_t)i + 2] = newM0;
     drops_out[5 * (size_t)i + 3] = newM1;
     drops_out[5 * (size_t)i + 4] = fmaxf(newDensity, 0.0f);
-    // claim key: later iteration > earlier; at equal iteration a copy that is (still / newly) ACTIVE beats a rank that
-    // merely evaluated the spawn probe of its stale inactive copy; then the lower rank
-    if (claim) sp.keys[i] = sp.keyval + (newM0 >= 0.0f ? 1024 : 0);
+    if (sp.stamp) { // what the exchange needs to know: did the status flip, and did I have the droplet in my owned columns
+      if ((m0 >= 0.0f) != (newM0 >= 0.0f)) sp.flips[i] |= (unsigned short)(1u << (sp.stamp - 1));
+      sp.owned_once[i] = (unsigned char)((sp.owned_once[i] & 0x80) | sp.stamp | (claim ? 0x80 : 0));
+    }
   }
 
   // inactive-droplet count: the reference blends +1 into texel (0,0) per droplet
@@ -822,7 +839,7 @@ __global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg,
 
 // lightningLocationShader.frag:24-38 + the 600-iteration inactive count (app.js:5957-5966), one thread
 // (slab handles: the mailbox texels are not part of the local feedback texture -- the request is taken from the
-// accumulator directly, the inactive count is refreshed by wx_particles_adopt)
+// accumulator directly, the inactive count is refreshed by wx_pool_edges_pack)
 __global__ void k_lightning(float iterNum, int refresh_inactive, const float4 *__restrict__ fb, DevState *st, int mailbox)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -837,29 +854,143 @@ __global__ void k_lightning(float iterNum, int refresh_inactive, const float4 *_
   st->lightning[3] = n.w;
 }
 
-// ---- slab particle reconciliation (see SlabP) ----
-__global__ void k_drops_contribute(int n, const int *__restrict__ keys, const int *__restrict__ win, const float *__restrict__ drops,
-                                   float *__restrict__ out)
+// ---- slab particle pool exchange (see SlabP) ----
+struct PoolEvent { // 32 bytes
+  int gid;
+  int key;      // smaller wins: first flip << 18 | (15 - number of flips) << 14 | (15 - last iteration processed) << 10 | rank
+  float rec[5]; // final record of the reporting rank
+  int pad;
+};
+struct PoolRec { // 24 bytes: an active droplet handed to a neighbour as ghost copy
+  int gid;
+  float rec[5];
+};
+// buffers start with a 16-byte header whose first int is the number of entries
+constexpr int POOL_HDR = 16;
+
+__global__ void k_pool_events_pack(int n, int rank, int cap, unsigned short *__restrict__ flips, unsigned char *__restrict__ owned_once,
+                                   const float *__restrict__ drops, int *__restrict__ hdr, PoolEvent *__restrict__ ev)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const bool mine = win[i] > 0 && keys[i] == win[i];
-  for (int c = 0; c < 5; c++) out[5 * (size_t)i + c] = mine ? drops[5 * (size_t)i + c] : 0.0f;
+  const unsigned f = flips[i], meta = owned_once[i];
+  const bool mine = (meta & 0x80) != 0;
+  flips[i] = 0;
+  owned_once[i] = 0;
+  if (!f || !mine) return;
+  const int at = atomicAdd(hdr, 1);
+  if (at >= cap) return; // (the host reports hdr[0] > cap as an error)
+  PoolEvent e;
+  e.gid = i;
+  e.key = ((__ffs((int)f) - 1) << 18) | ((15 - __popc(f)) << 14) | ((15 - (int)(meta & 15)) << 10) | rank;
+  for (int c = 0; c < 5; c++) e.rec[c] = drops[5 * (size_t)i + c];
+  e.pad = 0;
+  ev[at] = e;
 }
-__global__ void k_drops_adopt(int n, int *__restrict__ keys, const int *__restrict__ win, const float *__restrict__ state,
-                              float *__restrict__ drops, DevState *st, int count_inactive)
+// pass 1 over the gathered events of all ranks: per droplet the smallest key
+__global__ void k_pool_events_best(int n_ranks, size_t stride_bytes, int cap, const char *__restrict__ bufs, int *__restrict__ best)
+{
+  const int r = blockIdx.y;
+  const int *hdr = reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
+  const PoolEvent *ev = reinterpret_cast<const PoolEvent *>(bufs + (size_t)r * stride_bytes + POOL_HDR);
+  const int cnt = min(hdr[0], cap);
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) atomicMin(&best[ev[k].gid], ev[k].key);
+}
+// pass 2: every rank but the reporter takes the winner's record (a rank that spawned a phantom loses it here). Whether an ACTIVE
+// droplet is then tracked here -- as owner or as ghost copy -- is decided by its position in k_pool_edges_pack, which runs next
+__global__ void k_pool_events_apply(int n_ranks, size_t stride_bytes, int cap, const char *__restrict__ bufs, int *__restrict__ best, int my_rank,
+                                    float *__restrict__ drops, unsigned char *__restrict__ remote)
+{
+  const int r = blockIdx.y;
+  const int *hdr = reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
+  const PoolEvent *ev = reinterpret_cast<const PoolEvent *>(bufs + (size_t)r * stride_bytes + POOL_HDR);
+  const int cnt = min(hdr[0], cap);
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
+    const PoolEvent e = ev[k];
+    if (best[e.gid] != e.key || (e.key & 1023) == my_rank) continue;
+    for (int c = 0; c < 5; c++) drops[5 * (size_t)e.gid + c] = e.rec[c];
+    remote[e.gid] = 0;
+  }
+}
+__global__ void k_pool_events_reset(int n_ranks, size_t stride_bytes, int cap, const char *__restrict__ bufs, int *__restrict__ best)
+{
+  const int r = blockIdx.y;
+  const int *hdr = reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
+  const PoolEvent *ev = reinterpret_cast<const PoolEvent *>(bufs + (size_t)r * stride_bytes + POOL_HDR);
+  const int cnt = min(hdr[0], cap);
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) best[ev[k].gid] = 0x7fffffff;
+}
+// active droplets I hold: outside my owned columns -> the owner is elsewhere (remote); inside and within `halo` columns of an edge ->
+// a ghost copy for that neighbour. count_inactive != 0: also count the inactive records into st->px_count (the 600-iteration refresh
+// of the `inactiveDroplets` uniform, app.js:5957-5966: every rank holds every inactive record, so the count needs no collective).
+__global__ void k_pool_edges_pack(Geo g, int n, int own_lo, int own_hi, int halo, int cap, float *__restrict__ drops, unsigned char *__restrict__ remote,
+                                  int *__restrict__ hdrL, PoolRec *__restrict__ recL, int *__restrict__ hdrR, PoolRec *__restrict__ recR,
+                                  DevState *st, int count_inactive)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool inactive = false;
-  if (i < n) {
-    if (win[i] > 0)
-      for (int c = 0; c < 5; c++) drops[5 * (size_t)i + c] = state[5 * (size_t)i + c];
-    keys[i] = 0;
-    inactive = drops[5 * (size_t)i + 2] < 0.0f;
+  if (i < n && !remote[i]) {
+    const float px = drops[5 * (size_t)i], m0 = drops[5 * (size_t)i + 2];
+    inactive = m0 < 0.0f;
+    if (!inactive) {
+      const int lc = local_col(g, px / 2.0f + 0.5f);
+      if (lc < own_lo || lc >= own_hi) {
+        remote[i] = 1;
+      } else {
+        PoolRec r;
+        r.gid = i;
+        for (int c = 0; c < 5; c++) r.rec[c] = drops[5 * (size_t)i + c];
+        if (hdrL && lc < own_lo + halo) {
+          const int at = atomicAdd(hdrL, 1);
+          if (at < cap) recL[at] = r;
+        }
+        if (hdrR && lc >= own_hi - halo) {
+          const int at = atomicAdd(hdrR, 1);
+          if (at < cap) recR[at] = r;
+        }
+      }
+    }
   }
-  if (count_inactive) { // the 600-iteration refresh of the `inactiveDroplets` uniform (app.js:5957-5966); st->px_count was zeroed by the host
+  if (count_inactive) {
     const unsigned long long m = __ballot(inactive);
     if (m != 0ull && (threadIdx.x & 63) == __ffsll((long long)m) - 1) unsafeAtomicAdd(&st->px_count, (float)__popcll(m));
+  }
+}
+__global__ void k_pool_edges_apply(int cap, const int *__restrict__ hdr, const PoolRec *__restrict__ rec, float *__restrict__ drops,
+                                   unsigned char *__restrict__ remote)
+{
+  const int cnt = min(hdr[0], cap);
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
+    const PoolRec r = rec[k];
+    for (int c = 0; c < 5; c++) drops[5 * (size_t)r.gid + c] = r.rec[c];
+    remote[r.gid] = 0;
+  }
+}
+// readback aid: 0 = tracked elsewhere (the local record is stale), 1 = inactive (every rank's record), 2 = active in my owned columns
+// (this rank's record is THE record), 3 = active ghost copy
+__global__ void k_pool_flags(Geo g, int n, int own_lo, int own_hi, const float *__restrict__ drops, const unsigned char *__restrict__ remote,
+                             unsigned char *__restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned char f = 0;
+  if (!remote[i]) {
+    const float px = drops[5 * (size_t)i], m0 = drops[5 * (size_t)i + 2];
+    if (m0 < 0.0f) {
+      f = 1;
+    } else {
+      const int lc = local_col(g, px / 2.0f + 0.5f);
+      f = (lc >= own_lo && lc < own_hi) ? 2 : 3;
+    }
+  }
+  out[i] = f;
+}
+__global__ void k_pool_check(int n_bufs, size_t stride_bytes, int cap, const char *__restrict__ bufs, DevState *st)
+{
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_bufs) {
+    const int cnt = *reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
+    if (cnt > cap) atomicMax(&st->pool_overflow, cnt);
   }
 }
 __global__ void k_inactive_from_count(DevState *st)

@@ -71,7 +71,13 @@ struct wx_sim {
   half4 *emitted = nullptr; // RGBA16F, allocated by the first read
   int drop_cur = 0;      // particle buffer holding the latest state
   // slab handles with particles (see SlabP in wx_kernels.h)
-  int *keys = nullptr;   // per-droplet claim key of the current exchange period
+  // the partitioned droplet pool (SlabP): per droplet "tracked by another rank", status flips / ownership of the current period,
+  // scratch for the event resolution; capacities of the exchange buffers
+  unsigned char *pool_remote = nullptr, *pool_owned = nullptr;
+  unsigned short *pool_flips = nullptr;
+  int *pool_best = nullptr;
+  int pool_event_cap = 0, pool_edge_cap = 0;
+  bool pool_check = false; // an exchange buffer may have overflowed since the flags were last looked at
   int period_j = 0;      // iterations since wx_slab_period_begin: halo - 6*j ghost columns are still valid
   int rank = 0;          // tie-break of the claim keys (wx_slab_set_rank)
   int seam = 0;          // local column of global column 0 if strictly inside the local array
@@ -703,7 +709,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   { // everything allocated below, to the byte (plus the splat grids of handles with droplets)
     const size_t nd = (size_t)(n_droplets > 0 ? n_droplets : 1);
     size_t total = n * (3 * 16 + 3 * 16 + 2 * 16 + 2 * 4 + 4 + 8 + 16 + 8 + 3 * 16 + (n_droplets > 0 ? 4 : 0)) + 2 * nd * 20 + 4 * ((size_t)Y + 8) * 4 + (size_t)s->X * 16 + 65536;
-    if (n_droplets > 0) total += ((size_t)s->X + 8) * ((size_t)Y + 8) * 24 + n / 64 + (size_t)n_droplets * 4 + (1u << 20);
+    if (n_droplets > 0) total += ((size_t)s->X + 8) * ((size_t)Y + 8) * 24 + n / 64 + (size_t)n_droplets * 8 + (1u << 20);
     rc = arena_begin(s, total);
   }
   for (int i = 0; i < 2 && rc == WX_OK; i++) {
@@ -743,9 +749,16 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
     if (rc == WX_OK) rc = dalloc(s, &sg.dirty, (size_t)sg.TXn * sg.TYn);
     if (rc == WX_OK) rc = dalloc(s, &sg.fb_zero, (size_t)sg.TXn * sg.TYn);
     if (rc == WX_OK) rc = dalloc(s, &sg.work, 8 + 3 * (size_t)sg.TXn * sg.TYn);
-    if (rc == WX_OK && halo > 0) rc = dalloc(s, &s->keys, (size_t)n_droplets);
+    if (rc == WX_OK && halo > 0) rc = dalloc(s, &s->pool_remote, (size_t)n_droplets);
+    if (rc == WX_OK && halo > 0) rc = dalloc(s, &s->pool_owned, (size_t)n_droplets);
+    if (rc == WX_OK && halo > 0) rc = dalloc(s, &s->pool_flips, (size_t)n_droplets);
+    if (rc == WX_OK && halo > 0) rc = dalloc(s, &s->pool_best, (size_t)n_droplets);
     if (rc == WX_OK && halo > 0) {
-      if (hipMemset(s->keys, 0, (size_t)n_droplets * 4) != hipSuccess) rc = WX_E_DEVICE;
+      if (hipMemset(s->pool_best, 0x7f, (size_t)n_droplets * 4) != hipSuccess) rc = WX_E_DEVICE; // (0x7f7f7f7f: larger than any event key)
+      // capacities of the exchange buffers: status flips of one period (a few hundred in a storm) and the droplets within `halo`
+      // columns of an edge; generous, fixed, and checked (an overflow is reported by the next blocking call)
+      s->pool_event_cap = std::max(4096, n_droplets / 16);
+      s->pool_edge_cap = std::max(4096, n_droplets / 8);
       int xoff = (x0 - halo) % X_global;
       if (xoff < 0) xoff += X_global;
       s->seam = (xoff > 0 && xoff + s->X > X_global) ? X_global - xoff : 0;
@@ -802,7 +815,10 @@ void wx_destroy(wx_sim *s)
     hipEventDestroy(s->ev_unpacked);
   }
   dfree(s, s->state);
-  dfree(s, s->keys);
+  dfree(s, s->pool_remote);
+  dfree(s, s->pool_owned);
+  dfree(s, s->pool_flips);
+  dfree(s, s->pool_best);
   dfree(s, s->tdisp);
   for (int i = 0; i < 3; i++) {
     dfree(s, s->lp[i].x);
@@ -883,7 +899,14 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 16, s->stream));
   HIPCHK(s, hipMemsetAsync(s->dep, 0, n * 8, s->stream));
   HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
-  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 32, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow
+  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 36, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow, pool_overflow
+  if (s->pool_remote) { // partitioned pool: every rank was handed the whole pool; keep what lies in the local array (owned + ghost columns)
+    HIPCHK(s, hipMemsetAsync(s->pool_remote, 0, (size_t)s->n_drops, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->pool_owned, 0, (size_t)s->n_drops, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->pool_flips, 0, (size_t)s->n_drops * 2, s->stream));
+    hipLaunchKernelGGL(k_pool_edges_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, s->n_drops, 0, s->X, 0, 0, s->drops[0], s->pool_remote,
+                       nullptr, nullptr, nullptr, nullptr, s->state, 0);
+  }
   if (s->sg.acc4) {
     HIPCHK(s, hipMemsetAsync(s->sg.acc4, 0, (size_t)s->sg.AP * s->sg.AH * 16, s->stream));
     HIPCHK(s, hipMemsetAsync(s->sg.acc2, 0, (size_t)s->sg.AP * s->sg.AH * 8, s->stream));
@@ -997,8 +1020,8 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   // ... and the water texture stays known trivial only through water-free dry iterations (iterate_dry's `water == false` case)
   if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] != 0.0f || s->p.soundingForcing != 0.0f) s->water_trivial = false;
   if (s->p.userInputType >= 10) s->air_from_row = -1; // wall tools: the terrain may grow (re-measured after the call)
-  if (precip && s->keys && n_iter > 0) { // slab with particles: refuse an over-long call BEFORE any iteration runs
-    const int allowed = (s->halo - 6) / WX_SLAB_CONE - s->period_j;
+  if (precip && s->pool_remote && n_iter > 0) { // slab with particles: refuse an over-long call BEFORE any iteration runs
+    const int allowed = std::min((s->halo - 6) / WX_SLAB_CONE, 15) - s->period_j; // (the flip history of a period is a 16-bit mask)
     if (n_iter > allowed)
       return fail(s, WX_E_STATE, "wx_step: %d iterations asked, %d done since the last halo exchange; %d ghost columns allow %d per period with particles",
                   n_iter, s->period_j, s->halo, (s->halo - 6) / WX_SLAB_CONE);
@@ -1035,15 +1058,18 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       u.iterI = (int)u.iterNum;
       {
         ProfScope ps(s, K_PRECIP);
-        SlabP sp{0, s->X, 0, s->X, 0, 0, nullptr};
-        if (s->keys) { // slab: the grid of this iteration is valid on the owned columns + (halo - 6*(j+1)) ghost columns; the
+        SlabP sp{0, s->X, 0, s->X, 0, 0, nullptr, nullptr, nullptr};
+        const float *d_in = s->drops[src];
+        float *d_out = s->drops[dst];
+        if (s->pool_remote) { // slab: the grid of this iteration is valid on the owned columns + (halo - 6*(j+1)) ghost columns; the
           // feedback texture is exact where every droplet within a sprite radius (6 px) was processed, so the owned columns
           // need 6 valid ghost columns even in the last iteration of a period
           const int margin = s->halo - WX_SLAB_CONE * (s->period_j + 1); // >= 6: checked before the loop
-          sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, (s->period_j + 1) * 2048 + (1023 - s->rank), s->keys};
+          sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, s->period_j + 1, s->pool_remote, s->pool_flips, s->pool_owned};
+          d_in = d_out = s->drops[0]; // the partitioned pool is updated in place
         }
-        hipLaunchKernelGGL(k_precipitation, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, u, s->n_drops, s->drops[src],
-                           two_kernel ? s->base[0] : ((fused || dry) ? s->base[2] : s->base[1]), s->water[1], s->state, s->drops[dst], s->sg, sp,
+        hipLaunchKernelGGL(k_precipitation, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, u, s->n_drops, d_in,
+                           two_kernel ? s->base[0] : ((fused || dry) ? s->base[2] : s->base[1]), s->water[1], s->state, d_out, s->sg, sp,
                            two_kernel ? s->tdisp : nullptr, DetSplat{s->splat_order ? s->det_key[0] : nullptr, s->det_val});
         LAUNCH_CHECK(s, "precipitation");
       }
@@ -1058,14 +1084,14 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       {
         ProfScope ps(s, K_SPLAT);
         const int T = s->sg.TXn * s->sg.TYn, par = s->splat_par;
-        hipLaunchKernelGGL(k_splat_classify, dim3((T + 255) / 256), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->keys ? 0 : 1, par);
+        hipLaunchKernelGGL(k_splat_classify, dim3((T + 255) / 256), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->pool_remote ? 0 : 1, par);
         hipLaunchKernelGGL(k_splat_box, dim3(T < 2048 ? T : 2048), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->state, s->fb, s->dep, s->seam,
-                           s->keys ? 0 : 1, par);
+                           s->pool_remote ? 0 : 1, par);
         LAUNCH_CHECK(s, "splat_classify / splat_box");
       }
       {
         ProfScope ps(s, K_LIGHTNING);
-        hipLaunchKernelGGL(k_lightning, dim3(1), dim3(64), 0, s->stream, u.iterNum, (int)(s->iter % 600 == 0), s->fb, s->state, s->keys ? 0 : 1);
+        hipLaunchKernelGGL(k_lightning, dim3(1), dim3(64), 0, s->stream, u.iterNum, (int)(s->iter % 600 == 0), s->fb, s->state, s->pool_remote ? 0 : 1);
         LAUNCH_CHECK(s, "lightning");
       }
       {
@@ -1075,9 +1101,9 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
         LAUNCH_CHECK(s, "splat_clear");
         s->splat_par ^= 1;
       }
-      s->drop_cur = dst;
+      s->drop_cur = s->pool_remote ? 0 : dst;
       s->fb_dirty = true;
-      if (s->keys) s->period_j++;
+      if (s->pool_remote) s->period_j++;
     } else if (s->fb_dirty) { // particles were switched off: the reference's clear leaves both textures zero
       hipMemsetAsync(s->fb, 0, n * 16, s->stream);
       hipMemsetAsync(s->dep, 0, n * 8, s->stream);
@@ -1138,6 +1164,17 @@ static int validate_ghost_flag(wx_sim *s)
       HIPCHK(s, hipMemsetAsync(&s->state->fix_overflow, 0, 4, s->stream));
       return fail(s, WX_E_STATE, "%d output cells of one iteration were fed by velocities >= 0.9 cells/iteration; the exact path holds %d: the state has "
                                  "left the simulation's range (velocities are documented as -1 .. 1) and the results since are invalid", over, s->fix_cap);
+    }
+  }
+  if (s->pool_check) {
+    int over = 0;
+    HIPCHK(s, hipMemcpyAsync(&over, &s->state->pool_overflow, 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    s->pool_check = false;
+    if (over) {
+      HIPCHK(s, hipMemsetAsync(&s->state->pool_overflow, 0, 4, s->stream));
+      return fail(s, WX_E_STATE, "a droplet-pool exchange buffer received %d entries (event capacity %d, edge capacity %d): droplets were lost", over,
+                  s->pool_event_cap, s->pool_edge_cap);
     }
   }
   if (!s->ghost_check) return WX_OK;
@@ -1215,7 +1252,7 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
   if (!s) return WX_E_INVALID;
   if (tries < 1 || iters_per_try < 1) return fail(s, WX_E_INVALID, "wx_tune_placement: tries >= 1, iters_per_try >= 1");
   if (!s->uploaded || !s->have_params) return fail(s, WX_E_STATE, "wx_tune_placement before wx_upload / wx_set_params");
-  if (s->keys) return fail(s, WX_E_STATE, "wx_tune_placement: not on slab handles with particles (the exchange period would advance)");
+  if (s->pool_remote) return fail(s, WX_E_STATE, "wx_tune_placement: not on slab handles with particles (the exchange period would advance)");
   if (int rc = wx_sync(s)) return rc;
   TuneSnap snap;
   if (!s->arena || !snap_take(s, snap)) return fail(s, WX_E_STATE, "wx_tune_placement: the handle's planes do not live in one arena (WX_ARENA=0?)");
@@ -1571,7 +1608,7 @@ int wx_local_width(const wx_sim *s) { return s ? s->X : 0; }
 
 // base_0, water_1, light_0, light_1 (float4), wall_0 (char4); handles that carry particles also exchange the feedback
 // (float4) and deposition (float2) textures, which the boundary pass of the next iteration reads
-size_t wx_halo_bytes(const wx_sim *s) { return s ? (size_t)s->halo * s->Y * (4 * 16 + 4 + (s->keys ? 16 + 8 : 0)) : 0; }
+size_t wx_halo_bytes(const wx_sim *s) { return s ? (size_t)s->halo * s->Y * (4 * 16 + 4 + (s->pool_remote ? 16 + 8 : 0)) : 0; }
 
 static int halo_xstart(const wx_sim *s, int side, bool pack)
 {
@@ -1586,8 +1623,8 @@ int wx_halo_pack(wx_sim *s, int side, void *dev_buf)
   const int n = s->halo * s->Y;
   const LightPlanes none{nullptr, nullptr, nullptr};
   HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
-             s->keys ? s->fb : nullptr, s->keys ? s->dep : nullptr};
-  const size_t o8 = (size_t)n * (s->keys ? 80 : 64), o4 = o8 + (s->keys ? (size_t)n * 8 : 0);
+             s->pool_remote ? s->fb : nullptr, s->pool_remote ? s->dep : nullptr};
+  const size_t o8 = (size_t)n * (s->pool_remote ? 80 : 64), o4 = o8 + (s->pool_remote ? (size_t)n * 8 : 0);
   hipStream_t st = s->stream;
   if (s->comm_stream) { // the packed columns are final behind ev_edges (or, without an edge-first step, behind everything enqueued so far)
     if (!s->edges_recorded) {
@@ -1611,8 +1648,8 @@ int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
   const int n = s->halo * s->Y;
   const LightPlanes none{nullptr, nullptr, nullptr};
   HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
-             s->keys ? s->fb : nullptr, s->keys ? s->dep : nullptr};
-  const size_t o8 = (size_t)n * (s->keys ? 80 : 64), o4 = o8 + (s->keys ? (size_t)n * 8 : 0);
+             s->pool_remote ? s->fb : nullptr, s->pool_remote ? s->dep : nullptr};
+  const size_t o8 = (size_t)n * (s->pool_remote ? 80 : 64), o4 = o8 + (s->pool_remote ? (size_t)n * 8 : 0);
   hipStream_t st = s->comm_stream ? s->comm_stream : s->stream;
   ProfScope ps(s, K_HALO);
   hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256), dim3(256), 0, st, f, s->X, s->Y, s->halo, halo_xstart(s, side, false),
@@ -1623,7 +1660,7 @@ int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
     HIPCHK(s, hipEventRecord(s->ev_unpacked, s->comm_stream));
     s->unpack_pending = true;
   }
-  if (s->keys) { // the ghost tiles of the feedback texture now hold a neighbour's values: nothing is "known zero" any more
+  if (s->pool_remote) { // the ghost tiles of the feedback texture now hold a neighbour's values: nothing is "known zero" any more
     hipMemsetAsync(s->sg.fb_zero, 0, (size_t)s->sg.TXn * s->sg.TYn, s->stream);
     s->fb_dirty = true;
   }
@@ -1646,33 +1683,76 @@ int wx_slab_period_begin(wx_sim *s)
   return WX_OK;
 }
 
-int wx_particles_keys(wx_sim *s, int32_t *dev_keys_out)
-{
-  if (!s || !dev_keys_out) return WX_E_INVALID;
-  if (!s->keys) return fail(s, WX_E_STATE, "wx_particles_keys: not a slab handle with particles");
-  HIPCHK(s, hipMemcpyAsync(dev_keys_out, s->keys, (size_t)s->n_drops * 4, hipMemcpyDeviceToDevice, s->stream));
-  return WX_OK;
-}
+size_t wx_pool_event_bytes(const wx_sim *s) { return s && s->pool_remote ? POOL_HDR + (size_t)s->pool_event_cap * sizeof(PoolEvent) : 0; }
+size_t wx_pool_edge_bytes(const wx_sim *s) { return s && s->pool_remote ? POOL_HDR + (size_t)s->pool_edge_cap * sizeof(PoolRec) : 0; }
 
-int wx_particles_contribute(wx_sim *s, const int32_t *dev_winner_keys, float *dev_state_out)
+#define POOL_ONLY(s, what) \
+  if (!(s)->pool_remote) return fail((s), WX_E_STATE, what ": not a slab handle with particles")
+
+int wx_pool_events_pack(wx_sim *s, void *dev_buf)
 {
-  if (!s || !dev_winner_keys || !dev_state_out) return WX_E_INVALID;
-  if (!s->keys) return fail(s, WX_E_STATE, "wx_particles_contribute: not a slab handle with particles");
-  hipLaunchKernelGGL(k_drops_contribute, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->keys, dev_winner_keys,
-                     s->drops[s->drop_cur], dev_state_out);
+  if (!s || !dev_buf) return WX_E_INVALID;
+  POOL_ONLY(s, "wx_pool_events_pack");
+  HIPCHK(s, hipMemsetAsync(dev_buf, 0, POOL_HDR, s->stream));
+  hipLaunchKernelGGL(k_pool_events_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->rank, s->pool_event_cap, s->pool_flips, s->pool_owned,
+                     s->drops[0], (int *)dev_buf, (PoolEvent *)((char *)dev_buf + POOL_HDR));
   HIPCHK(s, hipGetLastError());
   return WX_OK;
 }
 
-int wx_particles_adopt(wx_sim *s, const int32_t *dev_winner_keys, const float *dev_state, int refresh_inactive)
+int wx_pool_events_apply(wx_sim *s, const void *dev_bufs, int n_ranks)
 {
-  if (!s || !dev_winner_keys || !dev_state) return WX_E_INVALID;
-  if (!s->keys) return fail(s, WX_E_STATE, "wx_particles_adopt: not a slab handle with particles");
+  if (!s || !dev_bufs || n_ranks < 1) return WX_E_INVALID;
+  POOL_ONLY(s, "wx_pool_events_apply");
+  const size_t stride = wx_pool_event_bytes(s);
+  const dim3 grid(64, n_ranks), block(256);
+  const char *b = (const char *)dev_bufs;
+  hipLaunchKernelGGL(k_pool_check, dim3(1), dim3(64), 0, s->stream, n_ranks, stride, s->pool_event_cap, b, s->state);
+  hipLaunchKernelGGL(k_pool_events_best, grid, block, 0, s->stream, n_ranks, stride, s->pool_event_cap, b, s->pool_best);
+  hipLaunchKernelGGL(k_pool_events_apply, grid, block, 0, s->stream, n_ranks, stride, s->pool_event_cap, b, s->pool_best, s->rank, s->drops[0], s->pool_remote);
+  hipLaunchKernelGGL(k_pool_events_reset, grid, block, 0, s->stream, n_ranks, stride, s->pool_event_cap, b, s->pool_best);
+  s->pool_check = true;
+  HIPCHK(s, hipGetLastError());
+  return WX_OK;
+}
+
+int wx_pool_edges_pack(wx_sim *s, void *dev_left, void *dev_right, int refresh_inactive)
+{
+  if (!s || !dev_left || !dev_right) return WX_E_INVALID;
+  POOL_ONLY(s, "wx_pool_edges_pack");
+  HIPCHK(s, hipMemsetAsync(dev_left, 0, POOL_HDR, s->stream));
+  HIPCHK(s, hipMemsetAsync(dev_right, 0, POOL_HDR, s->stream));
   if (refresh_inactive) HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 4, s->stream));
-  hipLaunchKernelGGL(k_drops_adopt, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->keys, dev_winner_keys, dev_state,
-                     s->drops[s->drop_cur], s->state, refresh_inactive);
+  hipLaunchKernelGGL(k_pool_edges_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, s->n_drops, s->halo, s->X - s->halo, s->halo, s->pool_edge_cap,
+                     s->drops[0], s->pool_remote, (int *)dev_left, (PoolRec *)((char *)dev_left + POOL_HDR), (int *)dev_right,
+                     (PoolRec *)((char *)dev_right + POOL_HDR), s->state, refresh_inactive);
   if (refresh_inactive) hipLaunchKernelGGL(k_inactive_from_count, dim3(1), dim3(1), 0, s->stream, s->state);
   HIPCHK(s, hipGetLastError());
+  return WX_OK;
+}
+
+int wx_pool_edges_apply(wx_sim *s, const void *dev_buf)
+{
+  if (!s || !dev_buf) return WX_E_INVALID;
+  POOL_ONLY(s, "wx_pool_edges_apply");
+  hipLaunchKernelGGL(k_pool_check, dim3(1), dim3(64), 0, s->stream, 1, (size_t)0, s->pool_edge_cap, (const char *)dev_buf, s->state);
+  hipLaunchKernelGGL(k_pool_edges_apply, dim3(64), dim3(256), 0, s->stream, s->pool_edge_cap, (const int *)dev_buf, (const PoolRec *)((const char *)dev_buf + POOL_HDR),
+                     s->drops[0], s->pool_remote);
+  s->pool_check = true;
+  HIPCHK(s, hipGetLastError());
+  return WX_OK;
+}
+
+int wx_pool_flags(wx_sim *s, uint8_t *host_dst)
+{
+  if (!s || !host_dst) return WX_E_INVALID;
+  POOL_ONLY(s, "wx_pool_flags");
+  unsigned char *d = nullptr;
+  if (hipMalloc((void **)&d, (size_t)s->n_drops) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_pool_flags");
+  hipLaunchKernelGGL(k_pool_flags, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, s->n_drops, s->halo, s->X - s->halo, s->drops[0], s->pool_remote, d);
+  const hipError_t e1 = hipMemcpyAsync(host_dst, d, (size_t)s->n_drops, hipMemcpyDeviceToHost, s->stream), e2 = hipStreamSynchronize(s->stream);
+  hipFree(d);
+  if (e1 != hipSuccess || e2 != hipSuccess) return fail(s, WX_E_DEVICE, "wx_pool_flags: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
   return WX_OK;
 }
 

@@ -30,8 +30,8 @@ EXPORTS = [
     "wx_create", "wx_create_slab", "wx_destroy", "wx_last_error", "wx_abi_version", "wx_upload", "wx_set_params",
     "wx_step", "wx_sync", "wx_get_iter", "wx_set_iter", "wx_read_rect", "wx_read_particles", "wx_set_stream",
     "wx_device_ptr", "wx_local_width", "wx_halo_bytes", "wx_halo_pack", "wx_halo_unpack", "wx_profile",
-    "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_particles_keys",
-    "wx_particles_contribute", "wx_particles_adopt", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns",
+    "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_pool_event_bytes",
+    "wx_pool_edge_bytes", "wx_pool_events_pack", "wx_pool_events_apply", "wx_pool_edges_pack", "wx_pool_edges_apply", "wx_pool_flags", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns",
     "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait", "wx_set_comm_stream", "wx_step_overlap",
     "wx_set_option", "wx_water_free", "wx_slab_assert_water_free", "wx_tune_placement",
 ]
@@ -104,9 +104,15 @@ def lib() -> C.CDLL:
     L.wx_kernel_name.restype = C.c_char_p
     L.wx_slab_set_rank.argtypes = [vp, i32]
     L.wx_slab_period_begin.argtypes = [vp]
-    L.wx_particles_keys.argtypes = [vp, vp]
-    L.wx_particles_contribute.argtypes = [vp, vp, vp]
-    L.wx_particles_adopt.argtypes = [vp, vp, vp, i32]
+    L.wx_pool_event_bytes.argtypes = [vp]
+    L.wx_pool_event_bytes.restype = C.c_size_t
+    L.wx_pool_edge_bytes.argtypes = [vp]
+    L.wx_pool_edge_bytes.restype = C.c_size_t
+    L.wx_pool_events_pack.argtypes = [vp, vp]
+    L.wx_pool_events_apply.argtypes = [vp, vp, i32]
+    L.wx_pool_edges_pack.argtypes = [vp, vp, vp, i32]
+    L.wx_pool_edges_apply.argtypes = [vp, vp]
+    L.wx_pool_flags.argtypes = [vp, vp]
     L.wx_lightning_get.argtypes = [vp, vp]
     L.wx_lightning_set.argtypes = [vp, vp]
     L.wx_setup_columns.argtypes = [vp] + [vp] * 8
@@ -339,14 +345,29 @@ class Handle:
     def slab_period_begin(self):
         self._chk(lib().wx_slab_period_begin(self._h))
 
-    def particles_keys(self, dev_ptr: int):
-        self._chk(lib().wx_particles_keys(self._h, C.c_void_p(dev_ptr)))
+    def pool_event_bytes(self) -> int:
+        return lib().wx_pool_event_bytes(self._h)
 
-    def particles_contribute(self, dev_winner: int, dev_state_out: int):
-        self._chk(lib().wx_particles_contribute(self._h, C.c_void_p(dev_winner), C.c_void_p(dev_state_out)))
+    def pool_edge_bytes(self) -> int:
+        return lib().wx_pool_edge_bytes(self._h)
 
-    def particles_adopt(self, dev_winner: int, dev_state: int, refresh_inactive: bool = False):
-        self._chk(lib().wx_particles_adopt(self._h, C.c_void_p(dev_winner), C.c_void_p(dev_state), 1 if refresh_inactive else 0))
+    def pool_events_pack(self, dev_buf: int):
+        self._chk(lib().wx_pool_events_pack(self._h, C.c_void_p(dev_buf)))
+
+    def pool_events_apply(self, dev_bufs: int, n_ranks: int):
+        self._chk(lib().wx_pool_events_apply(self._h, C.c_void_p(dev_bufs), int(n_ranks)))
+
+    def pool_edges_pack(self, dev_left: int, dev_right: int, refresh_inactive: bool = False):
+        self._chk(lib().wx_pool_edges_pack(self._h, C.c_void_p(dev_left), C.c_void_p(dev_right), 1 if refresh_inactive else 0))
+
+    def pool_edges_apply(self, dev_buf: int):
+        self._chk(lib().wx_pool_edges_apply(self._h, C.c_void_p(dev_buf)))
+
+    def pool_flags(self) -> np.ndarray:
+        """Per droplet: 0 tracked by another rank, 1 inactive, 2 active in this rank's owned columns, 3 ghost copy."""
+        out = np.zeros(self.n_droplets, np.uint8)
+        self._chk(lib().wx_pool_flags(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def lightning(self) -> np.ndarray:
         out = np.zeros(4, np.float32)

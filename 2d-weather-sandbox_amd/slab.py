@@ -15,11 +15,13 @@ soon as the columns the neighbours need are final and proceeds while the interio
 launches the interior strips first and the edge strips -- the only ones that read ghost columns -- once the unpack event has
 fired (``EDGES_LAST``). The host never blocks.
 
-Particles (``n_droplets > 0``): every rank holds the whole droplet pool and processes, redundantly in the ghost
-zones, the droplets whose sample position lies where its grid is still valid (csrc/wx_kernels.h, ``SlabP``). At every
-halo exchange (which then also carries the feedback / deposition textures) the pool is reconciled: all-reduce(MAX)
-of the per-droplet claim keys, all-reduce(SUM) of the winners' states (the 4-float lightning state rides along) --
-the only collectives of the path, ``20 B x n_droplets`` every ``(halo - 6) // 6`` iterations.
+Particles (``n_droplets > 0``): the droplet pool is PARTITIONED (csrc/wx_kernels.h, ``SlabP``). An active droplet is tracked by the
+rank whose owned columns contain it (and as a ghost copy by the neighbour while it is within ``halo`` columns of the common edge);
+inactive droplets are static records every rank holds and tests against its own columns (their spawn probe hashes to anywhere in
+the domain). At every halo exchange (which then also carries the feedback / deposition textures): an all-gather of the few hundred
+droplets whose active / inactive status flipped during the period (32 B each; a rank that spawned a phantom from a stale record loses
+it here), then the droplets near the slab edges travel to the ring neighbours in the SAME batch of send / recv as the grid halos
+(24 B each). The 4-float lightning state is reconciled with two tiny all-reduces. No message grows with the pool size.
 
 ``SlabSim`` is written against a small engine interface so that the identical exchange logic runs on the HIP
 engine (``HipSlabEngine``, device tensors + NCCL) and on a checker engine in the CPU tests (gloo).
@@ -95,20 +97,24 @@ class HipSlabEngine:
     def assert_water_free(self, agreed: bool):
         self.h.slab_assert_water_free(agreed)
 
-    # particle pool reconciliation (device tensors in, device tensors out)
-    def new_particle_buffers(self):
-        """(claim keys, droplet states): one extra int / five extra floats at the end carry the lightning state."""
-        return (torch.zeros(self.n_droplets + 1, dtype=torch.int32, device=self.device),
-                torch.zeros(self.n_droplets * 5 + 5, dtype=torch.float32, device=self.device))
+    # partitioned droplet pool (device tensors in, device tensors out)
+    def new_pool_buffers(self, world: int):
+        """(my event buffer, the gathered event buffers of all ranks, [edge buffers to left / right], [from left / right])."""
+        eb, gb = self.h.pool_event_bytes(), self.h.pool_edge_bytes()
+        z = lambda n: torch.zeros(n, dtype=torch.uint8, device=self.device)
+        return z(eb), z(eb * world), [z(gb), z(gb)], [z(gb), z(gb)]
 
-    def particle_keys(self, keys: torch.Tensor):
-        self.h.particles_keys(keys.data_ptr())
+    def pool_events_pack(self, buf: torch.Tensor):
+        self.h.pool_events_pack(buf.data_ptr())
 
-    def particle_contribute(self, winner: torch.Tensor, state: torch.Tensor):
-        self.h.particles_contribute(winner.data_ptr(), state.data_ptr())
+    def pool_events_apply(self, gathered: torch.Tensor, world: int):
+        self.h.pool_events_apply(gathered.data_ptr(), world)
 
-    def particle_adopt(self, winner: torch.Tensor, state: torch.Tensor, refresh_inactive: bool):
-        self.h.particles_adopt(winner.data_ptr(), state.data_ptr(), refresh_inactive)
+    def pool_edges_pack(self, left: torch.Tensor, right: torch.Tensor, refresh_inactive: bool):
+        self.h.pool_edges_pack(left.data_ptr(), right.data_ptr(), refresh_inactive)
+
+    def pool_edges_apply(self, buf: torch.Tensor):
+        self.h.pool_edges_apply(buf.data_ptr())
 
     def lightning(self):
         return self.h.lightning()
@@ -149,6 +155,8 @@ class SlabSim:
         self.particles = getattr(engine, "n_droplets", 0) > 0
         # with particles the owned columns need a sprite radius (6 px) of valid ghost columns in the last iteration too
         self.iters_per_exchange = max(1, (halo - 6 if self.particles else halo) // CONE_PER_ITERATION)
+        if self.particles:
+            self.iters_per_exchange = min(self.iters_per_exchange, 15)  # (the droplets' flip history of a period is a 16-bit mask)
         self.left, self.right = (rank - 1) % world, (rank + 1) % world
         self._since_exchange = 0
         self._iters = 0
@@ -158,7 +166,7 @@ class SlabSim:
             self.send = [engine.new_buffer(), engine.new_buffer()]  # [to left, to right]
             self.recv = [engine.new_buffer(), engine.new_buffer()]  # [from left, from right]
             if self.particles:
-                self.keys, self.state = engine.new_particle_buffers()
+                self.ev, self.ev_all, self.psend, self.precv = engine.new_pool_buffers(world)
             # gloo has no device-tensor send/recv (it is the CPU-test / single-GPU plumbing transport): stage through the host
             self._stage = dist.get_backend() == "gloo" and self.send[0].is_cuda
             if self._stage:
@@ -182,9 +190,14 @@ class SlabSim:
     def handle(self):
         return getattr(self.engine, "h", self.engine)
 
+    def _staged(self, t: torch.Tensor) -> torch.Tensor:
+        return t.cpu() if self._stage else t
+
     def exchange(self):
         """Ring exchange: my left edge -> left neighbour's right ghosts, my right edge -> right neighbour's left ghosts. Everything
-        is enqueued (on the engine's comm stream when it has one); nothing here waits on the host except the gloo staging path."""
+        is enqueued (on the engine's comm stream when it has one); nothing here waits on the host except the gloo staging path.
+        With particles the droplet-pool exchange rides along: status-flip events (all-gather), then the edge droplets in the same
+        batch of send / recv as the grid halos."""
         if self.world == 1:
             return
         e = self.engine
@@ -192,64 +205,77 @@ class SlabSim:
         with ctx:
             e.pack(0, self.send[0])
             e.pack(1, self.send[1])
-            send, recv = self.send, self.recv
+            if self.particles:
+                # 1. who flipped between active and inactive this period, and what did it become (a few hundred droplets)
+                e.pool_events_pack(self.ev)
+                if self._stage:
+                    e.sync()
+                    parts = [torch.empty_like(self.ev, device="cpu") for _ in range(self.world)]
+                    dist.all_gather(parts, self.ev.cpu())
+                    self.ev_all.copy_(torch.cat(parts))
+                else:
+                    dist.all_gather_into_tensor(self.ev_all, self.ev)
+                e.pool_events_apply(self.ev_all, self.world)
+                # 2. ownership by position; the droplets near my edges become the neighbours' ghost copies
+                refresh = (self._iters // 600) != ((self._iters - self._since_exchange) // 600)  # app.js:5957-5966: every 600 iterations
+                e.pool_edges_pack(self.psend[0], self.psend[1], refresh)
+            out = [self.send[0], self.send[1]] + (self.psend if self.particles else [])
+            inn = [self.recv[0], self.recv[1]] + (self.precv if self.particles else [])
             if self._stage:
                 e.sync()
-                for hb, b in zip(self._hsend, self.send):
-                    hb.copy_(b)
-                send, recv = self._hsend, self._hrecv
-            if self.world == 2:
-                # both neighbours are the same rank: order the two messages identically on both sides
-                ops = [dist.P2POp(dist.isend, send[0], self.left), dist.P2POp(dist.isend, send[1], self.right),
-                       dist.P2POp(dist.irecv, recv[1], self.right), dist.P2POp(dist.irecv, recv[0], self.left)]
+                out = [t.cpu() for t in out]
+                hin = [torch.empty_like(t, device="cpu") for t in inn]
             else:
-                ops = [dist.P2POp(dist.isend, send[0], self.left), dist.P2POp(dist.irecv, recv[1], self.right),
-                       dist.P2POp(dist.isend, send[1], self.right), dist.P2POp(dist.irecv, recv[0], self.left)]
+                hin = inn
+            ops = []
+            for k in range(0, len(out), 2):  # pairs (to / from left, to / from right)
+                if self.world == 2:
+                    # both neighbours are the same rank: order the two messages identically on both sides
+                    ops += [dist.P2POp(dist.isend, out[k], self.left), dist.P2POp(dist.isend, out[k + 1], self.right),
+                            dist.P2POp(dist.irecv, hin[k + 1], self.right), dist.P2POp(dist.irecv, hin[k], self.left)]
+                else:
+                    ops += [dist.P2POp(dist.isend, out[k], self.left), dist.P2POp(dist.irecv, hin[k + 1], self.right),
+                            dist.P2POp(dist.isend, out[k + 1], self.right), dist.P2POp(dist.irecv, hin[k], self.left)]
             for r in dist.batch_isend_irecv(ops):
                 r.wait()  # NCCL / RCCL: orders the current (comm) stream behind the transfer, does not block the host
             if self._stage:
-                for hb, b in zip(self._hrecv, self.recv):
+                for hb, b in zip(hin, inn):
                     b.copy_(hb)
             e.unpack(0, self.recv[0])  # left ghosts  <- left neighbour's right edge
             e.unpack(1, self.recv[1])  # right ghosts <- right neighbour's left edge
+            if self.particles:
+                e.pool_edges_apply(self.precv[0])
+                e.pool_edges_apply(self.precv[1])
         if self.particles:
-            self.reconcile_particles()
+            self.reconcile_lightning()
+            e.period_begin()
         self._since_exchange = 0
         self._exchanged = True
 
-    def reconcile_particles(self):
-        """Make every rank's copy of the droplet pool the copy of the rank that tracked each droplet last, and every
-        rank's lightning state the latest strike any rank registered. Two all-reduces: MAX over the claim keys (+ the
-        strike key), SUM over the winners' states (+ the winning strike). Device tensors only: no host round trip.
+    def reconcile_lightning(self):
+        """Every rank's lightning state becomes the latest strike any rank registered: MAX over a strike key, SUM of the winner's four
+        floats. Device tensors only: no host round trip.
 
-        Strike key = start iteration << 10 | (1023 - rank), reduced in its OWN int64 tensor (the iteration is never wrapped: an
-        int32 key would wrap after 2^20 iterations and an old strike would then beat every new one): the latest strike wins; two
-        ranks that registered different strikes in the same iteration are told apart by the rank, so exactly one of them
+        Strike key = start iteration << 10 | (1023 - rank) in an int64 tensor (the iteration is never wrapped): the latest strike wins;
+        two ranks that registered different strikes in the same iteration are told apart by the rank, so exactly one of them
         contributes (no averaging of two bolts)."""
-        e, n = self.engine, self.engine.n_droplets
-        e.particle_keys(self.keys)
+        e = self.engine
         live = hasattr(e, "lightning_tensor")
-        light = e.lightning_tensor() if live else torch.from_numpy(np.asarray(e.lightning(), np.float32).copy()).to(self.keys.device)
-        it = light[2].to(torch.int64)
-        my_key = torch.where(light[2] > 0, it * 1024 + (1023 - self.rank), torch.zeros_like(it)).reshape(1)
+        dev = self.send[0].device if (self.send[0].is_cuda and not self._stage) else torch.device("cpu")
+        light = e.lightning_tensor() if live else torch.from_numpy(np.asarray(e.lightning(), np.float32).copy())
+        lw = light.to(dev)
+        it = lw[2].to(torch.int64)
+        my_key = torch.where(lw[2] > 0, it * 1024 + (1023 - self.rank), torch.zeros_like(it)).reshape(1)
         win_key = my_key.clone()
-        dist.all_reduce(self.keys, op=dist.ReduceOp.MAX)
         dist.all_reduce(win_key, op=dist.ReduceOp.MAX)
-        e.particle_contribute(self.keys, self.state)
         mine = ((my_key > 0) & (my_key == win_key)).to(torch.float32)[0]
-        self.state[5 * n] = mine
-        self.state[5 * n + 1:] = light * mine
-        dist.all_reduce(self.state, op=dist.ReduceOp.SUM)
-        # the reference refreshes the `inactiveDroplets` uniform every 600 iterations (app.js:5957-5966)
-        refresh = (self._iters // 600) != ((self._iters - self._since_exchange) // 600)
-        e.particle_adopt(self.keys, self.state, refresh)
-        tail = self.state[5 * n:]
-        new_light = torch.where(tail[0] > 0, tail[1:], light)  # exactly one rank contributed the winning strike
+        tail = torch.cat([mine.reshape(1), lw * mine])
+        dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+        new_light = torch.where(tail[0] > 0, tail[1:], lw)  # exactly one rank contributed the winning strike
         if live:
-            light.copy_(new_light)
+            light.copy_(new_light.to(light.device))
         else:
             e.set_lightning(new_light.cpu().numpy())
-        e.period_begin()
 
     def step(self, n: int):
         done = 0
@@ -313,6 +339,20 @@ class SlabSim:
         eng.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]), drops)
         eng.set_params(u)
         return cls(eng, rank, world, halo)
+
+    def gather_particles(self) -> Optional[np.ndarray]:
+        """The whole droplet pool (n_droplets x 5) assembled on rank 0 (None elsewhere): an active droplet's record comes from the rank
+        that has it in its owned columns, an inactive one's is the same on every rank (wx_pool_flags). Host-side, for readback / saves."""
+        h = self.handle
+        d, f = h.read_particles(), h.pool_flags()
+        if self.world == 1:
+            return d
+        mine = torch.from_numpy(np.where((f == 2)[:, None], d, 0).astype(np.float32))
+        cnt = torch.from_numpy((f == 2).astype(np.int32))
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)  # (exactly one owner per active droplet: the sum IS its record)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        out = np.where((cnt.numpy() > 0)[:, None], mine.numpy(), d)  # nobody owns it: inactive, my own record is everybody's
+        return out if self.rank == 0 else None
 
     def owned(self, field: str) -> np.ndarray:
         """This rank's owned columns of a field (host array)."""

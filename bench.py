@@ -330,7 +330,7 @@ def main():
         from weather_sandbox_amd import slab
         if a.workload == "dry":
             drv = slab.SlabSim.from_dry_generator(pkg, X, Y, u, rank, world, device)
-        elif a.particles:  # the whole droplet pool on every rank; halo 64: sprite clipping needs tile-aligned slab edges
+        elif a.particles:  # partitioned droplet pool (every rank is handed the whole initial pool once); halo 64: sprite clipping needs tile-aligned slab edges
             drv = slab.SlabSim.from_generator(pkg, X, Y, u, rank, world, device, halo=64,
                                               drops=pkg.synth.init_rain_drops(a.particles), cloud_deck=True)
         else:
@@ -405,7 +405,7 @@ def main():
                 whole.close()
                 verify = "ok" if not bad else "MISMATCH: " + ", ".join(bad)
         elif a.verify:
-            verify = "not available with particles (replicated pool: compare with tests/test_slab_gpu_ranks.py)"
+            verify = "not available with particles (a period may differ from the undecomposed run by a few re-spawn probes: tests/test_gpu_fullsize.py quantifies it)"
 
     if rank == 0:
         cells = X * Y
@@ -456,7 +456,7 @@ def main():
         if world == 1:
             deco = "none"
         elif a.particles:
-            deco = f"{world} x-slabs, 64 ghost columns, ring halo exchange + droplet-pool reconciliation every 9 iterations"
+            deco = f"{world} x-slabs, 64 ghost columns, partitioned droplet pool; every 9 iterations: ring halo exchange + edge droplets (one batch of send/recv), status-flip events (all-gather of a few KB)"
         else:
             deco = f"{world} x-slabs, 48 ghost columns, ring halo exchange every 8 iterations (RCCL send/recv on a side stream, overlapped with compute)"
         A = 36 if a.workload == "dry" else 72

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WX_ABI_VERSION 5
+#define WX_ABI_VERSION 6
 
 /* error codes */
 #define WX_OK 0
@@ -234,22 +234,34 @@ int wx_slab_assert_water_free(wx_sim *s, int agreed);
 int wx_set_comm_stream(wx_sim *s, void *hip_stream); /* NULL: pack / unpack on the compute stream again */
 int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags);
 
-/* Particles on slabs (n_droplets > 0 with halo > 0; halo and X_owned multiples of 64). Every rank holds the WHOLE droplet
- * pool (same wx_upload drops array on every rank) and, in each iteration, processes the droplets whose sample position
- * (precipitationShader.vert:82-84 spawn probe, or own position) lies in the columns where its grid is still valid; a
- * droplet processed inside the OWNED columns in iteration j of the exchange period gets the claim key
- * (j+1)*2048 + (still active ? 1024 : 0) + (1023 - rank). At the end of a period (when the halo is exchanged; the halo buffers then also carry the
- * feedback / deposition textures) the ranks reconcile the pool:
- *   wx_particles_keys -> all-reduce(MAX) -> wx_particles_contribute -> all-reduce(SUM) -> wx_particles_adopt,
+/* Particles on slabs (n_droplets > 0 with halo > 0; halo and X_owned multiples of 64): the PARTITIONED droplet pool.
+ * wx_upload hands every rank the whole pool once; from then on an active droplet is tracked by the rank whose owned columns contain
+ * it (and, as a ghost copy, by the neighbour while it is within `halo` columns of the common edge); the other ranks only know
+ * "active elsewhere" and skip it. Inactive droplets are static records that every rank holds; every rank tests every inactive
+ * record's hashed spawn probe (precipitationShader.vert:82-84: anywhere in the domain) against its own columns and acts on the ones
+ * that land where its grid is valid. Nothing is communicated inside an exchange period ((halo - 6) / WX_SLAB_CONE iterations, at
+ * most 15). At the halo exchange (all buffers are DEVICE pointers; calls are enqueued on the handle's stream):
+ *   wx_pool_events_pack  -> all-gather of the wx_pool_event_bytes() buffers -> wx_pool_events_apply(gathered, n_ranks):
+ *       the droplets whose active / inactive status flipped (spawned, evaporated, deposited) with their final records; per droplet
+ *       the report with the earliest first flip wins, then the longest flip history, then the rank that processed it last -- a rank
+ *       that spawned a droplet from a stale inactive record after another rank had (it cannot know inside a period) drops its phantom;
+ *   wx_pool_edges_pack(left, right, refresh_inactive) -> send / recv with the ring neighbours (same batch as the grid halos)
+ *       -> wx_pool_edges_apply(buffer received from either neighbour): active droplets that left the owned columns are handed over,
+ *       the ones within `halo` columns of an edge become the neighbour's ghost copies. refresh_inactive != 0 also refreshes the
+ *       `inactiveDroplets` uniform (app.js:5957-5966) from the inactive records -- every rank holds all of them: no collective;
  *   lightning state: wx_lightning_get -> pick the latest strike -> wx_lightning_set;  then wx_slab_period_begin.
- * All buffers are DEVICE pointers (n_droplets int32 keys, 5*n_droplets floats); calls are enqueued on the handle's stream.
- * refresh_inactive != 0 also refreshes the `inactiveDroplets` uniform from the reconciled pool (the reference does that
- * every 600 iterations, app.js:5957-5966). */
+ * Buffer overflows (more status flips / edge droplets than the fixed capacities) are reported by the next blocking call (WX_E_STATE).
+ * wx_read_particles returns the LOCAL view of the pool; wx_pool_flags says per droplet what it is worth: 0 = tracked by another rank
+ * (stale here), 1 = inactive (the same record on every rank), 2 = active inside this rank's owned columns (THE record), 3 = ghost copy. */
 int wx_slab_set_rank(wx_sim *s, int rank);
 int wx_slab_period_begin(wx_sim *s);
-int wx_particles_keys(wx_sim *s, int32_t *dev_keys_out);
-int wx_particles_contribute(wx_sim *s, const int32_t *dev_winner_keys, float *dev_state_out);
-int wx_particles_adopt(wx_sim *s, const int32_t *dev_winner_keys, const float *dev_state, int refresh_inactive);
+size_t wx_pool_event_bytes(const wx_sim *s);
+size_t wx_pool_edge_bytes(const wx_sim *s);
+int wx_pool_events_pack(wx_sim *s, void *dev_buf);
+int wx_pool_events_apply(wx_sim *s, const void *dev_bufs, int n_ranks);
+int wx_pool_edges_pack(wx_sim *s, void *dev_left, void *dev_right, int refresh_inactive);
+int wx_pool_edges_apply(wx_sim *s, const void *dev_buf);
+int wx_pool_flags(wx_sim *s, uint8_t *host_dst);
 int wx_lightning_get(wx_sim *s, float out[4]);
 int wx_lightning_set(wx_sim *s, const float in[4]);
 

@@ -812,13 +812,53 @@ def test_dry_slab_wrong_water_free_assertion_is_reported(pkg, E):
         h.close()
 
 
-@pytest.mark.parametrize("nslab", [2, 4])
-def test_slab_particles_equal_whole_domain(pkg, E, nslab):
-    """Particles on column slabs (replicated droplet pool, ghost-zone processing, claim-key reconciliation): N slab
-    handles on one GPU, the collectives of slab.py emulated with torch ops, against the undecomposed handle. Droplets
-    sit on slab edges, in ghost zones and within a sprite radius of the domain edge (sprites are clipped there, never
-    wrapped). Droplet arithmetic is order independent; the splat sums are fp32 atomics, so fields agree to summation
-    order."""
+def _pool_exchange(slabs, nslab, ev, pl, pr):
+    """The droplet-pool part of slab.SlabSim.exchange() with the all-gather and the send / recv spelled out (handles of one process)."""
+    import torch
+    for r, h in enumerate(slabs):
+        h.pool_events_pack(ev[r].data_ptr())
+        h.sync()
+    gathered = torch.cat(ev).contiguous()
+    for h in slabs:
+        h.pool_events_apply(gathered.data_ptr(), nslab)
+    for r, h in enumerate(slabs):
+        h.pool_edges_pack(pl[r].data_ptr(), pr[r].data_ptr(), False)
+        h.sync()
+    for r, h in enumerate(slabs):
+        h.pool_edges_apply(pr[(r - 1) % nslab].data_ptr())  # my left neighbour's right-edge droplets
+        h.pool_edges_apply(pl[(r + 1) % nslab].data_ptr())
+        h.sync()
+    best = max((h.lightning() for h in slabs), key=lambda v: float(v[2]))
+    for h in slabs:
+        h.set_lightning(best)
+        h.slab_period_begin()
+
+
+def _assemble_pool(slabs):
+    """The global pool from the partitioned one: every active droplet is owned (flag 2) by exactly one handle, every other droplet is
+    inactive with the same record on every handle."""
+    d = [h.read_particles() for h in slabs]
+    f = np.stack([h.pool_flags() for h in slabs])
+    owners = (f == 2).sum(0)
+    assert owners.max() <= 1, "an active droplet is owned by two ranks"
+    inactive = owners == 0
+    assert (f[:, inactive] == 1).all(), "a droplet nobody owns must be inactive on every rank"
+    for k in range(1, len(slabs)):
+        assert np.array_equal(d[k][inactive], d[0][inactive]), "inactive records differ between ranks"
+    out = d[0].copy()
+    for k, h in enumerate(slabs):
+        out[f[k] == 2] = d[k][f[k] == 2]
+    return out, f
+
+
+@pytest.mark.parametrize("nslab,order", [(2, 0), (4, 0), (4, 1)])
+def test_slab_particles_equal_whole_domain(pkg, E, nslab, order):
+    """Particles on column slabs: the PARTITIONED droplet pool (owner = slab containing the droplet, ghost copies within `halo`
+    columns of an edge, static inactive records everywhere, status-flip events at the exchange) -- N slab handles on one GPU, the
+    all-gather and the neighbour send / recv of slab.py emulated with torch ops, against the undecomposed handle. Droplets sit on
+    slab edges, in ghost zones and within a sprite radius of the domain edge (sprites are clipped there, never wrapped) and drift
+    across the slab edges. With the deterministic splat order (order 1) the whole coupled run is BIT-IDENTICAL to the undecomposed
+    one; with atomics the fields agree to summation order."""
     import torch
     X, Y, halo, n_iter, N = 512, 128, 64, 25, 6000
     base, water, wall = pkg.synth.terrain_grid(X, Y)
@@ -847,6 +887,7 @@ def test_slab_particles_equal_whole_domain(pkg, E, nslab):
     whole = E.Handle(X, Y, N)
     whole.upload(base, water, wall, drops)
     whole.set_params(p, u["initial_T"])
+    whole.set_option(whole.OPT_SPLAT_ORDER, order)
     slabs, bufs = [], []
     for r in range(nslab):
         h = E.Handle(xo, Y, N, X_global=X, x0=r * xo, halo=halo)
@@ -854,11 +895,15 @@ def test_slab_particles_equal_whole_domain(pkg, E, nslab):
         idx = (r * xo - halo + np.arange(xo + 2 * halo)) % X
         h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]), drops)
         h.set_params(p, u["initial_T"])
+        h.set_option(h.OPT_SPLAT_ORDER, order)
         assert h.halo_bytes() == halo * Y * 92  # + feedback 16 + deposition 8
         slabs.append(h)
         bufs.append([torch.empty(h.halo_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2)])
-    keys = [torch.zeros(N, dtype=torch.int32, device="cuda") for _ in range(nslab)]
-    state = [torch.zeros(5 * N, dtype=torch.float32, device="cuda") for _ in range(nslab)]
+    ev = [torch.zeros(h.pool_event_bytes(), dtype=torch.uint8, device="cuda") for h in slabs]
+    pl = [torch.zeros(h.pool_edge_bytes(), dtype=torch.uint8, device="cuda") for h in slabs]
+    pr = [torch.zeros(h.pool_edge_bytes(), dtype=torch.uint8, device="cuda") for h in slabs]
+    f0 = np.stack([h.pool_flags() for h in slabs])  # after the upload: every active droplet has one owner, the far ranks dropped it
+    assert ((f0 == 2).sum(0) == (drops[:, 2] >= 0)).all() and (f0 == 0).sum() > 0
     per = (halo - 6) // 6  # a sprite radius of valid ghost columns must remain in the last iteration
     with pytest.raises(E.WxError):  # more iterations than the ghost columns allow: refused before any iteration runs
         slabs[0].step(per + 1)
@@ -877,41 +922,35 @@ def test_slab_particles_equal_whole_domain(pkg, E, nslab):
         for r, h in enumerate(slabs):
             h.halo_unpack(0, bufs[(r - 1) % nslab][1].data_ptr())
             h.halo_unpack(1, bufs[(r + 1) % nslab][0].data_ptr())
-        # reconcile_particles() of slab.py with the all-reduces spelled out
-        for r, h in enumerate(slabs):
-            h.particles_keys(keys[r].data_ptr())
-            h.sync()
-        win = torch.stack(keys).max(0).values.contiguous()
-        assert int((win > 0).sum()) == N  # every droplet was tracked inside somebody's owned columns
-        for r, h in enumerate(slabs):
-            h.particles_contribute(win.data_ptr(), state[r].data_ptr())
-            h.sync()
-        total = torch.stack(state).sum(0).contiguous()
-        best = max((h.lightning() for h in slabs), key=lambda v: float(v[2]))
-        for h in slabs:
-            h.particles_adopt(win.data_ptr(), total.data_ptr(), False)
-            h.set_lightning(best)
-            h.slab_period_begin()
-            h.sync()
+        _pool_exchange(slabs, nslab, ev, pl, pr)
     whole.step(n_iter)
     d_ref = whole.read_particles()
     assert (d_ref[:, 2] >= 0).sum() > 500 and (d_ref[:, 2] < 0).sum() > 500
-    for h in slabs:
-        d = h.read_particles()
-        assert np.array_equal(d[:, 2] >= 0, d_ref[:, 2] >= 0), "same droplets active"
+    d, f = _assemble_pool(slabs)
+    assert np.array_equal(d[:, 2] >= 0, d_ref[:, 2] >= 0), "same droplets active"
+    assert (f == 3).sum() > 0, "ghost copies exist"
+    if order == 1:
+        assert np.array_equal(d, d_ref)
+    else:
         assert np.abs(d - d_ref).max() <= 1e-6
     tol = {"PRECIP_FB": 1e-6, "PRECIP_DEP": 1e-6, "BASE_CUR": 1e-6, "WATER_CUR": 1e-6}
-    for f, t in tol.items():
-        ref = whole.read_rect(f)
+    for fld, t in tol.items():
+        ref = whole.read_rect(fld)
         for r, h in enumerate(slabs):
-            a, b = h.read_rect(f, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]
-            if f == "PRECIP_FB" and r == 0:  # texels (0,0) / (1,0) are the reference's mailboxes, not kept on slabs
+            a, b = h.read_rect(fld, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]
+            if fld == "PRECIP_FB" and r == 0:  # texels (0,0) / (1,0) are the reference's mailboxes, not kept on slabs
                 a, b = a.copy(), b.copy()
                 a[0, :2], b[0, :2] = 0, 0
-            assert np.abs(a - b).max() <= t * max(1.0, np.abs(b).max()), (f, r, np.abs(a - b).max())
+            if order == 1:
+                assert np.array_equal(a, b), (fld, r)
+            else:
+                assert np.abs(a - b).max() <= t * max(1.0, np.abs(b).max()), (fld, r, np.abs(a - b).max())
     assert np.abs(whole.read_rect("PRECIP_FB")).max() > 0
     for r, h in enumerate(slabs):
         assert np.array_equal(h.read_rect("WALL_CUR", halo, 0, xo, Y), whole.read_rect("WALL_CUR")[:, r * xo:(r + 1) * xo])
+    for h in slabs:
+        h.close()
+    whole.close()
 
 
 @pytest.mark.parametrize("X,Y,cols", [(512, 128, None), (130, 50, None), (4096, 256, (4000, 300))])

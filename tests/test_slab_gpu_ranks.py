@@ -1,6 +1,7 @@
 """Two processes on ONE GPU (gloo transport): the product's multi-rank driver slab.SlabSim on the HIP engine, with
-particles, end to end -- ring halo exchange (send/recv) + droplet-pool reconciliation (two all-reduces) -- against the
-undecomposed handle. The RCCL run on N GPUs uses exactly this code with backend "nccl"."""
+particles, end to end -- ring halo exchange (send/recv) + the partitioned droplet pool (status-flip events all-gathered, edge
+droplets in the halos' batch of send / recv) -- against the undecomposed handle. The RCCL run on N GPUs uses exactly this code
+with backend "nccl"."""
 import os
 import socket
 import sys
@@ -53,11 +54,14 @@ def _worker(rank, world, port, out_dir, particles):
     drv = slab.SlabSim.from_arrays(X, Y, base, water, wall, u, rank, world, torch.device("cuda", 0), halo=HALO, drops=drops)
     assert drv.iters_per_exchange == (9 if particles else 10)
     drv.step(N_ITER)
-    drv.exchange()  # bring every rank's copy of the pool up to date before reading it
+    drv.exchange()  # settle ownership of the droplets before reading the pool
     drv.sync()
     out = {f: drv.owned(f) for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "PRECIP_FB", "PRECIP_DEP")}
     if particles:
-        out["drops"] = drv.handle.read_particles()
+        out["flags"] = drv.handle.pool_flags()
+        pool = drv.gather_particles()  # the whole pool, assembled on rank 0
+        if rank == 0:
+            out["drops"] = pool
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()
@@ -85,11 +89,14 @@ def test_slab_sim_two_ranks(pkg, tmp_path, particles):
     xo = X // 2
     for r in range(2):
         got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
-        if particles:
+        if particles and r == 0:
             d_ref = whole.read_particles()
             assert (d_ref[:, 2] >= 0).sum() > 300
             assert np.array_equal(got["drops"][:, 2] >= 0, d_ref[:, 2] >= 0)
             assert np.abs(got["drops"] - d_ref).max() <= 1e-6
+            flags = np.stack([np.load(os.path.join(str(tmp_path), f"rank{q}.npz"))["flags"] for q in range(2)])
+            assert np.array_equal((flags == 2).sum(0), (d_ref[:, 2] >= 0).astype(int))  # one owner per active droplet
+            assert (flags[:, d_ref[:, 2] < 0] == 1).all()  # inactive records: on every rank
         assert np.array_equal(got["WALL_CUR"], whole.read_rect("WALL_CUR")[:, r * xo:(r + 1) * xo])
         for f in ("BASE_CUR", "WATER_CUR", "PRECIP_FB", "PRECIP_DEP"):
             a, b = got[f], whole.read_rect(f)[:, r * xo:(r + 1) * xo]
