@@ -353,7 +353,13 @@ static int arena_begin(wx_sim *s, size_t bytes)
     if (atoi(e) == 0) return WX_OK; // (one hipMalloc per plane, as rounds 1-2 did)
   }
   bytes += 128 * (4096 + s->arena_skew);
-  if (hipMalloc((void **)&s->arena, bytes) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_create: %zu bytes of device memory", bytes);
+  hipError_t e = hipErrorUnknown;
+  if (const char *c = getenv("WX_ARENA_CONTIG")) { // experiment: physically contiguous VRAM (the largest page-table fragments)
+    if (atoi(c) != 0) e = hipExtMallocWithFlags((void **)&s->arena, bytes, hipDeviceMallocContiguous);
+    if (e != hipSuccess) (void)hipGetLastError();
+  }
+  if (e != hipSuccess) e = hipMalloc((void **)&s->arena, bytes);
+  if (e != hipSuccess) return fail(s, WX_E_NOMEM, "wx_create: %zu bytes of device memory", bytes);
   s->arena_size = bytes;
   HIPCHK(s, hipMemset(s->arena, 0, bytes));
   return WX_OK;
@@ -755,9 +761,10 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
     if (rc == WX_OK && halo > 0) rc = dalloc(s, &s->pool_best, (size_t)n_droplets);
     if (rc == WX_OK && halo > 0) {
       if (hipMemset(s->pool_best, 0x7f, (size_t)n_droplets * 4) != hipSuccess) rc = WX_E_DEVICE; // (0x7f7f7f7f: larger than any event key)
-      // capacities of the exchange buffers: status flips of one period (a few hundred in a storm) and the droplets within `halo`
-      // columns of an edge; generous, fixed, and checked (an overflow is reported by the next blocking call)
-      s->pool_event_cap = std::max(4096, n_droplets / 16);
+      // capacities of the exchange buffers: status flips of one period (a few hundred in a storm, at most every droplet) and the
+      // droplets within `halo` columns of an edge (generous, fixed, checked: an overflow is reported by the next blocking call)
+      s->pool_event_cap = n_droplets; // (worst case: every droplet flips in one period -- the start-up burst of an all-inactive pool; the
+                                      // hosts only transfer the filled part, see wx_pool_events_apply)
       s->pool_edge_cap = std::max(4096, n_droplets / 8);
       int xoff = (x0 - halo) % X_global;
       if (xoff < 0) xoff += X_global;
@@ -1700,17 +1707,19 @@ int wx_pool_events_pack(wx_sim *s, void *dev_buf)
   return WX_OK;
 }
 
-int wx_pool_events_apply(wx_sim *s, const void *dev_bufs, int n_ranks)
+int wx_pool_events_apply(wx_sim *s, const void *dev_bufs, int n_ranks, size_t stride_bytes)
 {
   if (!s || !dev_bufs || n_ranks < 1) return WX_E_INVALID;
   POOL_ONLY(s, "wx_pool_events_apply");
-  const size_t stride = wx_pool_event_bytes(s);
+  const size_t stride = stride_bytes ? stride_bytes : wx_pool_event_bytes(s);
+  if (stride < (size_t)POOL_HDR || stride > wx_pool_event_bytes(s)) return fail(s, WX_E_INVALID, "wx_pool_events_apply: stride %zu outside 16 .. %zu", stride, wx_pool_event_bytes(s));
   const dim3 grid(64, n_ranks), block(256);
   const char *b = (const char *)dev_bufs;
-  hipLaunchKernelGGL(k_pool_check, dim3(1), dim3(64), 0, s->stream, n_ranks, stride, s->pool_event_cap, b, s->state);
-  hipLaunchKernelGGL(k_pool_events_best, grid, block, 0, s->stream, n_ranks, stride, s->pool_event_cap, b, s->pool_best);
-  hipLaunchKernelGGL(k_pool_events_apply, grid, block, 0, s->stream, n_ranks, stride, s->pool_event_cap, b, s->pool_best, s->rank, s->drops[0], s->pool_remote);
-  hipLaunchKernelGGL(k_pool_events_reset, grid, block, 0, s->stream, n_ranks, stride, s->pool_event_cap, b, s->pool_best);
+  const int cap = (int)((stride - POOL_HDR) / sizeof(PoolEvent)); // entries a rank's (possibly truncated) buffer holds
+  hipLaunchKernelGGL(k_pool_check, dim3(1), dim3(64), 0, s->stream, n_ranks, stride, cap, b, s->state);
+  hipLaunchKernelGGL(k_pool_events_best, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best);
+  hipLaunchKernelGGL(k_pool_events_apply, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best, s->rank, s->drops[0], s->pool_remote);
+  hipLaunchKernelGGL(k_pool_events_reset, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best);
   s->pool_check = true;
   HIPCHK(s, hipGetLastError());
   return WX_OK;

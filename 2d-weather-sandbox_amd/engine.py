@@ -109,7 +109,7 @@ def lib() -> C.CDLL:
     L.wx_pool_edge_bytes.argtypes = [vp]
     L.wx_pool_edge_bytes.restype = C.c_size_t
     L.wx_pool_events_pack.argtypes = [vp, vp]
-    L.wx_pool_events_apply.argtypes = [vp, vp, i32]
+    L.wx_pool_events_apply.argtypes = [vp, vp, i32, C.c_size_t]
     L.wx_pool_edges_pack.argtypes = [vp, vp, vp, i32]
     L.wx_pool_edges_apply.argtypes = [vp, vp]
     L.wx_pool_flags.argtypes = [vp, vp]
@@ -354,8 +354,8 @@ class Handle:
     def pool_events_pack(self, dev_buf: int):
         self._chk(lib().wx_pool_events_pack(self._h, C.c_void_p(dev_buf)))
 
-    def pool_events_apply(self, dev_bufs: int, n_ranks: int):
-        self._chk(lib().wx_pool_events_apply(self._h, C.c_void_p(dev_bufs), int(n_ranks)))
+    def pool_events_apply(self, dev_bufs: int, n_ranks: int, stride_bytes: int = 0):
+        self._chk(lib().wx_pool_events_apply(self._h, C.c_void_p(dev_bufs), int(n_ranks), int(stride_bytes)))
 
     def pool_edges_pack(self, dev_left: int, dev_right: int, refresh_inactive: bool = False):
         self._chk(lib().wx_pool_edges_pack(self._h, C.c_void_p(dev_left), C.c_void_p(dev_right), 1 if refresh_inactive else 0))

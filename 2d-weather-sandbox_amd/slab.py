@@ -107,8 +107,8 @@ class HipSlabEngine:
     def pool_events_pack(self, buf: torch.Tensor):
         self.h.pool_events_pack(buf.data_ptr())
 
-    def pool_events_apply(self, gathered: torch.Tensor, world: int):
-        self.h.pool_events_apply(gathered.data_ptr(), world)
+    def pool_events_apply(self, gathered: torch.Tensor, world: int, stride: int = 0):
+        self.h.pool_events_apply(gathered.data_ptr(), world, stride)
 
     def pool_edges_pack(self, left: torch.Tensor, right: torch.Tensor, refresh_inactive: bool):
         self.h.pool_edges_pack(left.data_ptr(), right.data_ptr(), refresh_inactive)
@@ -208,14 +208,26 @@ class SlabSim:
             if self.particles:
                 # 1. who flipped between active and inactive this period, and what did it become (a few hundred droplets)
                 e.pool_events_pack(self.ev)
-                if self._stage:
-                    e.sync()
-                    parts = [torch.empty_like(self.ev, device="cpu") for _ in range(self.world)]
-                    dist.all_gather(parts, self.ev.cpu())
-                    self.ev_all.copy_(torch.cat(parts))
+                # The buffer has room for every droplet (the start-up burst of an all-inactive pool), a normal period fills a few KB of it:
+                # the counts travel first (16 B per rank; the one host synchronisation of an exchange), then only the filled part
+                hdr = self.ev[:16].cpu() if self.ev.is_cuda else self.ev[:16].clone()
+                hdrs = [torch.empty_like(hdr) for _ in range(self.world)]
+                if dist.get_backend() == "nccl":
+                    dh = [t.to(self.ev.device) for t in hdrs]
+                    dist.all_gather(dh, hdr.to(self.ev.device))
+                    hdrs = [t.cpu() for t in dh]
                 else:
-                    dist.all_gather_into_tensor(self.ev_all, self.ev)
-                e.pool_events_apply(self.ev_all, self.world)
+                    dist.all_gather(hdrs, hdr)
+                most = max(int(t.view(torch.int32)[0]) for t in hdrs)
+                stride = min(len(self.ev), (16 + most * 32 + 4095) // 4096 * 4096)
+                mine, every = self.ev[:stride], self.ev_all[:stride * self.world]
+                if self._stage:
+                    parts = [torch.empty(stride, dtype=torch.uint8) for _ in range(self.world)]
+                    dist.all_gather(parts, mine.cpu())
+                    every.copy_(torch.cat(parts))
+                else:
+                    dist.all_gather_into_tensor(every, mine)
+                e.pool_events_apply(every, self.world, stride)
                 # 2. ownership by position; the droplets near my edges become the neighbours' ghost copies
                 refresh = (self._iters // 600) != ((self._iters - self._since_exchange) // 600)  # app.js:5957-5966: every 600 iterations
                 e.pool_edges_pack(self.psend[0], self.psend[1], refresh)

@@ -241,7 +241,10 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags);
  * record's hashed spawn probe (precipitationShader.vert:82-84: anywhere in the domain) against its own columns and acts on the ones
  * that land where its grid is valid. Nothing is communicated inside an exchange period ((halo - 6) / WX_SLAB_CONE iterations, at
  * most 15). At the halo exchange (all buffers are DEVICE pointers; calls are enqueued on the handle's stream):
- *   wx_pool_events_pack  -> all-gather of the wx_pool_event_bytes() buffers -> wx_pool_events_apply(gathered, n_ranks):
+ *   wx_pool_events_pack  -> all-gather of the buffers -> wx_pool_events_apply(gathered, n_ranks, stride_bytes):
+ *       a buffer = 16-byte header (first int32: number of events) + 32-byte events, wx_pool_event_bytes() in all (room for every
+ *       droplet: the start-up burst of an all-inactive pool flips most of them in one period); the hosts normally gather only the
+ *       filled part -- stride_bytes = bytes per rank in `gathered` (0 = whole buffers), the same on every rank, >= the largest count;
  *       the droplets whose active / inactive status flipped (spawned, evaporated, deposited) with their final records; per droplet
  *       the report with the earliest first flip wins, then the longest flip history, then the rank that processed it last -- a rank
  *       that spawned a droplet from a stale inactive record after another rank had (it cannot know inside a period) drops its phantom;
@@ -258,7 +261,7 @@ int wx_slab_period_begin(wx_sim *s);
 size_t wx_pool_event_bytes(const wx_sim *s);
 size_t wx_pool_edge_bytes(const wx_sim *s);
 int wx_pool_events_pack(wx_sim *s, void *dev_buf);
-int wx_pool_events_apply(wx_sim *s, const void *dev_bufs, int n_ranks);
+int wx_pool_events_apply(wx_sim *s, const void *dev_bufs, int n_ranks, size_t stride_bytes);
 int wx_pool_edges_pack(wx_sim *s, void *dev_left, void *dev_right, int refresh_inactive);
 int wx_pool_edges_apply(wx_sim *s, const void *dev_buf);
 int wx_pool_flags(wx_sim *s, uint8_t *host_dst);

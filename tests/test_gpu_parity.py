@@ -818,9 +818,11 @@ def _pool_exchange(slabs, nslab, ev, pl, pr):
     for r, h in enumerate(slabs):
         h.pool_events_pack(ev[r].data_ptr())
         h.sync()
-    gathered = torch.cat(ev).contiguous()
+    most = max(int(e[:4].view(torch.int32)[0]) for e in ev)  # slab.py: the counts travel first, then only the filled part
+    stride = min(len(ev[0]), (16 + most * 32 + 4095) // 4096 * 4096)
+    gathered = torch.cat([e[:stride] for e in ev]).contiguous()
     for h in slabs:
-        h.pool_events_apply(gathered.data_ptr(), nslab)
+        h.pool_events_apply(gathered.data_ptr(), nslab, stride)
     for r, h in enumerate(slabs):
         h.pool_edges_pack(pl[r].data_ptr(), pr[r].data_ptr(), False)
         h.sync()

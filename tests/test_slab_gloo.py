@@ -196,9 +196,9 @@ class ModelPoolEngine:
         raw[16:16 + ev.nbytes] = ev.view(np.uint8)
         buf.copy_(torch.from_numpy(raw))
 
-    def pool_events_apply(self, gathered, world):
+    def pool_events_apply(self, gathered, world, stride=0):
         raw = gathered.numpy()
-        stride = len(raw) // world
+        stride = stride or len(raw) // world
         evs = []
         for r in range(world):
             cnt = int(raw[r * stride:r * stride + 4].view("<i4")[0])

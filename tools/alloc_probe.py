@@ -17,6 +17,7 @@ SPECS = [a.split(":") for a in sys.argv[1:]] or [["0", "0"]] * 6
 
 def make(spec):
     os.environ["WX_ARENA"], os.environ["WX_ARENA_SKEW"] = spec[0], spec[1]
+    os.environ["WX_ARENA_CONTIG"] = spec[2] if len(spec) > 2 else "0"
     gui = pkg.params.merge_settings(None)
     gui["sunAngle"] = 50.0
     u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
@@ -51,4 +52,5 @@ for (h, r), sp in zip(zip(hs, res), SPECS):
     print(f"arena {sp[0]} skew {sp[1]:>8s}:", " ".join(f"{t:.4f}" for t in r), " ".join(f"{p:#x}" for p in ptrs))
 
 # placement tuning on the first handle: candidates tried, then the sustained time of the winner
-print("wx_tune_placement(tries=8, iters=30) on handle 0: first candidate / winner ms:", hs[0].tune_placement(8, 30), " sustained:", " ".join(f"{timed(hs[0]):.4f}" for _ in range(3)))
+if os.environ.get("WX_PROBE_TUNE"):
+    print("wx_tune_placement(tries=8, iters=30) on handle 0: first candidate / winner ms:", hs[0].tune_placement(8, 30), " sustained:", " ".join(f"{timed(hs[0]):.4f}" for _ in range(3)))

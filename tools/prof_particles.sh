@@ -2,7 +2,7 @@
 # GPU-box script: kernel-trace stats + HBM traffic passes for the particle workload (BASELINE configs[4] on one GPU) after a
 # warm-up long enough for the droplet pool to be active. Outputs under gpurun_out/<tag>_*.
 R=$GRAFT_REPO_ROOT; TAG=${1:-particles}; O=$R/gpurun_out; N=${PARTICLES:-1048576}
-ARGS="--particles $N --no-cpu-baseline --no-pmc --no-north-star"
+ARGS="--particles $N --no-cpu-baseline --no-pmc --no-north-star --no-extras --tune 0"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -o trace -- python $R/bench.py $ARGS --steps 100 --warmup 500 > $O/${TAG}_trace_bench.json 2> $O/${TAG}.err
 rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o p -- python $R/bench.py $ARGS --steps 10 --warmup 500 > /dev/null 2>> $O/${TAG}.err
