@@ -59,6 +59,11 @@ struct ProfRec {
 
 } // namespace
 
+struct Block {
+  char *p;
+  size_t bytes;
+};
+
 struct wx_sim {
   int X = 0, Y = 0;      // local width (owned + 2*halo), height
   int Xg = 0, x0 = 0;    // global width, global x of the first OWNED column
@@ -141,11 +146,15 @@ struct wx_sim {
   bool ghost_check = false;   // ghost columns were unpacked while water_trivial: DevState::ghost_nontrivial is validated by the next blocking call
   bool local_water_free = false; // what the last upload established for THIS handle's cells (wx_water_free)
   bool slab_dry_agreed = false;  // the host asserted that every slab of the domain was uploaded water-free (wx_slab_assert_water_free)
-  // all grid-sized planes of the handle come from ONE device allocation, carved at chosen offsets (see arena_begin)
-  char *arena = nullptr;
-  size_t arena_size = 0, arena_used = 0, arena_skew = 0;
+  // device storage of the handle (see storage_begin): blocks[0] = the arena of the small objects (or of everything: WX_ARENA=1), then one
+  // allocation per large plane; every pointer member that lives in a block is registered, so that wx_tune_placement can move the
+  // whole state to another set of allocations
+  std::vector<Block> blocks;
+  size_t small_used = 0;
+  bool one_arena = false;
+  size_t arena_skew = 0;
   int arena_count = 0;
-  std::vector<void **> arena_slots; // every pointer member that was carved out of the arena (wx_tune_placement re-bases them)
+  std::vector<void **> slots;
   // profiling
   bool profiling = false;
   std::vector<ProfRec> prof;
@@ -339,52 +348,69 @@ void build_uni(wx_sim *s)
   }
 }
 
-// Device storage. The marching kernels stream ~13 planes at once; where those planes lie relative to each other in (physical) memory
-// decides how evenly the streams spread over the HBM channels: with one hipMalloc per plane the SAME binary ran the 16384 x 2048
-// iteration in 0.724 .. 0.837 ms depending on which addresses the allocator happened to hand out (eight handles alive in one
-// process, each time reproducible to 0.1 %; tools/alloc_probe.py) -- the "box to box" spread of rounds 1 and 2. So the handle takes ONE
-// allocation and carves the planes out of it at offsets it controls: plane k starts `arena_skew` bytes further than a dense packing
-// would put it (WX_ARENA_SKEW), which staggers the streams' phase in the channel interleave.
-static int arena_begin(wx_sim *s, size_t bytes)
+// Device storage. The marching kernels stream ~13 planes at once; where those planes lie relative to each other in PHYSICAL memory
+// decides how the streams spread over the HBM channels: the SAME binary ran the 16384 x 2048 iteration in 0.72 .. 0.87 ms depending on
+// the addresses the allocator happened to hand out (several handles alive in one process, each time reproducible to 0.1 %;
+// profiles/r03_alloc_probe.txt) -- the "box to box" spread of rounds 1 and 2. Planes at power-of-two distances in one physically
+// contiguous range alias in the channel hash (hipDeviceMallocContiguous: always the slowest level); ONE allocation carved into planes
+// tends to be like that (0.76 - 0.84), one allocation PER PLANE scatters them (0.72 - 0.75 most of the time, 0.80 - 0.84 sometimes).
+// Hence: one allocation per large plane (default; WX_ARENA=1: everything in one arena, WX_ARENA_SKEW / WX_ARENA_CONTIG: experiments),
+// the small objects share blocks[0], and every pointer is registered so that wx_tune_placement can try other sets of allocations.
+static int block_of(const std::vector<Block> &B, const void *p)
+{
+  for (size_t i = 0; i < B.size(); i++)
+    if ((const char *)p >= B[i].p && (const char *)p < B[i].p + B[i].bytes) return (int)i;
+  return -1;
+}
+static hipError_t block_alloc(size_t bytes, Block *out)
+{
+  out->p = nullptr;
+  out->bytes = bytes;
+  hipError_t e = hipErrorUnknown;
+  if (const char *c = getenv("WX_ARENA_CONTIG")) { // experiment: physically contiguous VRAM (the largest page-table fragments)
+    if (atoi(c) != 0) e = hipExtMallocWithFlags((void **)&out->p, bytes, hipDeviceMallocContiguous);
+    if (e != hipSuccess) (void)hipGetLastError();
+  }
+  if (e != hipSuccess) e = hipMalloc((void **)&out->p, bytes);
+  return e;
+}
+static int storage_begin(wx_sim *s, size_t total_bytes, size_t small_bytes)
 {
   s->arena_skew = 0;
   if (const char *e = getenv("WX_ARENA_SKEW")) s->arena_skew = (size_t)atoll(e);
-  if (const char *e = getenv("WX_ARENA")) {
-    if (atoi(e) == 0) return WX_OK; // (one hipMalloc per plane, as rounds 1-2 did)
-  }
-  bytes += 128 * (4096 + s->arena_skew);
-  hipError_t e = hipErrorUnknown;
-  if (const char *c = getenv("WX_ARENA_CONTIG")) { // experiment: physically contiguous VRAM (the largest page-table fragments)
-    if (atoi(c) != 0) e = hipExtMallocWithFlags((void **)&s->arena, bytes, hipDeviceMallocContiguous);
-    if (e != hipSuccess) (void)hipGetLastError();
-  }
-  if (e != hipSuccess) e = hipMalloc((void **)&s->arena, bytes);
-  if (e != hipSuccess) return fail(s, WX_E_NOMEM, "wx_create: %zu bytes of device memory", bytes);
-  s->arena_size = bytes;
-  HIPCHK(s, hipMemset(s->arena, 0, bytes));
+  if (const char *e = getenv("WX_ARENA")) s->one_arena = atoi(e) != 0;
+  Block b;
+  const size_t bytes = s->one_arena ? total_bytes + 128 * (4096 + s->arena_skew) : small_bytes;
+  if (block_alloc(bytes, &b) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_create: %zu bytes of device memory", bytes);
+  HIPCHK(s, hipMemset(b.p, 0, bytes));
+  s->blocks.push_back(b);
   return WX_OK;
 }
-static bool in_arena(const wx_sim *s, const void *p) { return s->arena && (const char *)p >= s->arena && (const char *)p < s->arena + s->arena_size; }
 static void dfree(wx_sim *s, void *p)
 {
-  if (p && !in_arena(s, p)) hipFree(p);
+  if (p && block_of(s->blocks, p) < 0) hipFree(p);
 }
 template <class T> int dalloc(wx_sim *s, T **p, size_t n)
 {
   const size_t bytes = n * sizeof(T);
-  if (s->arena) {
-    size_t off = (s->arena_used + 255) & ~(size_t)255;
-    if (bytes >= (1u << 20)) off += s->arena_skew * (size_t)(++s->arena_count); // (large planes only)
+  const bool large = bytes >= (1u << 20);
+  if (!s->blocks.empty() && (s->one_arena || !large)) { // carve it out of blocks[0]
+    size_t off = (s->small_used + 255) & ~(size_t)255;
+    if (large) off += s->arena_skew * (size_t)(++s->arena_count);
     off = (off + 255) & ~(size_t)255;
-    if (off + bytes <= s->arena_size) {
-      *p = reinterpret_cast<T *>(s->arena + off);
-      s->arena_used = off + bytes;
-      s->arena_slots.push_back(reinterpret_cast<void **>(p));
-      return WX_OK; // (zeroed with the arena)
+    if (off + bytes <= s->blocks[0].bytes) {
+      *p = reinterpret_cast<T *>(s->blocks[0].p + off);
+      s->small_used = off + bytes;
+      s->slots.push_back(reinterpret_cast<void **>(p));
+      return WX_OK; // (zeroed with the block)
     }
   }
-  HIPCHK(s, hipMalloc((void **)p, bytes));
-  HIPCHK(s, hipMemset(*p, 0, bytes));
+  Block b;
+  if (block_alloc(bytes ? bytes : 256, &b) != hipSuccess) return fail(s, WX_E_NOMEM, "%zu bytes of device memory", bytes);
+  HIPCHK(s, hipMemset(b.p, 0, b.bytes));
+  s->blocks.push_back(b);
+  *p = reinterpret_cast<T *>(b.p);
+  s->slots.push_back(reinterpret_cast<void **>(p));
   return WX_OK;
 }
 
@@ -716,7 +742,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
     const size_t nd = (size_t)(n_droplets > 0 ? n_droplets : 1);
     size_t total = n * (3 * 16 + 3 * 16 + 2 * 16 + 2 * 4 + 4 + 8 + 16 + 8 + 3 * 16 + (n_droplets > 0 ? 4 : 0)) + 2 * nd * 20 + 4 * ((size_t)Y + 8) * 4 + (size_t)s->X * 16 + 65536;
     if (n_droplets > 0) total += ((size_t)s->X + 8) * ((size_t)Y + 8) * 24 + n / 64 + (size_t)n_droplets * 8 + (1u << 20);
-    rc = arena_begin(s, total);
+    rc = storage_begin(s, total, (size_t)16 << 20);
   }
   for (int i = 0; i < 2 && rc == WX_OK; i++) {
     if ((rc = dalloc(s, &s->base[i], n))) break;
@@ -848,7 +874,7 @@ void wx_destroy(wx_sim *s)
   }
   dfree(s, s->det_val);
   hipFree(s->det_tmp);
-  hipFree(s->arena);
+  for (Block &b : s->blocks) hipFree(b.p);
   delete s;
 }
 
@@ -1200,8 +1226,12 @@ static int validate_ghost_flag(wx_sim *s)
 
 // ---- placement tuning ----
 namespace {
-struct TuneSnap { // host-side state that iterations change; the rotating plane pointers as offsets into the arena
-  ptrdiff_t base[3], water[3], light[2], wall[2], drops[2], lpx[3], lpy[3], lpzw[3];
+struct Ref { // a pointer as (block, offset)
+  int block;
+  size_t off;
+};
+struct TuneSnap { // host-side state that iterations change; the rotating plane pointers as block references
+  Ref base[3], water[3], light[2], wall[2], drops[2], lpx[3], lpy[3], lpzw[3];
   int even, drop_cur, splat_par, period_j, air_from_row;
   int64_t iter;
   bool ran_fused, light_planar, fb_dirty, water_trivial, wall_veg_ok, ghost_check, emit_lit, fix_check, wet_shape_valid;
@@ -1210,50 +1240,88 @@ struct TuneSnap { // host-side state that iterations change; the rotating plane 
 bool snap_take(const wx_sim *s, TuneSnap &t)
 {
   bool ok = true;
-  auto off = [&](const void *p) {
-    ok = ok && in_arena(s, p);
-    return (const char *)p - s->arena;
+  auto ref = [&](const void *p) {
+    const int i = block_of(s->blocks, p);
+    ok = ok && i >= 0;
+    return Ref{i, i >= 0 ? (size_t)((const char *)p - s->blocks[i].p) : 0};
   };
-  for (int i = 0; i < 3; i++) { t.base[i] = off(s->base[i]); t.water[i] = off(s->water[i]); t.lpx[i] = off(s->lp[i].x); t.lpy[i] = off(s->lp[i].y); t.lpzw[i] = off(s->lp[i].zw); }
-  for (int i = 0; i < 2; i++) { t.light[i] = off(s->light[i]); t.wall[i] = off(s->wall[i]); t.drops[i] = off(s->drops[i]); }
+  for (int i = 0; i < 3; i++) { t.base[i] = ref(s->base[i]); t.water[i] = ref(s->water[i]); t.lpx[i] = ref(s->lp[i].x); t.lpy[i] = ref(s->lp[i].y); t.lpzw[i] = ref(s->lp[i].zw); }
+  for (int i = 0; i < 2; i++) { t.light[i] = ref(s->light[i]); t.wall[i] = ref(s->wall[i]); t.drops[i] = ref(s->drops[i]); }
   t.even = s->even; t.drop_cur = s->drop_cur; t.splat_par = s->splat_par; t.period_j = s->period_j; t.air_from_row = s->air_from_row; t.iter = s->iter;
   t.ran_fused = s->ran_fused; t.light_planar = s->light_planar; t.fb_dirty = s->fb_dirty; t.water_trivial = s->water_trivial; t.wall_veg_ok = s->wall_veg_ok;
   t.ghost_check = s->ghost_check; t.emit_lit = s->emit_lit; t.fix_check = s->fix_check; t.wet_shape_valid = s->wet_shape_valid; t.emit_uni = s->emit_uni;
   return ok;
 }
-void snap_put(wx_sim *s, const TuneSnap &t) // (relative to the arena the handle points at NOW)
+void snap_put(wx_sim *s, const TuneSnap &t) // (into the block set the handle points at NOW)
 {
-  char *a = s->arena;
+  auto at = [&](const Ref &r) { return s->blocks[r.block].p + r.off; };
   for (int i = 0; i < 3; i++) {
-    s->base[i] = (float4 *)(a + t.base[i]); s->water[i] = (float4 *)(a + t.water[i]);
-    s->lp[i].x = (float *)(a + t.lpx[i]); s->lp[i].y = (float *)(a + t.lpy[i]); s->lp[i].zw = (float2 *)(a + t.lpzw[i]);
+    s->base[i] = (float4 *)at(t.base[i]); s->water[i] = (float4 *)at(t.water[i]);
+    s->lp[i].x = (float *)at(t.lpx[i]); s->lp[i].y = (float *)at(t.lpy[i]); s->lp[i].zw = (float2 *)at(t.lpzw[i]);
   }
-  for (int i = 0; i < 2; i++) { s->light[i] = (float4 *)(a + t.light[i]); s->wall[i] = (char4 *)(a + t.wall[i]); s->drops[i] = (float *)(a + t.drops[i]); }
+  for (int i = 0; i < 2; i++) { s->light[i] = (float4 *)at(t.light[i]); s->wall[i] = (char4 *)at(t.wall[i]); s->drops[i] = (float *)at(t.drops[i]); }
   s->even = t.even; s->drop_cur = t.drop_cur; s->splat_par = t.splat_par; s->period_j = t.period_j; s->air_from_row = t.air_from_row; s->iter = t.iter;
   s->ran_fused = t.ran_fused; s->light_planar = t.light_planar; s->fb_dirty = t.fb_dirty; s->water_trivial = t.water_trivial; s->wall_veg_ok = t.wall_veg_ok;
   s->ghost_check = t.ghost_check; s->emit_lit = t.emit_lit; s->fix_check = t.fix_check; s->wet_shape_valid = t.wet_shape_valid; s->emit_uni = t.emit_uni;
 }
-// every arena-resident pointer of the handle moves from the current arena to `to` (same offsets)
-int rebase(wx_sim *s, char *to)
+// every registered pointer of the handle moves from the current block set to `to` (same block, same offset)
+int rebase(wx_sim *s, const std::vector<Block> &to)
 {
-  char *from = s->arena;
-  for (void **slot : s->arena_slots) {
-    char *v = reinterpret_cast<char *>(*slot);
-    if (v >= from && v < from + s->arena_size) *slot = to + (v - from);
+  for (void **slot : s->slots) {
+    const int i = block_of(s->blocks, *slot);
+    if (i >= 0) *slot = to[i].p + (reinterpret_cast<char *>(*slot) - s->blocks[i].p);
   }
-  s->arena = to;
-  FullCtx fc{s->geo, s->uni, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel}; // (holds device pointers into the arena)
+  s->blocks = to;
+  FullCtx fc{s->geo, s->uni, s->initial_T, s->snd_T, s->snd_W, s->snd_Vel}; // (holds device pointers into the blocks)
   HIPCHK(s, hipMemcpyAsync(s->full_ctx, &fc, sizeof(fc), hipMemcpyHostToDevice, s->stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
+  return WX_OK;
+}
+void free_set(std::vector<Block> &B)
+{
+  for (Block &b : B) hipFree(b.p);
+  B.clear();
+}
+size_t set_bytes(const std::vector<Block> &B)
+{
+  size_t n = 0;
+  for (const Block &b : B) n += b.bytes;
+  return n;
+}
+// a new set of allocations with the sizes of `like`; allocated in a different order each time (`variant`) with an odd-sized pad in
+// between, so that the new set does not simply land at a fixed stride behind the previous one (pads are appended to `pads`)
+bool alloc_set(const std::vector<Block> &like, std::vector<Block> &out, int variant, std::vector<char *> &pads)
+{
+  const size_t n = like.size();
+  out.assign(n, Block{nullptr, 0});
+  for (size_t k = 0; k < n; k++) {
+    const size_t i = (variant & 1) ? n - 1 - (k + (size_t)variant * 5) % n : (k + (size_t)variant * 5) % n;
+    if (k % 3 == 0) {
+      char *pad = nullptr;
+      if (hipMalloc((void **)&pad, (size_t)(3 + 14 * ((variant + (int)k) % 7)) << 20) == hipSuccess) pads.push_back(pad);
+      else (void)hipGetLastError();
+    }
+    if (block_alloc(like[i].bytes, &out[i]) != hipSuccess) {
+      (void)hipGetLastError();
+      free_set(out);
+      return false;
+    }
+  }
+  return true;
+}
+int copy_set(wx_sim *s, const std::vector<Block> &dst, const std::vector<Block> &src)
+{
+  for (size_t i = 0; i < src.size(); i++) HIPCHK(s, hipMemcpyAsync(dst[i].p, src[i].p, src[i].bytes, hipMemcpyDeviceToDevice, s->stream));
   return WX_OK;
 }
 } // namespace
 
 // Where the planes lie in physical memory decides how the kernel's ~13 concurrent streams spread over the HBM channels -- the same
-// iteration takes 0.72 .. 0.84 ms depending on the allocation (see arena_begin). wx_tune_placement times the handle's OWN iteration
-// (current parameters / pass mask; two untimed + iters_per_try timed iterations) on the arena it has and on `tries` further
-// allocations that each receive a copy of the state; the fastest one becomes the handle's storage and gets the state back from a
-// pristine backup taken at the start. The simulation state, iteration counter and every field are exactly what they were before the call.
+// iteration takes 0.72 .. 0.87 ms depending on the allocations (see storage_begin). wx_tune_placement times the handle's OWN iteration
+// (current parameters / pass mask; the clocks brought to steady state first; four untimed + iters_per_try timed iterations) on the
+// allocations it has and on `tries` further sets that each receive a copy of the state; the winner is confirmed against the incumbent
+// back to back, becomes the handle's storage and gets the state back from a pristine backup taken at the start. The simulation
+// state, iteration counter and every field are exactly what they were before the call.
 int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before, float *ms_after)
 {
   if (!s) return WX_E_INVALID;
@@ -1262,13 +1330,13 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
   if (s->pool_remote) return fail(s, WX_E_STATE, "wx_tune_placement: not on slab handles with particles (the exchange period would advance)");
   if (int rc = wx_sync(s)) return rc;
   TuneSnap snap;
-  if (!s->arena || !snap_take(s, snap)) return fail(s, WX_E_STATE, "wx_tune_placement: the handle's planes do not live in one arena (WX_ARENA=0?)");
+  if (s->blocks.empty() || !snap_take(s, snap)) return fail(s, WX_E_STATE, "wx_tune_placement: the handle's planes are not in registered blocks");
   hipEvent_t e0, e1;
   HIPCHK(s, hipEventCreate(&e0));
   HIPCHK(s, hipEventCreate(&e1));
   const bool was_profiling = s->profiling; // (the probes' launches are not the caller's)
   s->profiling = false;
-  char *const original = s->arena;
+  const bool dbg = getenv("WX_TUNE_DEBUG") != nullptr;
   auto probe = [&](float *ms) -> int { // four untimed iterations (launch shape, terrain scan, caches), then the timed ones
     int rc = wx_step(s, 4);
     if (rc == WX_OK && hipEventRecord(e0, s->stream) != hipSuccess) rc = WX_E_DEVICE;
@@ -1277,16 +1345,23 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
     *ms /= (float)iters_per_try;
     return rc;
   };
-  // A pristine copy of the state (not a candidate): every arena, the current one included, is probed in place and the winner gets
-  // the state back from here.
-  char *backup = nullptr;
-  if (hipMalloc((void **)&backup, s->arena_used) != hipSuccess || hipMemcpyAsync(backup, original, s->arena_used, hipMemcpyDeviceToDevice, s->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    hipFree(backup);
+  const std::vector<Block> original = s->blocks;
+  const size_t total = set_bytes(original);
+  std::vector<char *> pads;
+  auto room_for = [&](size_t bytes) {
+    size_t free_b = 0, total_b = 0;
+    return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > bytes + (size_t(2) << 30);
+  };
+  // A pristine copy of the state (not a candidate): every set, the current one included, is probed in place and the winner gets the
+  // state back from here.
+  std::vector<Block> backup;
+  if (!room_for(total) || !alloc_set(original, backup, 0, pads) || copy_set(s, backup, original) != WX_OK) {
+    free_set(backup);
+    for (char *p : pads) hipFree(p);
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     s->profiling = was_profiling;
-    return fail(s, WX_E_NOMEM, "wx_tune_placement: no room for a copy of the state (%zu bytes)", s->arena_used);
+    return fail(s, WX_E_NOMEM, "wx_tune_placement: no room for a copy of the state (%zu bytes)", total);
   }
   int rc = WX_OK;
   float first_ms = 0.f, best_ms = 0.f;
@@ -1296,44 +1371,34 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
   snap_put(s, snap);
   if (rc == WX_OK) rc = probe(&first_ms);
   snap_put(s, snap);
-  if (rc == WX_OK) rc = probe(&first_ms); // the allocation the handle has
+  if (rc == WX_OK) rc = probe(&first_ms); // the allocations the handle has
   snap_put(s, snap);
-  char *best = original;
+  std::vector<Block> best = original;
   best_ms = first_ms;
-  if (getenv("WX_TUNE_DEBUG")) fprintf(stderr, "[wx_tune_placement] current arena %p: %.4f ms / iteration\n", (void *)original, first_ms);
-  // Rejected candidates stay allocated while there is room: a free()d arena is handed straight back by the next hipMalloc (same
+  if (dbg) fprintf(stderr, "[wx_tune_placement] current allocations (%zu blocks, %zu MB): %.4f ms / iteration\n", original.size(), total >> 20, first_ms);
+  // Rejected candidates stay allocated while there is room: freed memory is handed straight back by the next hipMalloc (same
   // memory, nothing learned). They are released at the end, or earlier when device memory runs short.
-  std::vector<char *> rejects;
+  std::vector<std::vector<Block>> rejects;
   for (int t = 1; t <= tries && rc == WX_OK; t++) {
-    char *cand = nullptr;
-    { // Back-to-back allocations of one size land at a fixed stride in physical memory and tend to share one speed level:
-      // an odd-sized pad in between (kept until the end) shifts the next candidate to a different phase
-      char *pad = nullptr;
-      const size_t pad_bytes = (size_t)(97 + 331 * t) << 20;
-      size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 2 * s->arena_size + pad_bytes + (size_t(4) << 30) && hipMalloc((void **)&pad, pad_bytes) == hipSuccess)
-        rejects.push_back(pad);
-      else
-        (void)hipGetLastError();
-    }
+    std::vector<Block> cand;
+    bool got = false;
     for (;;) {
-      size_t free_b = 0, total_b = 0;
-      const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > s->arena_size + (size_t(2) << 30);
-      if (room && hipMalloc((void **)&cand, s->arena_size) == hipSuccess) break;
-      (void)hipGetLastError();
-      cand = nullptr;
+      if (room_for(total) && alloc_set(original, cand, t, pads)) {
+        got = true;
+        break;
+      }
       if (rejects.empty()) break;
-      hipFree(rejects.front());
+      free_set(rejects.front());
       rejects.erase(rejects.begin());
     }
-    if (!cand) break; // out of device memory: keep the best so far
-    if (hipMemcpyAsync(cand, backup, s->arena_used, hipMemcpyDeviceToDevice, s->stream) != hipSuccess) rc = WX_E_DEVICE;
+    if (!got) break; // out of device memory: keep the best so far
+    rc = copy_set(s, cand, backup);
     if (rc == WX_OK) rc = rebase(s, cand);
     snap_put(s, snap);
     float ms = 0.f;
     if (rc == WX_OK) rc = probe(&ms);
     snap_put(s, snap);
-    if (getenv("WX_TUNE_DEBUG")) fprintf(stderr, "[wx_tune_placement] candidate %d at %p: %.4f ms / iteration\n", t, (void *)cand, ms);
+    if (dbg) fprintf(stderr, "[wx_tune_placement] candidate %d (first plane at %p): %.4f ms / iteration\n", t, (void *)(cand.size() > 1 ? cand[1].p : cand[0].p), ms);
     if (rc == WX_OK && ms < best_ms) {
       rejects.push_back(best);
       best = cand;
@@ -1342,7 +1407,8 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
       rejects.push_back(cand);
     }
   }
-  if (best != original && rc == WX_OK) { // confirm against the incumbent, back to back (a probe is ~1 % noisy; clocks drift over the call)
+  const bool moved = best[0].p != original[0].p;
+  if (moved && rc == WX_OK) { // confirm against the incumbent, back to back (a probe is ~1 % noisy; clocks drift over the call)
     float ms_o = 0.f, ms_b = 0.f;
     rc = rebase(s, original);
     snap_put(s, snap);
@@ -1352,10 +1418,10 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
     snap_put(s, snap);
     if (rc == WX_OK) rc = probe(&ms_b);
     snap_put(s, snap);
-    if (getenv("WX_TUNE_DEBUG")) fprintf(stderr, "[wx_tune_placement] confirmation: incumbent %.4f, winner %.4f ms / iteration\n", ms_o, ms_b);
+    if (dbg) fprintf(stderr, "[wx_tune_placement] confirmation: incumbent %.4f, winner %.4f ms / iteration\n", ms_o, ms_b);
     if (rc == WX_OK && !(ms_b < ms_o * 0.99f)) { // not clearly better: stay where we are
-      for (size_t i = 0; i < rejects.size(); i++)
-        if (rejects[i] == original) rejects[i] = best;
+      for (auto &r : rejects)
+        if (!r.empty() && r[0].p == original[0].p) r = best;
       best = original;
       best_ms = first_ms = ms_o;
     } else {
@@ -1363,13 +1429,14 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
       first_ms = ms_o;
     }
   }
-  // give the winner (possibly the arena the handle had) the pristine state back, then move in -- in this order: the state holds the
-  // FullCtx block with device pointers into the arena it was copied from, which rebase() rewrites
-  if (hipMemcpyAsync(best, backup, s->arena_used, hipMemcpyDeviceToDevice, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) rc = WX_E_DEVICE;
+  // give the winner (possibly the allocations the handle had) the pristine state back, then move in -- in this order: the state holds
+  // the FullCtx block with device pointers into the set it was copied from, which rebase() rewrites
+  if (copy_set(s, best, backup) != WX_OK || hipStreamSynchronize(s->stream) != hipSuccess) rc = WX_E_DEVICE;
   if (rebase(s, best) != WX_OK) rc = WX_E_DEVICE;
   snap_put(s, snap);
-  for (char *r : rejects) hipFree(r);
-  hipFree(backup);
+  for (auto &r : rejects) free_set(r);
+  for (char *p : pads) hipFree(p);
+  free_set(backup);
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   s->profiling = was_profiling;

@@ -186,9 +186,9 @@ int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst);
 int wx_stream_wait(wx_sim *s);
 
 /* Placement tuning (no reference counterpart). Where a handle's planes lie in physical device memory decides how the ~13 streams of
- * the marching kernels spread over the HBM channels: the same binary runs the same iteration in 0.72 .. 0.84 ms depending on the
- * allocation (profiles/r03_alloc_probe.txt). wx_tune_placement times the handle's own iteration (current parameters and
- * pass mask; 2 untimed + iters_per_try timed iterations) on the allocation it has and on up to `tries` further ones that receive a
+ * the marching kernels spread over the HBM channels: the same binary runs the same iteration in 0.72 .. 0.87 ms depending on the
+ * allocations (profiles/r03_alloc_probe.txt). wx_tune_placement times the handle's own iteration (current parameters and
+ * pass mask; 4 untimed + iters_per_try timed iterations) on the allocations it has and on up to `tries` further sets that receive a
  * copy of the state, keeps the fastest as the handle's storage and restores the state from a backup taken at the start: state,
  * iteration counter and all fields are unchanged;
  * device pointers obtained from wx_device_ptr before the call are invalid afterwards. ms_before / ms_after (may be NULL): the

@@ -21,4 +21,6 @@ if has trace_wet; then bash tools/prof_bench.sh r3p/wet_march > $O/wet_march_con
 if has trace_dry; then BENCH_ARGS="--workload dry --X 32768 --Y 4096" bash tools/prof_bench.sh r3p/dry_march > $O/dry_march_console.txt 2>&1; fi
 if has ablation; then BENCH_ARGS="--flow 0 --tune 0" STEPS=40 bash tools/wet_variants.sh > $O/wet_ablation.txt 2>&1; fi
 if has particles; then bash tools/prof_particles.sh r3p/particles > $O/particles_console.txt 2>&1; fi
+# keep the summaries, drop the raw rocprofv3 databases (gpurun copies back at most 64 MiB)
+find $O -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
 ls $O
