@@ -589,7 +589,11 @@ __device__ __forceinline__ float smoothstepf(float e0, float e1, float x)
 // (condensation = max(negative * 0.2, -0) = -0, dT = -0) and water zero, so they are not evaluated.
 // NO_WALL (wave-uniform, established by the caller): neither the cell nor any texel of its back-trace footprints is a wall
 // cell, so the wall-aware interpolation reduces to the plain one (same weights, same operations) and the wall branch is dead.
-template <bool NO_WATER = false, bool NO_WALL = false, class UT, class FP, class A>
+// NO_ZW (wave-uniform, established by the caller; only with NO_WALL): the precipitation-visual channel (z) and the smoke channel (w)
+// of the post-boundary water are zero in every texel the footprints can reach -- free air without rain, snow or smoke, i.e. most of
+// the sky. Their interpolations are then 0 + t * (0 - 0) = 0 for the finite weights of this path, so they are not evaluated (one
+// footprint, eight taps and six lerps less).
+template <bool NO_WATER = false, bool NO_WALL = false, bool NO_ZW = false, class UT, class FP, class A>
 __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const FP initial_T, const FP snd_T, const FP snd_W, const FP snd_Vel, int x, int y,
                                                const A &a, float4 &base_out,
                                                float4 &water_out, char4 &wall_out)
@@ -651,14 +655,16 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
         const float4 qc = f.water(0, 1), qd = f.water(1, 1);
         w.x = bilerp4(qa.x, qb.x, qc.x, qd.x, mAB, mCD, mY);
         w.y = bilerp4(qa.y, qb.y, qc.y, qd.y, mAB, mCD, mY);
-        w.w = bilerp4(qa.w, qb.w, qc.w, qd.w, mAB, mCD, mY);
+        w.w = (NO_WALL && NO_ZW) ? 0.0f : bilerp4(qa.w, qb.w, qc.w, qd.w, mAB, mCD, mY);
       }
     }
     if (NO_WATER) {
       w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       if (tcy > u.globalEffectsStartAlt && tcy < u.globalEffectsEndAlt) b.w += u.globalHeating;
     } else {
-    {
+    if (NO_WALL && NO_ZW) {
+      w.z = 0.0f;
+    } else {
       // precipitation visualisation channel, +0.05 in y (:103). Its x position is (fx - velAtP_x) + 0.0: the same number as above
       // except -0 -> +0, and both give the same stx = -0.5 -- so the x half of the footprint is the one already computed
       Taps t = mktaps(cc, y, fx - velAtP_x, fy - velAtP_y + 0.05f);

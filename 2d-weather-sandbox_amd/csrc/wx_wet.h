@@ -78,6 +78,9 @@ namespace wx {
 #ifndef WX_WET_NT_STORES
 #define WX_WET_NT_STORES 0
 #endif
+#ifndef WX_WET_ZW0
+#define WX_WET_ZW0 1 // wave-uniform skip of the precipitation-visual / smoke interpolations where those channels are zero (advection_cell NO_ZW)
+#endif
 #ifndef WX_WET_AIR
 #define WX_WET_AIR 1 // wave-uniform free-air instantiations of the boundary / advection / lighting stages
 #endif
@@ -529,6 +532,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   char4 adv_w_prev = make_char4(0, 0, 0, 0);
   int big1 = 0, big2 = 0, big3 = 0;                                   // "some |v| >= 0.9" of post-boundary rows r-3, r-4, r-5
   int nowall1 = 0, nowall2 = 0, nowall3 = 0;                          // "no wall cell" of the same rows
+  int zw0_1 = 0, zw0_2 = 0, zw0_3 = 0;                                // "precipitation-visual and smoke channels of the water are all zero" of the same rows
   int near1 = 1, near2 = 1, near3 = 1, near4 = 1;                     // "some cell at or next to a wall" of input rows r .. r-3
   // outputs of the previous step, stored at the top of this one
   float4 st_p = make_float4(0.f, 0.f, 0.f, 0.f), st_q = st_p, st_l = st_p, st_ab = st_p;
@@ -743,6 +747,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         // back-traces of this row that may leave the 3x3 cells? (lanes 2 .. 60 feed an advection that is used)
         big1 = __any(lane >= 2 && lane <= 60 && !(fmaxf(fabsf(bb.x), fabsf(bb.y)) < 0.9f));
         nowall1 = __all(lane < 2 || lane > 60 || bwl.y != 0); // no wall cell in this post-boundary row (as far as advection reads it)
+        zw0_1 = __all(bq.z == 0.0f && bq.w == 0.0f);          // no rain / snow / smoke anywhere in it
         if (OPT_OUT) {
           const int yo = r - 3;
           if (lane_out && yo >= y_lo && yo < y_hi) st_row(out.water0 + (size_t)yo * X, so16, bq);
@@ -799,10 +804,14 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       fast = false;
 #endif
       if (fast) {
-        if (WX_ABL_FORCE_AIR || (WX_WET_AIR && (nowall1 & nowall2 & nowall3))) // (wave-uniform) plain instead of wall-aware interpolation, no wall branch
-          advection_cell<false, true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
-        else
+        if (WX_ABL_FORCE_AIR || (WX_WET_AIR && (nowall1 & nowall2 & nowall3))) { // (wave-uniform) plain instead of wall-aware interpolation, no wall branch
+          if (WX_WET_ZW0 && (zw0_1 & zw0_2 & zw0_3)) // ... and nothing to interpolate in the precipitation-visual / smoke channels
+            advection_cell<false, true, true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
+          else
+            advection_cell<false, true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
+        } else {
           advection_cell<false, false>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
+        }
       } else { // placeholder (the post-boundary texel): this cell and the two it feeds are recomputed after the loop
         ab = a.base(0, 0);
         aw = a.water_off(0, 0);
@@ -852,6 +861,8 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     big2 = big1;
     nowall3 = nowall2;
     nowall2 = nowall1;
+    zw0_3 = zw0_2;
+    zw0_2 = zw0_1;
     near4 = near3;
     near3 = near2;
     near2 = near1;
