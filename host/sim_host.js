@@ -306,6 +306,10 @@ WeatherSim.prototype.frame = function(nIter) {
   this.addon.step(this.h, n);
 };
 WeatherSim.prototype.sync = function() { this.addon.sync(this.h); };
+// engine options with no counterpart in app.js: deterministic particle splats (option 1), per-launch checks (option 2), and the
+// search for a fast placement of the handle's planes in device memory (returns [ms before, ms after]; the state is unchanged)
+WeatherSim.prototype.setOption = function(option, value) { this.addon.setOption(this.h, option, value); };
+WeatherSim.prototype.tunePlacement = function(tries, itersPerTry) { return this.addon.tunePlacement(this.h, tries || 6, itersPerTry || 30); };
 WeatherSim.prototype.iterNum = function() { return this.addon.getIter(this.h); };
 WeatherSim.prototype.readRect = function(field, x, y, w, h, Type) {
   const id = typeof field === 'string' ? FIELD[field] : field;

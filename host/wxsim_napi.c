@@ -26,6 +26,8 @@ static struct {
   int (*set_params)(wx_sim *, const wx_params *, const float *, const float *, const float *, const float *);
   int (*step)(wx_sim *, int);
   int (*sync)(wx_sim *);
+  int (*set_option)(wx_sim *, int, int);
+  int (*tune_placement)(wx_sim *, int, int, float *, float *);
   int64_t (*get_iter)(const wx_sim *);
   int (*set_iter)(wx_sim *, int64_t);
   int (*read_rect)(wx_sim *, int, int, int, int, int, void *, int);
@@ -281,6 +283,43 @@ static napi_value Step(napi_env env, napi_callback_info info)
   return NULL;
 }
 
+/* setOption(h, option, value): wx_set_option (1 = WX_OPT_SPLAT_ORDER: deterministic particle splats, 2 = WX_OPT_CHECK_LAUNCHES) */
+static napi_value SetOption(napi_env env, napi_callback_info info)
+{
+  napi_value a[3];
+  if (get_args(env, info, 3, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  int32_t opt, val;
+  NAPI_CALL(env, napi_get_value_int32(env, a[1], &opt));
+  NAPI_CALL(env, napi_get_value_int32(env, a[2], &val));
+  int rc = L.set_option(s, opt, val);
+  if (rc) return throw_wx(env, s, rc, "wx_set_option");
+  return NULL;
+}
+
+/* tunePlacement(h, tries, itersPerTry) -> [msBefore, msAfter]: wx_tune_placement (the state is unchanged) */
+static napi_value TunePlacement(napi_env env, napi_callback_info info)
+{
+  napi_value a[3];
+  if (get_args(env, info, 3, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  int32_t tries, iters;
+  NAPI_CALL(env, napi_get_value_int32(env, a[1], &tries));
+  NAPI_CALL(env, napi_get_value_int32(env, a[2], &iters));
+  float before = 0.f, after = 0.f;
+  int rc = L.tune_placement(s, tries, iters, &before, &after);
+  if (rc) return throw_wx(env, s, rc, "wx_tune_placement");
+  napi_value arr, v0, v1;
+  NAPI_CALL(env, napi_create_array_with_length(env, 2, &arr));
+  NAPI_CALL(env, napi_create_double(env, before, &v0));
+  NAPI_CALL(env, napi_create_double(env, after, &v1));
+  NAPI_CALL(env, napi_set_element(env, arr, 0, v0));
+  NAPI_CALL(env, napi_set_element(env, arr, 1, v1));
+  return arr;
+}
+
 static napi_value Sync(napi_env env, napi_callback_info info)
 {
   napi_value a[1];
@@ -479,7 +518,7 @@ static int load_lib(napi_env env)
   SYM(upload, "wx_upload") SYM(set_params, "wx_set_params") SYM(step, "wx_step") SYM(sync, "wx_sync") SYM(get_iter, "wx_get_iter")
   SYM(set_iter, "wx_set_iter") SYM(read_rect, "wx_read_rect") SYM(read_particles, "wx_read_particles")
   SYM(setup_columns, "wx_setup_columns") SYM(stream_bytes, "wx_stream_bytes") SYM(host_alloc, "wx_host_alloc") SYM(host_free, "wx_host_free")
-  SYM(stream_frame, "wx_stream_frame") SYM(stream_wait, "wx_stream_wait")
+  SYM(stream_frame, "wx_stream_frame") SYM(stream_wait, "wx_stream_wait") SYM(set_option, "wx_set_option") SYM(tune_placement, "wx_tune_placement")
 #undef SYM
   return 0;
 }
@@ -495,6 +534,7 @@ static napi_value Init(napi_env env, napi_value exports)
     {"readRect", 0, ReadRect, 0, 0, 0, napi_default, 0},   {"readParticles", 0, ReadParticles, 0, 0, 0, napi_default, 0},
     {"abiVersion", 0, AbiVersion, 0, 0, 0, napi_default, 0}, {"setupColumns", 0, SetupColumns, 0, 0, 0, napi_default, 0},
     {"streamFrame", 0, StreamFrame, 0, 0, 0, napi_default, 0}, {"streamWait", 0, StreamWait, 0, 0, 0, napi_default, 0},
+    {"setOption", 0, SetOption, 0, 0, 0, napi_default, 0},   {"tunePlacement", 0, TunePlacement, 0, 0, 0, napi_default, 0},
   };
   NAPI_CALL(env, napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d));
   return exports;

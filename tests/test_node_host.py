@@ -99,14 +99,16 @@ def test_node_new_simulation_and_streaming(pkg, tmp_path):
     out_file = str(tmp_path / "new.weathersandbox")
     js = ("const H=require('%s'), fs=require('fs');"
           "const sim=H.WeatherSim.newSimulation(%d,%d,{sunFixed:true,settings:{enablePrecipitation:false}});"
-          "sim.frame(%d); const fr=sim.streamFrame(8,4,64,32); sim.frame(5); const v=fr.wait();"
+          "sim.frame(%d); const tp=sim.tunePlacement(2,3); sim.setOption(2,0);"  # (placement search + an option through N-API: the state must not change)
+          "const fr=sim.streamFrame(8,4,64,32); sim.frame(5); const v=fr.wait();"
           "let s=0; for (const x of v.WATER_CUR) s+=x; let t=0; for (const x of v.BASE_DISP) t+=x; let e=0; for (const x of v.EMITTED) e+=x;"
           "const eh=new Uint16Array(4*3*2); sim.addon.readRect(sim.h, H.FIELD.EMITTED, 8, 80, 3, 2, eh);"
           "const ef=new Float32Array(4*3*2); sim.addon.readRect(sim.h, H.FIELD.EMITTED, 8, 80, 3, 2, ef);"
-          "console.log(JSON.stringify({iter:sim.iterNum(), water:s, base:t, wall0:v.WALL_DISP[0], n:v.CURL.length, emitted:e, eh:Array.from(eh), ef:Array.from(ef)}));"
+          "console.log(JSON.stringify({iter:sim.iterNum(), water:s, base:t, wall0:v.WALL_DISP[0], n:v.CURL.length, emitted:e, eh:Array.from(eh), ef:Array.from(ef), tp:tp}));"
           "fs.writeFileSync('%s', H.encodeSave(sim.toSave())); sim.destroy();" % (os.path.join(ROOT, "host", "sim_host.js"), X, Y, n, out_file))
     info = json.loads(subprocess.check_output([NODE, "-e", js]).decode().strip().split("\n")[-1])
     assert info["iter"] == n + 5 and info["n"] == 64 * 32
+    assert len(info["tp"]) == 2 and 0 < info["tp"][1] <= info["tp"][0]
     E = pkg.engine
     gui = pkg.params.merge_settings({"enablePrecipitation": False})  # droplets exist (the save format needs X*Y/25) but stay inert
     u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)  # the hosts' default (sim.py / sim_host.js)
