@@ -938,11 +938,115 @@ struct WetPatchAcc {
   }
 };
 
+// The patch of post-boundary texels is built COOPERATIVELY, stage by stage through LDS, the way the reference's passes follow each
+// other (round 3, second version; the first let every lane rebuild its texel recursively from global memory -- velocity, curl and
+// vortForce of the same cells up to 45 times per lane -- and took ~33 us per list entry):
+//   base / wall      13 x 13  [-6, 6]   loaded once
+//   velocity output  12 x 12  [-6, 5]   velocity_cell
+//   curl             11 x 11  [-6, 4]   curl_cell
+//   vortForce         9 x 9   [-5, 3]   vorticity_cell
+//   boundary          8 x 8   [-4, 3]   boundary_cell on an accessor that reads the stages (water, light_0, feedback: global)
+// Same cell functions, same operands: the same values as the marching loop computes.
+constexpr int WSB = 13, WSV = 12, WSC = 11, WSF = 9; // stage widths; all stages start at offset -6 but vortForce (-5) and the patch (-4)
+struct WetFixStage {
+  float bx[WSB * WSB], by[WSB * WSB], bP[WSB * WSB], bT[WSB * WSB];
+  char4 bw[WSB * WSB];
+  float vx[WSV * WSV], vy[WSV * WSV];
+  float cu[WSC * WSC];
+  float fx[WSF * WSF], fy[WSF * WSF];
+};
+struct WetStageBoundaryAcc { // the interface of GWetRecomputeAcc, served from the stages; (px, py) = patch coordinates of the own texel
+  const WetFixStage &st;
+  const Uni &u_;
+  const WetIn &in_;
+  int X, Y, x, y; // wrapped global coordinates of the own texel
+  int px, py;
+  __device__ __forceinline__ float4 base(int dx, int dy) const
+  { // the velocity pass's output: vx, vy from the velocity stage, P and T unchanged (offset -6 -> patch offset -4: +2)
+    const int iv = (py + 2 + dy) * WSV + (px + 2 + dx), ib = (py + 2 + dy) * WSB + (px + 2 + dx);
+    return make_float4(st.vx[iv], st.vy[iv], st.bP[ib], st.bT[ib]);
+  }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return st.bw[(py + 2 + dy) * WSB + (px + 2 + dx)]; }
+  __device__ __forceinline__ float4 water(int dx, int dy) const { return in_.water[fidx(wrapmod(x + dx, X), wrapmod(y + dy, Y), X)]; }
+  __device__ __forceinline__ float2 vort(int dx, int dy) const
+  { // vortForce stage starts at -5: patch offset -4 -> +1
+    const int i = (py + 1 + dy) * WSF + (px + 1 + dx);
+    return make_float2(st.fx[i], st.fy[i]);
+  }
+  __device__ __forceinline__ float light_y0() const { return in_.l0.y[fidx(x, y, X)]; }
+  __device__ __forceinline__ float light_x0() const { return in_.l0.x[fidx(x, y, X)]; }
+  __device__ __forceinline__ float2 light_xy_up() const
+  {
+    const size_t i = fidx(x, y + 1 > Y - 1 ? Y - 1 : y + 1, X); // light textures: CLAMP_TO_EDGE in T
+    return make_float2(in_.l0.x[i], in_.l0.y[i]);
+  }
+  __device__ __forceinline__ bool has_fb() const { return in_.fb != nullptr; }
+  __device__ __forceinline__ float4 fb() const { return in_.fb ? in_.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ float2 dep() const { return in_.dep ? in_.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
+};
+// the 8 x 8 patch of post-boundary texels around (cx, cy), all 64 lanes of the wave
+__device__ __noinline__ void wet_fix_build_patch(const FullCtx *__restrict__ c, const WetIn *__restrict__ in, float iterNum, WetFixStage *__restrict__ stp,
+                                                 WetPatch *__restrict__ ptp, int cx, int cy, int lane)
+{
+  WetFixStage &st = *stp;
+  WetPatch &pt = *ptp;
+  const int X = c->g.X, Y = c->g.Y;
+  for (int i = lane; i < WSB * WSB; i += 64) { // base_0 and wall_0 of the 13 x 13 neighbourhood
+    const int sy = i / WSB, sx = i - sy * WSB;
+    const size_t gi = fidx(wrapmod(cx - 6 + sx, X), wrapmod(cy - 6 + sy, Y), X);
+    const float4 b = in->base[gi];
+    st.bx[i] = b.x;
+    st.by[i] = b.y;
+    st.bP[i] = b.z;
+    st.bT[i] = b.w;
+    st.bw[i] = in->wall[gi];
+  }
+  wave_fence();
+  for (int i = lane; i < WSV * WSV; i += 64) { // velocity pass
+    const int sy = i / WSV, sx = i - sy * WSV, ib = sy * WSB + sx;
+    const float4 v = velocity_cell(c->u, make_float4(st.bx[ib], st.by[ib], st.bP[ib], st.bT[ib]), st.bP[ib + 1], st.bP[ib + WSB], st.bw[ib].y);
+    st.vx[i] = v.x;
+    st.vy[i] = v.y;
+  }
+  wave_fence();
+  for (int i = lane; i < WSC * WSC; i += 64) { // curl
+    const int sy = i / WSC, sx = i - sy * WSC, iv = sy * WSV + sx;
+    st.cu[i] = curl_cell(st.vx[iv], st.vy[iv], st.vy[iv + 1], st.vx[iv + WSV]);
+  }
+  wave_fence();
+  for (int i = lane; i < WSF * WSF; i += 64) { // vortForce of [-5, 3]: curl index +1
+    const int sy = i / WSF, sx = i - sy * WSF, ic = (sy + 1) * WSC + (sx + 1);
+    const float2 f = vorticity_cell(st.cu[ic], st.cu[ic - 1], st.cu[ic + 1], st.cu[ic - WSC], st.cu[ic + WSC]);
+    st.fx[i] = f.x;
+    st.fy[i] = f.y;
+  }
+  wave_fence();
+  { // boundary pass, one patch texel per lane
+    const int px = lane & (WPATCH - 1), py = lane >> 3;
+    const int gx = wrapmod(cx - WPATCH_C + px, X), gy = wrapmod(cy - WPATCH_C + py, Y);
+    const WetStageBoundaryAcc a{st, c->u, *in, X, Y, gx, gy, px, py};
+    float4 bb, bq;
+    char4 bwl;
+    boundary_cell(c->u, iterNum, (int)iterNum, c->g, c->initial_T, gx, gy, a, bb, bq, bwl);
+    pt.vx[lane] = bb.x;
+    pt.vy[lane] = bb.y;
+    pt.P[lane] = bb.z;
+    pt.T[lane] = bb.w;
+    pt.qx[lane] = bq.x;
+    pt.qy[lane] = bq.y;
+    pt.qz[lane] = bq.z;
+    pt.qw[lane] = bq.w;
+    pt.wl[lane] = bwl;
+  }
+  wave_fence();
+}
+
 template <bool OPT_OUT>
 __global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out, int *__restrict__ count,
                                                  const int2 *__restrict__ cells, int cap, int *__restrict__ overflow)
 {
   __shared__ WetPatch patches[4];
+  __shared__ WetFixStage stages[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   WetPatch &pt = patches[wave];
   const int total = *count, n = total < cap ? total : cap;
@@ -951,19 +1055,7 @@ __global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx
   const WetSlowArgs sa{ctx, in, iterNum};
   for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
     const int2 c = cells[i];
-    { // one post-boundary texel of the patch per lane
-      const BOut t = wet_boundary_texel_global(&sa, wrapmod(c.x - WPATCH_C + (lane & (WPATCH - 1)), X), wrapmod(c.y - WPATCH_C + (lane >> 3), Y));
-      pt.vx[lane] = t.b.x;
-      pt.vy[lane] = t.b.y;
-      pt.P[lane] = t.b.z;
-      pt.T[lane] = t.b.w;
-      pt.qx[lane] = t.w.x;
-      pt.qy[lane] = t.w.y;
-      pt.qz[lane] = t.w.z;
-      pt.qw[lane] = t.w.w;
-      pt.wl[lane] = t.wl;
-    }
-    wave_fence();
+    wet_fix_build_patch(ctx, &in, iterNum, &stages[wave], &pt, c.x, c.y, lane);
     AdvOut o;
     o.b = o.w = make_float4(0.f, 0.f, 0.f, 0.f);
     o.wl = make_char4(0, 0, 0, 0);

@@ -6,7 +6,7 @@ from weather_sandbox_amd import devtools
 X,Y=16384,2048
 gui=pkg.params.merge_settings(None); gui["sunAngle"]=50.0
 u=pkg.params.uniforms_from_gui(gui,Y,quad_scale=0); u["enablePrecipitation"]=0
-for sigma in (0.2,0.3,0.4,0.6):
+for sigma in (0.2,0.3,0.4):
     h=pkg.engine.Handle(X,Y,0)
     h.setup_columns(pkg.synth.terrain_columns(X,Y)); h.set_params(pkg.params.fill_struct(pkg.params.WxParams(),u),u["initial_T"])
     devtools.seed_flow(h,sigma)
