@@ -275,8 +275,8 @@ struct SlabP {
   unsigned char *owned_once;   // per droplet: low 4 bits = last iteration (+1) of this period in which this rank processed it; bit 7 =
                                // processed inside the OWNED columns at least once (this rank reports its flips)
 };
-#ifndef WX_PRECIP_COUNT_MODE
-#define WX_PRECIP_COUNT_MODE 1
+#ifndef WX_ABL_PRECIP
+#define WX_ABL_PRECIP 0 // (timing builds, wrong results) 2: no deposit atomics, 4: the gathers read a fixed texel
 #endif
 struct DevState {
   float inactiveDroplets; // the `inactiveDroplets` uniform, refreshed on the device every 600 iterations
@@ -359,6 +359,9 @@ __device__ __forceinline__ int local_col(const Geo &g, float u_)
 __device__ __forceinline__ size_t texel(const Geo &g, float u_, float v_)
 {
   const int iy = wrapmod((int)floorf(v_ * (float)g.Y), g.Y);
+#if WX_ABL_PRECIP & 4
+  return (cidx(local_col(g, u_), iy, g.X) & 255) + (size_t)(g.Y / 2) * g.X;
+#endif
   return cidx(local_col(g, u_), iy, g.X);
 }
 
@@ -367,15 +370,16 @@ __device__ __forceinline__ void atomic_add_f(float *p, float v)
   if (v != 0.0f) unsafeAtomicAdd(p, v);
 }
 
-__global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops, const float *__restrict__ drops_in,
-                                                        const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
-                                                        DevState *__restrict__ st, float *__restrict__ drops_out, SplatGrid sg, SlabP sp,
-                                                        const float *__restrict__ t_in, DetSplat det)
+// one droplet of the pool: transform-feedback update + its deposit. Returns true for a droplet that stays inactive (the reference
+// blends +1 per such droplet into texel (0,0), precipitationShader.vert:158-159: counted by the caller).
+__device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const Uni &u, int n_drops, const float *__restrict__ drops_in,
+                                               const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
+                                               DevState *__restrict__ st, float *__restrict__ drops_out, const SplatGrid &sg, const SlabP &sp,
+                                               const float *__restrict__ t_in, const DetSplat &det)
 {
   // t_in != nullptr (two-kernel path): base_in is the POST-pressure base texture, whose velocity components equal the
   // post-advection ones the reference samples (pressure_cell only touches P and T), and t_in holds the post-advection
   // temperature -- kernel B then stores 4 instead of 16 extra bytes per cell for the droplets.
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = i < n_drops;
   if (live && det.key) det.key[i] = DET_KEY_NONE; // (overwritten below if this droplet deposits something)
   const int Y = g.Y;
@@ -413,18 +417,32 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
       tcx = random2d(m0, dpx + u.iterNum * 0.3754f);
       tcy = random2d(m1, dpx + u.iterNum * 0.073162f);
       const size_t t = texel(g, tcx, tcy);
-      base = base_in[t];
-      if (t_in) base.w = t_in[t];
+      // A spawn probe lands on a random texel: every plane it touches is a cache line of its own from HBM, and those random lines are
+      // what the kernel's time goes into. Cloud water first: a probe into cloud-free air (most of them) is over without the
+      // temperature -- it cannot pass either threshold; the velocity is only fetched by a probe that spawns.
       water = water_in[t];
+      const bool cloudy = water.y > fminf(u.aboveZeroThreshold, u.subZeroThreshold);
+      if (cloudy) {
+        if (t_in)
+          base.w = t_in[t];
+        else
+          base = base_in[t];
+      }
       realTemp = base.w - tcy * u.dryLapse;
       const float threshold = (realTemp > CtoK(0.0f)) ? u.aboveZeroThreshold : u.subZeroThreshold;
-      if (water.y > threshold && base.w < 500.0f) {
+      if (cloudy && water.y > threshold && base.w < 500.0f) {
         const float spawnChance = ((water.y - threshold) / (st->inactiveDroplets + 10.0f)) * resX * resY * u.spawnChanceMult;
         const float c10 = water.y * 10.0f;
         const float pw = c10 * c10; // pow(x, 2.0)
         const float nrmRand = pw - floorf(pw);
         if (spawnChance > nrmRand) {
           spawned = true;
+          if (t_in) {
+            const float4 b = base_in[t];
+            base.x = b.x;
+            base.y = b.y;
+            base.z = b.z;
+          }
           newPosx = (tcx - 0.5f) * 2.0f;
           newPosy = (tcy - 0.5f) * 2.0f;
           if (realTemp < CtoK(0.0f)) {
@@ -553,26 +571,10 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
     }
   }
 
-  // inactive-droplet count: the reference blends +1 into texel (0,0) per droplet
-  // (precipitationShader.vert:158-159); here one atomic per wavefront carries the lane count
-#if WX_PRECIP_COUNT_MODE == 0
-  {
-    const unsigned long long m = __ballot(count_inactive);
-    if (m != 0ull) {
-      const int lane = threadIdx.x & 63;
-      if (lane == __ffsll((long long)m) - 1) unsafeAtomicAdd(&st->px_count, (float)__popcll(m));
-    }
-  }
-#elif WX_PRECIP_COUNT_MODE == 1
-  { // one atomic per 256-thread block: 16 384 same-address atomics per launch were serialising in L2
-    const int c = __syncthreads_count(count_inactive);
-    if (threadIdx.x == 0 && c) unsafeAtomicAdd(&st->px_count, (float)c);
-  }
-#endif
-  if (!live || count_inactive) return;
+  if (!live || count_inactive) return count_inactive;
 
   // point sprite: clip test on the centre (precipitationShader.vert gl_Position / gl_PointSize)
-  if (!(gposx >= -1.0f && gposx <= 1.0f && gposy >= -1.0f && gposy <= 1.0f)) return;
+  if (!(gposx >= -1.0f && gposx <= 1.0f && gposy >= -1.0f && gposy <= 1.0f)) return false;
   const float xw = (gposx + 1.0f) * 0.5f * resX, yw = (gposy + 1.0f) * 0.5f * resY;
   if (size <= 1.0f) {
     // the only 1-px sprite that reaches this point is a lightning request, drawn at pixel (1,0)
@@ -580,13 +582,13 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
     if (det.key) {
       det.key[i] = det_key_light(sg);
       for (int c = 0; c < 4; c++) det.val[5 * (size_t)i + c] = feedback[c];
-      return;
+      return false;
     }
     atomic_add_f(&st->px_light[0], feedback[0]);
     atomic_add_f(&st->px_light[1], feedback[1]);
     atomic_add_f(&st->px_light[2], feedback[2]);
     atomic_add_f(&st->px_light[3], feedback[3]);
-    return;
+    return false;
   }
   // 12x12 sprite: every pixel whose centre lies in [w - 6, w + 6); one deposit at the anchor pixel
   int q = (int)ceilf(xw - 6.0f - 0.5f) + 6;
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
     q += sp.seam + 1; // low-x side of the domain edge: right of the seam, stored one column further right
   else
     q -= g.xoff;
-  if (q < 0 || q >= sg.AP) return; // the sprite lies outside this slab
+  if (q < 0 || q >= sg.AP) return false; // the sprite lies outside this slab
   const size_t ai = (size_t)r * sg.AP + q;
   if (det.key) {
     det.key[i] = (int)ai;
@@ -605,8 +607,11 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
     det.val[5 * (size_t)i + 2] = feedback[2];
     det.val[5 * (size_t)i + 3] = deposition[0];
     det.val[5 * (size_t)i + 4] = deposition[1];
-    return;
+    return false;
   }
+#if WX_ABL_PRECIP & 2
+  return false;
+#endif
   float *f = reinterpret_cast<float *>(sg.acc4 + ai);
   atomic_add_f(f + 0, feedback[0]);
   atomic_add_f(f + 1, feedback[1]);
@@ -615,6 +620,33 @@ __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops
   atomic_add_f(d + 0, deposition[0]);
   atomic_add_f(d + 1, deposition[1]);
   sg.dirty[(r / STY) * sg.TXn + (q / STX)] = 1;
+  return false;
+}
+
+// The pool is walked by a fixed number of workgroups in chunks of 256 droplets (grid-stride): one workgroup per chunk meant 16 384
+// wavefronts of a few microseconds each at 1 M droplets, and the launch lived on ~1 500 resident waves of the 8 192 the chip holds
+// (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES, profiles/r03_particles_precip_counters.txt) whatever its gathers and atomics cost.
+__global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops, const float *__restrict__ drops_in,
+                                                        const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
+                                                        DevState *__restrict__ st, float *__restrict__ drops_out, SplatGrid sg, SlabP sp,
+                                                        const float *__restrict__ t_in, DetSplat det)
+{
+  // t_in != nullptr (two-kernel path): base_in is the POST-pressure base texture, whose velocity components equal the
+  // post-advection ones the reference samples (pressure_cell only touches P and T), and t_in holds the post-advection
+  // temperature -- kernel B then stores 4 instead of 16 extra bytes per cell for the droplets.
+  int count = 0; // still-inactive droplets seen by this wave (wave-uniform)
+  for (int base_i = blockIdx.x * 256; base_i < n_drops; base_i += gridDim.x * 256) {
+    const bool c = precip_droplet(base_i + (int)threadIdx.x, g, u, n_drops, drops_in, base_in, water_in, st, drops_out, sg, sp, t_in, det);
+    count += __popcll(__ballot(c));
+  }
+  // one atomic per workgroup (integers: exact in fp32 in any order)
+  __shared__ int wave_count[4];
+  if ((threadIdx.x & 63) == 0) wave_count[threadIdx.x >> 6] = count;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int c = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    if (c) unsafeAtomicAdd(&st->px_count, (float)c);
+  }
 }
 
 // deterministic splat order: one thread per sorted record; the first record of a run of equal keys adds the run in order
@@ -733,11 +765,8 @@ __device__ __forceinline__ void splat_box_tile(float (*pl)[STY + 11][77], int X,
     for (int i = 0; i < WH - 3; i++) a[i] = a[i] + a[i + 2];
 #pragma unroll
     for (int j = 0; j < STY; j++) vres[j] = (a[j] + a[j + 4]) + a[j + 8];
-  }
-  __syncthreads();
-  if (vtask) {
 #pragma unroll
-    for (int j = 0; j < STY; j++) pl[vc][j][vx] = vres[j];
+    for (int j = 0; j < STY; j++) pl[vc][j][vx] = vres[j]; // (the column is this thread's alone until the barrier)
   }
   __syncthreads();
   // horizontal pass: a run of 4 output cells of one row per thread, all channels of the texture
@@ -755,13 +784,22 @@ __device__ __forceinline__ void splat_box_tile(float (*pl)[STY + 11][77], int X,
 #pragma unroll
     for (int m = 0; m < 4; m++) res[c][m] = (a[m] + a[m + 4]) + a[m + 8];
   }
-  const int y = y0 + row;
+  // The sums go back through the staging buffer so that a wavefront stores whole rows: written straight from the run-of-four layout,
+  // every store instruction scattered 16-byte pieces at a 64-byte stride -- four times the write requests, and the kernel's stores
+  // alone took as long as everything else in it (timing builds, profiles/r03_particles_ablation.txt).
+  __syncthreads(); // every thread has read its window columns
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
-    const int x = x0 + run * 4 + m;
+  for (int c = 0; c < NCH; c++)
+#pragma unroll
+    for (int m = 0; m < 4; m++) pl[c][row][run * 4 + m] = res[c][m];
+  __syncthreads();
+  const int cx = tid & 63, cyg = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < STY / 4; k++) {
+    const int ry = cyg + 4 * k, x = x0 + cx, y = y0 + ry;
     if (x < X && y < Y) {
       if (KIND == 0) {
-        float4 v = make_float4(res[0][m], res[1][m], res[2][m], 0.f);
+        float4 v = make_float4(pl[0][ry][cx], pl[1][ry][cx], pl[2][ry][cx], 0.f);
         if (corner && y == 0 && x == 0) v.x += st->px_count;
         if (corner && y == 0 && x == 1) {
           v.x += st->px_light[0];
@@ -771,7 +809,7 @@ __device__ __forceinline__ void splat_box_tile(float (*pl)[STY + 11][77], int X,
         }
         fb[(size_t)y * X + x] = v;
       } else {
-        dep[(size_t)y * X + x] = make_float2(res[0][m], res[1][m]);
+        dep[(size_t)y * X + x] = make_float2(pl[0][ry][cx], pl[1][ry][cx]);
       }
     }
   }
@@ -786,7 +824,10 @@ __global__ __launch_bounds__(256, 4) void k_splat_box(int X, int Y, SplatGrid sg
   const int tid = threadIdx.x;
   const int T = sg.TXn * sg.TYn, n_box = sg.work[4 * par], n_zero = sg.work[4 * par + 1];
   const int cx = tid & 63, cyg = tid >> 6;
-  // items: (tile, texture) for the tiles to box-sum, then the tiles to zero
+  // items: (tile, texture) for the tiles to box-sum, then the tiles to zero, dealt out round-robin. The launch must not hold more
+  // workgroups than the chip does at once (splat_box_grid): with 2048 of them on a chip that holds 1536, the 512 of the second round
+  // started their twelve items when the first round had finished. (Handing the items out through an atomic counter instead costs more
+  // than it balances: 24 000 returning atomics on one address serialise, 0.37 instead of 0.25 ms.)
   for (int wi = blockIdx.x; wi < 2 * n_box + n_zero; wi += gridDim.x) {
     const bool any_dirty = wi < 2 * n_box;
     const int tile = any_dirty ? sg.work[8 + (wi >> 1)] : sg.work[8 + T + (wi - 2 * n_box)];
@@ -807,15 +848,34 @@ __global__ __launch_bounds__(256, 4) void k_splat_box(int X, int Y, SplatGrid sg
         }
       }
       if (tid == 0) sg.fb_zero[tile] = corner ? 0 : 1;
-      continue;
-    }
-    if ((wi & 1) == 0) {
+    } else if ((wi & 1) == 0) {
       splat_box_tile<0>(pl, X, Y, sg, st, fb, dep, x0, y0, qmin, qmax, qshift, corner);
       if (tid == 0) sg.fb_zero[tile] = 0;
     } else {
       splat_box_tile<1>(pl, X, Y, sg, st, fb, dep, x0, y0, qmin, qmax, qshift, corner);
     }
   }
+}
+
+// workgroups of a k_splat_box launch: what the device holds at once
+inline int splat_box_grid()
+{
+  static int grid = 0;
+  if (!grid) {
+    if (const char *e = getenv("WX_SPLAT_BOX_WGS")) grid = atoi(e); // (tuning)
+  }
+  if (grid <= 0) {
+    int dev = 0, ncu = 0, nb = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_splat_box, 256, 0) != hipSuccess || ncu <= 0 || nb <= 0)
+      grid = 1024;
+    else {
+      hipFuncAttributes fa; // (the occupancy API can answer one workgroup per CU too many: bound it by the LDS the kernel really uses)
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_splat_box)) == hipSuccess && fa.sharedSizeBytes > 0) nb = std::min(nb, (int)(160 * 1024 / fa.sharedSizeBytes));
+      grid = ncu * std::max(nb, 1);
+    }
+  }
+  return grid;
 }
 
 // zero the accumulation tiles that hold deposits (after k_splat_box consumed them)

@@ -1101,7 +1101,9 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
           sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, s->period_j + 1, s->pool_remote, s->pool_flips, s->pool_owned};
           d_in = d_out = s->drops[0]; // the partitioned pool is updated in place
         }
-        hipLaunchKernelGGL(k_precipitation, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, u, s->n_drops, d_in,
+        static const int precip_wgs = [] { const char *e = getenv("WX_PRECIP_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+        const int chunks = (s->n_drops + 255) / 256;
+        hipLaunchKernelGGL(k_precipitation, dim3(chunks < precip_wgs ? chunks : precip_wgs), dim3(256), 0, s->stream, s->geo, u, s->n_drops, d_in,
                            two_kernel ? s->base[0] : ((fused || dry) ? s->base[2] : s->base[1]), s->water[1], s->state, d_out, s->sg, sp,
                            two_kernel ? s->tdisp : nullptr, DetSplat{s->splat_order ? s->det_key[0] : nullptr, s->det_val});
         LAUNCH_CHECK(s, "precipitation");
@@ -1118,7 +1120,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
         ProfScope ps(s, K_SPLAT);
         const int T = s->sg.TXn * s->sg.TYn, par = s->splat_par;
         hipLaunchKernelGGL(k_splat_classify, dim3((T + 255) / 256), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->pool_remote ? 0 : 1, par);
-        hipLaunchKernelGGL(k_splat_box, dim3(T < 2048 ? T : 2048), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->state, s->fb, s->dep, s->seam,
+        hipLaunchKernelGGL(k_splat_box, dim3(std::min(T, splat_box_grid())), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->state, s->fb, s->dep, s->seam,
                            s->pool_remote ? 0 : 1, par);
         LAUNCH_CHECK(s, "splat_classify / splat_box");
       }
