@@ -83,6 +83,9 @@ __device__ __forceinline__ MDryFp make_fp(const MDryAcc &a, int dx0, int dy0) { 
 // WRITE_WALL = false: the host has established that advection cannot change the wall texture in this launch (no brush,
 // no airplane crash, no negative vegetation left to clamp -- the only three ways, advectionShader.frag:189-227, 229-457),
 // so the pass-through store is dropped and the wall buffers are not swapped: 36 B/cell, SURVEY's A_dry.
+#ifndef WX_MARCH_UNROLL
+#define WX_MARCH_UNROLL 1 // row steps per loop iteration. 2: 1.08 instead of 0.95 ms at 32768x4096 (more registers, fewer waves per SIMD), unlike k_march_wet
+#endif
 template <bool WRITE_DISP, bool WRITE_WALL>
 __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u_arg, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows,
                                                                      int n_full, int n_half, int band_h, int n_seg, int strip_lo
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     b_new = ld_row_v(in.base + e, lo16);
     w_new = ld_row_v(wall_raw + e, lo4);
   }
-  for (; r <= y_hi + 1; r++) {
+  auto step = [&]() __attribute__((always_inline)) {
     const int rc = r + 8; // non-negative ring counter
     const float4 b_cur = b_new;
     int w_raw = w_new;
@@ -239,7 +242,23 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     big2 = big1;
     yw_p1 = yw_p1 + 1 == Y ? 0 : yw_p1 + 1;
     yw_m2 = yw_m2 + 1 == Y ? 0 : yw_m2 + 1;
+  };
+#if WX_MARCH_UNROLL >= 2
+  // several row steps per loop iteration: the values carried from step to step (prefetched row, previous rows, deferred stores)
+  // change registers between the copies instead of being moved (cf. WX_WET_UNROLL2)
+  for (; r <= y_hi + 1;) {
+    step();
+    r++;
+#pragma unroll
+    for (int k = 1; k < WX_MARCH_UNROLL; k++) {
+      if (r > y_hi + 1) break;
+      step();
+      r++;
+    }
   }
+#else
+  for (; r <= y_hi + 1; r++) step();
+#endif
   if (st_valid && lane_out) { // the last row
     const size_t e = (size_t)(y_hi - 1) * X;
     st_row_v(out.base + e, so16, st_p);

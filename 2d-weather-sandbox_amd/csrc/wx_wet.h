@@ -81,6 +81,9 @@ namespace wx {
 #ifndef WX_WET_ZW0
 #define WX_WET_ZW0 1 // wave-uniform skip of the precipitation-visual / smoke interpolations where those channels are zero (advection_cell NO_ZW)
 #endif
+#ifndef WX_WET_PRIO_MEM
+#define WX_WET_PRIO_MEM 0 // s_setprio level while a step issues its prefetch and its deferred stores (0: none)
+#endif
 #ifndef WX_WET_UNROLL2
 #define WX_WET_UNROLL2 1 // two row steps per loop iteration (measured -1.2 .. -1.6 % at 16384x2048: fewer register moves for the carried values)
 #endif
@@ -599,6 +602,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #ifdef WX_STAGE_MARKS
     asm volatile("; @@prefetch");
 #endif
+#if WX_WET_PRIO_MEM
+    __builtin_amdgcn_s_setprio(WX_WET_PRIO_MEM); // the step's loads and stores go out ahead of the other waves' arithmetic
+#endif
     // ---- software prefetch: the loads of the next step are in flight while this one computes ----
     if (r < y_hi + 3) {
       {
@@ -673,6 +679,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #endif
     }
     st_valid = false;
+#if WX_WET_PRIO_MEM
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef WX_STAGE_MARKS
     asm volatile("; @@velocity");
 #endif
@@ -810,7 +819,15 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       if (fast) {
         if (WX_ABL_FORCE_AIR || (WX_WET_AIR && (nowall1 & nowall2 & nowall3))) { // (wave-uniform) plain instead of wall-aware interpolation, no wall branch
           if (WX_WET_ZW0 && (zw0_1 & zw0_2 & zw0_3)) // ... and nothing to interpolate in the precipitation-visual / smoke channels
+          {
+#ifdef WX_STAGE_MARKS
+            asm volatile("; @@advair");
+#endif
             advection_cell<false, true, true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
+#ifdef WX_STAGE_MARKS
+            asm volatile("; @@advairend");
+#endif
+          }
           else
             advection_cell<false, true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
         } else {
@@ -887,6 +904,11 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     if (r > y_hi + 3) break;
     step();
     r++, t++;
+#if WX_WET_UNROLL2 >= 3
+    if (r > y_hi + 3) break;
+    step();
+    r++, t++;
+#endif
   }
 #else
   for (; r <= y_hi + 3; r++, t++) step();
