@@ -83,6 +83,20 @@ __device__ __forceinline__ MDryFp make_fp(const MDryAcc &a, int dx0, int dy0) { 
 // WRITE_WALL = false: the host has established that advection cannot change the wall texture in this launch (no brush,
 // no airplane crash, no negative vegetation left to clamp -- the only three ways, advectionShader.frag:189-227, 229-457),
 // so the pass-through store is dropped and the wall buffers are not swapped: 36 B/cell, SURVEY's A_dry.
+#ifndef WX_MARCH_FENCE
+#define WX_MARCH_FENCE 0 // 1: wavefront-scope fence instead of __syncthreads() between the stages (the workgroup is one wave)
+#endif
+__device__ __forceinline__ void march_fence()
+{
+#if WX_MARCH_FENCE
+  wave_fence();
+#else
+  __syncthreads();
+#endif
+}
+#ifndef WX_MARCH_AIR
+#define WX_MARCH_AIR 1 // wave-uniform free-air instantiation of the advection stage (rows without wall cells)
+#endif
 #ifndef WX_MARCH_UNROLL
 #define WX_MARCH_UNROLL 1 // row steps per loop iteration. 2: 1.08 instead of 0.95 ms at 32768x4096 (more registers, fewer waves per SIMD), unlike k_march_wet
 #endif
@@ -151,6 +165,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
   float adv_vy_prev = 0.f, adv_T_prev = 0.f;
   char4 adv_w_prev = make_char4(0, 0, 0, 0);
   int big1 = 0, big2 = 0, big3 = 0; // "some |v| >= 0.9" of velocity rows r-1, r-2, r-3
+  int nw1 = 0, nw2 = 0, nw3 = 0;    // "no wall cell in the row" of input rows r-1, r-2, r-3 (the wall texture does not change in this kernel)
   // the output row of the previous step, stored at the top of this one (right behind the prefetch): the single vmcnt wait of a
   // step then covers a load and a store that have both had a whole step to complete (gfx9: one in-order counter for both)
   float4 st_p = make_float4(0.f, 0.f, 0.f, 0.f), st_ab = st_p;
@@ -171,6 +186,9 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     int w_raw = w_new;
     asm volatile("" : "+v"(w_raw)); // keeps the byte unpacking on this side of the prefetch
     const char4 w_cur = make_char4((signed char)(w_raw & 0xff), (signed char)((w_raw >> 8) & 0xff), (signed char)((w_raw >> 16) & 0xff), (signed char)(w_raw >> 24));
+#if WX_MARCH_AIR
+    const int nw0 = __all(w_cur.y != 0);
+#endif
     // software prefetch: next row's loads are in flight while this row is processed
     if (r < y_hi + 1) {
       const size_t e = (size_t)yw_p1 * X;
@@ -188,7 +206,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     MarchRing::put(rg.P, rc & 3, lane, b_cur.z);
     MarchRing::put(rg.T, rc & 3, lane, b_cur.w);
     MarchRing::put(rg.w, rc & 3, lane, w_cur);
-    __syncthreads(); // one wave per workgroup: orders the wave's LDS traffic, no cross-wave wait
+    march_fence(); // one wave per workgroup: orders the wave's LDS traffic, no cross-wave wait
 
     if (r >= y_lo - 1) { // velocity of row r-1: P of the right neighbour from the ring, P above = this row
       const int s1 = (rc - 1) & 3;
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
       MarchRing::put(rg.vy, s1, lane, v.y);
       big1 = __any(fmaxf(fabsf(v.x), fabsf(v.y)) >= 0.9f); // any back-trace of this row that may leave the 3x3 cells?
     }
-    __syncthreads();
+    march_fence();
 
     if (r >= y_lo + 1) { // advection of row y = r-2 (velocity rows r-3 .. r-1 are in the ring)
       const int y = yw_m2;
@@ -217,7 +235,12 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
         }
         if (fast) {
           MDryAcc a{rg, l1, yc};
-          advection_cell<true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
+#if WX_MARCH_AIR
+          if (nw1 & nw2 & nw3) // (wave-uniform) no wall cell in the three rows the footprints reach: plain interpolation, no wall branch
+            advection_cell<true, true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
+          else
+#endif
+            advection_cell<true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
         } else { // exact out-of-line path (velocity recomputed from global memory)
           const AdvOut o = advection_cell_dry_global(ctx, in, false, col, y);
           ab = o.b;
@@ -240,6 +263,11 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     w_prev = w_cur;
     big3 = big2;
     big2 = big1;
+#if WX_MARCH_AIR
+    nw3 = nw2;
+    nw2 = nw1;
+    nw1 = nw0;
+#endif
     yw_p1 = yw_p1 + 1 == Y ? 0 : yw_p1 + 1;
     yw_m2 = yw_m2 + 1 == Y ? 0 : yw_m2 + 1;
   };
