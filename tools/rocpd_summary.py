@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 (ROCm 7.x) rocpd SQLite result: per-kernel stats (== `--stats`) and PMC sums.
 
-usage: tools/rocpd_summary.py <results.db> [--skip N]   ->  markdown table on stdout
-`--skip N` ignores the first N dispatches of every kernel (warm-up launches).
+usage: tools/rocpd_summary.py <results.db> [--skip N | --last N]   ->  markdown table on stdout
+`--skip N` ignores the first N dispatches of every kernel (warm-up launches); `--last N` keeps only the last N dispatches of every
+kernel (the timed region of a bench run that tuned the placement of its planes first: the probes ran the same kernels elsewhere).
 """
 import sqlite3
 import sys
@@ -12,6 +13,7 @@ from collections import defaultdict
 def main():
     db = sys.argv[1]
     skip = int(sys.argv[sys.argv.index("--skip") + 1]) if "--skip" in sys.argv else 0
+    last = int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else 0
     c = sqlite3.connect(db)
     rows = c.execute("select k.kernel_name, d.start, d.end, d.grid_size_x, d.grid_size_y, d.workgroup_size_x, d.workgroup_size_y, "
                      "k.arch_vgpr_count, k.sgpr_count, d.group_segment_size, d.id, d.event_id "
@@ -28,8 +30,11 @@ def main():
             pmc[eid][pname].append(val)
     except sqlite3.Error:
         pass
+    if last:
+        per = {k: v[-last:] for k, v in per.items()}
+        skip = 0
     total = sum(sum(d for d, _ in v[skip:]) for v in per.values())
-    print(f"source: {db}  (dispatches: {len(rows)}, skipped first {skip} per kernel)\n")
+    print(f"source: {db}  (dispatches: {len(rows)}, " + (f"last {last} per kernel" if last else f"skipped first {skip} per kernel") + ")\n")
     print("| kernel | calls | total ms | avg us | min us | max us | % | grid | wg | vgpr | sgpr | lds B |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
     for name, v in sorted(per.items(), key=lambda kv: -sum(d for d, _ in kv[1][skip:])):
