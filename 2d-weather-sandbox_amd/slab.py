@@ -40,7 +40,9 @@ from . import params
 from .engine import Handle
 
 CONE_PER_ITERATION = 6  # columns per side, see module docstring
-DEFAULT_HALO = 48       # eight iterations per exchange: amortises the ~0.1 ms P2P round trip, 4.7 % redundant columns at 2048/GPU
+DEFAULT_HALO = 42       # seven iterations per exchange: amortises the ~0.1 ms P2P round trip, 4.1 % redundant columns at 2048/GPU.
+                        # Not 48: a 4096 + 96 = 4192-column slab has a row pitch of 131 x 512 B, and the dry stencil runs 14 % slower on it
+                        # than on 4180 or 4144 columns (profiles/r03_slab_shapes.txt) -- rows a power-of-two multiple apart share channels
 
 
 def slab_columns(X: int, rank: int, world: int):

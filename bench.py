@@ -458,7 +458,8 @@ def main():
         elif a.particles:
             deco = f"{world} x-slabs, 64 ghost columns, partitioned droplet pool; every 9 iterations: ring halo exchange + edge droplets (one batch of send/recv), status-flip events (all-gather of a few KB)"
         else:
-            deco = f"{world} x-slabs, 48 ghost columns, ring halo exchange every 8 iterations (RCCL send/recv on a side stream, overlapped with compute)"
+            deco = (f"{world} x-slabs, {drv.halo} ghost columns, ring halo exchange every {drv.iters_per_exchange} iterations "
+                    "(RCCL send/recv on a side stream, overlapped with compute)")
         A = 36 if a.workload == "dry" else 72
         out = {
             "metric": "Mcell-steps/s", "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": a.steps,

@@ -15,7 +15,7 @@ fi
 if has lottery; then python tools/copy_lottery.py > $O/copy_lottery.txt 2>&1; fi
 if has ubench; then { for i in 1 2 3; do tools/ubench_hbm 16384 2048 64 15; done; tools/ubench_hbm 32768 4096 32 15; tools/ubench_hbm 16384 2048 256 15; } > $O/ubench_hbm.txt 2>&1; fi
 if has sweep; then { python tools/shape_sweep_whole.py 16384 2048 "4x1,1x0.5,1x0.25" "3x1,1x0.5,1x0.25" "2x1,1x0.5,1x0.25" "5x1,1x0.5,1x0.25"; python tools/shape_sweep_whole.py 32768 4096 "7x1,1x0.5,1x0.25,1x0.125" "6x1,1x0.5,1x0.25" "5x1,1x0.5,1x0.25"; python tools/slab_sweep.py; } 2>&1 | grep -v amdgpu.ids > $O/shape_sweep.txt; fi
-if has slabs; then { python tools/slab_shapes.py 48 3; python tools/slab_shapes.py 24 3; } 2>&1 | grep -v amdgpu.ids > $O/slab_shapes.txt; fi
+if has slabs; then { python tools/slab_shapes.py 48 3; python tools/slab_shapes.py 42 3; python tools/slab_shapes.py 24 3; } 2>&1 | grep -v amdgpu.ids > $O/slab_shapes.txt; fi
 if has flow; then sed -i 's/for sigma in ([^)]*):/for sigma in (0.05,0.1,0.15,0.2,0.3,0.4):/' tools/flow_probe.py; python tools/flow_probe.py 2>&1 | grep -v amdgpu.ids > $O/flow_probe.txt; fi
 if has trace_wet; then bash tools/prof_bench.sh r3p/wet_march > $O/wet_march_console.txt 2>&1; fi
 if has trace_dry; then BENCH_ARGS="--workload dry --X 32768 --Y 4096" bash tools/prof_bench.sh r3p/dry_march > $O/dry_march_console.txt 2>&1; fi
