@@ -129,6 +129,9 @@ struct WetFixList {
   int *count;
   int2 *cells;
   int cap;
+  const int *hint_host; // (host address of the same word)
+  int *hint; // host-visible word (pinned, mapped): the fix pass leaves the length of the list it consumed here; the host looks at it
+             // (stale, never waited for) to size the NEXT fix launches -- a launch over the whole chip costs 10 us to find an empty list
 };
 
 // ---- exact out-of-line path: the post-boundary texel of an ARBITRARY cell recomputed from global memory (velocity, curl
@@ -1083,7 +1086,7 @@ __device__ __noinline__ void wet_fix_build_patch(const FullCtx *__restrict__ c, 
 
 template <bool OPT_OUT>
 __global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx, float iterNum, WetIn in, WetOut out, int *__restrict__ count,
-                                                 const int2 *__restrict__ cells, int cap, int *__restrict__ overflow)
+                                                 const int2 *__restrict__ cells, int cap, int *__restrict__ overflow, int *__restrict__ hint)
 {
   __shared__ WetPatch patches[4];
   __shared__ WetFixStage stages[4];
@@ -1134,6 +1137,7 @@ __global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx
   if (threadIdx.x == 0 && atomicAdd(count + 1, 1) == (int)gridDim.x - 1) {
     count[1] = 0;
     __hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (hint) __hip_atomic_store(hint, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1307,11 +1311,14 @@ inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *c
 inline void launch_wet_fix(float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, const WetFixList &fix, int *overflow, bool opt_out,
                            hipStream_t stream)
 {
-  const dim3 grid(512), block(256);
+  // the whole chip (512 workgroups = one wavefront per list entry up to 2048 entries) while the last list the host has heard of held
+  // entries, a corner of it while the lists are empty; any grid is correct (grid-stride loop)
+  const int last = fix.hint ? *(volatile const int *)fix.hint_host : 1;
+  const dim3 grid(last > 0 ? 512 : 32), block(256);
   if (opt_out)
-    hipLaunchKernelGGL((k_wet_fix<true>), grid, block, 0, stream, ctx, iterNum, in, out, fix.count, fix.cells, fix.cap, overflow);
+    hipLaunchKernelGGL((k_wet_fix<true>), grid, block, 0, stream, ctx, iterNum, in, out, fix.count, fix.cells, fix.cap, overflow, fix.hint);
   else
-    hipLaunchKernelGGL((k_wet_fix<false>), grid, block, 0, stream, ctx, iterNum, in, out, fix.count, fix.cells, fix.cap, overflow);
+    hipLaunchKernelGGL((k_wet_fix<false>), grid, block, 0, stream, ctx, iterNum, in, out, fix.count, fix.cells, fix.cap, overflow, fix.hint);
 }
 
 // lowest row above which every cell is free air in the sense of air_cell(): 1 + the highest row holding a wall cell, a cell next

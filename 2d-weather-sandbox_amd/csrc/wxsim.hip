@@ -121,6 +121,7 @@ struct wx_sim {
   // marching wet kernel: output cells fed by a back-trace longer than 0.9 cells, recomputed exactly by k_wet_fix (wx_wet.h)
   int *fix_count = nullptr;
   int2 *fix_cells = nullptr;
+  int *fix_hint_host = nullptr, *fix_hint_dev = nullptr; // pinned + mapped word: length of the last exact-path list (WetFixList::hint)
   int fix_cap = 0;
   bool fix_check = false; // a marching iteration ran since the overflow flag was last looked at
   // overlap of the halo exchange with compute (wx_set_comm_stream / wx_step_overlap)
@@ -576,10 +577,19 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
         hipMemsetAsync(s->fix_count, 0, 8, s->stream) != hipSuccess) // {entries, arrival ticket of the fix pass}: the fix pass leaves both at 0
       return fail(s, WX_E_NOMEM, "wx_step: %zu bytes for the exact-path cell list", cap * sizeof(int2));
     s->fix_cap = (int)cap;
+    // (optional: without the mapped word every fix launch covers the whole chip)
+    if (!(getenv("WX_FIX_HINT") && atoi(getenv("WX_FIX_HINT")) == 0) && // (WX_FIX_HINT=0: tuning)
+        hipHostMalloc((void **)&s->fix_hint_host, sizeof(int), hipHostMallocMapped) == hipSuccess && s->fix_hint_host) {
+      *s->fix_hint_host = 1;
+      if (hipHostGetDevicePointer((void **)&s->fix_hint_dev, s->fix_hint_host, 0) != hipSuccess) s->fix_hint_dev = nullptr;
+    } else {
+      s->fix_hint_host = nullptr;
+      (void)hipGetLastError();
+    }
   }
   {
     ProfScope ps(s, K_MARCH_WET);
-    const WetFixList fix{s->fix_count, s->fix_cells, s->fix_cap};
+    const WetFixList fix{s->fix_count, s->fix_cells, s->fix_cap, s->fix_hint_host, s->fix_hint_dev};
     // one launch group: marching kernel over a strip range (or two) -> the fix pass over what it recorded (leaves the list empty)
     auto group = [&](int lo0, int cnt0, int lo1 = 0, int cnt1 = 0) {
       launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, fix, opt_out, s->stream, lo0, cnt0);
@@ -862,6 +872,7 @@ void wx_destroy(wx_sim *s)
   dfree(s, s->zero_row);
   hipFree(s->fix_count);
   hipFree(s->fix_cells);
+  if (s->fix_hint_host) hipHostFree(s->fix_hint_host);
   dfree(s, s->water[2]);
   dfree(s, s->sg.acc4);
   dfree(s, s->sg.acc2);
