@@ -898,10 +898,11 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     yw_m1 = yw_m1 + 1 == Y ? 0 : yw_m1 + 1;
     yw_p1 = yw_p1 + 1 == Y ? 0 : yw_p1 + 1;
   };
-  if (WX_WET_UNROLL2 && !HAS_FB) {
+  if (WX_WET_UNROLL2 && !HAS_FB && !OPT_OUT) {
     // two steps per loop iteration: the values carried from step to step (prefetched rows, the previous rows' registers, the deferred
     // stores) change registers between the two copies instead of being moved: -1.4 % without feedback loads; WITH them (particles on)
-    // the doubled loop is 4-6 % slower, so that instantiation keeps the plain loop (profiles/r03_unroll_variants.txt)
+    // the doubled loop is 4-6 % slower, and the display-writing one (every tenth iteration) loses 2-8 %: only the plain instantiation
+    // is doubled (profiles/r03_unroll_variants.txt)
     for (; r <= y_hi + 3;) {
       step();
       r++, t++;
