@@ -322,6 +322,37 @@ def test_fast_cells_exact_path_vs_oracle(pkg, oracle, E, monkeypatch, X, Y, band
     h.close()
 
 
+def test_fix_pass_sized_for_an_empty_list_meets_fast_cells(pkg, oracle, E, monkeypatch):
+    """The fix pass is launched with a few workgroups while the last list the host has heard of was empty (WetFixList::hint). A calm
+    state first (the hint drops to 0), then a state full of fast cells uploaded into the SAME handle: the small launch has to work
+    through a long list -- any grid is correct (grid-stride loop). Bit-exact against the oracle."""
+    monkeypatch.setenv("WX_FUSED", "2")
+    X, Y = 700, 200
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 30.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+    h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
+    h.step(3)  # nothing moves: empty lists, and the host reads the hint at the next enqueue
+    h.sync()
+    rng = np.random.Generator(np.random.Philox(17))
+    air = wall[..., 1] != 0
+    base = base.copy()
+    base[..., 0] += np.where(air, rng.normal(0, 0.5, (Y, X)), 0).astype(np.float32)
+    base[..., 1] += np.where(air, rng.normal(0, 0.5, (Y, X)), 0).astype(np.float32)
+    assert (np.abs(base[..., :2]).max(-1) >= 0.9).sum() > 5000
+    h.upload(base, water, wall)
+    o.upload(base, water, wall)
+    h.iter = o.iter = 0
+    for n in (1, 2):
+        h.step(n)
+        o.step(n)
+        _assert_grid_equal(h, o)
+    h.sync()
+    h.close()
+
+
 def test_exact_path_overflow_is_reported(pkg, E, monkeypatch):
     """More fast cells in one iteration than the exact-path list holds: WX_E_STATE from the next blocking call, not silence."""
     monkeypatch.setenv("WX_FUSED", "2")
