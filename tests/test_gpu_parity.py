@@ -339,9 +339,9 @@ def test_fix_pass_sized_for_an_empty_list_meets_fast_cells(pkg, oracle, E, monke
     rng = np.random.Generator(np.random.Philox(17))
     air = wall[..., 1] != 0
     base = base.copy()
-    base[..., 0] += np.where(air, rng.normal(0, 0.5, (Y, X)), 0).astype(np.float32)
-    base[..., 1] += np.where(air, rng.normal(0, 0.5, (Y, X)), 0).astype(np.float32)
-    assert (np.abs(base[..., :2]).max(-1) >= 0.9).sum() > 5000
+    base[..., 0] += np.where(air, rng.normal(0, 0.33, (Y, X)), 0).astype(np.float32)
+    base[..., 1] += np.where(air, rng.normal(0, 0.33, (Y, X)), 0).astype(np.float32)
+    assert (np.abs(base[..., :2]).max(-1) >= 0.9).sum() > 1000  # (a few times that many list entries; the list holds 65 536)
     h.upload(base, water, wall)
     o.upload(base, water, wall)
     h.iter = o.iter = 0
