@@ -81,6 +81,9 @@ namespace wx {
 #ifndef WX_WET_ZW0
 #define WX_WET_ZW0 1 // wave-uniform skip of the precipitation-visual / smoke interpolations where those channels are zero (advection_cell NO_ZW)
 #endif
+#ifndef WX_WET_DEP_NEAR
+#define WX_WET_DEP_NEAR 1 // deposition rows are only loaded where a surface wall cell can read them
+#endif
 #ifndef WX_WET_PRIO_MEM
 #define WX_WET_PRIO_MEM 0 // s_setprio level while a step issues its prefetch and its deferred stores (0: none)
 #endif
@@ -648,14 +651,16 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #if WX_WET_FB_COND
           if (fb_have) {
             pf_fb = ld_row(in.fb + e, lo16);
-            pf_dep = ld_row(in.dep + e, lo8);
+            pf_dep = ld_row((!WX_WET_DEP_NEAR || near3) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
           } else {
             pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);
             pf_dep = make_float2(0.f, 0.f);
           }
 #else
           pf_fb = ld_row(fb_have ? in.fb + e : in.zero_row, lo16);
-          pf_dep = ld_row(fb_have ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
+          // (the deposition texture is only read by surface wall cells, boundaryShader.frag:390-475: rows without a cell at or next to
+          // a wall take it from the row of zeros too)
+          pf_dep = ld_row((fb_have && (!WX_WET_DEP_NEAR || near3)) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
 #endif
         }
 #endif
