@@ -198,6 +198,30 @@ def test_config4_particles_16384x2048_1M_vs_oracle(pkg, oracle, E, config4):
     gc.collect()
 
 
+def test_ragged_droplet_pool_grid_stride_bit_exact(pkg, oracle, E):
+    """A pool whose size is no multiple of anything (300 017 droplets = 1172 chunks of 256, the last one ragged) on a 2048 x 512 grid:
+    k_precipitation walks it with 1024 workgroups, so some take two chunks and the tail is partial. Deterministic splat order, the
+    coupled run bit for bit against the oracle."""
+    X, Y, N = 2048, 512, 300017
+    base, water, wall = _wet_state(pkg, X, Y, 61)
+    pkg.synth.add_cloud_deck(water, wall)
+    drops, n_inactive = _storm_population(N, X, Y, 62)
+    u = _uniforms(pkg, Y)
+    u["enablePrecipitation"] = 1
+    u["inactiveDroplets"] = float(n_inactive)
+    h, o = _particle_pair(pkg, oracle, E, (X, Y, N, base, water, wall, drops, u), det=True)
+    for n in (1, 2):
+        h.step(n)
+        o.step(n)
+        assert np.array_equal(h.read_particles(), o.field("DROPS"))
+        _assert_equal(h, o, ["PRECIP_FB", "PRECIP_DEP"] + FIELDS_WET)
+    d = h.read_particles()
+    assert int(((drops[:, 2] < 0) & (d[:, 2] >= 0)).sum()) > 5  # spawns happened
+    h.close()
+    o.close()
+    gc.collect()
+
+
 def test_config4_particles_deterministic_order_bit_exact(pkg, oracle, E, config4):
     """The same configuration with the deterministic splat order on both sides (WX_OPT_SPLAT_ORDER 1 / the oracle's splat_order 1:
     per-anchor sums in droplet-index order + index-anchored box trees): the coupled particle <-> grid run is compared BIT FOR BIT --
