@@ -251,6 +251,35 @@ def test_dry_marching_kernel(pkg, oracle, E, X, Y, monkeypatch):
     assert prof["march_dry_vel_advect_pressure"][1] == 21, prof  # the marching kernel is what ran
 
 
+@pytest.mark.parametrize("X,Y", [(700, 160), (130, 96)])
+def test_dry_marching_kernel_with_obstacles(pkg, oracle, E, X, Y, monkeypatch):
+    """Wall blocks inside the dry domain: the marching dry kernel switches between its free-air instantiation of the advection stage
+    (rows whose footprints reach no wall cell: one vote per input row, three rows of history) and the wall-aware one, several times
+    per segment, next to strip borders and the periodic seam. Bit-exact vs the oracle."""
+    monkeypatch.setenv("WX_DRY_MARCH", "1")
+    monkeypatch.setenv("WX_FUSED", "1")
+    base, water, wall = pkg.synth.dry_grid(X, Y)
+    rng = np.random.default_rng(23)
+    for x0, x1, y0, y1 in [(10, 40, 20, 22), (55, 70, 30, 47), (X - 6, X, 50, 58), (0, 5, 50, 58), (X // 2, X // 2 + 1, 70, 71),
+                           (X // 3, X // 3 + 90, Y - 30, Y - 29), (120 % X, 125 % X, 3, 4)]:
+        wall[y0:y1, x0:x1, 1] = 0  # distance 0 = wall
+        wall[y0:y1, x0:x1, 0] = 0  # inert type
+    base[..., 2] += rng.normal(0, 1e-3, (Y, X)).astype(np.float32)
+    base[1:, :, 0] += rng.normal(0, 0.3, (Y - 1, X)).astype(np.float32)
+    base[1:, :, 1] += rng.normal(0, 0.2, (Y - 1, X)).astype(np.float32)
+    base[wall[..., 1] == 0, 0:2] = 0.0
+    water[wall[..., 1] == 0, 0] = 1001.0  # the marker the advection pass gives wall cells (advectionShader.frag:403-409): "water-free" state
+    u = pkg.params.uniforms_from_gui(pkg.params.merge_settings(None), Y, pass_mask=pkg.params.PASS_DRY)
+    h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
+    h.profile(True)
+    for _ in range(3):
+        h.step(5)
+        o.step(5)
+        _assert_grid_equal(h, o, ["BASE_CUR", "BASE_DISP", "WATER_CUR", "WALL_CUR"])
+    assert h.profile_read()["march_dry_vel_advect_pressure"][1] == 15  # the marching kernel is what ran
+    h.close()
+
+
 def test_dry_water_free_flag_is_dropped_when_water_appears(pkg, oracle, E, monkeypatch):
     """The water-free specialisation of the dry iteration (NO_WATER marching / tiled kernel) is only valid while the water
     texture is identically zero in air. A moisture brush during a dry step, or a full step in between, puts water there:
