@@ -276,7 +276,7 @@ struct SlabP {
                                // processed inside the OWNED columns at least once (this rank reports its flips)
 };
 #ifndef WX_ABL_PRECIP
-#define WX_ABL_PRECIP 0 // (timing builds, wrong results) 2: no deposit atomics, 4: the gathers read a fixed texel
+#define WX_ABL_PRECIP 0 // (timing builds, wrong results) 2: no deposit atomics, 4: the gathers read a fixed texel, 8: the pool is not written back
 #endif
 struct DevState {
   float inactiveDroplets; // the `inactiveDroplets` uniform, refreshed on the device every 600 iterations
@@ -560,11 +560,16 @@ __device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const 
       gposy = newPosy;
     }
 
-    drops_out[5 * (size_t)i + 0] = newPosx;
-    drops_out[5 * (size_t)i + 1] = newPosy;
-    drops_out[5 * (size_t)i + 2] = newM0;
-    drops_out[5 * (size_t)i + 3] = newM1;
-    drops_out[5 * (size_t)i + 4] = fmaxf(newDensity, 0.0f);
+#if WX_ABL_PRECIP & 8
+    if (newPosx == 12345.f) // (timing build: the pool is not written back)
+#endif
+    {
+      drops_out[5 * (size_t)i + 0] = newPosx;
+      drops_out[5 * (size_t)i + 1] = newPosy;
+      drops_out[5 * (size_t)i + 2] = newM0;
+      drops_out[5 * (size_t)i + 3] = newM1;
+      drops_out[5 * (size_t)i + 4] = fmaxf(newDensity, 0.0f);
+    }
     if (sp.stamp) { // what the exchange needs to know: did the status flip, and did I have the droplet in my owned columns
       if ((m0 >= 0.0f) != (newM0 >= 0.0f)) sp.flips[i] |= (unsigned short)(1u << (sp.stamp - 1));
       sp.owned_once[i] = (unsigned char)((sp.owned_once[i] & 0x80) | sp.stamp | (claim ? 0x80 : 0));
