@@ -542,10 +542,14 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   float l0x1 = 0.f, l0y1 = 0.f, lz1 = 0.f;                            // light_0 sunlight / net heating, source IR_down of row r-3
   float adv_vy_prev = 0.f, adv_T_prev = 0.f;                          // advection output row r-5
   char4 adv_w_prev = make_char4(0, 0, 0, 0);
-  int big1 = 0, big2 = 0, big3 = 0;                                   // "some |v| >= 0.9" of post-boundary rows r-3, r-4, r-5
-  int nowall1 = 0, nowall2 = 0, nowall3 = 0;                          // "no wall cell" of the same rows
-  int zw0_1 = 0, zw0_2 = 0, zw0_3 = 0;                                // "precipitation-visual and smoke channels of the water are all zero" of the same rows
-  int near1 = 1, near2 = 1, near3 = 1, near4 = 1;                     // "some cell at or next to a wall" of input rows r .. r-3
+  // wave-uniform row flags as bit histories (bit 0 = the newest row, shifted up by one per step; one SGPR each instead of one per row:
+  // the loop is short of them -- every spilled SGPR is a v_writelane / v_readlane, i.e. a vector instruction)
+  unsigned h_big = 0;    // "some |v| >= 0.9" of post-boundary rows r-3, r-4, r-5
+  unsigned h_nowall = 0; // "no wall cell" of the same rows
+  unsigned h_zw0 = 0;    // "precipitation-visual and smoke channels of the water are all zero" of the same rows
+  unsigned h_near = 15;  // "some cell at or next to a wall" of input rows r .. r-3
+#define WX_H_SET(h, v) h = ((h) & ~1u) | ((v) ? 1u : 0u)
+#define WX_H_ROT(h) h = ((h) << 1) | ((h) & 1u)
   // outputs of the previous step, stored at the top of this one
   float4 st_p = make_float4(0.f, 0.f, 0.f, 0.f), st_q = st_p, st_l = st_p, st_ab = st_p;
   char4 st_w = make_char4(0, 0, 0, 0);
@@ -630,8 +634,8 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         pf_l0y = ld_row(in.l0.y + ew, lo4);
         // light_0's sunlight is only read by cells next to a wall and by surface wall cells, of rows r-1 and r-2: skipped while
         // none of the wall rows loaded so far (r-3 .. r) has such a cell (in even iterations the load coincides with pf_lx anyway)
-        if (WX_WET_SKIP_LOADS) near1 = __any(w_cur.y <= 1);
-        if (!WX_WET_SKIP_LOADS || (near1 | near2 | near3 | near4)) pf_l0x = ld_row(in.l0.x + ew, lo4);
+        if (WX_WET_SKIP_LOADS) WX_H_SET(h_near, __any(w_cur.y <= 1));
+        if (!WX_WET_SKIP_LOADS || (h_near & 15u)) pf_l0x = ld_row(in.l0.x + ew, lo4);
       }
       if (HAS_FB) {
         // does any of the (up to three) 64x16 tiles under this strip hold feedback in row r-2? The flag byte was loaded one step
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #if WX_WET_FB_COND
           if (fb_have) {
             pf_fb = ld_row(in.fb + e, lo16);
-            pf_dep = ld_row((!WX_WET_DEP_NEAR || near3) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
+            pf_dep = ld_row((!WX_WET_DEP_NEAR || (h_near & 4u)) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
           } else {
             pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);
             pf_dep = make_float2(0.f, 0.f);
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
           pf_fb = ld_row(fb_have ? in.fb + e : in.zero_row, lo16);
           // (the deposition texture is only read by surface wall cells, boundaryShader.frag:390-475: rows without a cell at or next to
           // a wall take it from the row of zeros too)
-          pf_dep = ld_row((fb_have && (!WX_WET_DEP_NEAR || near3)) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
+          pf_dep = ld_row((fb_have && (!WX_WET_DEP_NEAR || (h_near & 4u))) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
 #endif
         }
 #endif
@@ -766,9 +770,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         (&rg.qz[0][0])[oq] = bq.z;
         (&rg.qw[0][0])[oq] = bq.w;
         // back-traces of this row that may leave the 3x3 cells? (lanes 2 .. 60 feed an advection that is used)
-        big1 = __any(lane >= 2 && lane <= 60 && !(fmaxf(fabsf(bb.x), fabsf(bb.y)) < 0.9f));
-        nowall1 = __all(lane < 2 || lane > 60 || bwl.y != 0); // no wall cell in this post-boundary row (as far as advection reads it)
-        zw0_1 = __all(bq.z == 0.0f && bq.w == 0.0f);          // no rain / snow / smoke anywhere in it
+        WX_H_SET(h_big, __any(lane >= 2 && lane <= 60 && !(fmaxf(fabsf(bb.x), fabsf(bb.y)) < 0.9f)));
+        WX_H_SET(h_nowall, __all(lane < 2 || lane > 60 || bwl.y != 0)); // no wall cell in this post-boundary row (as far as advection reads it)
+        WX_H_SET(h_zw0, __all(bq.z == 0.0f && bq.w == 0.0f));          // no rain / snow / smoke anywhere in it
         if (OPT_OUT) {
           const int yo = r - 3;
           if (lane_out && yo >= y_lo && yo < y_hi) st_row(out.water0 + (size_t)yo * X, so16, bq);
@@ -794,7 +798,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       MWAdvAcc a{rg, li, {ring_back(s0, 5, WD) * WRW, ring_back(s0, 4, WD) * WRW, ring_back(s0, 3, WD) * WRW},
                  {ring_back(sq3, 2, WQ) * WRW, ring_back(sq3, 1, WQ) * WRW, sq3 * WRW}};
       bool fast = true;
-      if (big1 | big2 | big3) { // wave-uniform: some velocity of rows ya-1 .. ya+1 is large -> per-lane test of the eight that matter
+      if (h_big & 7u) { // wave-uniform: some velocity of rows ya-1 .. ya+1 is large -> per-lane test of the eight that matter
         const float *vxp = &rg.vx[0][0], *vyp = &rg.vy[0][0];
         const int o0 = a.ob[1] + li, om = a.ob[0] + li, op = a.ob[2] + li;
         const float m = fmaxf(fmaxf(fmaxf(fabsf(vxp[o0]), fabsf(vxp[o0 - 1])), fmaxf(fabsf(vxp[op]), fabsf(vxp[op - 1]))),
@@ -825,8 +829,8 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       fast = false;
 #endif
       if (fast) {
-        if (WX_ABL_FORCE_AIR || (WX_WET_AIR && (nowall1 & nowall2 & nowall3))) { // (wave-uniform) plain instead of wall-aware interpolation, no wall branch
-          if (WX_WET_ZW0 && (zw0_1 & zw0_2 & zw0_3)) // ... and nothing to interpolate in the precipitation-visual / smoke channels
+        if (WX_ABL_FORCE_AIR || (WX_WET_AIR && (h_nowall & 7u) == 7u)) { // (wave-uniform) plain instead of wall-aware interpolation, no wall branch
+          if (WX_WET_ZW0 && (h_zw0 & 7u) == 7u) // ... and nothing to interpolate in the precipitation-visual / smoke channels
           {
 #ifdef WX_STAGE_MARKS
             asm volatile("; @@advair");
@@ -886,15 +890,10 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     l0x1 = l0x_cur;
     l0y1 = l0y_cur;
     lz1 = lzw_cur.x;
-    big3 = big2;
-    big2 = big1;
-    nowall3 = nowall2;
-    nowall2 = nowall1;
-    zw0_3 = zw0_2;
-    zw0_2 = zw0_1;
-    near4 = near3;
-    near3 = near2;
-    near2 = near1;
+    WX_H_ROT(h_big);
+    WX_H_ROT(h_nowall);
+    WX_H_ROT(h_zw0);
+    WX_H_ROT(h_near);
     s0 = s0 + 1 == WD ? 0 : s0 + 1;
     sq3 = sq3 + 1 == WQ ? 0 : sq3 + 1;
     yw_m4 = yw_m3;
@@ -944,6 +943,8 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 }
 
 #undef WX_WALL_RAW
+#undef WX_H_SET
+#undef WX_H_ROT
 
 // ---- k_wet_fix: the output cells on the fix list, recomputed exactly -- one wavefront per cell ----
 // Output (X0, Y0) = pressure + lighting of the advected cells (X0, Y0), (X0 - 1, Y0) [vx of the left neighbour] and (X0, Y0 - 1)
