@@ -84,16 +84,22 @@ DEG2RAD = 0.0174533  # app.js:340 (the reference's own rounded constant)
 RAD2DEG = 57.2957795
 
 
-def merge_settings(saved: Optional[Dict[str, Any]]) -> Dict[str, Any]:
+def merge_settings(saved: Optional[Dict[str, Any]], sim_height: float = 12000) -> Dict[str, Any]:
     """Settings as the reference sees them after loading a save.
 
     Rule (libraries/dat.gui.min.js:136-150, app.js:3394-3398): a missing numeric control is created as
     -1 and then replaced by its default - so a legitimately saved -1 is reset too; a missing boolean
     becomes False; a missing selector gets its first option (irrelevant to the simulation).
-    With ``saved is None`` the defaults are used (new simulation, app.js:3380-3391).
+    With ``saved is None`` (new simulation, app.js:3378-3391) the defaults are used, with ``simHeight`` AND
+    ``globalEffectsEndAlt`` set to the height chosen in the start dialog (``sim_height``, app.js:437, 3380-3381) -- so a new
+    simulation's drying / heating window ends at the top of the domain, not at the default slider value of 10 000 m
+    (found by executing those lines: tests/golden/host_uniforms.json).
     """
     if saved is None:
-        return dict(GUI_DEFAULTS)
+        out = dict(GUI_DEFAULTS)
+        out["simHeight"] = sim_height
+        out["globalEffectsEndAlt"] = sim_height
+        return out
     out = dict(saved)
     for key, dflt in GUI_DEFAULTS.items():
         if isinstance(dflt, bool):
@@ -116,16 +122,24 @@ def initial_temperature_profile(Y: int, sim_height: float, dry_lapse: float) -> 
     return pot.astype(np.float32)
 
 
-def sounding_arrays(raw_sounding, Y: int, sim_height: float, dry_lapse: float):
+REFERENCE_CELL_HEIGHT_AT_LOAD = 12000.0 / 300.0  # app.js:435
+
+
+def sounding_arrays(raw_sounding, Y: int, sim_height: float, dry_lapse: float, cell_height: float = REFERENCE_CELL_HEIGHT_AT_LOAD):
     """``realWorldSounding_T / _W / _Vel`` (Y + 1 entries each) from a raw sounding, as app.js builds them for the
     sounding-forcing term of the advection pass: ``rawSoundingToSimSounding`` (app.js:149-186) + app.js:5444-5463.
 
     ``raw_sounding``: samples ordered from the TOP of the sounding to the ground (the scraper's order: the reference
     walks the list from its last element upward), each with ``alt`` [m], ``t`` and ``td`` [deg C], ``vel`` [km/h] and
     ``angle`` [deg]; samples with a NaN in t / td / vel are skipped. Returns float32 arrays for ``wx_set_params``:
-    potential temperature [K], total water of the dew point (maxWater), horizontal velocity in cells / iteration."""
+    potential temperature [K], total water of the dew point (maxWater), horizontal velocity in cells / iteration.
+
+    ``cell_height``: what ``msToRawVelocity`` divides by. In the reference that is the GLOBAL ``cellHeight``, which still holds its
+    page-load value 12000 / 300 = 40 m when mainScript builds these arrays (app.js:5444-5463) -- it is assigned
+    ``simHeight / sim_res_y`` only afterwards (app.js:5476). The velocity profile is therefore scaled for 40 m cells whatever the
+    grid (found by executing those lines, tests/golden/host_uniforms.json); the default reproduces the reference, pass
+    ``sim_height / Y`` for the physically consistent value."""
     s = list(raw_sounding)
-    cell_height = sim_height / Y                      # cellHeight, app.js:5476
     time_per_iteration = 0.00008                      # hours, app.js:449
     invalid = lambda d: any(math.isnan(float(d[k])) for k in ("t", "td", "vel"))  # sampleIsInvalid, app.js:147
     T = np.zeros(Y + 1, np.float32)

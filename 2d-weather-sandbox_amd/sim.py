@@ -40,6 +40,14 @@ def initial_sim_datetime(month: float, time_of_day: float, day_night_cycle: bool
     return t
 
 
+def advance_sim_datetime(t: _dt.datetime, delta_hours: float):
+    """The clock part of ``updateSunlight(deltaT_hours)`` (app.js:6513-6516): ``new Date(getTime() + deltaT_hours * 3600 * 1000)`` -- a
+    Date holds whole milliseconds, the sum is truncated -- and the two sliders recomputed from it. Returns (t, timeOfDay, month)."""
+    ms = int((t - _EPOCH) / _dt.timedelta(milliseconds=1) + delta_hours * 3600 * 1000)
+    t = _EPOCH + _dt.timedelta(milliseconds=ms)
+    return t, t.hour + t.minute / 60.0 + t.second / 3600.0, t.month + t.day / 30.5 + t.hour / 720.0
+
+
 class WeatherSim:
     def __init__(self, X: int, Y: int, base, water, wall, droplets=None, settings: Optional[Dict[str, Any]] = None, *,
                  sun_angle_deg: Optional[float] = None, quad_scale: int = 0, pass_mask: int = params.PASS_ALL, columns=None):
@@ -124,12 +132,7 @@ class WeatherSim:
     def update_sunlight(self, delta_hours: Optional[float]):
         """``updateSunlight(deltaT_hours)`` (app.js:6510-6561): advance the clock, recompute the sun."""
         if delta_hours is not None:
-            # `new Date(getTime() + deltaT_hours * 3600 * 1000)`: a Date holds whole milliseconds (the sum is truncated)
-            ms = int((self.sim_datetime - _EPOCH) / _dt.timedelta(milliseconds=1) + delta_hours * 3600 * 1000)
-            self.sim_datetime = _EPOCH + _dt.timedelta(milliseconds=ms)
-            t = self.sim_datetime
-            self.gui["timeOfDay"] = t.hour + t.minute / 60.0 + t.second / 3600.0
-            self.gui["month"] = t.month + t.day / 30.5 + t.hour / 720.0
+            self.sim_datetime, self.gui["timeOfDay"], self.gui["month"] = advance_sim_datetime(self.sim_datetime, delta_hours)
         self.gui["sunAngle"] = params.sun_angle_from_time(self.gui["timeOfDay"], self.gui["month"], self.gui["latitude"])
         self._manual_sun = None
         self._push_uniforms()

@@ -93,9 +93,10 @@ function encodeSave(sf)
 }
 
 // ---- settings merge: missing numeric (or a saved -1) -> default, missing boolean -> false ----
-function mergeSettings(saved)
+function mergeSettings(saved, simHeight)
 {
-  if (saved == null) return Object.assign({}, GUI_DEFAULTS);
+  // new simulation (app.js:3378-3391): the defaults, with simHeight AND globalEffectsEndAlt = the start dialog's height (app.js:437, 3380-3381)
+  if (saved == null) return Object.assign({}, GUI_DEFAULTS, {simHeight: simHeight || 12000, globalEffectsEndAlt: simHeight || 12000});
   const out = Object.assign({}, saved);
   Object.keys(GUI_DEFAULTS).forEach(function(k) {
     const d = GUI_DEFAULTS[k];
@@ -168,9 +169,12 @@ function initRainDrops(n, rng)
 }
 // realWorldSounding_T / _W / _Vel from a raw sounding: rawSoundingToSimSounding (app.js:149-186) + app.js:5444-5463.
 // `raw`: samples ordered from the top of the sounding down to the ground, {alt [m], t, td [deg C], vel [km/h], angle [deg]}.
-function soundingArrays(raw, Y, simHeight, dryLapse)
+// msToRawVelocity divides by the GLOBAL cellHeight, which still holds its page-load value 12000 / 300 = 40 m (app.js:435) when mainScript
+// builds these arrays -- it is assigned simHeight / sim_res_y only afterwards (app.js:5476): the default reproduces that.
+function soundingArrays(raw, Y, simHeight, dryLapse, cellHeight)
 {
-  const cellHeight = simHeight / Y, bad = function(d) { return isNaN(d.t) || isNaN(d.td) || isNaN(d.vel); };
+  if (cellHeight == null) cellHeight = 12000.0 / 300.0;
+  const bad = function(d) { return isNaN(d.t) || isNaN(d.td) || isNaN(d.vel); };
   const T = new Float32Array(Y + 1), W = new Float32Array(Y + 1), V = new Float32Array(Y + 1);
   let idx = raw.length - 1;
   for (let y = 0; y < Y + 1; y++) {
@@ -220,6 +224,12 @@ function initialSimDateTime(month, timeOfDay, dayNightCycle)
     t.setMonth(m, (m % 1) * 30);
   }
   return t;
+}
+// the clock part of updateSunlight(deltaT_hours), app.js:6513-6516
+function advanceSimDateTime(t0, deltaHours)
+{
+  const t = new Date(t0.getTime() + deltaHours * 3600 * 1000);
+  return {t: t, timeOfDay: t.getHours() + t.getMinutes() / 60. + t.getSeconds() / 3600., month: t.getMonth() + 1 + t.getDate() / 30.5 + t.getHours() / 720.};
 }
 function uniformsFromGui(gui, Y, opts)
 {
@@ -289,10 +299,10 @@ WeatherSim.prototype.setBrush = function(type, x, y, intensity, brushSize, move)
 };
 WeatherSim.prototype.updateSunlight = function(deltaHours) { // app.js:6510-6561
   if (deltaHours != null) {
-    this.simDateTime = new Date(this.simDateTime.getTime() + deltaHours * 3600 * 1000);
-    const t = this.simDateTime;
-    this.gui.timeOfDay = t.getHours() + t.getMinutes() / 60. + t.getSeconds() / 3600.;
-    this.gui.month = t.getMonth() + 1 + t.getDate() / 30.5 + t.getHours() / 720.;
+    const c = advanceSimDateTime(this.simDateTime, deltaHours);
+    this.simDateTime = c.t;
+    this.gui.timeOfDay = c.timeOfDay;
+    this.gui.month = c.month;
   }
   this.gui.sunAngle = sunAngleFromTime(this.gui.timeOfDay, this.gui.month, this.gui.latitude);
   this.manualSun = null;
@@ -359,7 +369,7 @@ WeatherSim.newSimulation = function(X, Y, opts) {
   return new WeatherSim({X: X, Y: Y, settings: gui, columns: terrainColumns(X, Y, gui, opts), droplets: nDrops ? initRainDrops(nDrops, opts.rng) : null}, opts);
 };
 
-module.exports = {WeatherSim: WeatherSim, initialSimDateTime: initialSimDateTime, loadSave: loadSave, decodeSave: decodeSave, encodeSave: encodeSave, mergeSettings: mergeSettings,
+module.exports = {WeatherSim: WeatherSim, initialSimDateTime: initialSimDateTime, advanceSimDateTime: advanceSimDateTime, loadSave: loadSave, decodeSave: decodeSave, encodeSave: encodeSave, mergeSettings: mergeSettings,
                   uniformsFromGui: uniformsFromGui, initialTemperatureProfile: initialTemperatureProfile, sunFromAngle: sunFromAngle,
                   sunAngleFromTime: sunAngleFromTime, terrainColumns: terrainColumns, initRainDrops: initRainDrops, soundingArrays: soundingArrays, GUI_DEFAULTS: GUI_DEFAULTS,
                   FIELD: FIELD};

@@ -271,7 +271,8 @@ function run(o)
   }
   T.curl = tex(gl.R32F, X, Y, gl.RED, gl.FLOAT, null, gl.NEAREST);
   T.vort = tex(gl.RG32F, X, Y, gl.RG, gl.FLOAT, null, gl.NEAREST);
-  T.emitted = tex(gl.RGBA16F, X, Y, gl.RGBA, gl.HALF_FLOAT, null, gl.LINEAR);
+  T.emitted = tex(gl.RGBA16F, X, Y, gl.RGBA, gl.HALF_FLOAT, null, gl.LINEAR, true); // new FBO(..., gl.LINEAR), app.js:786-801, 838: clamped in S and T
+  gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_WRAP_S, gl.CLAMP_TO_EDGE);
   T.fb = tex(gl.RGBA32F, X, Y, gl.RGBA, gl.FLOAT, null, gl.NEAREST);
   T.dep = tex(gl.RG32F, X, Y, gl.RG, gl.FLOAT, null, gl.NEAREST);
   T.lightning = tex(gl.RGBA32F, 1, 1, gl.RGBA, gl.FLOAT, null, gl.NEAREST);
@@ -572,7 +573,9 @@ function run(o)
     if (it == 1) { gl.finish(); t0 = performance.now(); }
     var pp = null;
     if (o.perpass_iter === it) pp = out.perpass;
+    if (typeof o.mark == 'function') o.mark('iteration', it, gl); // (run_harness_mock.js: cuts the recorded GL calls into iterations)
     iteration(pp);
+    if (typeof o.mark == 'function') o.mark('iteration_end', it, gl);
     if (dumpAt[it + 1]) dumpState(String(it + 1));
   }
   // a 1x1 readback forces completion (gl.finish is not a reliable sync under ANGLE)

@@ -181,7 +181,7 @@ def test_sounding_arrays_interpolation(pkg):
     assert np.isclose(T[2], t + 273.15 + (2 / Y) * lapse, rtol=1e-6)
     vel = (10.0 + 300 / 500.0) * (1 - a) + (10.0 + 800 / 500.0) * a
     ang = (30.0 + 300 / 200.0) * (1 - a) + (30.0 + 800 / 200.0) * a
-    assert np.isclose(V[2], vel * np.cos(ang * 0.0174533) / 3.6 * 3600.0 / (sim_h / Y) * 0.00008, rtol=1e-6)
+    assert np.isclose(V[2], vel * np.cos(ang * 0.0174533) / 3.6 * 3600.0 / 40.0 * 0.00008, rtol=1e-6)  # (40 m: the reference's cellHeight at that point)
     # 2100 m (y = 7): the invalid 3000 m sample is skipped, interpolation runs from 1500 m to 6000 m ... with the sample
     # BELOW taken as the next list element (the invalid one) exactly like the reference does -> NaN dew point propagates
     assert np.isnan(W[7]) and np.isfinite(T[7])
