@@ -67,7 +67,10 @@ def test_settings_merge_rule(pkg):
     assert m["waterWeight"] == 0.25  # a saved -1 is reset too (dat.GUI patch side effect)
     assert m["dynamicWaterTemperature"] is False  # missing boolean -> false
     assert m["globalEffectsEndAlt"] == 10000 and m["globalEffectsStartAlt"] == 0
-    assert P.merge_settings(None) == P.GUI_DEFAULTS
+    # new simulation: the defaults with simHeight / globalEffectsEndAlt = the start dialog's height (app.js:3380-3381; executed in
+    # tests/test_host_golden.py)
+    assert P.merge_settings(None) == dict(P.GUI_DEFAULTS, simHeight=12000, globalEffectsEndAlt=12000)
+    assert P.merge_settings(None, sim_height=8000)["globalEffectsEndAlt"] == 8000
 
 
 def test_derived_uniforms(pkg):
