@@ -89,9 +89,9 @@ def js_number(x) -> str:
     exponents as e-7 / e+21. Non-finite values become null, like JSON.stringify does."""
     if isinstance(x, bool):
         return "true" if x else "false"
-    if isinstance(x, int):
+    if isinstance(x, int) and abs(x) < 10 ** 21:
         return str(x)
-    x = float(x)
+    x = float(x)  # (integers from 1e21 on print in exponent form like any other Number: 1e+21)
     if x != x or x in (float("inf"), float("-inf")):
         return "null"
     if x == 0:

@@ -129,6 +129,16 @@ struct wx_sim {
   hipEvent_t ev_edges = nullptr, ev_unpacked = nullptr; // edge strips of the last iteration done (compute stream) / ghosts written (comm stream)
   bool edges_recorded = false;   // ev_edges was recorded behind the edge strips of the latest iteration
   bool unpack_pending = false;   // ghost columns were unpacked on the comm stream since the compute stream last waited
+  // transport inside the library (wx_comm_init / wx_exchange / wx_slab_step; in-process groups: wx_group_*)
+  int device = 0;                 // HIP device the handle lives on
+  void *comm = nullptr;           // ncclComm_t of a one-rank-per-process job (wx_comm_init)
+  int comm_rank = 0, comm_world = 1;
+  char *xsend[2] = {nullptr, nullptr}, *xrecv[2] = {nullptr, nullptr}; // halo buffers [left, right] of wx_exchange / wx_group_step
+  size_t xbytes = 0;
+  hipStream_t own_stream = nullptr, own_comm_stream = nullptr; // streams the library created itself (groups, wx_comm_init)
+  hipEvent_t ev_packed = nullptr, ev_copied = nullptr;         // in-process transport: my send buffers are full / my recv copies are done
+  int since_exchange = 0;         // iterations since the ghost columns were last fresh (upload or exchange)
+  bool exchanged = false;         // ... and they came from an exchange (the next step may run its interior strips first)
   int air_from_row = -1;       // lowest row above which every cell is free air (cost model of the row segmentation); -1: to be measured
   WetLaunch wet_shape{};       // cached launch shape for that value
   bool wet_shape_valid = false;
@@ -164,6 +174,25 @@ struct wx_sim {
   int prof_n[K_COUNT] = {0};
   std::string err;
 };
+
+// makes the handle's device current for the scope (the slabs of a wx_group live on different devices)
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(const wx_sim *s)
+  {
+    int cur = -1;
+    if (s && hipGetDevice(&cur) == hipSuccess && cur != s->device) {
+      prev = cur;
+      (void)hipSetDevice(s->device);
+    }
+  }
+  ~DeviceScope()
+  {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+extern "C" void transport_release(wx_sim *s); // wx_comm.h
 
 namespace {
 
@@ -738,6 +767,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (e != hipSuccess || ndev == 0)
     return fail(nullptr, WX_E_DEVICE, "no HIP device available (%s): libwxsim has no CPU fallback", hipGetErrorString(e));
   wx_sim *s = new wx_sim();
+  (void)hipGetDevice(&s->device);
   s->X = X_owned + 2 * halo;
   s->Y = Y;
   s->Xg = X_global;
@@ -814,6 +844,15 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   }
   s->p.pass_mask = WX_PASS_ALL;
   build_geo(s);
+  // The allocations above were zeroed with hipMemset on the default stream, which may return before the device is done. A host that
+  // then works on a NON-BLOCKING stream of its own (wx_set_stream; the slabs of a wx_group) is not ordered behind the default stream:
+  // its first upload could be overwritten by a zeroing that is still in flight (seen: a slab of a freshly created group reading back
+  // as zeros). The handle is complete when this returns.
+  if (hipStreamSynchronize(nullptr) != hipSuccess) {
+    g_create_error = "wx_create: device error while zeroing the handle's storage";
+    wx_destroy(s);
+    return WX_E_DEVICE;
+  }
   *out = s;
   return WX_OK;
 }
@@ -823,8 +862,11 @@ int wx_create(int X, int Y, int n_droplets, wx_sim **out) { return wx_create_sla
 void wx_destroy(wx_sim *s)
 {
   if (!s) return;
+  DeviceScope ds(s);
   if (s->stream) hipStreamSynchronize(s->stream);
   else hipDeviceSynchronize();
+  if (s->comm_stream) hipStreamSynchronize(s->comm_stream);
+  transport_release(s);
   for (auto &r : s->prof) {
     hipEventDestroy(r.a);
     hipEventDestroy(r.b);
@@ -903,6 +945,7 @@ static int drain_comm(wx_sim *s)
 int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wall, const float *drops)
 {
   if (!s) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   if (!base || !water || !wall) return fail(s, WX_E_INVALID, "wx_upload: NULL grid array");
   if (int rc = drain_comm(s)) return rc;
   const size_t n = ncell(s);
@@ -965,6 +1008,8 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   s->ghost_check = false;
   s->light_planar = false; // the interleaved light textures were just zeroed
   s->period_j = 0;
+  s->since_exchange = 0; // (wx_slab_step / wx_group_step: the ghost columns are fresh, and not from an exchange)
+  s->exchanged = false;
   s->ran_fused = false;
   s->even = 1;
   s->emit_lit = false; // (the reference re-creates the emittedLight texture with the others)
@@ -979,6 +1024,7 @@ int wx_setup_columns(wx_sim *s, const int32_t *wall_rows, const uint8_t *sea_col
                      const float *T_air, const float *total_water, const float *cloud_water, const float *drops)
 {
   if (!s) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   if (!wall_rows || !sea_column || !veg_noise || !snow || !T_air || !total_water || !cloud_water)
     return fail(s, WX_E_INVALID, "wx_setup_columns: NULL descriptor array");
   if (int rc = drain_comm(s)) return rc;
@@ -1022,6 +1068,7 @@ int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const f
                   const float *sounding_Vel)
 {
   if (!s || !p) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   if (!initial_T && !s->have_params) return fail(s, WX_E_INVALID, "wx_set_params: initial_T is required on the first call");
   s->p = *p;
   build_geo(s);
@@ -1047,6 +1094,7 @@ int wx_step(wx_sim *s, int n_iter) { return wx_step_overlap(s, n_iter, 0u); }
 int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
 {
   if (!s) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   if (n_iter < 0) return fail(s, WX_E_INVALID, "wx_step: n_iter < 0");
   if (!s->uploaded || !s->have_params) return fail(s, WX_E_STATE, "wx_step before wx_upload / wx_set_params");
   const unsigned mask = s->p.pass_mask;
@@ -1062,7 +1110,9 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   // the vegetation byte stays known non-negative only while nothing but the brush-free dry iteration touches the wall texture
   if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] > 0.9f) s->wall_veg_ok = false;
   // ... and the water texture stays known trivial only through water-free dry iterations (iterate_dry's `water == false` case)
-  if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] != 0.0f || s->p.soundingForcing != 0.0f) s->water_trivial = false;
+  // (local_water_free goes with it: it is what wx_slab_assert_water_free re-arms water_trivial from, and after a step that can create
+  // water only a new upload may establish it again -- ADVICE round 3)
+  if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] != 0.0f || s->p.soundingForcing != 0.0f) s->water_trivial = s->local_water_free = false;
   if (s->p.userInputType >= 10) s->air_from_row = -1; // wall tools: the terrain may grow (re-measured after the call)
   if (precip && s->pool_remote && n_iter > 0) { // slab with particles: refuse an over-long call BEFORE any iteration runs
     const int allowed = std::min((s->halo - 6) / WX_SLAB_CONE, 15) - s->period_j; // (the flip history of a period is a 16-bit mask)
@@ -1230,7 +1280,7 @@ static int validate_ghost_flag(wx_sim *s)
   HIPCHK(s, hipStreamSynchronize(s->stream));
   s->ghost_check = false;
   if (flag) {
-    s->water_trivial = s->wall_veg_ok = false;
+    s->water_trivial = s->local_water_free = s->wall_veg_ok = false;
     return fail(s, WX_E_STATE, "a neighbour's ghost columns carry water (or a negative vegetation byte) although wx_slab_assert_water_free(1) was "
                                "called: the water-free dry iteration that ran since is invalid");
   }
@@ -1247,7 +1297,7 @@ struct TuneSnap { // host-side state that iterations change; the rotating plane 
   Ref base[3], water[3], light[2], wall[2], drops[2], lpx[3], lpy[3], lpzw[3];
   int even, drop_cur, splat_par, period_j, air_from_row;
   int64_t iter;
-  bool ran_fused, light_planar, fb_dirty, water_trivial, wall_veg_ok, ghost_check, emit_lit, fix_check, wet_shape_valid;
+  bool ran_fused, light_planar, fb_dirty, water_trivial, local_water_free, wall_veg_ok, ghost_check, emit_lit, fix_check, wet_shape_valid;
   Uni emit_uni;
 };
 bool snap_take(const wx_sim *s, TuneSnap &t)
@@ -1261,7 +1311,7 @@ bool snap_take(const wx_sim *s, TuneSnap &t)
   for (int i = 0; i < 3; i++) { t.base[i] = ref(s->base[i]); t.water[i] = ref(s->water[i]); t.lpx[i] = ref(s->lp[i].x); t.lpy[i] = ref(s->lp[i].y); t.lpzw[i] = ref(s->lp[i].zw); }
   for (int i = 0; i < 2; i++) { t.light[i] = ref(s->light[i]); t.wall[i] = ref(s->wall[i]); t.drops[i] = ref(s->drops[i]); }
   t.even = s->even; t.drop_cur = s->drop_cur; t.splat_par = s->splat_par; t.period_j = s->period_j; t.air_from_row = s->air_from_row; t.iter = s->iter;
-  t.ran_fused = s->ran_fused; t.light_planar = s->light_planar; t.fb_dirty = s->fb_dirty; t.water_trivial = s->water_trivial; t.wall_veg_ok = s->wall_veg_ok;
+  t.ran_fused = s->ran_fused; t.light_planar = s->light_planar; t.fb_dirty = s->fb_dirty; t.water_trivial = s->water_trivial; t.local_water_free = s->local_water_free; t.wall_veg_ok = s->wall_veg_ok;
   t.ghost_check = s->ghost_check; t.emit_lit = s->emit_lit; t.fix_check = s->fix_check; t.wet_shape_valid = s->wet_shape_valid; t.emit_uni = s->emit_uni;
   return ok;
 }
@@ -1274,7 +1324,7 @@ void snap_put(wx_sim *s, const TuneSnap &t) // (into the block set the handle po
   }
   for (int i = 0; i < 2; i++) { s->light[i] = (float4 *)at(t.light[i]); s->wall[i] = (char4 *)at(t.wall[i]); s->drops[i] = (float *)at(t.drops[i]); }
   s->even = t.even; s->drop_cur = t.drop_cur; s->splat_par = t.splat_par; s->period_j = t.period_j; s->air_from_row = t.air_from_row; s->iter = t.iter;
-  s->ran_fused = t.ran_fused; s->light_planar = t.light_planar; s->fb_dirty = t.fb_dirty; s->water_trivial = t.water_trivial; s->wall_veg_ok = t.wall_veg_ok;
+  s->ran_fused = t.ran_fused; s->light_planar = t.light_planar; s->fb_dirty = t.fb_dirty; s->water_trivial = t.water_trivial; s->local_water_free = t.local_water_free; s->wall_veg_ok = t.wall_veg_ok;
   s->ghost_check = t.ghost_check; s->emit_lit = t.emit_lit; s->fix_check = t.fix_check; s->wet_shape_valid = t.wet_shape_valid; s->emit_uni = t.emit_uni;
 }
 // every registered pointer of the handle moves from the current block set to `to` (same block, same offset)
@@ -1338,6 +1388,7 @@ int copy_set(wx_sim *s, const std::vector<Block> &dst, const std::vector<Block> 
 int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before, float *ms_after)
 {
   if (!s) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   if (tries < 1 || iters_per_try < 1) return fail(s, WX_E_INVALID, "wx_tune_placement: tries >= 1, iters_per_try >= 1");
   if (!s->uploaded || !s->have_params) return fail(s, WX_E_STATE, "wx_tune_placement before wx_upload / wx_set_params");
   if (s->pool_remote) return fail(s, WX_E_STATE, "wx_tune_placement: not on slab handles with particles (the exchange period would advance)");
@@ -1472,6 +1523,7 @@ int wx_slab_assert_water_free(wx_sim *s, int agreed)
 int wx_sync(wx_sim *s)
 {
   if (!s) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   if (s->comm_stream) HIPCHK(s, hipStreamSynchronize(s->comm_stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
   return validate_ghost_flag(s);
@@ -1533,6 +1585,7 @@ static int emitted_rect(wx_sim *s, int x, int y, int w, int h)
 int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, int dtype)
 {
   if (!s || !dst) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   if (field == WX_FIELD_LIGHTNING) {
     if (dtype != WX_DTYPE_F32 || x != 0 || y != 0 || w != 1 || h != 1) return fail(s, WX_E_RANGE, "lightning data is a 1x1 f32 texture");
     HIPCHK(s, hipMemcpyAsync(dst, s->state->lightning, 16, hipMemcpyDeviceToHost, s->stream));
@@ -1586,6 +1639,7 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
 int wx_read_particles(wx_sim *s, int first, int count, float *dst)
 {
   if (!s || !dst) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   if (first < 0 || count < 0 || first + count > s->n_drops) return fail(s, WX_E_RANGE, "wx_read_particles: [%d, %d) outside 0..%d", first, first + count, s->n_drops);
   if (count == 0) return WX_OK;
   HIPCHK(s, hipMemcpyAsync(dst, s->drops[s->drop_cur] + 5 * (size_t)first, (size_t)count * 20, hipMemcpyDeviceToHost, s->stream));
@@ -1668,6 +1722,7 @@ int wx_set_stream(wx_sim *s, void *hip_stream)
 int wx_set_comm_stream(wx_sim *s, void *hip_stream)
 {
   if (!s) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   HIPCHK(s, hipStreamSynchronize(s->stream));
   if (s->comm_stream) HIPCHK(s, hipStreamSynchronize(s->comm_stream));
   s->comm_stream = (hipStream_t)hip_stream;
@@ -1706,6 +1761,7 @@ static int halo_xstart(const wx_sim *s, int side, bool pack)
 int wx_halo_pack(wx_sim *s, int side, void *dev_buf)
 {
   if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   if (s->halo == 0) return fail(s, WX_E_STATE, "handle has no halo");
   const int n = s->halo * s->Y;
   const LightPlanes none{nullptr, nullptr, nullptr};
@@ -1731,6 +1787,7 @@ int wx_halo_pack(wx_sim *s, int side, void *dev_buf)
 int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
 {
   if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   if (s->halo == 0) return fail(s, WX_E_STATE, "handle has no halo");
   const int n = s->halo * s->Y;
   const LightPlanes none{nullptr, nullptr, nullptr};
@@ -1887,5 +1944,7 @@ int wx_profile_read(wx_sim *s, int cap, float *ms, int *launches)
   }
   return WX_OK;
 }
+
+#include "wx_comm.h"
 
 } // extern "C"

@@ -34,6 +34,8 @@ EXPORTS = [
     "wx_pool_edge_bytes", "wx_pool_events_pack", "wx_pool_events_apply", "wx_pool_edges_pack", "wx_pool_edges_apply", "wx_pool_flags", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns",
     "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait", "wx_set_comm_stream", "wx_step_overlap",
     "wx_set_option", "wx_water_free", "wx_slab_assert_water_free", "wx_tune_placement",
+    "wx_comm_unique_id", "wx_comm_init", "wx_exchange", "wx_slab_step", "wx_group_create", "wx_group_destroy", "wx_group_last_error",
+    "wx_group_count", "wx_group_transport", "wx_group_slab", "wx_group_agree", "wx_group_step", "wx_group_sync",
 ]
 
 
@@ -124,6 +126,22 @@ def lib() -> C.CDLL:
     L.wx_host_free.restype = None
     L.wx_stream_frame.argtypes = [vp, i32, i32, i32, i32, vp]
     L.wx_stream_wait.argtypes = [vp]
+    L.wx_comm_unique_id.argtypes = [vp]
+    L.wx_comm_init.argtypes = [vp, vp, i32, i32]
+    L.wx_exchange.argtypes = [vp]
+    L.wx_slab_step.argtypes = [vp, i32]
+    L.wx_group_create.argtypes = [i32, vp, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.wx_group_destroy.argtypes = [vp]
+    L.wx_group_destroy.restype = None
+    L.wx_group_last_error.argtypes = [vp]
+    L.wx_group_last_error.restype = C.c_char_p
+    L.wx_group_count.argtypes = [vp]
+    L.wx_group_transport.argtypes = [vp]
+    L.wx_group_slab.argtypes = [vp, i32]
+    L.wx_group_slab.restype = vp
+    L.wx_group_agree.argtypes = [vp]
+    L.wx_group_step.argtypes = [vp, i32]
+    L.wx_group_sync.argtypes = [vp]
     _lib = L
     return L
 
@@ -149,12 +167,27 @@ class Handle:
         self._h = h
         self.X_owned, self.Y, self.n_droplets, self.halo = X, Y, n_droplets, halo
         self.X = L.wx_local_width(h)
+        self.generation = 0  # bumped whenever device pointers obtained earlier become invalid (tune_placement)
+
+    @classmethod
+    def _borrowed(cls, ptr, X_owned: int, Y: int, halo: int, owner) -> "Handle":
+        """A slab of a Group: the group destroys it (``owner`` is kept alive as long as this wrapper is)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(ptr)
+        self._owner = owner
+        self.X_owned, self.Y, self.n_droplets, self.halo = X_owned, Y, 0, halo
+        self.X = lib().wx_local_width(self._h)
+        self.generation = 0
+        return self
 
     def _chk(self, rc: int):
         if rc != 0:
             raise WxError(rc, (lib().wx_last_error(self._h) or b"").decode())
 
     def close(self):
+        if getattr(self, "_owner", None) is not None:  # a group's slab
+            self._h = None
+            return
         if getattr(self, "_h", None):
             lib().wx_destroy(self._h)  # (waits for a streamed frame in flight)
             self._h = None
@@ -215,6 +248,7 @@ class Handle:
         """wx_tune_placement: try ``tries`` further device allocations for the handle's planes, keep the fastest; returns
         (ms per iteration of the first candidate, of the winner). The state is unchanged."""
         a, b = C.c_float(0), C.c_float(0)
+        self.generation += 1  # (the planes move: every cached view of device memory -- device_ptr, devtools.field_tensor -- dangles)
         self._chk(lib().wx_tune_placement(self._h, int(tries), int(iters_per_try), C.byref(a), C.byref(b)))
         return float(a.value), float(b.value)
 
@@ -378,6 +412,29 @@ class Handle:
         v = np.ascontiguousarray(v, np.float32)
         self._chk(lib().wx_lightning_set(self._h, v.ctypes.data_as(C.c_void_p)))
 
+    # ---- the halo exchange inside the library (one rank per process; see include/wxsim.h) ----
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId: 128 bytes that rank 0 hands to every other rank (any side channel: torch.distributed, a file, MPI)."""
+        buf = C.create_string_buffer(128)
+        rc = lib().wx_comm_unique_id(buf)
+        if rc != 0:
+            raise WxError(rc, (lib().wx_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != 128:
+            raise ValueError("the unique id has 128 bytes")
+        self._chk(lib().wx_comm_init(self._h, C.c_char_p(unique_id), int(rank), int(world)))
+
+    def exchange(self):
+        """Ring halo exchange over RCCL (pack, send / recv, unpack), enqueued on the handle's comm stream."""
+        self._chk(lib().wx_exchange(self._h))
+
+    def slab_step(self, n: int):
+        """n iterations with an exchange every halo / 6 iterations, overlapped with compute (wx_slab_step)."""
+        self._chk(lib().wx_slab_step(self._h, int(n)))
+
     def profile(self, enable: bool):
         self._chk(lib().wx_profile(self._h, 1 if enable else 0))
 
@@ -388,3 +445,69 @@ class Handle:
         cnt = (C.c_int * n)()
         self._chk(L.wx_profile_read(self._h, n, ms, cnt))
         return {L.wx_kernel_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(n) if cnt[k] > 0}
+
+
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_LOCAL = 0, 1, 2
+
+
+class Group:
+    """N column slabs of one periodic domain in THIS process (wx_group_*): one handle per slab -- on N devices with RCCL between them,
+    or several per device with device-to-device copies -- stepped together with the halo exchange inside the library."""
+
+    def __init__(self, n_slabs: int, X_global: int, Y: int, halo: int = 42, devices=None, transport: int = TRANSPORT_AUTO):
+        L = lib()
+        g = C.c_void_p()
+        dev = None
+        if devices is not None:
+            dev = (C.c_int * n_slabs)(*[int(d) for d in devices])
+        rc = L.wx_group_create(int(n_slabs), dev, int(X_global), int(Y), int(halo), 0, int(transport), C.byref(g))
+        if rc != 0:
+            raise WxError(rc, (L.wx_group_last_error(None) or b"").decode())
+        self._g = g
+        self.n, self.X, self.Y = n_slabs, X_global, Y
+        self.halo = halo if n_slabs > 1 else 0
+        self.xo = X_global // n_slabs
+        self.transport = L.wx_group_transport(g)
+        self.slabs = [Handle._borrowed(L.wx_group_slab(g, i), self.xo, Y, self.halo, self) for i in range(n_slabs)]
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise WxError(rc, (lib().wx_group_last_error(self._g) or b"").decode())
+
+    def columns(self, i: int) -> np.ndarray:
+        """Global column of every local column of slab i (owned + ghost columns, periodic)."""
+        return (i * self.xo - self.halo + np.arange(self.xo + 2 * self.halo)) % self.X
+
+    def upload(self, base, water, wall):
+        """Whole-domain arrays (Y, X, 4) cut into the slabs' local arrays."""
+        for i, h in enumerate(self.slabs):
+            idx = self.columns(i)
+            h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]))
+        self._chk(lib().wx_group_agree(self._g))
+
+    def set_params(self, p: WxParams, initial_T=None, snd_T=None, snd_W=None, snd_Vel=None):
+        for h in self.slabs:
+            h.set_params(p, initial_T, snd_T, snd_W, snd_Vel)
+
+    def step(self, n: int = 1):
+        self._chk(lib().wx_group_step(self._g, int(n)))
+
+    def sync(self):
+        self._chk(lib().wx_group_sync(self._g))
+
+    def read(self, field: str) -> np.ndarray:
+        """The whole domain's field assembled from the slabs' owned columns."""
+        return np.concatenate([h.read_rect(field, self.halo, 0, self.xo, self.Y) for h in self.slabs], axis=1)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for h in self.slabs:
+                h._h = None
+            lib().wx_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

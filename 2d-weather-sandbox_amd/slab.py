@@ -72,6 +72,13 @@ class HipSlabEngine:
             self.h.set_comm_stream(self.comm.cuda_stream)
         self.nbytes = self.h.halo_bytes()
         self._light = None
+        self._light_gen = -1
+
+    def comm_init_native(self, rank: int, world: int):
+        """RCCL inside the library (wx_comm_init): rank 0 draws the 128-byte id, torch.distributed only carries it to the others."""
+        box = [Handle.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        self.h.comm_init(box[0], rank, world)
 
     @property
     def supports_overlap(self) -> bool:
@@ -83,7 +90,9 @@ class HipSlabEngine:
 
     def lightning_tensor(self) -> torch.Tensor:
         """Live device view of the handle's 4-float lightning state (x, y, start iteration, intensity): no host round trip."""
-        if self._light is None:
+        if self._light is None or self._light_gen != self.h.generation:  # (wx_tune_placement moves the planes: cached views dangle)
+            self._light_gen = self.h.generation
+
             class _Dev:  # the CUDA array interface is all torch needs to wrap a foreign device pointer
                 def __init__(self, ptr):
                     self.__cuda_array_interface__ = {"shape": (4,), "typestr": "<f4", "data": (ptr, False), "version": 2}
@@ -175,6 +184,14 @@ class SlabSim:
                 self._hsend = [torch.empty_like(b, device="cpu") for b in self.send]
                 self._hrecv = [torch.empty_like(b, device="cpu") for b in self.recv]
             self.agree_water_free()
+        # Grid-only slabs on GPUs: the exchange runs INSIDE the library (wx_comm_init / wx_slab_step: pack -> ncclSend / ncclRecv ->
+        # unpack on the handle's comm stream); torch.distributed is then only the launcher and the carrier of the communicator's id.
+        # The host-driven path below stays for slabs with particles and for the gloo transport of the CPU tests.
+        self._native = False
+        if (world > 1 and not self.particles and hasattr(engine, "comm_init_native") and dist.get_backend() == "nccl"
+                and os.environ.get("WX_SLAB_NATIVE", "1") != "0"):
+            engine.comm_init_native(rank, world)
+            self._native = True
 
     def agree_water_free(self):
         """The water-free dry iteration (36 B/cell) is only valid on a slab if NO slab of the domain carries water (ghost columns
@@ -292,6 +309,10 @@ class SlabSim:
             e.set_lightning(new_light.cpu().numpy())
 
     def step(self, n: int):
+        if self._native:  # periods, launch order around the exchange and the exchange itself: wx_slab_step
+            self.engine.h.slab_step(n)
+            self._iters += n
+            return
         done = 0
         while done < n:
             k = min(self.iters_per_exchange - self._since_exchange, n - done)
@@ -358,14 +379,23 @@ class SlabSim:
         """The whole droplet pool (n_droplets x 5) assembled on rank 0 (None elsewhere): an active droplet's record comes from the rank
         that has it in its owned columns, an inactive one's is the same on every rank (wx_pool_flags). Host-side, for readback / saves."""
         h = self.handle
+        if self.world > 1 and self._since_exchange != 0:
+            # inside a period a droplet can be "owned" by two ranks at once (a phantom spawn from a stale record, resolved by the next
+            # exchange): the sum below would then add two records
+            raise RuntimeError("gather_particles: call it right after an exchange (step a whole number of exchange periods)")
         d, f = h.read_particles(), h.pool_flags()
         if self.world == 1:
             return d
-        mine = torch.from_numpy(np.where((f == 2)[:, None], d, 0).astype(np.float32))
-        cnt = torch.from_numpy((f == 2).astype(np.int32))
-        dist.all_reduce(mine, op=dist.ReduceOp.SUM)  # (exactly one owner per active droplet: the sum IS its record)
+        # (RCCL reduces device tensors only; gloo -- the CPU tests -- host tensors)
+        dev = self.send[0].device if (self.send[0].is_cuda and not self._stage) else torch.device("cpu")
+        mine = torch.from_numpy(np.where((f == 2)[:, None], d, 0).astype(np.float32)).to(dev)
+        cnt = torch.from_numpy((f == 2).astype(np.int32)).to(dev)
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)  # (exactly one owner per active droplet right after an exchange: the sum IS its record)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        out = np.where((cnt.numpy() > 0)[:, None], mine.numpy(), d)  # nobody owns it: inactive, my own record is everybody's
+        cnt, mine = cnt.cpu().numpy(), mine.cpu().numpy()
+        if cnt.max(initial=0) > 1:
+            raise RuntimeError("gather_particles: a droplet is owned by more than one rank")
+        out = np.where((cnt > 0)[:, None], mine, d)  # nobody owns it: inactive, my own record is everybody's
         return out if self.rank == 0 else None
 
     def owned(self, field: str) -> np.ndarray:

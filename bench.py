@@ -272,6 +272,69 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
     return res
 
 
+def measure_handle(h, cells, steps, warmup, frame, algo_bytes=None):
+    """warm-up, clock conditioning, `steps` timed iterations on one handle with the per-kernel profile: the entry of one configuration."""
+    run_frames(h.step, warmup, frame)
+    condition_clocks(h.step, h.sync, frame)
+    dt, prof = timed_run(h, steps, frame)
+    out = {"value": cells * steps / dt / 1e6, "unit": "Mcell-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+           "kernels_ms_per_step": {k: v[0] / steps for k, v in prof.items()}}
+    if prof:
+        name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
+        ab = (algo_bytes or {}).get(name, ALGO_BYTES.get(name))
+        out["dominant_kernel"] = name
+        out["avg_launch_ms"] = ms / cnt
+        if ab:
+            out["algo_bytes_per_cell"] = ab
+            out["roofline_frac"] = ab * cells / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return out
+
+
+def other_configs(a, pkg):
+    """The other single-GPU configurations of BASELINE.json, measured in the same process so that the driver's record carries them:
+    configs[0] (the reference's own 100 x 100 save, 1000 iterations; inputs from tests/golden/save100raw.npz), configs[1] (4096 x 1024
+    dry, SURVEY 8d C2: 200 warm-up + 1000 timed) and configs[4] on one GPU (16384 x 2048 + 1 048 576 droplets over a cloud deck,
+    200 iterations of spin-up, 200 timed; SURVEY's C5 protocol -- 2000 + 1000 -- is `bench.py --particles 1048576 --warmup 2000 --steps 1000`)."""
+    import numpy as np
+    out = {}
+    # configs[0]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "save100raw.npz"))
+    u = json.loads(str(g["uniforms_json"]))
+    u["initial_T"] = g["initial_T"]
+    for k in ("userInputValues", "userInputMove", "airplaneValues"):
+        u[k] = tuple(u[k])
+    u = dict(u, quad_scale=0, enablePrecipitation=0)
+    X, Y = int(g["X"]), int(g["Y"])
+    h = pkg.engine.Handle(X, Y, 0)
+    h.upload(g["in_base"], g["in_water"], g["in_wall"])
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    out["c0_save100x100_1000_iterations"] = dict(measure_handle(h, X * Y, 1000, 100, a.frame), note="launch-bound (two launches per iteration); the reference "
+                                                 "under SwiftShader on 8 vCPU: 2.0-2.2 Mcell-steps/s (BASELINE.md)")
+    h.close()
+    # configs[1]
+    X, Y = 4096, 1024
+    gui = pkg.params.merge_settings(None)
+    ud = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, pass_mask=pkg.params.PASS_DRY)
+    ud["enablePrecipitation"] = 0
+    h = pkg.engine.Handle(X, Y, 0)
+    h.upload(*pkg.synth.dry_grid(X, Y))
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), ud), ud["initial_T"])
+    out["c1_dry_4096x1024"] = measure_handle(h, X * Y, 1000, 200, a.frame)
+    h.close()
+    # configs[4] on one GPU
+    X, Y, N = 16384, 2048, 1048576
+    gui["sunAngle"] = 50.0
+    uw = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    uw["enablePrecipitation"] = 1
+    h = pkg.engine.Handle(X, Y, N)
+    h.setup_columns(pkg.synth.terrain_columns(X, Y, cloud_deck=True), pkg.synth.init_rain_drops(N))
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), uw), uw["initial_T"])
+    # with the feedback / deposition textures the marching kernel's compulsory bytes are SURVEY's A_full = 128 B/cell (104 + feedback 16 + deposition 8)
+    out["c4_particles_1M_16384x2048_one_gpu"] = measure_handle(h, X * Y, 200, 200, a.frame, {"march_wet_full_iteration": 128})
+    h.close()
+    return out
+
+
 def p2p_selftest(dist, torch, rank, world, device):
     """First contact with the transport: every rank sends its rank number to both ring neighbours and checks what arrives, with a
     bounded wait -- so that a broken RCCL path fails here, readably, instead of hanging in the timed region."""
@@ -528,6 +591,8 @@ def main():
         if world == 1 and not a.no_north_star and a.workload == "wet" and not a.particles:
             stepper.close()
             out["north_star_dry"] = north_star_dry(a, pkg)
+        if world == 1 and not a.no_extras and not a.no_north_star and a.workload == "wet" and not a.particles and (X, Y) == (16384, 2048):
+            out["configs"] = other_configs(a, pkg)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

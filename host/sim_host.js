@@ -265,12 +265,47 @@ function WeatherSim(sf, opts)
   this.nDroplets = sf.droplets ? Math.floor(sf.droplets.length / 5) : 0;
   this.opts = opts;
   this.manualSun = opts.sunFixed ? this.gui.sunAngle : null; // updateSunlight('MANUAL_ANGLE')
-  this.h = this.addon.create(this.X, this.Y, this.nDroplets);
-  if (sf.columns) { // new simulation: textures filled on the device from the 1-D descriptors (setupShader.frag)
-    const c = sf.columns;
-    this.addon.setupColumns(this.h, c.wallRows, c.sea, c.vegNoise, c.snow, c.T_air, c.totalWater, c.cloudWater, this.nDroplets ? sf.droplets : null);
+  this.slabs = null;
+  if (opts.gpus > 1) {
+    // The domain cut into opts.gpus column slabs, one per GPU (periodic in x like the textures' REPEAT wrap), each with `halo` ghost columns
+    // per side; the library exchanges the halos itself (RCCL send / recv between the devices, or device-to-device copies where several
+    // slabs share a device) every halo / 6 iterations, overlapped with compute: wx_group_* in include/wxsim.h. Same results as one
+    // handle, bit for bit. The droplet pool is not decomposed on this path yet: particles stay off.
+    if (this.X % opts.gpus) throw new Error('the grid width ' + this.X + ' is not divisible by ' + opts.gpus + ' slabs');
+    this.nDroplets = 0;
+    this.savedDroplets = sf.droplets || null; // (written back unchanged: the save format carries X * Y / 25 droplets)
+    this.gui.enablePrecipitation = false;
+    const halo = opts.halo != null ? opts.halo : 42, xo = this.X / opts.gpus, wl = xo + 2 * halo, Y = this.Y, X = this.X;
+    this.group = this.addon.groupCreate(opts.gpus, X, Y, halo, opts.transport || 0);
+    this.slabs = [];
+    for (let i = 0; i < opts.gpus; i++) {
+      const h = this.addon.groupSlab(this.group, i, Y), x0 = i * xo;
+      const gx = new Int32Array(wl); // global column of every local one
+      for (let c = 0; c < wl; c++) gx[c] = ((x0 - halo + c) % X + X) % X;
+      if (sf.columns) {
+        const c = sf.columns, pick = function(a) { const o = new a.constructor(wl); for (let k = 0; k < wl; k++) o[k] = a[gx[k]]; return o; };
+        this.addon.setupColumns(h, pick(c.wallRows), pick(c.sea), pick(c.vegNoise), pick(c.snow), c.T_air, c.totalWater, c.cloudWater, null);
+      } else {
+        const cut = function(a) {
+          const o = new a.constructor(wl * Y * 4);
+          for (let y = 0; y < Y; y++)
+            for (let k = 0; k < wl; k++) o.set(a.subarray((y * X + gx[k]) * 4, (y * X + gx[k]) * 4 + 4), (y * wl + k) * 4);
+          return o;
+        };
+        this.addon.upload(h, cut(sf.base), cut(sf.water), cut(sf.wall), null);
+      }
+      this.slabs.push({h: h, x0: x0, xo: xo, halo: halo, wl: wl});
+    }
+    this.addon.groupAgree(this.group);
+    this.h = null;
   } else {
-    this.addon.upload(this.h, sf.base, sf.water, sf.wall, this.nDroplets ? sf.droplets : null);
+    this.h = this.addon.create(this.X, this.Y, this.nDroplets);
+    if (sf.columns) { // new simulation: textures filled on the device from the 1-D descriptors (setupShader.frag)
+      const c = sf.columns;
+      this.addon.setupColumns(this.h, c.wallRows, c.sea, c.vegNoise, c.snow, c.T_air, c.totalWater, c.cloudWater, this.nDroplets ? sf.droplets : null);
+    } else {
+      this.addon.upload(this.h, sf.base, sf.water, sf.wall, this.nDroplets ? sf.droplets : null);
+    }
   }
   // startSimulation(): clock from month / timeOfDay (app.js:3902)
   const m = this.gui.month;
@@ -283,8 +318,11 @@ WeatherSim.prototype.pushUniforms = function() {
   const u = uniformsFromGui(this.gui, this.Y, {sunAngleDeg: this.manualSun, quadScale: this.opts.quadScale, passMask: this.opts.passMask});
   Object.assign(u, this.brush);
   u.inactiveDroplets = this.inactivePushed ? -1.0 : 0.0; // keep the engine's 600-iteration measurement (app.js:5957-5966)
-  if (this.sounding) this.addon.setParams(this.h, u, u.initial_T, this.sounding.T, this.sounding.W, this.sounding.Vel);
-  else this.addon.setParams(this.h, u, u.initial_T);
+  const hs = this.slabs ? this.slabs.map(function(sl) { return sl.h; }) : [this.h];
+  for (const h of hs) {
+    if (this.sounding) this.addon.setParams(h, u, u.initial_T, this.sounding.T, this.sounding.W, this.sounding.Vel);
+    else this.addon.setParams(h, u, u.initial_T);
+  }
   this.inactivePushed = true;
 };
 WeatherSim.prototype.setGui = function(changes) { Object.assign(this.gui, changes); this.pushUniforms(); };
@@ -313,20 +351,32 @@ WeatherSim.prototype.frame = function(nIter) {
   const n = nIter != null ? nIter : this.gui.IterPerFrame;
   if (this.gui.paused) return;
   if (this.gui.dayNightCycle && this.manualSun == null) this.updateSunlight(TIME_PER_ITERATION * n);
-  this.addon.step(this.h, n);
+  if (this.slabs) this.addon.groupStep(this.group, n); // every slab: n iterations + the halo exchanges that fall into them
+  else this.addon.step(this.h, n);
 };
-WeatherSim.prototype.sync = function() { this.addon.sync(this.h); };
+WeatherSim.prototype.sync = function() { if (this.slabs) this.addon.groupSync(this.group); else this.addon.sync(this.h); };
 // engine options with no counterpart in app.js: deterministic particle splats (option 1), per-launch checks (option 2), and the
 // search for a fast placement of the handle's planes in device memory (returns [ms before, ms after]; the state is unchanged)
-WeatherSim.prototype.setOption = function(option, value) { this.addon.setOption(this.h, option, value); };
-WeatherSim.prototype.tunePlacement = function(tries, itersPerTry) { return this.addon.tunePlacement(this.h, tries || 6, itersPerTry || 30); };
-WeatherSim.prototype.iterNum = function() { return this.addon.getIter(this.h); };
+WeatherSim.prototype.setOption = function(option, value) { (this.slabs ? this.slabs.map(function(sl) { return sl.h; }) : [this.h]).forEach(function(h) { this.addon.setOption(h, option, value); }, this); };
+WeatherSim.prototype.tunePlacement = function(tries, itersPerTry) {
+  if (this.slabs) throw new Error('tunePlacement: single-handle simulations only');
+  return this.addon.tunePlacement(this.h, tries || 6, itersPerTry || 30);
+};
+WeatherSim.prototype.iterNum = function() { return this.addon.getIter(this.slabs ? this.slabs[0].h : this.h); };
 WeatherSim.prototype.readRect = function(field, x, y, w, h, Type) {
   const id = typeof field === 'string' ? FIELD[field] : field;
   const ch = id === FIELD.CURL ? 1 : (id === FIELD.VORT || id === FIELD.PRECIP_DEP) ? 2 : 4;
   const isWall = id === FIELD.WALL_CUR || id === FIELD.WALL_DISP;
-  const dst = new (Type || (isWall ? Int8Array : Float32Array))(w * h * ch);
-  return this.addon.readRect(this.h, id, x, y, w, h, dst);
+  const T = Type || (isWall ? Int8Array : Float32Array), dst = new T(w * h * ch);
+  if (!this.slabs) return this.addon.readRect(this.h, id, x, y, w, h, dst);
+  if (x < 0 || x + w > this.X) throw new RangeError('readRect: columns outside the grid (no wrap, as readPixels)');
+  for (const sl of this.slabs) { // the owned columns of every slab the rectangle touches
+    const a = Math.max(x, sl.x0), b = Math.min(x + w, sl.x0 + sl.xo);
+    if (a >= b) continue;
+    const part = this.addon.readRect(sl.h, id, a - sl.x0 + sl.halo, y, b - a, h, new T((b - a) * h * ch));
+    for (let r = 0; r < h; r++) dst.set(part.subarray(r * (b - a) * ch, (r + 1) * (b - a) * ch), (r * w + (a - x)) * ch);
+  }
+  return dst;
 };
 WeatherSim.prototype.measureStation = function(x, y) { // Weatherstation.measure, app.js:1084-1092
   return {base: this.readRect('BASE_CUR', x, y - 1, 1, 3), water: this.readRect('WATER_0', x, y - 1, 1, 2)};
@@ -340,11 +390,13 @@ WeatherSim.prototype.readParticles = function() {
 };
 WeatherSim.prototype.toSave = function() { // prepareDownload(): FB0 = base_0, water_0, wall_0 (app.js:6584-6593)
   return {X: this.X, Y: this.Y, base: this.readRect('BASE_CUR', 0, 0, this.X, this.Y), water: this.readRect('WATER_0', 0, 0, this.X, this.Y),
-          wall: this.readRect('WALL_CUR', 0, 0, this.X, this.Y), droplets: this.readParticles(), stations: [], settings: this.gui};
+          wall: this.readRect('WALL_CUR', 0, 0, this.X, this.Y), droplets: this.slabs && this.savedDroplets ? this.savedDroplets : this.readParticles(),
+          stations: [], settings: this.gui};
 };
 // display fields of a viewport, copied asynchronously into pinned memory (what the renderer binds, app.js:6081-6219):
 // returns {wait()} whose result holds typed-array views BASE_DISP, WATER_CUR, WALL_DISP, LIGHT_0, CURL, PRECIP_FB
 WeatherSim.prototype.streamFrame = function(x, y, w, h) {
+  if (this.slabs) throw new Error('streamFrame: single-handle simulations only (read the slabs with readRect)');
   const self = this, ab = this.addon.streamFrame(this.h, x, y, w, h), n = w * h;
   return {wait: function() {
     self.addon.streamWait(self.h);
@@ -360,7 +412,7 @@ WeatherSim.prototype.streamFrame = function(x, y, w, h) {
     return out;
   }};
 };
-WeatherSim.prototype.destroy = function() { this.addon.destroy(this.h); };
+WeatherSim.prototype.destroy = function() { if (this.slabs) { this.addon.groupDestroy(this.group); this.slabs = []; } else this.addon.destroy(this.h); };
 // startup without a save file: what mainScript() does for a new simulation (setup pass + initRainDrops)
 WeatherSim.newSimulation = function(X, Y, opts) {
   opts = opts || {};
@@ -379,11 +431,14 @@ if (require.main === module) {
   const flags = args.filter(function(a) { return a.startsWith('--'); });
   const pos = args.filter(function(a) { return !a.startsWith('--'); });
   if (pos.length < 2) {
-    console.error('usage: node sim_host.js <in.weathersandbox> <iterations> [out.weathersandbox] [--sun-fixed] [--selftest]');
+    console.error('usage: node sim_host.js <in.weathersandbox> <iterations> [out.weathersandbox] [--sun-fixed] [--gpus N [--halo H] [--transport rccl|local]]');
     process.exit(2);
   }
   const sf = loadSave(pos[0]);
-  const sim = new WeatherSim(sf, {sunFixed: flags.indexOf('--sun-fixed') >= 0});
+  const num = function(flag, dflt) { const i = args.indexOf(flag); return i >= 0 ? parseInt(args[i + 1], 10) : dflt; };
+  const tr = args.indexOf('--transport') >= 0 ? args[args.indexOf('--transport') + 1] : 'auto';
+  const sim = new WeatherSim(sf, {sunFixed: flags.indexOf('--sun-fixed') >= 0, gpus: num('--gpus', 1), halo: num('--halo', 42),
+                                  transport: tr == 'rccl' ? 1 : tr == 'local' ? 2 : 0});
   const n = parseInt(pos[1], 10);
   const t0 = Date.now();
   let left = n;

@@ -39,6 +39,17 @@ static struct {
   void (*host_free)(void *);
   int (*stream_frame)(wx_sim *, int, int, int, int, void *);
   int (*stream_wait)(wx_sim *);
+  /* N slabs in one process (wx_group_*: the decomposed domain from a JavaScript host) */
+  int (*group_create)(int, const int *, int, int, int, int, int, wx_group **);
+  void (*group_destroy)(wx_group *);
+  const char *(*group_last_error)(const wx_group *);
+  int (*group_count)(const wx_group *);
+  int (*group_transport)(const wx_group *);
+  wx_sim *(*group_slab)(wx_group *, int);
+  int (*group_agree)(wx_group *);
+  int (*group_step)(wx_group *, int);
+  int (*group_sync)(wx_group *);
+  int (*local_width)(const wx_sim *);
 } L;
 
 #define NAPI_CALL(env, call)                                                        \
@@ -62,7 +73,11 @@ static napi_value throw_wx(napi_env env, wx_sim *s, int rc, const char *what)
 typedef struct {
   wx_sim *s;
   int32_t X, Y, N;
+  int32_t borrowed; /* a slab of a group: the group destroys it */
 } wx_slot;
+typedef struct {
+  wx_group *g;
+} wx_gslot;
 
 static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv)
 {
@@ -120,7 +135,7 @@ static int is_nullish(napi_env env, napi_value v)
 static void finalize_handle(napi_env env, void *data, void *hint)
 {
   wx_slot *slot = (wx_slot *)data;
-  if (slot->s) L.destroy(slot->s);
+  if (slot->s && !slot->borrowed) L.destroy(slot->s);
   free(slot);
 }
 
@@ -151,6 +166,7 @@ static napi_value Create(napi_env env, napi_callback_info info)
   slot->X = X;
   slot->Y = Y;
   slot->N = N;
+  slot->borrowed = 0;
   napi_value ext;
   NAPI_CALL(env, napi_create_external(env, slot, finalize_handle, NULL, &ext));
   return ext;
@@ -162,7 +178,7 @@ static napi_value Destroy(napi_env env, napi_callback_info info)
   if (get_args(env, info, 1, a)) return NULL;
   void *p = NULL;
   if (napi_get_value_external(env, a[0], &p) == napi_ok && p && *(wx_sim **)p) {
-    L.destroy(*(wx_sim **)p);
+    if (!((wx_slot *)p)->borrowed) L.destroy(*(wx_sim **)p);
     *(wx_sim **)p = NULL;
   }
   return NULL;
@@ -480,6 +496,128 @@ static napi_value StreamWait(napi_env env, napi_callback_info info)
   return NULL;
 }
 
+/* ---- the decomposed domain: N column slabs in this process (wx_group_*, include/wxsim.h) ---- */
+static void finalize_group(napi_env env, void *data, void *hint)
+{
+  wx_gslot *gs = (wx_gslot *)data;
+  if (gs->g) L.group_destroy(gs->g);
+  free(gs);
+}
+static wx_gslot *get_group(napi_env env, napi_value v)
+{
+  void *p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((wx_gslot *)p)->g) {
+    napi_throw_type_error(env, NULL, "expected a slab group");
+    return NULL;
+  }
+  return (wx_gslot *)p;
+}
+static napi_value throw_group(napi_env env, wx_group *g, int rc, const char *what)
+{
+  char buf[640];
+  snprintf(buf, sizeof(buf), "%s failed (%d): %s", what, rc, L.group_last_error(g));
+  napi_throw_error(env, NULL, buf);
+  return NULL;
+}
+/* groupCreate(nSlabs, Xglobal, Y, halo, transport) -> group   (transport: 0 auto, 1 RCCL, 2 local copies) */
+static napi_value GroupCreate(napi_env env, napi_callback_info info)
+{
+  napi_value a[5];
+  if (get_args(env, info, 5, a)) return NULL;
+  int32_t v[5];
+  for (int i = 0; i < 5; i++) NAPI_CALL(env, napi_get_value_int32(env, a[i], &v[i]));
+  wx_group *g = NULL;
+  int rc = L.group_create(v[0], NULL, v[1], v[2], v[3], 0, v[4], &g);
+  if (rc) return throw_group(env, NULL, rc, "wx_group_create");
+  wx_gslot *gs = (wx_gslot *)malloc(sizeof(*gs));
+  gs->g = g;
+  napi_value ext;
+  NAPI_CALL(env, napi_create_external(env, gs, finalize_group, NULL, &ext));
+  return ext;
+}
+/* groupSlab(group, i) -> handle of slab i, usable with upload / setParams / readRect ... (owned by the group) */
+static napi_value GroupSlab(napi_env env, napi_callback_info info)
+{
+  napi_value a[3];
+  if (get_args(env, info, 3, a)) return NULL;
+  wx_gslot *gs = get_group(env, a[0]);
+  if (!gs) return NULL;
+  int32_t i, Y;
+  NAPI_CALL(env, napi_get_value_int32(env, a[1], &i));
+  NAPI_CALL(env, napi_get_value_int32(env, a[2], &Y));
+  wx_sim *s = L.group_slab(gs->g, i);
+  if (!s) {
+    napi_throw_range_error(env, NULL, "groupSlab: no such slab");
+    return NULL;
+  }
+  wx_slot *slot = (wx_slot *)malloc(sizeof(*slot));
+  slot->s = s;
+  slot->X = L.local_width(s);
+  slot->Y = Y;
+  slot->N = 0;
+  slot->borrowed = 1;
+  napi_value ext;
+  NAPI_CALL(env, napi_create_external(env, slot, finalize_handle, NULL, &ext));
+  return ext;
+}
+static napi_value GroupInfo(napi_env env, napi_callback_info info)
+{
+  napi_value a[1], o, v;
+  if (get_args(env, info, 1, a)) return NULL;
+  wx_gslot *gs = get_group(env, a[0]);
+  if (!gs) return NULL;
+  NAPI_CALL(env, napi_create_object(env, &o));
+  NAPI_CALL(env, napi_create_int32(env, L.group_count(gs->g), &v));
+  NAPI_CALL(env, napi_set_named_property(env, o, "slabs", v));
+  NAPI_CALL(env, napi_create_int32(env, L.group_transport(gs->g), &v));
+  NAPI_CALL(env, napi_set_named_property(env, o, "transport", v));
+  return o;
+}
+static napi_value GroupAgree(napi_env env, napi_callback_info info)
+{
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  wx_gslot *gs = get_group(env, a[0]);
+  if (!gs) return NULL;
+  int rc = L.group_agree(gs->g);
+  if (rc) return throw_group(env, gs->g, rc, "wx_group_agree");
+  return NULL;
+}
+/* groupStep(group, n): n iterations of every slab with the ring halo exchange every halo / 6 iterations  [loop body app.js:5830-6005] */
+static napi_value GroupStep(napi_env env, napi_callback_info info)
+{
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  wx_gslot *gs = get_group(env, a[0]);
+  if (!gs) return NULL;
+  int32_t n;
+  NAPI_CALL(env, napi_get_value_int32(env, a[1], &n));
+  int rc = L.group_step(gs->g, n);
+  if (rc) return throw_group(env, gs->g, rc, "wx_group_step");
+  return NULL;
+}
+static napi_value GroupSync(napi_env env, napi_callback_info info)
+{
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  wx_gslot *gs = get_group(env, a[0]);
+  if (!gs) return NULL;
+  int rc = L.group_sync(gs->g);
+  if (rc) return throw_group(env, gs->g, rc, "wx_group_sync");
+  return NULL;
+}
+static napi_value GroupDestroy(napi_env env, napi_callback_info info)
+{
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  void *p = NULL;
+  if (napi_get_value_external(env, a[0], &p) == napi_ok && p && ((wx_gslot *)p)->g) {
+    L.group_destroy(((wx_gslot *)p)->g);
+    ((wx_gslot *)p)->g = NULL;
+  }
+  return NULL;
+}
+
 static napi_value AbiVersion(napi_env env, napi_callback_info info)
 {
   napi_value r;
@@ -519,6 +657,9 @@ static int load_lib(napi_env env)
   SYM(set_iter, "wx_set_iter") SYM(read_rect, "wx_read_rect") SYM(read_particles, "wx_read_particles")
   SYM(setup_columns, "wx_setup_columns") SYM(stream_bytes, "wx_stream_bytes") SYM(host_alloc, "wx_host_alloc") SYM(host_free, "wx_host_free")
   SYM(stream_frame, "wx_stream_frame") SYM(stream_wait, "wx_stream_wait") SYM(set_option, "wx_set_option") SYM(tune_placement, "wx_tune_placement")
+  SYM(group_create, "wx_group_create") SYM(group_destroy, "wx_group_destroy") SYM(group_last_error, "wx_group_last_error") SYM(group_count, "wx_group_count")
+  SYM(group_transport, "wx_group_transport") SYM(group_slab, "wx_group_slab") SYM(group_agree, "wx_group_agree") SYM(group_step, "wx_group_step")
+  SYM(group_sync, "wx_group_sync") SYM(local_width, "wx_local_width")
 #undef SYM
   return 0;
 }
@@ -535,6 +676,10 @@ static napi_value Init(napi_env env, napi_value exports)
     {"abiVersion", 0, AbiVersion, 0, 0, 0, napi_default, 0}, {"setupColumns", 0, SetupColumns, 0, 0, 0, napi_default, 0},
     {"streamFrame", 0, StreamFrame, 0, 0, 0, napi_default, 0}, {"streamWait", 0, StreamWait, 0, 0, 0, napi_default, 0},
     {"setOption", 0, SetOption, 0, 0, 0, napi_default, 0},   {"tunePlacement", 0, TunePlacement, 0, 0, 0, napi_default, 0},
+    {"groupCreate", 0, GroupCreate, 0, 0, 0, napi_default, 0}, {"groupSlab", 0, GroupSlab, 0, 0, 0, napi_default, 0},
+    {"groupInfo", 0, GroupInfo, 0, 0, 0, napi_default, 0},     {"groupAgree", 0, GroupAgree, 0, 0, 0, napi_default, 0},
+    {"groupStep", 0, GroupStep, 0, 0, 0, napi_default, 0},     {"groupSync", 0, GroupSync, 0, 0, 0, napi_default, 0},
+    {"groupDestroy", 0, GroupDestroy, 0, 0, 0, napi_default, 0},
   };
   NAPI_CALL(env, napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d));
   return exports;

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WX_ABI_VERSION 6
+#define WX_ABI_VERSION 7
 
 /* error codes */
 #define WX_OK 0
@@ -267,6 +267,45 @@ int wx_pool_edges_apply(wx_sim *s, const void *dev_buf);
 int wx_pool_flags(wx_sim *s, uint8_t *host_dst);
 int wx_lightning_get(wx_sim *s, float out[4]);
 int wx_lightning_set(wx_sim *s, const float in[4]);
+
+/* ---- the halo exchange inside the library (no reference counterpart: the reference is single-GPU; BASELINE north_star: "halo
+ * exchange on RCCL send/recv over xGMI overlapped on a side HIP stream; host code stays in JavaScript"). RCCL is bound at run time
+ * (dlopen), so nothing here is needed to run on one GPU. Slabs with particles keep the host-driven exchange of the functions above.
+ *
+ * One rank per process (what `bench.py --gpus N` runs under torchrun, which then only launches the ranks and carries the 128-byte
+ * id from rank 0 to the others):
+ *   wx_comm_unique_id(id)                  ncclGetUniqueId
+ *   wx_comm_init(s, id, rank, world)       ncclCommInitRank on the handle's device; rank r owns columns [r, r + 1) * X_global / world
+ *   wx_exchange(s)                         pack both edges -> ncclGroupStart; ncclSend x 2; ncclRecv x 2; ncclGroupEnd -> unpack both
+ *                                          ghost strips, all enqueued on the handle's comm stream (one of the library's own unless
+ *                                          wx_set_comm_stream named one); never blocks the host
+ *   wx_slab_step(s, n)                     n iterations with one wx_exchange per halo / WX_SLAB_CONE iterations; the iteration before
+ *                                          an exchange launches its edge strips first, the one after it its interior strips first
+ *                                          (wx_step_overlap), so the transfer runs behind the interior of both. Replaces the loop
+ *                                          body app.js:5830-6005 for one slab of a decomposed domain.
+ * One process, N slabs (the Node host: `node host/sim_host.js --gpus N`): */
+#define WX_UNIQUE_ID_BYTES 128
+int wx_comm_unique_id(void *id128);
+int wx_comm_init(wx_sim *s, const void *id128, int rank, int world);
+int wx_exchange(wx_sim *s);
+int wx_slab_step(wx_sim *s, int n_iter);
+
+typedef struct wx_group wx_group;
+#define WX_TRANSPORT_AUTO 0  /* RCCL if every slab has a device of its own, else local */
+#define WX_TRANSPORT_RCCL 1  /* ncclCommInitAll over the slabs' devices (RCCL refuses two ranks on one device) */
+#define WX_TRANSPORT_LOCAL 2 /* device-to-device copies between the slabs' halo buffers, event-fenced: any number of slabs per device */
+/* n_slabs handles of X_global / n_slabs columns each (+ `halo` ghost columns per side), slab i on devices[i] (NULL: i modulo the
+ * device count), every slab with compute and comm streams of its own. Upload / set parameters / read through the per-slab handles
+ * (wx_group_slab; local arrays incl. ghost columns, as for wx_create_slab), then wx_group_agree once, then step the group. */
+int wx_group_create(int n_slabs, const int *devices, int X_global, int Y, int halo, int n_droplets, int transport, wx_group **out);
+void wx_group_destroy(wx_group *g); /* destroys the slab handles too */
+const char *wx_group_last_error(const wx_group *g);
+int wx_group_count(const wx_group *g);
+int wx_group_transport(const wx_group *g);
+wx_sim *wx_group_slab(wx_group *g, int i);
+int wx_group_agree(wx_group *g);            /* after the uploads: wx_water_free of every slab -> wx_slab_assert_water_free on all */
+int wx_group_step(wx_group *g, int n_iter); /* like wx_slab_step, for all slabs; asynchronous */
+int wx_group_sync(wx_group *g);
 
 /* Per-kernel device time from HIP events recorded on the handle's stream around every launch.
  * wx_profile(s, 1) starts collecting, wx_profile_read returns accumulated milliseconds and launch counts
