@@ -867,7 +867,7 @@ inline int splat_box_grid()
 {
   static int grid = 0;
   if (!grid) {
-    if (const char *e = getenv("WX_SPLAT_BOX_WGS")) grid = atoi(e); // (tuning)
+    if (const char *e = wx_tune_env("WX_SPLAT_BOX_WGS")) grid = atoi(e); // (tuning)
   }
   if (grid <= 0) {
     int dev = 0, ncu = 0, nb = 0;

@@ -313,16 +313,16 @@ inline int march_capacity()
       capacity = 256 * 4 * WX_MARCH_MINWAVES;
     else
       capacity = ncu * nb;
-    if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_march] CUs=%d blocks/CU=%d capacity=%d\n", ncu, nb, capacity);
+    if (wx_tune_env("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_march] CUs=%d blocks/CU=%d capacity=%d\n", ncu, nb, capacity);
   }
   return capacity;
 }
 inline int march_seg_rows(int n_strips, int Y)
 {
   const int capacity = march_capacity();
-  if (const char *e = getenv("WX_MARCH_SEG")) return atoi(e) < Y ? atoi(e) : Y;
+  if (const char *e = wx_tune_env("WX_MARCH_SEG")) return atoi(e) < Y ? atoi(e) : Y;
   int maxseg = WX_MARCH_MAXSEG;
-  if (const char *e = getenv("WX_MARCH_MAXSEG")) maxseg = atoi(e) > 0 ? atoi(e) : maxseg;
+  if (const char *e = wx_tune_env("WX_MARCH_MAXSEG")) maxseg = atoi(e) > 0 ? atoi(e) : maxseg;
   for (int k = 1; k < 64; k++) {
     const int nseg = (int)((long long)k * capacity / n_strips);
     if (nseg < 1) continue;
@@ -344,9 +344,9 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
   if (n_strips <= 0) return;
   int seg_rows = march_seg_rows(n_strips_all, g.Y);
   int n_seg = (g.Y + seg_rows - 1) / seg_rows, n_full = n_seg, n_half = 0, band_h = 0;
-  if (WX_MARCH_XCD && WX_MARCH_BANDS && !getenv("WX_MARCH_NOTAIL") && !getenv("WX_MARCH_SEG") && g.Y % 8 == 0) {
+  if (WX_MARCH_XCD && WX_MARCH_BANDS && !wx_tune_env("WX_MARCH_NOTAIL") && !wx_tune_env("WX_MARCH_SEG") && g.Y % 8 == 0) {
     int R = WX_MARCH_BAND_SEG;
-    if (const char *e = getenv("WX_MARCH_BAND_SEG")) R = atoi(e) >= 16 ? atoi(e) : R;
+    if (const char *e = wx_tune_env("WX_MARCH_BAND_SEG")) R = atoi(e) >= 16 ? atoi(e) : R;
     const int bh = g.Y / 8, tail = R / 2 + R / 4;
     if (bh >= 3 * R) { // tall enough for at least two full segments and the tail per band
       band_h = bh;
@@ -357,7 +357,7 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
     }
   }
   const dim3 grid(WX_MARCH_XCD ? 8 * ((n_strips * n_seg + 7) / 8) : n_strips * n_seg);
-  static bool dbg = getenv("WX_MARCH_DEBUG") != nullptr;
+  static bool dbg = wx_tune_env("WX_MARCH_DEBUG") != nullptr;
   if (dbg) {
     fprintf(stderr, "[wx_march] strips=%d seg_rows=%d segs=%d (bands of %d rows: %d full + 2 x %d short each) waves=%d\n", n_strips, seg_rows, n_seg, band_h, n_full, n_half, n_strips * n_seg);
     dbg = false;

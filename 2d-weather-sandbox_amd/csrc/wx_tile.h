@@ -5,6 +5,16 @@
 #pragma once
 #include "wx_cells.h"
 
+#include <cstdlib>
+// Tuning switches are environment variables ONLY in builds with -DWX_DEBUG (make debug: variants/libwxsim_debug.so; the experiment
+// scripts under tools/ load that one through WXSIM_LIB). The shipped library reads no environment variable: it has one launch shape,
+// and what a host may choose goes through wx_set_option.
+#ifdef WX_DEBUG
+inline const char *wx_tune_env(const char *name) { return std::getenv(name); }
+#else
+inline const char *wx_tune_env(const char *) { return nullptr; }
+#endif
+
 namespace wx {
 
 constexpr int TX = 64, TY = 16;

@@ -1188,42 +1188,44 @@ inline int wet_capacity()
       if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_march_wet<false, false>)) == hipSuccess) {
         if (fa.numRegs > 0) by_regs = (512 / (((fa.numRegs + 7) / 8) * 8)) * 4 / WX_WET_WPB;
         if (fa.sharedSizeBytes > 0) by_lds = (int)(163840 / fa.sharedSizeBytes);
-        if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] numRegs=%d lds=%zu: blocks/CU by registers %d, by LDS %d, occupancy API %d\n", fa.numRegs, fa.sharedSizeBytes, by_regs, by_lds, nb);
+        if (wx_tune_env("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] numRegs=%d lds=%zu: blocks/CU by registers %d, by LDS %d, occupancy API %d\n", fa.numRegs, fa.sharedSizeBytes, by_regs, by_lds, nb);
       }
       nb = std::max(1, std::min(nb, std::min(by_regs, by_lds)));
       capacity = ncu * nb * WX_WET_WPB;
     }
-    if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] CUs=%d blocks/CU=%d capacity=%d\n", ncu, nb, capacity);
+    if (wx_tune_env("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] CUs=%d blocks/CU=%d capacity=%d\n", ncu, nb, capacity);
   }
   return capacity;
 }
 inline double wet_alpha()
 {
   double alpha = WX_WET_ALPHA_DEFAULT;
-  if (const char *e = getenv("WX_WET_ALPHA")) alpha = atof(e) >= 1.0 ? atof(e) : alpha;
+  if (const char *e = wx_tune_env("WX_WET_ALPHA")) alpha = atof(e) >= 1.0 ? atof(e) : alpha;
   return alpha;
 }
-inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
+// bands_mode (WX_OPT_ROW_BANDS): 0 = column blocks, 1 = row bands on grids at least 512 rows high (default), 2 = row bands wherever
+// a band has two rows (tests: the shape of wide slabs on small grids)
+inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row, int bands_mode = 1)
 {
   WetLaunch w;
   // Grids at least 512 rows high: XCD k takes the row band [k*Y/8, (k+1)*Y/8) of ALL strips instead of a column block of every
   // segment -- each XCD then streams one contiguous eighth of every plane: -3..-8 % kernel time at 16384x2048 and 32768x4096,
   // -5 % on a 4192x4096 slab, -9 % on a 2144x2048 one (profiles/r02_wet_tail_shape.txt).
-  bool bands = WX_WET_BANDS && g.Y >= 8 * 64;
-  if (const char *e = getenv("WX_WET_BANDS")) bands = atoi(e) >= 2 ? g.Y >= 16 : (atoi(e) != 0 && g.Y >= 8 * 64); // (2: tests force it on small grids)
+  bool bands = bands_mode >= 2 ? g.Y >= 16 : (bands_mode != 0 && WX_WET_BANDS && g.Y >= 8 * 64);
+  if (const char *e = wx_tune_env("WX_WET_BANDS")) bands = atoi(e) >= 2 ? g.Y >= 16 : (atoi(e) != 0 && g.Y >= 8 * 64); // (2: tests force it on small grids)
   const int Y = bands ? (g.Y + 7) / 8 : g.Y; // (bands: the shape of ONE band; the kernel clips it to the band's own height)
   w.segs.bands = bands ? 1 : 0;
   w.n_strips = (g.X + WOUT - 1) / WOUT;
   int rounds = WX_WET_ROUNDS, minrows = 24; // (narrow slabs: 2144x2048 runs 17 % faster with 30-row unit segments + tail than with equal 32-row ones)
   const double alpha = wet_alpha();
-  if (const char *e = getenv("WX_WET_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
-  if (const char *e = getenv("WX_WET_MINROWS")) minrows = atoi(e) > 0 ? atoi(e) : minrows;
+  if (const char *e = wx_tune_env("WX_WET_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
+  if (const char *e = wx_tune_env("WX_WET_MINROWS")) minrows = atoi(e) > 0 ? atoi(e) : minrows;
   // workgroups per segment: 8 XCD column blocks x ceil(strips of the block / waves per workgroup); the device holds capacity / WPB
   const int wg_per_seg = bands ? 8 * ((w.n_strips + WX_WET_WPB - 1) / WX_WET_WPB) : 8 * (((w.n_strips + 7) / 8 + WX_WET_WPB - 1) / WX_WET_WPB);
   int n_seg = (int)((long long)rounds * (wet_capacity() / WX_WET_WPB) / wg_per_seg);
   double skew = 0.0; // > 0: earlier-dispatched (lower) segments get more rows: the SIMD issues its OLDEST ready wave first
-  if (const char *e = getenv("WX_WET_SKEW")) skew = atof(e);
-  if (const char *e = getenv("WX_WET_SEG")) n_seg = atoi(e) > 0 ? (Y + atoi(e) - 1) / atoi(e) : n_seg;
+  if (const char *e = wx_tune_env("WX_WET_SKEW")) skew = atof(e);
+  if (const char *e = wx_tune_env("WX_WET_SEG")) n_seg = atoi(e) > 0 ? (Y + atoi(e) - 1) / atoi(e) : n_seg;
   n_seg = n_seg < 1 ? 1 : (n_seg > WMAXSEG ? WMAXSEG : n_seg);
   if (n_seg > (Y + minrows - 1) / minrows) n_seg = (Y + minrows - 1) / minrows; // (8 warm-up rows per segment are redundant work)
   const int A = (air_from_row < 0 || air_from_row > Y) ? 0 : air_from_row;           // unknown: uniform segments
@@ -1233,7 +1235,7 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
   // drain phase of the launch, in which finished waves are not replaced
   double wt[WMAXSEG];
   for (int sg = 0; sg < n_seg; sg++) wt[sg] = 1.0 + skew * (0.5 - (n_seg > 1 ? (double)sg / (n_seg - 1) : 0.5));
-  if (WX_WET_TAIL && skew == 0.0 && !getenv("WX_WET_SEG") && !getenv("WX_WET_NOTAIL")) {
+  if (WX_WET_TAIL && skew == 0.0 && !wx_tune_env("WX_WET_SEG") && !wx_tune_env("WX_WET_NOTAIL")) {
     // default shape: (rounds - 1) rounds of full segments, then about half a round each of segments of weight 1/2, 1/4 and 1/8.
     // The launch ends with a drain phase in which finished waves are not replaced; short segments at the end of the dispatch order
     // make it short: -5 % kernel time against equal segments (interleaved A/B, profiles/r02_wet_tail_shape.txt)
@@ -1259,7 +1261,7 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row)
       }
     }
   }
-  if (const char *e = getenv("WX_WET_SPEC")) {
+  if (const char *e = wx_tune_env("WX_WET_SPEC")) {
     int n = 0;
     for (const char *q = e; *q && n < WMAXSEG;) {
       char *end = nullptr;
@@ -1297,7 +1299,7 @@ inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *c
   if (ns <= 0) return;
   // 8 XCDs x (workgroups of the largest column block) x segments; surplus workgroups / waves exit at once
   const dim3 grid(8 * (((w.segs.bands ? ns : (ns + 7) / 8) + WX_WET_WPB - 1) / WX_WET_WPB) * w.segs.n_seg);
-  static bool dbg = getenv("WX_MARCH_DEBUG") != nullptr;
+  static bool dbg = wx_tune_env("WX_MARCH_DEBUG") != nullptr;
   if (dbg) {
     fprintf(stderr, "[wx_wet] strips=%d segs=%d waves=%d first/last segment rows=%d/%d\n", w.n_strips, w.segs.n_seg, w.n_strips * w.segs.n_seg,
             w.segs.start[1] - w.segs.start[0], w.segs.start[w.segs.n_seg] - w.segs.start[w.segs.n_seg - 1]);

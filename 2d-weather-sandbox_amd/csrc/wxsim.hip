@@ -89,6 +89,8 @@ struct wx_sim {
   int64_t iter = 0;
   int dry_march = 1;     // water-free dry iteration: 1 = row-marching wavefront kernel (wx_march.h, default: 0.32 vs 0.38 ms at
                          // 16384x2048), 0 = LDS-tiled kernel (wx_dry.h); env WX_DRY_MARCH
+  int bands_mode = 1;    // WX_OPT_ROW_BANDS
+  int fix_cap_request = 0; // WX_OPT_FIX_CAP (0: a quarter of the grid)
   int fused = 2;         // non-zero (default): the whole iteration as one row-marching kernel (wx_wet.h); 0: one kernel per reference
                          // pass (env WX_FUSED; the independent cross-check of the parity tests)
   wx_params p{};
@@ -397,7 +399,7 @@ static hipError_t block_alloc(size_t bytes, Block *out)
   out->p = nullptr;
   out->bytes = bytes;
   hipError_t e = hipErrorUnknown;
-  if (const char *c = getenv("WX_ARENA_CONTIG")) { // experiment: physically contiguous VRAM (the largest page-table fragments)
+  if (const char *c = wx_tune_env("WX_ARENA_CONTIG")) { // experiment: physically contiguous VRAM (the largest page-table fragments)
     if (atoi(c) != 0) e = hipExtMallocWithFlags((void **)&out->p, bytes, hipDeviceMallocContiguous);
     if (e != hipSuccess) (void)hipGetLastError();
   }
@@ -407,8 +409,8 @@ static hipError_t block_alloc(size_t bytes, Block *out)
 static int storage_begin(wx_sim *s, size_t total_bytes, size_t small_bytes)
 {
   s->arena_skew = 0;
-  if (const char *e = getenv("WX_ARENA_SKEW")) s->arena_skew = (size_t)atoll(e);
-  if (const char *e = getenv("WX_ARENA")) s->one_arena = atoi(e) != 0;
+  if (const char *e = wx_tune_env("WX_ARENA_SKEW")) s->arena_skew = (size_t)atoll(e);
+  if (const char *e = wx_tune_env("WX_ARENA")) s->one_arena = atoi(e) != 0;
   Block b;
   const size_t bytes = s->one_arena ? total_bytes + 128 * (4096 + s->arena_skew) : small_bytes;
   if (block_alloc(bytes, &b) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_create: %zu bytes of device memory", bytes);
@@ -594,20 +596,20 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
     s->wet_shape_valid = false;
   }
   if (!s->wet_shape_valid) {
-    s->wet_shape = wet_launch_shape(s->geo, s->air_from_row);
+    s->wet_shape = wet_launch_shape(s->geo, s->air_from_row, s->bands_mode);
     s->wet_shape_valid = true;
-    if (getenv("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] air_from_row=%d of %d\n", s->air_from_row, s->Y);
+    if (wx_tune_env("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] air_from_row=%d of %d\n", s->air_from_row, s->Y);
   }
   const WetLaunch &shape = s->wet_shape;
   if (!s->fix_cells) { // (once per handle) room for a quarter of the grid's cells, at most 8 M entries
     size_t cap = std::min<size_t>(std::max<size_t>(ncell(s) / 4, 1u << 16), 1u << 23);
-    if (const char *e = getenv("WX_WET_FIX_CAP")) cap = atoi(e) > 0 ? (size_t)atoi(e) : cap; // (tests: provoke the overflow report)
+    if (s->fix_cap_request > 0) cap = (size_t)s->fix_cap_request; // (WX_OPT_FIX_CAP; tests: provoke the overflow report)
     if (hipMalloc((void **)&s->fix_count, 8) != hipSuccess || hipMalloc((void **)&s->fix_cells, cap * sizeof(int2)) != hipSuccess ||
         hipMemsetAsync(s->fix_count, 0, 8, s->stream) != hipSuccess) // {entries, arrival ticket of the fix pass}: the fix pass leaves both at 0
       return fail(s, WX_E_NOMEM, "wx_step: %zu bytes for the exact-path cell list", cap * sizeof(int2));
     s->fix_cap = (int)cap;
     // (optional: without the mapped word every fix launch covers the whole chip)
-    if (!(getenv("WX_FIX_HINT") && atoi(getenv("WX_FIX_HINT")) == 0) && // (WX_FIX_HINT=0: tuning)
+    if (!(wx_tune_env("WX_FIX_HINT") && atoi(wx_tune_env("WX_FIX_HINT")) == 0) && // (WX_FIX_HINT=0: tuning)
         hipHostMalloc((void **)&s->fix_hint_host, sizeof(int), hipHostMallocMapped) == hipSuccess && s->fix_hint_host) {
       *s->fix_hint_host = 1;
       if (hipHostGetDevicePointer((void **)&s->fix_hint_dev, s->fix_hint_host, 0) != hipSuccess) s->fix_hint_dev = nullptr;
@@ -748,6 +750,9 @@ const char *wx_last_error(const wx_sim *s) { return s ? s->err.c_str() : g_creat
 int wx_kernel_count(void) { return K_COUNT; }
 const char *wx_kernel_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }
 
+// process-wide defaults of the options a handle takes at creation (wx_set_option(NULL, ...))
+static int g_opt_kernel_set = 1, g_opt_dry_kernel = 1, g_opt_row_bands = 1, g_opt_fix_cap = 0;
+
 int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_droplets, wx_sim **out)
 {
   if (!out) return fail(nullptr, WX_E_INVALID, "wx_create: out is NULL");
@@ -774,8 +779,10 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   s->x0 = x0;
   s->halo = halo;
   s->n_drops = n_droplets;
-  if (const char *f = getenv("WX_FUSED")) s->fused = atoi(f);
-  if (const char *f = getenv("WX_DRY_MARCH")) s->dry_march = atoi(f);
+  s->fused = g_opt_kernel_set ? 2 : 0;
+  s->dry_march = g_opt_dry_kernel;
+  s->bands_mode = g_opt_row_bands;
+  s->fix_cap_request = g_opt_fix_cap;
   const size_t n = ncell(s);
   int rc = WX_OK;
   { // everything allocated below, to the byte (plus the splat grids of handles with droplets)
@@ -1162,7 +1169,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
           sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, s->period_j + 1, s->pool_remote, s->pool_flips, s->pool_owned};
           d_in = d_out = s->drops[0]; // the partitioned pool is updated in place
         }
-        static const int precip_wgs = [] { const char *e = getenv("WX_PRECIP_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+        static const int precip_wgs = [] { const char *e = wx_tune_env("WX_PRECIP_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
         const int chunks = (s->n_drops + 255) / 256;
         hipLaunchKernelGGL(k_precipitation, dim3(chunks < precip_wgs ? chunks : precip_wgs), dim3(256), 0, s->stream, s->geo, u, s->n_drops, d_in,
                            two_kernel ? s->base[0] : ((fused || dry) ? s->base[2] : s->base[1]), s->water[1], s->state, d_out, s->sg, sp,
@@ -1218,8 +1225,33 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
 
 int wx_set_option(wx_sim *s, int option, int value)
 {
-  if (!s) return WX_E_INVALID;
+  if (!s) { // defaults of handles created from now on
+    switch (option) {
+    case WX_OPT_KERNEL_SET: g_opt_kernel_set = value != 0; return WX_OK;
+    case WX_OPT_DRY_KERNEL: g_opt_dry_kernel = value != 0; return WX_OK;
+    case WX_OPT_ROW_BANDS: if (value < 0 || value > 2) return WX_E_INVALID; g_opt_row_bands = value; return WX_OK;
+    case WX_OPT_FIX_CAP: if (value < 0) return WX_E_INVALID; g_opt_fix_cap = value; return WX_OK;
+    default: return WX_E_INVALID;
+    }
+  }
   switch (option) {
+  case WX_OPT_KERNEL_SET:
+    if (int rc = wx_sync(s)) return rc;
+    s->fused = value != 0 ? 2 : 0;
+    return WX_OK;
+  case WX_OPT_DRY_KERNEL:
+    s->dry_march = value != 0;
+    return WX_OK;
+  case WX_OPT_ROW_BANDS:
+    if (value < 0 || value > 2) return fail(s, WX_E_INVALID, "wx_set_option: WX_OPT_ROW_BANDS takes 0, 1 or 2");
+    s->bands_mode = value;
+    s->wet_shape_valid = false;
+    return WX_OK;
+  case WX_OPT_FIX_CAP:
+    if (value < 0) return fail(s, WX_E_INVALID, "wx_set_option: WX_OPT_FIX_CAP >= 0");
+    if (s->fix_cells) return fail(s, WX_E_STATE, "wx_set_option: WX_OPT_FIX_CAP before the first step");
+    s->fix_cap_request = value;
+    return WX_OK;
   case WX_OPT_SPLAT_ORDER: {
     if (value != 0 && value != 1) return fail(s, WX_E_INVALID, "wx_set_option: WX_OPT_SPLAT_ORDER takes 0 (atomics) or 1 (deterministic)");
     if (value && s->n_drops > 0 && !s->det_val) { // the deposit records and the sort's scratch space, once
@@ -1400,7 +1432,7 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
   HIPCHK(s, hipEventCreate(&e1));
   const bool was_profiling = s->profiling; // (the probes' launches are not the caller's)
   s->profiling = false;
-  const bool dbg = getenv("WX_TUNE_DEBUG") != nullptr;
+  const bool dbg = wx_tune_env("WX_TUNE_DEBUG") != nullptr;
   auto probe = [&](float *ms) -> int { // four untimed iterations (launch shape, terrain scan, caches), then the timed ones
     int rc = wx_step(s, 4);
     if (rc == WX_OK && hipEventRecord(e0, s->stream) != hipSuccess) rc = WX_E_DEVICE;

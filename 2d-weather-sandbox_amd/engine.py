@@ -146,6 +146,24 @@ def lib() -> C.CDLL:
     return L
 
 
+def set_default_option(option: int, value: int):
+    """wx_set_option(NULL, ...): the default of handles created afterwards (kernel set, dry kernel, row bands, exact-path capacity)."""
+    rc = lib().wx_set_option(None, int(option), int(value))
+    if rc != 0:
+        raise ValueError(f"wx_set_option(NULL, {option}, {value}) -> {rc}")
+
+
+# The C library reads no environment variable. The test-suite and the experiment scripts select the kernel set etc. per process
+# through these variables, which THIS wrapper turns into wx_set_option defaults before it creates a handle.
+_ENV_OPTIONS = (("WX_FUSED", 3, 1), ("WX_DRY_MARCH", 4, 1), ("WX_WET_BANDS", 5, 1), ("WX_WET_FIX_CAP", 6, 0))
+
+
+def _apply_env_defaults():
+    for name, opt, dflt in _ENV_OPTIONS:
+        v = os.environ.get(name)
+        set_default_option(opt, dflt if v is None else (min(int(v), 1) if opt in (3, 4) else int(v)))
+
+
 class WxError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"libwxsim error {code}: {msg}")
@@ -158,6 +176,7 @@ class Handle:
     def __init__(self, X: int, Y: int, n_droplets: int = 0, *, X_global: Optional[int] = None, x0: int = 0, halo: int = 0):
         L = lib()
         h = C.c_void_p()
+        _apply_env_defaults()
         if X_global is None:
             rc = L.wx_create(X, Y, n_droplets, C.byref(h))
         else:
@@ -260,7 +279,7 @@ class Handle:
         """The host's assertion that EVERY slab of the domain was uploaded water-free (wx_slab_assert_water_free)."""
         self._chk(lib().wx_slab_assert_water_free(self._h, 1 if agreed else 0))
 
-    OPT_SPLAT_ORDER, OPT_CHECK_LAUNCHES = 1, 2
+    OPT_SPLAT_ORDER, OPT_CHECK_LAUNCHES, OPT_KERNEL_SET, OPT_DRY_KERNEL, OPT_ROW_BANDS, OPT_FIX_CAP = 1, 2, 3, 4, 5, 6
 
     def set_option(self, option: int, value: int):
         """wx_set_option: OPT_SPLAT_ORDER 1 = deterministic particle splats (sorted, droplet-index order); OPT_CHECK_LAUNCHES 1 =
@@ -457,6 +476,7 @@ class Group:
     def __init__(self, n_slabs: int, X_global: int, Y: int, halo: int = 42, devices=None, transport: int = TRANSPORT_AUTO):
         L = lib()
         g = C.c_void_p()
+        _apply_env_defaults()
         dev = None
         if devices is not None:
             dev = (C.c_int * n_slabs)(*[int(d) for d in devices])

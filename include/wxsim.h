@@ -153,9 +153,20 @@ int wx_sync(wx_sim *s);
  *      texel's deposits are added in droplet-index order, so the feedback / deposition textures (and everything downstream)
  *      are a pure function of the state. Slower; meant for tests that compare coupled particle runs bit for bit.
  * WX_OPT_CHECK_LAUNCHES: 1 = synchronise after every kernel launch of wx_step and report a fault with the kernel's name
- *   (debugging; the launch status itself is always checked). */
+ *   (debugging; the launch status itself is always checked).
+ * WX_OPT_KERNEL_SET: 1 (default) = the row-marching single-kernel iteration; 0 = one kernel per reference pass -- the independent
+ *   cross-check every parity test also runs. WX_OPT_DRY_KERNEL: the water-free dry iteration as the row-marching kernel (1, default)
+ *   or the LDS-tiled one (0). WX_OPT_ROW_BANDS: launch shape of the marching wet kernel -- 0 column blocks per XCD, 1 (default) row
+ *   bands per XCD on grids at least 512 rows high, 2 row bands on any grid (tests). WX_OPT_FIX_CAP: entries of the exact-path cell
+ *   list (default: a quarter of the grid's cells; tests provoke the overflow report), before the first step.
+ * With s == NULL an option becomes the process-wide default of handles created afterwards (the library itself reads NO environment
+ * variable; tuning switches exist only in -DWX_DEBUG builds). */
 #define WX_OPT_SPLAT_ORDER 1
 #define WX_OPT_CHECK_LAUNCHES 2
+#define WX_OPT_KERNEL_SET 3
+#define WX_OPT_DRY_KERNEL 4
+#define WX_OPT_ROW_BANDS 5
+#define WX_OPT_FIX_CAP 6
 int wx_set_option(wx_sim *s, int option, int value);
 
 /* iterNum global (app.js:440) */

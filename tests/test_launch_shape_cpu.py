@@ -20,7 +20,8 @@ def harness(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
     exe = str(tmp_path_factory.mktemp("shape") / "shape_harness")
-    subprocess.check_call([HIPCC, "-O1", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-o", exe,
+    # -DWX_DEBUG: the tuning environment switches exist only in debug builds (the shipped library reads none)
+    subprocess.check_call([HIPCC, "-O1", "-std=c++17", "--offload-arch=gfx950", "-DWX_DEBUG", "-Wno-unused-value", "-o", exe,
                            os.path.join(ROOT, "tests", "native", "shape_harness.hip")])
     return exe
 

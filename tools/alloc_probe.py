@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Does the kernel time depend on WHERE the planes were allocated? Several handles of the same grid alive at once (different device
 addresses), each timed alone, interleaved; prints kernel time and the device addresses of a few planes."""
+# (tuning environment switches exist only in the -DWX_DEBUG build of the library: make -C 2d-weather-sandbox_amd/csrc debug)
+import os as _os
+_dbg = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "2d-weather-sandbox_amd", "csrc", "variants", "libwxsim_debug.so")
+if "WXSIM_LIB" not in _os.environ and _os.path.exists(_dbg):
+    _os.environ["WXSIM_LIB"] = _dbg
 import os
 import sys
 import time

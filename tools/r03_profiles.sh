@@ -1,5 +1,8 @@
 #!/bin/bash
 # GPU box: the round-3 evidence in one call -> gpurun_out/r3p/ (copied into profiles/ by hand). Sections can be selected: tools/r03_profiles.sh "probe ablation ..."
+# (tuning environment switches exist only in the -DWX_DEBUG build of the library: make -C 2d-weather-sandbox_amd/csrc debug)
+export WXSIM_LIB=${WXSIM_LIB:-$GRAFT_REPO_ROOT/2d-weather-sandbox_amd/csrc/variants/libwxsim_debug.so}
+[ -f "$WXSIM_LIB" ] || make -C $GRAFT_REPO_ROOT/2d-weather-sandbox_amd/csrc debug
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3p; mkdir -p $O; cd $R; export TMPDIR=/tmp
 WHAT=${1:-"probe lottery ubench sweep slabs flow trace_wet trace_dry"}
 has() { [[ " $WHAT " == *" $1 "* ]]; }

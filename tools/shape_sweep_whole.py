@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Launch-shape sweep of the wet marching kernel on the WHOLE metric grid (16384 x 2048): WX_WET_* environment settings, one handle per
 configuration, interleaved repetitions; kernel time from the engine's HIP events. Usage: python tools/shape_sweep_whole.py [X Y]"""
+# (tuning environment switches exist only in the -DWX_DEBUG build of the library: make -C 2d-weather-sandbox_amd/csrc debug)
+import os as _os
+_dbg = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "2d-weather-sandbox_amd", "csrc", "variants", "libwxsim_debug.so")
+if "WXSIM_LIB" not in _os.environ and _os.path.exists(_dbg):
+    _os.environ["WXSIM_LIB"] = _dbg
 import os
 import sys
 import time

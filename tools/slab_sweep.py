@@ -2,6 +2,11 @@
 """Launch-shape sweep of the wet marching kernel on ONE slab shape (default 2144 x 2048 = a configs[2] slab of an 8-GPU run).
 Each configuration = environment settings read by wet_launch_shape (WX_WET_*); a fresh handle per configuration, interleaved repetitions.
 Usage: python tools/slab_sweep.py [X_owned Y halo]"""
+# (tuning environment switches exist only in the -DWX_DEBUG build of the library: make -C 2d-weather-sandbox_amd/csrc debug)
+import os as _os
+_dbg = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "2d-weather-sandbox_amd", "csrc", "variants", "libwxsim_debug.so")
+if "WXSIM_LIB" not in _os.environ and _os.path.exists(_dbg):
+    _os.environ["WXSIM_LIB"] = _dbg
 import os
 import sys
 import time

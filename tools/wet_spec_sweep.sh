@@ -1,5 +1,8 @@
 #!/bin/bash
 # GPU box: wet marching kernel time vs explicit segment-weight lists (WX_WET_SPEC), alpha 1 and 2
+# (tuning environment switches exist only in the -DWX_DEBUG build of the library: make -C 2d-weather-sandbox_amd/csrc debug)
+export WXSIM_LIB=${WXSIM_LIB:-$GRAFT_REPO_ROOT/2d-weather-sandbox_amd/csrc/variants/libwxsim_debug.so}
+[ -f "$WXSIM_LIB" ] || make -C $GRAFT_REPO_ROOT/2d-weather-sandbox_amd/csrc debug
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 run() { python $R/bench.py --steps ${STEPS:-100} --warmup 10 --no-cpu-baseline --no-pmc --no-north-star 2>/dev/null | python -c "
 import json,sys
