@@ -274,6 +274,9 @@ struct SlabP {
   unsigned short *flips;       // per droplet: bit j set = active / inactive status flipped in iteration j of this period (as seen here)
   unsigned char *owned_once;   // per droplet: low 4 bits = last iteration (+1) of this period in which this rank processed it; bit 7 =
                                // processed inside the OWNED columns at least once (this rank reports its flips)
+  int exact;                   // WX_OPT_POOL_EXACT: the ranks exchange their status flips and lightning requests after EVERY iteration
+                               // (wx_pool_events_pack / _apply per iteration), so a lightning request counts once -- from the rank that
+                               // has the spawn position in its OWNED columns -- and is accepted or rejected on the sum over all ranks
 };
 #ifndef WX_ABL_PRECIP
 #define WX_ABL_PRECIP 0 // (timing builds, wrong results) 2: no deposit atomics, 4: the gathers read a fixed texel, 8: the pool is not written back
@@ -288,6 +291,7 @@ struct DevState {
                           // although the host asserted a water-free domain (wx_slab_assert_water_free): reported by the next blocking call
   int fix_overflow;       // set by k_wet_fix when more output cells needed the exact path than its list holds (the entry count)
   int pool_overflow;      // set when an exchange buffer of the partitioned droplet pool received more entries than it holds
+  int pool_retired;       // exact mode: droplets that ended the iteration inactive among this iteration's status flips (k_pool_events_apply)
 };
 
 // Splat accumulation: a 12x12 point sprite anchored at pixel (i0,j0) adds the same value to pixels
@@ -584,6 +588,7 @@ __device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const 
   if (size <= 1.0f) {
     // the only 1-px sprite that reaches this point is a lightning request, drawn at pixel (1,0)
     // (precipitationShader.vert:135-139)
+    if (sp.stamp && sp.exact && !claim) return false; // (exact slabs: the owner of the spawn position files the request, once)
     if (det.key) {
       det.key[i] = det_key_light(sg);
       for (int c = 0; c < 4; c++) det.val[5 * (size_t)i + c] = feedback[c];
@@ -905,9 +910,13 @@ __global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg,
 // lightningLocationShader.frag:24-38 + the 600-iteration inactive count (app.js:5957-5966), one thread
 // (slab handles: the mailbox texels are not part of the local feedback texture -- the request is taken from the
 // accumulator directly, the inactive count is refreshed by wx_pool_edges_pack)
-__global__ void k_lightning(float iterNum, int refresh_inactive, const float4 *__restrict__ fb, DevState *st, int mailbox)
+__global__ void k_lightning(float iterNum, int refresh_inactive, const float4 *__restrict__ fb, DevState *st, int mailbox, int defer)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (defer) { // exact slabs: the request stays in px_light until the ranks have summed theirs (k_pool_exact_resolve)
+    st->px_count = 0.f;
+    return;
+  }
   const float4 n = mailbox ? fb[1] : make_float4(st->px_light[0], st->px_light[1], st->px_light[2], st->px_light[3]); // texel (1,0)
   st->px_count = 0.f; // consumed by k_splat_box
   st->px_light[0] = st->px_light[1] = st->px_light[2] = st->px_light[3] = 0.f;
@@ -933,10 +942,27 @@ struct PoolRec { // 24 bytes: an active droplet handed to a neighbour as ghost c
 // buffers start with a 16-byte header whose first int is the number of entries
 constexpr int POOL_HDR = 16;
 
+// exact mode: the first thread also files this rank's ITERATION RECORD -- an event with gid -1 carrying the lightning request it
+// collected (px_light, then cleared) and the real deposit at the domain's texel (0,0) (what the 600-iteration count reads on top of
+// the inactive count, app.js:5957-5966; NULL on ranks that do not own global column 0)
 __global__ void k_pool_events_pack(int n, int rank, int cap, unsigned short *__restrict__ flips, unsigned char *__restrict__ owned_once,
-                                   const float *__restrict__ drops, int *__restrict__ hdr, PoolEvent *__restrict__ ev)
+                                   const float *__restrict__ drops, int *__restrict__ hdr, PoolEvent *__restrict__ ev, DevState *st, int exact,
+                                   const float4 *__restrict__ fb00)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (exact && i == 0) {
+    const int at = atomicAdd(hdr, 1);
+    if (at < cap) {
+      PoolEvent e;
+      e.gid = -1;
+      e.key = rank;
+      for (int c = 0; c < 4; c++) e.rec[c] = st->px_light[c];
+      e.rec[4] = fb00 ? fb00->x : 0.f;
+      e.pad = 0;
+      ev[at] = e;
+    }
+    st->px_light[0] = st->px_light[1] = st->px_light[2] = st->px_light[3] = 0.f;
+  }
   if (i >= n) return;
   const unsigned f = flips[i], meta = owned_once[i];
   const bool mine = (meta & 0x80) != 0;
@@ -959,12 +985,15 @@ __global__ void k_pool_events_best(int n_ranks, size_t stride_bytes, int cap, co
   const int *hdr = reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
   const PoolEvent *ev = reinterpret_cast<const PoolEvent *>(bufs + (size_t)r * stride_bytes + POOL_HDR);
   const int cnt = min(hdr[0], cap);
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) atomicMin(&best[ev[k].gid], ev[k].key);
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x)
+    if (ev[k].gid >= 0) atomicMin(&best[ev[k].gid], ev[k].key);
 }
 // pass 2: every rank but the reporter takes the winner's record (a rank that spawned a phantom loses it here). Whether an ACTIVE
 // droplet is then tracked here -- as owner or as ghost copy -- is decided by its position in k_pool_edges_pack, which runs next
+// exact mode (events every iteration, edges only once per period): a winner's ACTIVE record is kept as a ghost copy only where it lies
+// inside this rank's local array; `retired` counts the winners that ended the iteration inactive (once per droplet: the winner's)
 __global__ void k_pool_events_apply(int n_ranks, size_t stride_bytes, int cap, const char *__restrict__ bufs, int *__restrict__ best, int my_rank,
-                                    float *__restrict__ drops, unsigned char *__restrict__ remote)
+                                    float *__restrict__ drops, unsigned char *__restrict__ remote, Geo g, int exact, int *__restrict__ retired)
 {
   const int r = blockIdx.y;
   const int *hdr = reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
@@ -972,10 +1001,51 @@ __global__ void k_pool_events_apply(int n_ranks, size_t stride_bytes, int cap, c
   const int cnt = min(hdr[0], cap);
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) {
     const PoolEvent e = ev[k];
-    if (best[e.gid] != e.key || (e.key & 1023) == my_rank) continue;
+    if (e.gid < 0 || best[e.gid] != e.key) continue;
+    if (exact && retired && e.rec[2] < 0.0f) atomicAdd(retired, 1);
+    if ((e.key & 1023) == my_rank) continue;
     for (int c = 0; c < 5; c++) drops[5 * (size_t)e.gid + c] = e.rec[c];
-    remote[e.gid] = 0;
+    unsigned char rem = 0;
+    if (exact && e.rec[2] >= 0.0f) {
+      const int lc = local_col(g, e.rec[0] / 2.0f + 0.5f);
+      rem = (lc < 0 || lc >= g.X) ? 1 : 0;
+    }
+    remote[e.gid] = rem;
   }
+}
+// exact mode, after k_pool_events_apply: the iteration records of all ranks -> the lightning request of the whole domain, accepted or
+// rejected exactly as k_lightning does (two requests of one iteration add up to a start time that is discarded), and -- in the
+// iterations in which the reference refreshes it -- the `inactiveDroplets` uniform: the droplets that were inactive before AND after
+// this iteration (every rank holds every inactive record: counted locally into px_count, minus this iteration's retirements) plus the
+// real deposit at texel (0,0), in the order the mailbox texel is built (box sum + count)
+__global__ void k_pool_exact_resolve(int n_ranks, size_t stride_bytes, int cap, const char *__restrict__ bufs, DevState *st, float iterNum, int refresh,
+                                     const int *__restrict__ retired)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float n[4] = {0.f, 0.f, 0.f, 0.f}, fb00 = 0.f;
+  for (int r = 0; r < n_ranks; r++) { // (rank order: a fixed summation order)
+    const int *hdr = reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
+    const PoolEvent *ev = reinterpret_cast<const PoolEvent *>(bufs + (size_t)r * stride_bytes + POOL_HDR);
+    const int cnt = min(hdr[0], cap);
+    for (int k = 0; k < cnt; k++)
+      if (ev[k].gid < 0) {
+        for (int c = 0; c < 4; c++) n[c] += ev[k].rec[c];
+        fb00 += ev[k].rec[4];
+        break;
+      }
+  }
+  if (refresh) st->inactiveDroplets = fb00 + (st->px_count - (float)retired[0]);
+  st->px_count = 0.f;
+  if (n[2] < fmaxf(iterNum - 1.0f, 1.0f) || n[2] > iterNum) return; // discard
+  for (int c = 0; c < 4; c++) st->lightning[c] = n[c];
+}
+// inactive records this rank holds (exact mode: all of them, current), into px_count
+__global__ void k_pool_count_inactive(int n, const float *__restrict__ drops, const unsigned char *__restrict__ remote, DevState *st)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool inactive = i < n && !remote[i] && drops[5 * (size_t)i + 2] < 0.0f;
+  const unsigned long long m = __ballot(inactive);
+  if (m != 0ull && (threadIdx.x & 63) == __ffsll((long long)m) - 1) unsafeAtomicAdd(&st->px_count, (float)__popcll(m));
 }
 __global__ void k_pool_events_reset(int n_ranks, size_t stride_bytes, int cap, const char *__restrict__ bufs, int *__restrict__ best)
 {
@@ -983,7 +1053,8 @@ __global__ void k_pool_events_reset(int n_ranks, size_t stride_bytes, int cap, c
   const int *hdr = reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
   const PoolEvent *ev = reinterpret_cast<const PoolEvent *>(bufs + (size_t)r * stride_bytes + POOL_HDR);
   const int cnt = min(hdr[0], cap);
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x) best[ev[k].gid] = 0x7fffffff;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += gridDim.x * blockDim.x)
+    if (ev[k].gid >= 0) best[ev[k].gid] = 0x7fffffff;
 }
 // active droplets I hold: outside my owned columns -> the owner is elsewhere (remote); inside and within `halo` columns of an edge ->
 // a ghost copy for that neighbour. count_inactive != 0: also count the inactive records into st->px_count (the 600-iteration refresh

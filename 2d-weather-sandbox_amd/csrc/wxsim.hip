@@ -84,6 +84,8 @@ struct wx_sim {
   int pool_event_cap = 0, pool_edge_cap = 0;
   bool pool_check = false; // an exchange buffer may have overflowed since the flags were last looked at
   int period_j = 0;      // iterations since wx_slab_period_begin: halo - 6*j ghost columns are still valid
+  int pool_exact = 0;    // WX_OPT_POOL_EXACT
+  int exact_pending = 0; // iterations since the last wx_pool_events_apply (exact mode allows one)
   int rank = 0;          // tie-break of the claim keys (wx_slab_set_rank)
   int seam = 0;          // local column of global column 0 if strictly inside the local array
   int64_t iter = 0;
@@ -993,7 +995,7 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 16, s->stream));
   HIPCHK(s, hipMemsetAsync(s->dep, 0, n * 8, s->stream));
   HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
-  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 36, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow, pool_overflow
+  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 40, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow, pool_overflow, pool_retired
   if (s->pool_remote) { // partitioned pool: every rank was handed the whole pool; keep what lies in the local array (owned + ghost columns)
     HIPCHK(s, hipMemsetAsync(s->pool_remote, 0, (size_t)s->n_drops, s->stream));
     HIPCHK(s, hipMemsetAsync(s->pool_owned, 0, (size_t)s->n_drops, s->stream));
@@ -1015,6 +1017,7 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   s->ghost_check = false;
   s->light_planar = false; // the interleaved light textures were just zeroed
   s->period_j = 0;
+  s->exact_pending = 0;
   s->since_exchange = 0; // (wx_slab_step / wx_group_step: the ghost columns are fresh, and not from an exchange)
   s->exchanged = false;
   s->ran_fused = false;
@@ -1121,11 +1124,13 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   // water only a new upload may establish it again -- ADVICE round 3)
   if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] != 0.0f || s->p.soundingForcing != 0.0f) s->water_trivial = s->local_water_free = false;
   if (s->p.userInputType >= 10) s->air_from_row = -1; // wall tools: the terrain may grow (re-measured after the call)
+  if (precip && s->pool_remote && s->pool_exact && n_iter > 0 && (n_iter > 1 || s->exact_pending > 0))
+    return fail(s, WX_E_STATE, "wx_step: WX_OPT_POOL_EXACT takes one iteration per call, each followed by wx_pool_events_pack / all-gather / wx_pool_events_apply");
   if (precip && s->pool_remote && n_iter > 0) { // slab with particles: refuse an over-long call BEFORE any iteration runs
-    const int allowed = std::min((s->halo - 6) / WX_SLAB_CONE, 15) - s->period_j; // (the flip history of a period is a 16-bit mask)
+    const int allowed = WX_SLAB_PERIOD_PARTICLES(s->halo) - s->period_j; // (include/wxsim.h: 6 columns for the first iteration, 9 for every further one)
     if (n_iter > allowed)
       return fail(s, WX_E_STATE, "wx_step: %d iterations asked, %d done since the last halo exchange; %d ghost columns allow %d per period with particles",
-                  n_iter, s->period_j, s->halo, (s->halo - 6) / WX_SLAB_CONE);
+                  n_iter, s->period_j, s->halo, WX_SLAB_PERIOD_PARTICLES(s->halo));
   }
   // overlap needs the kernel that can be launched per strip range; everything else orders the exchange on the compute stream
   const bool can_split = (fused || (dry && dry_marches(s))) && !precip && s->comm_stream != nullptr && s->halo > 0;
@@ -1159,14 +1164,14 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       u.iterI = (int)u.iterNum;
       {
         ProfScope ps(s, K_PRECIP);
-        SlabP sp{0, s->X, 0, s->X, 0, 0, nullptr, nullptr, nullptr};
+        SlabP sp{0, s->X, 0, s->X, 0, 0, nullptr, nullptr, nullptr, 0};
         const float *d_in = s->drops[src];
         float *d_out = s->drops[dst];
         if (s->pool_remote) { // slab: the grid of this iteration is valid on the owned columns + (halo - 6*(j+1)) ghost columns; the
           // feedback texture is exact where every droplet within a sprite radius (6 px) was processed, so the owned columns
           // need 6 valid ghost columns even in the last iteration of a period
-          const int margin = s->halo - WX_SLAB_CONE * (s->period_j + 1); // >= 6: checked before the loop
-          sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, s->period_j + 1, s->pool_remote, s->pool_flips, s->pool_owned};
+          const int margin = s->halo - WX_SLAB_CONE - WX_SLAB_CONE_PARTICLES * s->period_j; // >= 6: checked before the loop
+          sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, s->period_j + 1, s->pool_remote, s->pool_flips, s->pool_owned, s->pool_exact};
           d_in = d_out = s->drops[0]; // the partitioned pool is updated in place
         }
         static const int precip_wgs = [] { const char *e = wx_tune_env("WX_PRECIP_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
@@ -1194,7 +1199,8 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       }
       {
         ProfScope ps(s, K_LIGHTNING);
-        hipLaunchKernelGGL(k_lightning, dim3(1), dim3(64), 0, s->stream, u.iterNum, (int)(s->iter % 600 == 0), s->fb, s->state, s->pool_remote ? 0 : 1);
+        hipLaunchKernelGGL(k_lightning, dim3(1), dim3(64), 0, s->stream, u.iterNum, (int)(s->iter % 600 == 0), s->fb, s->state, s->pool_remote ? 0 : 1,
+                           s->pool_remote && s->pool_exact ? 1 : 0);
         LAUNCH_CHECK(s, "lightning");
       }
       {
@@ -1207,6 +1213,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       s->drop_cur = s->pool_remote ? 0 : dst;
       s->fb_dirty = true;
       if (s->pool_remote) s->period_j++;
+      if (s->pool_remote && s->pool_exact) s->exact_pending++;
     } else if (s->fb_dirty) { // particles were switched off: the reference's clear leaves both textures zero
       hipMemsetAsync(s->fb, 0, n * 16, s->stream);
       hipMemsetAsync(s->dep, 0, n * 8, s->stream);
@@ -1246,6 +1253,12 @@ int wx_set_option(wx_sim *s, int option, int value)
     if (value < 0 || value > 2) return fail(s, WX_E_INVALID, "wx_set_option: WX_OPT_ROW_BANDS takes 0, 1 or 2");
     s->bands_mode = value;
     s->wet_shape_valid = false;
+    return WX_OK;
+  case WX_OPT_POOL_EXACT:
+    if (!s->pool_remote) return fail(s, WX_E_STATE, "wx_set_option: WX_OPT_POOL_EXACT is for slab handles with particles");
+    if (int rc = wx_sync(s)) return rc;
+    s->pool_exact = value != 0;
+    s->exact_pending = 0;
     return WX_OK;
   case WX_OPT_FIX_CAP:
     if (value < 0) return fail(s, WX_E_INVALID, "wx_set_option: WX_OPT_FIX_CAP >= 0");
@@ -1870,8 +1883,10 @@ int wx_pool_events_pack(wx_sim *s, void *dev_buf)
   if (!s || !dev_buf) return WX_E_INVALID;
   POOL_ONLY(s, "wx_pool_events_pack");
   HIPCHK(s, hipMemsetAsync(dev_buf, 0, POOL_HDR, s->stream));
+  // (exact mode: + this rank's iteration record; the deposit at the domain's texel (0,0) comes from the rank that owns global column 0)
   hipLaunchKernelGGL(k_pool_events_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->rank, s->pool_event_cap, s->pool_flips, s->pool_owned,
-                     s->drops[0], (int *)dev_buf, (PoolEvent *)((char *)dev_buf + POOL_HDR));
+                     s->drops[0], (int *)dev_buf, (PoolEvent *)((char *)dev_buf + POOL_HDR), s->state, s->pool_exact,
+                     (s->pool_exact && s->x0 == 0) ? s->fb + s->halo : nullptr);
   HIPCHK(s, hipGetLastError());
   return WX_OK;
 }
@@ -1887,7 +1902,16 @@ int wx_pool_events_apply(wx_sim *s, const void *dev_bufs, int n_ranks, size_t st
   const int cap = (int)((stride - POOL_HDR) / sizeof(PoolEvent)); // entries a rank's (possibly truncated) buffer holds
   hipLaunchKernelGGL(k_pool_check, dim3(1), dim3(64), 0, s->stream, n_ranks, stride, cap, b, s->state);
   hipLaunchKernelGGL(k_pool_events_best, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best);
-  hipLaunchKernelGGL(k_pool_events_apply, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best, s->rank, s->drops[0], s->pool_remote);
+  if (s->pool_exact) HIPCHK(s, hipMemsetAsync(&s->state->pool_retired, 0, 4, s->stream));
+  hipLaunchKernelGGL(k_pool_events_apply, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best, s->rank, s->drops[0], s->pool_remote, s->geo, s->pool_exact,
+                     s->pool_exact ? &s->state->pool_retired : nullptr);
+  if (s->pool_exact && s->exact_pending > 0) { // the iteration that just ran: lightning of the whole domain, the 600-iteration inactive count
+    const int64_t it = s->iter - 1;
+    const int refresh = it % 600 == 0 ? 1 : 0;
+    if (refresh) hipLaunchKernelGGL(k_pool_count_inactive, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->drops[0], s->pool_remote, s->state);
+    hipLaunchKernelGGL(k_pool_exact_resolve, dim3(1), dim3(64), 0, s->stream, n_ranks, stride, cap, b, s->state, (float)it, refresh, &s->state->pool_retired);
+    s->exact_pending = 0;
+  }
   hipLaunchKernelGGL(k_pool_events_reset, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best);
   s->pool_check = true;
   HIPCHK(s, hipGetLastError());

@@ -45,6 +45,11 @@ DEFAULT_HALO = 42       # seven iterations per exchange: amortises the ~0.1 ms P
                         # than on 4180 or 4144 columns (profiles/r03_slab_shapes.txt) -- rows a power-of-two multiple apart share channels
 
 
+def particle_period(halo: int) -> int:
+    """Iterations per exchange of a slab with particles (WX_SLAB_PERIOD_PARTICLES)."""
+    return 0 if halo < 12 else min(15, 1 + (halo - 12) // 9)
+
+
 def slab_columns(X: int, rank: int, world: int):
     if X % world:
         raise ValueError(f"X={X} is not divisible by the number of slabs {world}")
@@ -127,6 +132,9 @@ class HipSlabEngine:
     def pool_edges_apply(self, buf: torch.Tensor):
         self.h.pool_edges_apply(buf.data_ptr())
 
+    def set_pool_exact(self, on: bool):
+        self.h.set_option(Handle.OPT_POOL_EXACT, 1 if on else 0)
+
     def lightning(self):
         return self.h.lightning()
 
@@ -156,23 +164,34 @@ class HipSlabEngine:
         self.h.sync()
 
 
-class SlabSim:
-    """Drives one slab: ``step(n)`` = n iterations with a ring halo exchange every ``halo // 6`` iterations."""
+EXACT_EVENTS_PER_ITERATION = 16384  # status flips a rank can report per iteration in exact mode (the all-gather has a fixed stride: no
+                                     # host round trip for the counts); more is an error reported by the next blocking call
 
-    def __init__(self, engine, rank: int, world: int, halo: int):
+
+class SlabSim:
+    """Drives one slab: ``step(n)`` = n iterations with a ring halo exchange every ``halo // 6`` iterations.
+
+    ``exact`` (slabs with particles, WX_OPT_POOL_EXACT): status flips, lightning requests and the 600-iteration inactive count are
+    all-gathered after EVERY iteration, so that the decomposed run equals the undecomposed one exactly (bit for bit with the
+    deterministic splat order); the grid halos and edge droplets still travel once per period."""
+
+    def __init__(self, engine, rank: int, world: int, halo: int, exact: bool = False):
         if world > 1 and halo < CONE_PER_ITERATION:
             raise ValueError(f"halo must be >= {CONE_PER_ITERATION}")
         self.engine, self.rank, self.world, self.halo = engine, rank, world, halo
         self.particles = getattr(engine, "n_droplets", 0) > 0
         # with particles the owned columns need a sprite radius (6 px) of valid ghost columns in the last iteration too
-        self.iters_per_exchange = max(1, (halo - 6 if self.particles else halo) // CONE_PER_ITERATION)
-        if self.particles:
-            self.iters_per_exchange = min(self.iters_per_exchange, 15)  # (the droplets' flip history of a period is a 16-bit mask)
+        self.iters_per_exchange = max(1, halo // CONE_PER_ITERATION)
+        if self.particles:  # WX_SLAB_PERIOD_PARTICLES (include/wxsim.h): 6 columns for the first iteration, 9 for every further one, a sprite
+            self.iters_per_exchange = particle_period(halo)  # radius left in the last; at most 15 (16-bit flip history)
         self.left, self.right = (rank - 1) % world, (rank + 1) % world
         self._since_exchange = 0
         self._iters = 0
         self._exchanged = False  # ghost columns of the current period came from an exchange (not from the upload)
         self._overlap = world > 1 and bool(getattr(engine, "supports_overlap", False))
+        self.exact = bool(exact or os.environ.get("WX_SLAB_EXACT", "0") == "1") and self.particles and world > 1 and hasattr(engine, "set_pool_exact")
+        if self.exact:
+            engine.set_pool_exact(True)
         if world > 1:
             self.send = [engine.new_buffer(), engine.new_buffer()]  # [to left, to right]
             self.recv = [engine.new_buffer(), engine.new_buffer()]  # [from left, from right]
@@ -224,7 +243,9 @@ class SlabSim:
         with ctx:
             e.pack(0, self.send[0])
             e.pack(1, self.send[1])
-            if self.particles:
+            if self.particles and self.exact:  # flips, lightning and the inactive count are current already (exact_events after every iteration)
+                e.pool_edges_pack(self.psend[0], self.psend[1], False)
+            elif self.particles:
                 # 1. who flipped between active and inactive this period, and what did it become (a few hundred droplets)
                 e.pool_events_pack(self.ev)
                 # The buffer has room for every droplet (the start-up burst of an all-inactive pool), a normal period fills a few KB of it:
@@ -278,10 +299,26 @@ class SlabSim:
                 e.pool_edges_apply(self.precv[0])
                 e.pool_edges_apply(self.precv[1])
         if self.particles:
-            self.reconcile_lightning()
+            if not self.exact:
+                self.reconcile_lightning()
             e.period_begin()
         self._since_exchange = 0
         self._exchanged = True
+
+    def exact_events(self):
+        """Exact mode, after every iteration: all-gather of every rank's status flips + iteration record (lightning request, deposit at
+        texel (0,0)) with a FIXED stride -- nothing waits on the host -- and their application (wx_pool_events_pack / _apply)."""
+        e = self.engine
+        e.pool_events_pack(self.ev)
+        stride = min(len(self.ev), (16 + 32 * (1 + EXACT_EVENTS_PER_ITERATION) + 4095) // 4096 * 4096)
+        mine, every = self.ev[:stride], self.ev_all[:stride * self.world]
+        if self._stage:
+            parts = [torch.empty(stride, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, mine.cpu())
+            every.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(every, mine)
+        e.pool_events_apply(every, self.world, stride)
 
     def reconcile_lightning(self):
         """Every rank's lightning state becomes the latest strike any rank registered: MAX over a strike key, SUM of the winner's four
@@ -316,7 +353,11 @@ class SlabSim:
         done = 0
         while done < n:
             k = min(self.iters_per_exchange - self._since_exchange, n - done)
-            if self._overlap:
+            if self.exact:  # one iteration per call, each followed by the events of all ranks
+                for _ in range(k):
+                    self.engine.step(1)
+                    self.exact_events()
+            elif self._overlap:
                 # first iteration after an exchange: interior strips first, edge strips once the ghosts have arrived;
                 # last iteration before one: edge strips first, so that the exchange starts while the interior computes
                 flags = (2 if (self._since_exchange == 0 and self._exchanged) else 0) | (1 if self._since_exchange + k >= self.iters_per_exchange else 0)
@@ -345,14 +386,14 @@ class SlabSim:
     # ---- construction on the HIP engine ----
     @classmethod
     def from_generator(cls, pkg, X: int, Y: int, u: Dict[str, Any], rank: int, world: int, device: torch.device,
-                       halo: int = DEFAULT_HALO, drops=None, cloud_deck: bool = False) -> "SlabSim":
+                       halo: int = DEFAULT_HALO, drops=None, cloud_deck: bool = False, exact: bool = False) -> "SlabSim":
         """Each rank fills only its own slab (plus ghost columns) of the synthetic terrain grid, on the device
         (wx_setup_columns); ``drops`` is the WHOLE droplet pool (identical on every rank)."""
         x0, xo = slab_columns(X, rank, world)
         eng = HipSlabEngine(X, Y, x0, xo, halo, device, 0 if drops is None else len(drops), rank)
         eng.h.setup_columns(pkg.synth.terrain_columns(X, Y, cols=(x0 - halo, xo + 2 * halo), cloud_deck=cloud_deck), drops)
         eng.set_params(u)
-        return cls(eng, rank, world, halo)
+        return cls(eng, rank, world, halo, exact=exact)
 
     @classmethod
     def from_dry_generator(cls, pkg, X: int, Y: int, u: Dict[str, Any], rank: int, world: int, device: torch.device,
@@ -366,14 +407,14 @@ class SlabSim:
 
     @classmethod
     def from_arrays(cls, X: int, Y: int, base, water, wall, u: Dict[str, Any], rank: int, world: int, device: torch.device,
-                    halo: int = DEFAULT_HALO, drops=None) -> "SlabSim":
+                    halo: int = DEFAULT_HALO, drops=None, exact: bool = False) -> "SlabSim":
         """Cut this rank's slab out of whole-domain arrays (Y, X, 4); ``drops`` is the whole droplet pool."""
         x0, xo = slab_columns(X, rank, world)
         idx = (x0 - halo + np.arange(xo + 2 * halo)) % X
         eng = HipSlabEngine(X, Y, x0, xo, halo, device, 0 if drops is None else len(drops), rank)
         eng.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]), drops)
         eng.set_params(u)
-        return cls(eng, rank, world, halo)
+        return cls(eng, rank, world, halo, exact=exact)
 
     def gather_particles(self) -> Optional[np.ndarray]:
         """The whole droplet pool (n_droplets x 5) assembled on rank 0 (None elsewhere): an active droplet's record comes from the rank

@@ -555,7 +555,7 @@ def main():
         if world == 1:
             deco = "none"
         elif a.particles:
-            deco = f"{world} x-slabs, 64 ghost columns, partitioned droplet pool; every 9 iterations: ring halo exchange + edge droplets (one batch of send/recv), status-flip events (all-gather of a few KB)"
+            deco = f"{world} x-slabs, 64 ghost columns, partitioned droplet pool; every {drv.iters_per_exchange} iterations: ring halo exchange + edge droplets (one batch of send/recv), status-flip events (all-gather of a few KB)"
         else:
             deco = (f"{world} x-slabs, {drv.halo} ghost columns, ring halo exchange every {drv.iters_per_exchange} iterations "
                     "(RCCL send/recv on a side stream, overlapped with compute)")

@@ -110,9 +110,17 @@ int wx_create(int X, int Y, int n_droplets, wx_sim **out);
  * (local width X_owned + 2*halo; local column i is global column (x0 - halo + i) mod X_global). */
 int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_droplets, wx_sim **out);
 /* Dependency cone of one iteration, columns per side: `halo` ghost columns stay exact for halo / WX_SLAB_CONE
- * iterations ((halo - 6) / WX_SLAB_CONE with particles: the feedback texture needs every droplet within a sprite radius),
- * then the halo must be exchanged (wx_halo_pack / wx_halo_unpack). */
+ * iterations, then the halo must be exchanged (wx_halo_pack / wx_halo_unpack).
+ * With particles the cone is wider from the second iteration of a period on: a droplet deposits within a sprite radius (6 columns) of
+ * where it is, and the next boundary pass feeds that deposit through advection and pressure (3 more) -- 9 columns per iteration, after 6
+ * for the first (whose feedback texture came with the exchange). Iteration j (0-based) of a period is exact on the owned columns +
+ * halo - 6 - 9j ghost columns, droplets are processed there, and the owned columns need a sprite radius of that left in the last
+ * iteration: WX_SLAB_PERIOD_PARTICLES(halo) iterations per exchange (at most 15: the flip history is a 16-bit mask).
+ * (Rounds 2-3 assumed 6 per iteration throughout, which the measured spread -- 6 to 7 columns -- satisfied in every test but the
+ * worst case does not.) */
 #define WX_SLAB_CONE 6
+#define WX_SLAB_CONE_PARTICLES 9
+#define WX_SLAB_PERIOD_PARTICLES(halo) ((halo) < 12 ? 0 : ((1 + ((halo) - 12) / WX_SLAB_CONE_PARTICLES) < 15 ? (1 + ((halo) - 12) / WX_SLAB_CONE_PARTICLES) : 15))
 
 void wx_destroy(wx_sim *s);
 const char *wx_last_error(const wx_sim *s); /* also valid with s == NULL for create failures */
@@ -167,6 +175,16 @@ int wx_sync(wx_sim *s);
 #define WX_OPT_DRY_KERNEL 4
 #define WX_OPT_ROW_BANDS 5
 #define WX_OPT_FIX_CAP 6
+/* WX_OPT_POOL_EXACT (slab handles with particles): 1 = the partitioned droplet pool reproduces the undecomposed run EXACTLY. The
+ *   default protocol exchanges nothing inside an exchange period, so a droplet that retires is not probed for re-spawning by the other
+ *   ranks until the next exchange, a droplet can spawn a second time from a stale record, and the lightning state / inactive count are
+ *   a period late. In exact mode the hosts run ONE iteration per wx_step and follow it with wx_pool_events_pack -> all-gather ->
+ *   wx_pool_events_apply: the buffers then also carry every rank's lightning request (summed over the ranks before the accept test of
+ *   lightningLocationShader.frag:24-38, so two requests in one iteration cancel as in the reference) and, every 600 iterations, what the
+ *   `inactiveDroplets` refresh needs (app.js:5957-5966). Grid halos and edge droplets still travel once per period. With
+ *   WX_OPT_SPLAT_ORDER 1 the slabs are then bit-identical to one handle (SURVEY 8e's determinism check); the price is a latency-bound
+ *   all-gather of a few KB per iteration. */
+#define WX_OPT_POOL_EXACT 7
 int wx_set_option(wx_sim *s, int option, int value);
 
 /* iterNum global (app.js:440) */
@@ -250,7 +268,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags);
  * it (and, as a ghost copy, by the neighbour while it is within `halo` columns of the common edge); the other ranks only know
  * "active elsewhere" and skip it. Inactive droplets are static records that every rank holds; every rank tests every inactive
  * record's hashed spawn probe (precipitationShader.vert:82-84: anywhere in the domain) against its own columns and acts on the ones
- * that land where its grid is valid. Nothing is communicated inside an exchange period ((halo - 6) / WX_SLAB_CONE iterations, at
+ * that land where its grid is valid. Nothing is communicated inside an exchange period (WX_SLAB_PERIOD_PARTICLES(halo) iterations, at
  * most 15). At the halo exchange (all buffers are DEVICE pointers; calls are enqueued on the handle's stream):
  *   wx_pool_events_pack  -> all-gather of the buffers -> wx_pool_events_apply(gathered, n_ranks, stride_bytes):
  *       a buffer = 16-byte header (first int32: number of events) + 32-byte events, wx_pool_event_bytes() in all (room for every

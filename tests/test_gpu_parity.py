@@ -966,7 +966,7 @@ def test_slab_particles_equal_whole_domain(pkg, E, nslab, order):
     pr = [torch.zeros(h.pool_edge_bytes(), dtype=torch.uint8, device="cuda") for h in slabs]
     f0 = np.stack([h.pool_flags() for h in slabs])  # after the upload: every active droplet has one owner, the far ranks dropped it
     assert ((f0 == 2).sum(0) == (drops[:, 2] >= 0)).all() and (f0 == 0).sum() > 0
-    per = (halo - 6) // 6  # a sprite radius of valid ghost columns must remain in the last iteration
+    per = 1 + (halo - 12) // 9  # WX_SLAB_PERIOD_PARTICLES: 6 columns for the first iteration of a period, 9 for every further one
     with pytest.raises(E.WxError):  # more iterations than the ghost columns allow: refused before any iteration runs
         slabs[0].step(per + 1)
     assert slabs[0].iter == 0
@@ -1013,6 +1013,152 @@ def test_slab_particles_equal_whole_domain(pkg, E, nslab, order):
     for h in slabs:
         h.close()
     whole.close()
+
+
+def _pool_exact_iteration(slabs, nslab, ev):
+    """WX_OPT_POOL_EXACT: one iteration on every slab, then the per-iteration all-gather of status flips + iteration records."""
+    import torch
+    for h in slabs:
+        h.step(1)
+    for r, h in enumerate(slabs):
+        h.pool_events_pack(ev[r].data_ptr())
+        h.sync()
+    most = max(int(e[:4].view(torch.int32)[0]) for e in ev)
+    stride = min(len(ev[0]), (16 + most * 32 + 4095) // 4096 * 4096)
+    gathered = torch.cat([e[:stride] for e in ev]).contiguous()
+    for h in slabs:
+        h.pool_events_apply(gathered.data_ptr(), nslab, stride)
+    return most
+
+
+def _exact_period_end(slabs, nslab, bufs, pl, pr):
+    """... and once per period: grid halos + edge droplets (no events, no lightning reconciliation: both are current already)."""
+    for r, h in enumerate(slabs):
+        h.halo_pack(0, bufs[r][0].data_ptr())
+        h.halo_pack(1, bufs[r][1].data_ptr())
+    for h in slabs:
+        h.sync()
+    for r, h in enumerate(slabs):
+        h.halo_unpack(0, bufs[(r - 1) % nslab][1].data_ptr())
+        h.halo_unpack(1, bufs[(r + 1) % nslab][0].data_ptr())
+    for r, h in enumerate(slabs):
+        h.pool_edges_pack(pl[r].data_ptr(), pr[r].data_ptr(), False)
+        h.sync()
+    for r, h in enumerate(slabs):
+        h.pool_edges_apply(pr[(r - 1) % nslab].data_ptr())
+        h.pool_edges_apply(pl[(r + 1) % nslab].data_ptr())
+        h.sync()
+        h.slab_period_begin()
+
+
+@pytest.mark.parametrize("nslab", [2, 4])
+def test_slab_particles_exact_mode_is_bit_identical(pkg, E, nslab):
+    """WX_OPT_POOL_EXACT (SURVEY 8e's determinism check with particles): status flips, lightning requests and the 600-iteration inactive
+    count exchanged after EVERY iteration. A spawn-heavy scene -- a cold dense cloud deck, most of the pool inactive, spawn chance raised so
+    that droplets spawn, retire and re-spawn within one exchange period, lightning strikes -- run across iteration 600 with the
+    deterministic splat order: pool, feedback, deposition, lightning state and every grid field equal the undecomposed handle bit for bit
+    after every period; the default (per-period) protocol on the same scene does not."""
+    import torch
+    X, Y, halo, N = 512, 128, 64, 8000
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    pkg.synth.add_cloud_deck(water, wall)
+    rng = np.random.default_rng(11)
+    air = wall[..., 1] != 0
+    base[..., 0] += np.where(air, rng.normal(0, 0.3, (Y, X)), 0).astype(np.float32)
+    deck = air & (water[..., 1] > 0)
+    water[..., 1] += np.where(deck, 2.5, 0).astype(np.float32)  # dense: lightning requests
+    water[..., 0] += np.where(deck, 2.5, 0).astype(np.float32)
+    base[..., 3] -= np.where(deck, 25.0, 0).astype(np.float32)   # cold: snow spawns
+    drops = pkg.synth.init_rain_drops(N)
+    na = 1500
+    drops[:na, 0] = rng.uniform(-1, 1, na).astype(np.float32)
+    drops[:na, 1] = rng.uniform(-0.8, 0.3, na).astype(np.float32)
+    drops[:na, 2] = rng.uniform(0.03, 0.2, na).astype(np.float32)  # light: many evaporate (retire) soon
+    drops[:na, 3] = 0
+    drops[:na, 4] = 1.0
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 35.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 1
+    u["inactiveDroplets"] = float(N - na)
+    u["spawnChanceMult"] = 2e-3
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    xo, per, it0 = X // nslab, 1 + (halo - 12) // 9, 585
+    results = {}
+    for exact in (1, 0):
+        whole = E.Handle(X, Y, N)
+        whole.upload(base, water, wall, drops)
+        whole.set_params(p, u["initial_T"])
+        whole.set_option(whole.OPT_SPLAT_ORDER, 1)
+        whole.iter = it0
+        slabs, bufs = [], []
+        for r in range(nslab):
+            h = E.Handle(xo, Y, N, X_global=X, x0=r * xo, halo=halo)
+            h.slab_set_rank(r)
+            idx = (r * xo - halo + np.arange(xo + 2 * halo)) % X
+            h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]), drops)
+            h.set_params(p, u["initial_T"])
+            h.set_option(h.OPT_SPLAT_ORDER, 1)
+            h.set_option(h.OPT_POOL_EXACT, exact)
+            h.iter = it0
+            slabs.append(h)
+            bufs.append([torch.empty(h.halo_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2)])
+        ev = [torch.zeros(h.pool_event_bytes(), dtype=torch.uint8, device="cuda") for h in slabs]
+        pl = [torch.zeros(h.pool_edge_bytes(), dtype=torch.uint8, device="cuda") for h in slabs]
+        pr = [torch.zeros(h.pool_edge_bytes(), dtype=torch.uint8, device="cuda") for h in slabs]
+        if exact:
+            with pytest.raises(E.WxError):  # one iteration per call in exact mode
+                slabs[0].step(2)
+        identical, flips, strikes = True, 0, set()
+        for period in range(6):  # 36 iterations: 585 .. 620, across the refresh of iteration 600
+            if exact:
+                for _ in range(per):
+                    flips += _pool_exact_iteration(slabs, nslab, ev)
+                    strikes.add(float(slabs[0].lightning()[2]))
+                _exact_period_end(slabs, nslab, bufs, pl, pr)
+            else:
+                for h in slabs:
+                    h.step(per)
+                for r, h in enumerate(slabs):
+                    h.halo_pack(0, bufs[r][0].data_ptr())
+                    h.halo_pack(1, bufs[r][1].data_ptr())
+                for h in slabs:
+                    h.sync()
+                for r, h in enumerate(slabs):
+                    h.halo_unpack(0, bufs[(r - 1) % nslab][1].data_ptr())
+                    h.halo_unpack(1, bufs[(r + 1) % nslab][0].data_ptr())
+                _pool_exchange(slabs, nslab, ev, pl, pr)
+            whole.step(per)
+            d_ref = whole.read_particles()
+            if exact:
+                d, f = _assemble_pool(slabs)  # (asserts: one owner per active droplet, inactive records identical on every rank)
+            else:  # the default protocol may leave a stale record behind until a later exchange: assemble without those assertions
+                dd, f = [h.read_particles() for h in slabs], np.stack([h.pool_flags() for h in slabs])
+                d = dd[0].copy()
+                for k in range(nslab):
+                    d[f[k] == 2] = dd[k][f[k] == 2]
+            same = np.array_equal(d, d_ref) and all(np.array_equal(h.lightning(), whole.lightning()) for h in slabs)
+            for fld in ("PRECIP_FB", "PRECIP_DEP", "BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1"):
+                ref = whole.read_rect(fld)
+                for r, h in enumerate(slabs):
+                    a, b = h.read_rect(fld, halo, 0, xo, Y), ref[:, r * xo:(r + 1) * xo]
+                    if fld == "PRECIP_FB" and r == 0:
+                        a, b = a.copy(), b.copy()
+                        a[0, :2], b[0, :2] = 0, 0
+                    same = same and np.array_equal(a, b)
+            if exact:
+                assert same, f"period {period}: exact mode differs from the undecomposed handle"
+            identical = identical and same
+        results[exact] = identical
+        if exact:
+            spawned = int(((drops[:, 2] < 0) & (d_ref[:, 2] >= 0)).sum())
+            print(f"exact mode: {flips} status-flip events in 36 iterations, {spawned} of the initially inactive droplets active at the end, strike times seen {sorted(strikes)}")
+            assert flips > 400, "the scene must exercise the protocol"
+            assert max(strikes) > 0, "no lightning strike: the scene does not test the request path"
+        for h in slabs:
+            h.close()
+        whole.close()
+    assert results[1] and not results[0], results
 
 
 @pytest.mark.parametrize("X,Y,cols", [(512, 128, None), (130, 50, None), (4096, 256, (4000, 300))])

@@ -267,7 +267,7 @@ def _particle_worker(rank, world, port, out_dir):
     X, halo, n = 256 * world, 64, 8
     eng = ModelPoolEngine(rank, world, n, X, halo)
     drv = slab.SlabSim(eng, rank, world, halo)
-    assert drv.particles and drv.iters_per_exchange == (64 - 6) // 6
+    assert drv.particles and drv.iters_per_exchange == 1 + (64 - 12) // 9 == 6
     px = lambda col: np.float32((col + 0.5) / X * 2 - 1)
     xo, last = X // world, world - 1
     P = eng.pool

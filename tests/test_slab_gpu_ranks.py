@@ -51,8 +51,11 @@ def _worker(rank, world, port, out_dir, particles):
     base, water, wall, drops, u = _problem(pkg)
     if not particles:
         drops, u["enablePrecipitation"] = None, 0
-    drv = slab.SlabSim.from_arrays(X, Y, base, water, wall, u, rank, world, torch.device("cuda", 0), halo=HALO, drops=drops)
-    assert drv.iters_per_exchange == (9 if particles else 10)
+    exact = particles == "exact"
+    drv = slab.SlabSim.from_arrays(X, Y, base, water, wall, u, rank, world, torch.device("cuda", 0), halo=HALO, drops=drops, exact=exact)
+    assert drv.iters_per_exchange == (6 if particles else 10) and drv.exact == exact
+    if exact:
+        drv.handle.set_option(drv.handle.OPT_SPLAT_ORDER, 1)
     drv.step(N_ITER)
     drv.exchange()  # settle ownership of the droplets before reading the pool
     drv.sync()
@@ -67,8 +70,11 @@ def _worker(rank, world, port, out_dir, particles):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("particles", [False, True], ids=["grid", "particles"])
+@pytest.mark.parametrize("particles", [False, True, "exact"], ids=["grid", "particles", "particles-exact"])
 def test_slab_sim_two_ranks(pkg, tmp_path, particles):
+    """slab.SlabSim in two processes on the GPU (gloo transport): grid only (bit-identical), the partitioned droplet pool (atomics: to
+    summation order), and WX_OPT_POOL_EXACT with the deterministic splat order: the per-iteration all-gather of slab.py's exact_events
+    makes pool, feedback and every field BIT-IDENTICAL to the single handle."""
     import torch
     import torch.multiprocessing as mp
     E = pkg.engine
@@ -84,6 +90,9 @@ def test_slab_sim_two_ranks(pkg, tmp_path, particles):
     whole = E.Handle(X, Y, N if particles else 0)
     whole.upload(base, water, wall, drops)
     whole.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    exact = particles == "exact"
+    if exact:
+        whole.set_option(whole.OPT_SPLAT_ORDER, 1)
     whole.step(N_ITER)
     assert np.abs(whole.read_rect("BASE_CUR")[..., :2]).max() < 1.0  # precondition of the 6-column cone
     xo = X // 2
@@ -93,7 +102,7 @@ def test_slab_sim_two_ranks(pkg, tmp_path, particles):
             d_ref = whole.read_particles()
             assert (d_ref[:, 2] >= 0).sum() > 300
             assert np.array_equal(got["drops"][:, 2] >= 0, d_ref[:, 2] >= 0)
-            assert np.abs(got["drops"] - d_ref).max() <= 1e-6
+            assert np.array_equal(got["drops"], d_ref) if exact else np.abs(got["drops"] - d_ref).max() <= 1e-6
             flags = np.stack([np.load(os.path.join(str(tmp_path), f"rank{q}.npz"))["flags"] for q in range(2)])
             assert np.array_equal((flags == 2).sum(0), (d_ref[:, 2] >= 0).astype(int))  # one owner per active droplet
             assert (flags[:, d_ref[:, 2] < 0] == 1).all()  # inactive records: on every rank
@@ -104,7 +113,7 @@ def test_slab_sim_two_ranks(pkg, tmp_path, particles):
                 a, b = a.copy(), b.copy()
                 a[0, :2], b[0, :2] = 0, 0  # the reference's mailbox texels are not kept on slabs
             d = np.abs(a - b).max(-1)
-            assert d.max() <= (1e-6 * max(1.0, np.abs(b).max()) if particles else 0.0), (f, r, d.max(), np.nonzero((d > 1e-6).any(0))[0][:20])
+            assert d.max() <= (1e-6 * max(1.0, np.abs(b).max()) if particles and not exact else 0.0), (f, r, d.max(), np.nonzero((d > 1e-6).any(0))[0][:20])
 
 
 @pytest.mark.parametrize("workload,grid", [("wet", (2048, 256)), ("dry", (4096, 512))])
