@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--workload", choices=["wet", "dry"], default="wet",
                     help="wet: BASELINE configs[2] (default, the metric's config); dry: configs[1] pressure+velocity+advection only")
     ap.add_argument("--particles", type=int, default=0, help="also run the particle pass with N droplets (BASELINE configs[4])")
+    ap.add_argument("--splat-order", type=int, default=0, choices=[0, 1], help="with --particles: 1 = deterministic splat order (WX_OPT_SPLAT_ORDER: a sort per iteration)")
     ap.add_argument("--frame", type=int, default=10, help="iterations per wx_step call (the reference's IterPerFrame, app.js:398)")
     ap.add_argument("--flow", type=float, default=0.2, help="std of the seeded velocity field, cells / iteration (0: fluid at rest)")
     ap.add_argument("--flow-kind", choices=["eddies", "noise"], default="eddies",
@@ -408,6 +409,8 @@ def main():
             h.setup_columns(pkg.synth.terrain_columns(X, Y, cloud_deck=bool(a.particles)),
                             pkg.synth.init_rain_drops(a.particles) if a.particles else None)
         h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+        if a.particles and a.splat_order:
+            h.set_option(h.OPT_SPLAT_ORDER, 1)
         return h
 
     x0_owned = 0
