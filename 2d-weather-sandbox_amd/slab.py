@@ -79,11 +79,16 @@ class HipSlabEngine:
         self._light = None
         self._light_gen = -1
 
-    def comm_init_native(self, rank: int, world: int):
-        """RCCL inside the library (wx_comm_init): rank 0 draws the 128-byte id, torch.distributed only carries it to the others."""
+    @staticmethod
+    def comm_unique_id(rank: int) -> bytes:
+        """Rank 0 draws the 128-byte id of the library's RCCL communicator, torch.distributed only carries it to the others."""
         box = [Handle.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        self.h.comm_init(box[0], rank, world)
+        return box[0]
+
+    def comm_init_native(self, rank: int, world: int, uid: bytes):
+        """RCCL inside the library (wx_comm_init)."""
+        self.h.comm_init(uid, rank, world)
 
     @property
     def supports_overlap(self) -> bool:
@@ -207,10 +212,35 @@ class SlabSim:
         # unpack on the handle's comm stream); torch.distributed is then only the launcher and the carrier of the communicator's id.
         # The host-driven path below stays for slabs with particles and for the gloo transport of the CPU tests.
         self._native = False
+        self.transport = "host-driven (torch.distributed send / recv)"
         if (world > 1 and not self.particles and hasattr(engine, "comm_init_native") and dist.get_backend() == "nccl"
                 and os.environ.get("WX_SLAB_NATIVE", "1") != "0"):
-            engine.comm_init_native(rank, world)
-            self._native = True
+            # First contact insurance: communicator set-up and one real exchange (harmless right after an upload: the ghosts receive the
+            # values they already hold) under a watchdog -- a transport that cannot be initialised falls back to the host-driven
+            # exchange, one that hangs ends the process with a readable message instead of a silent timeout.
+            import threading
+            done, err = threading.Event(), []
+            uid = engine.comm_unique_id(rank)  # (a torch collective: on the main thread, whose current device is this rank's)
+
+            def first_contact():  # (library calls only: they make the handle's own device current themselves)
+                try:
+                    engine.comm_init_native(rank, world, uid)
+                    engine.h.exchange()
+                    engine.h.sync()
+                except Exception as e:  # noqa: BLE001
+                    err.append(e)
+                done.set()
+            threading.Thread(target=first_contact, daemon=True).start()
+            if not done.wait(float(os.environ.get("WX_DIST_TIMEOUT_S", "180"))):
+                print(f'{{"error": "rank {rank}: the in-library RCCL transport (wx_comm_init / wx_exchange) did not complete; set WX_SLAB_NATIVE=0 for the host-driven exchange"}}', flush=True)
+                os._exit(3)
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=self.send[0].device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # (all ranks or none)
+            if int(ok.item()) == 1:
+                self._native = True
+                self.transport = "in-library RCCL (wx_comm_init / wx_slab_step: ncclSend / ncclRecv on the comm stream)"
+            elif err:
+                print(f"[slab] rank {rank}: in-library transport unavailable ({err[0]}); using the host-driven exchange", flush=True)
 
     def agree_water_free(self):
         """The water-free dry iteration (36 B/cell) is only valid on a slab if NO slab of the domain carries water (ghost columns

@@ -576,7 +576,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "grid": [X, Y], "decomposition": deco, "iteration_algorithmic_bytes_per_cell": A,
                        "frame": a.frame, "flow_std": a.flow, "flow_kind": a.flow_kind},
-            "ranks_seen": ranks_seen, "verify": verify, "placement": placement,
+            "ranks_seen": ranks_seen, "verify": verify, "placement": placement, "transport": getattr(drv, "transport", None) if drv is not None else None,
             "flow": {"start_of_warmup": flow0, "end_of_timed_region": flow1},
             "iteration_roofline_frac_A_wet": cells * a.steps * A / dt / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roof,
