@@ -25,6 +25,7 @@ struct RcclApi {
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string why;
 };
@@ -52,6 +53,7 @@ static RcclApi *rccl_api()
       WX_SYM(GroupEnd, "ncclGroupEnd");
       WX_SYM(Send, "ncclSend");
       WX_SYM(Recv, "ncclRecv");
+      WX_SYM(AllGather, "ncclAllGather");
       WX_SYM(GetErrorString, "ncclGetErrorString");
 #undef WX_SYM
       if (!ok) {
@@ -70,13 +72,22 @@ static const char *rccl_missing() { return "RCCL is not available in this proces
     if (r_ != ncclSuccess) return fail((s), WX_E_DEVICE, "%s: %s", #expr, rccl_api()->GetErrorString(r_));          \
   } while (0)
 
-static int iters_per_exchange(const wx_sim *s) { return std::max(1, s->halo / WX_SLAB_CONE); }
+static int iters_per_exchange(const wx_sim *s) { return s->pool_remote ? std::max(1, WX_SLAB_PERIOD_PARTICLES(s->halo)) : std::max(1, s->halo / WX_SLAB_CONE); }
+// the stream the exchange of a slab runs on: its comm stream (grid-only slabs: overlapped with compute), else its compute stream
+// (slabs with particles: the pool exchange needs the finished iteration, so everything stays in order)
+static hipStream_t xstream(const wx_sim *s) { return s->comm_stream ? s->comm_stream : s->stream; }
+// bytes per rank in the all-gather of status-flip events: a fixed stride (no host round trip for the counts); a rank with more
+// flips than fit is reported by the next blocking call (pool_overflow)
+static size_t pool_stride(const wx_sim *s)
+{
+  const size_t want = (POOL_HDR + sizeof(PoolEvent) * (size_t)(1 + s->pool_stride_events) + 4095) / 4096 * 4096;
+  return std::min(want, wx_pool_event_bytes(s));
+}
 
-// send / recv buffers, a comm stream of the library's own if the host has not set one
-static int transport_prepare(wx_sim *s)
+// send / recv buffers (+ the droplet-pool buffers of slabs with particles), a comm stream of the library's own for grid-only slabs
+static int transport_prepare(wx_sim *s, int world)
 {
   if (s->halo == 0) return fail(s, WX_E_STATE, "the handle has no ghost columns (wx_create_slab with halo > 0)");
-  if (s->pool_remote) return fail(s, WX_E_STATE, "slabs with particles exchange through the host (slab.py): the droplet-pool protocol is not in wx_exchange yet");
   const size_t bytes = wx_halo_bytes(s);
   if (s->xbytes != bytes) {
     for (int i = 0; i < 2; i++) {
@@ -88,7 +99,21 @@ static int transport_prepare(wx_sim *s)
     }
     s->xbytes = bytes;
   }
-  if (!s->comm_stream) {
+  if (s->pool_remote && (!s->ev_mine || s->ev_world != world)) {
+    hipFree(s->ev_mine);
+    hipFree(s->ev_all);
+    s->ev_mine = s->ev_all = nullptr;
+    const size_t eb = wx_pool_event_bytes(s), gb = wx_pool_edge_bytes(s);
+    if (hipMalloc((void **)&s->ev_mine, eb) != hipSuccess || hipMalloc((void **)&s->ev_all, pool_stride(s) * (size_t)world) != hipSuccess)
+      return fail(s, WX_E_NOMEM, "droplet-pool event buffers");
+    for (int i = 0; i < 2; i++) {
+      hipFree(s->psend[i]);
+      hipFree(s->precv[i]);
+      if (hipMalloc((void **)&s->psend[i], gb) != hipSuccess || hipMalloc((void **)&s->precv[i], gb) != hipSuccess) return fail(s, WX_E_NOMEM, "droplet-pool edge buffers");
+    }
+    s->ev_world = world;
+  }
+  if (!s->pool_remote && !s->comm_stream) {
     if (!s->own_comm_stream) HIPCHK(s, hipStreamCreateWithFlags(&s->own_comm_stream, hipStreamNonBlocking));
     if (int rc = wx_set_comm_stream(s, s->own_comm_stream)) return rc;
   }
@@ -104,12 +129,18 @@ void transport_release(wx_sim *s)
   for (int i = 0; i < 2; i++) {
     hipFree(s->xsend[i]);
     hipFree(s->xrecv[i]);
-    s->xsend[i] = s->xrecv[i] = nullptr;
+    hipFree(s->psend[i]);
+    hipFree(s->precv[i]);
+    s->xsend[i] = s->xrecv[i] = s->psend[i] = s->precv[i] = nullptr;
   }
+  hipFree(s->ev_mine);
+  hipFree(s->ev_all);
+  s->ev_mine = s->ev_all = nullptr;
   s->xbytes = 0;
-  if (s->ev_packed) hipEventDestroy(s->ev_packed);
-  if (s->ev_copied) hipEventDestroy(s->ev_copied);
-  s->ev_packed = s->ev_copied = nullptr;
+  for (hipEvent_t *e : {&s->ev_packed, &s->ev_copied, &s->ev_evpacked, &s->ev_evcopied}) {
+    if (*e) hipEventDestroy(*e);
+    *e = nullptr;
+  }
   if (s->own_comm_stream) {
     if (s->comm_stream == s->own_comm_stream) s->comm_stream = nullptr;
     hipStreamDestroy(s->own_comm_stream);
@@ -120,6 +151,229 @@ void transport_release(wx_sim *s)
     hipStreamDestroy(s->own_stream);
     s->own_stream = nullptr;
   }
+}
+
+// ---- the exchange, written once for both ways of running it ----
+// The slabs this process drives: one (a rank of a job, RCCL) or all of them (a group, RCCL between devices or device-to-device copies).
+struct Party {
+  wx_sim *s;
+  ncclComm_t comm; // RCCL transports
+  int rank;        // position in the ring
+};
+struct Ring {
+  std::vector<Party> p;
+  int world = 1;
+  int transport = WX_TRANSPORT_RCCL;
+  std::string *err = nullptr; // where a group wants its messages
+};
+static int rfail(Ring &R, wx_sim *s, int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (s) s->err = buf;
+  if (R.err) *R.err = buf;
+  return code;
+}
+static int rpass(Ring &R, wx_sim *s, int rc)
+{
+  if (rc != WX_OK && R.err) *R.err = s->err;
+  return rc;
+}
+// local transport: every slab's exchange stream waits for event `ev` of every OTHER slab (or of its two ring neighbours only)
+static int local_wait(Ring &R, hipEvent_t wx_sim::*ev, bool neighbours_only)
+{
+  const int n = (int)R.p.size();
+  for (int i = 0; i < n; i++) {
+    wx_sim *s = R.p[i].s;
+    DeviceScope ds(s);
+    for (int r = 0; r < n; r++) {
+      if (r == i || (neighbours_only && r != (i + 1) % n && r != (i + n - 1) % n)) continue;
+      if (hipStreamWaitEvent(xstream(s), R.p[r].s->*ev, 0) != hipSuccess) return rfail(R, s, WX_E_DEVICE, "hipStreamWaitEvent");
+    }
+  }
+  return WX_OK;
+}
+static int local_record(Ring &R, hipEvent_t wx_sim::*ev)
+{
+  for (Party &q : R.p) {
+    DeviceScope ds(q.s);
+    if (hipEventRecord(q.s->*ev, xstream(q.s)) != hipSuccess) return rfail(R, q.s, WX_E_DEVICE, "hipEventRecord");
+  }
+  return WX_OK;
+}
+
+// status flips (+ the iteration / period record, `mode`: 1 = exact mode's lightning request, 2 = this rank's lightning state) of every
+// slab -> all-gather -> applied on every slab
+static int pool_events_round(Ring &R, int mode)
+{
+  const bool local = R.transport == WX_TRANSPORT_LOCAL;
+  if (local) // nobody may still be copying my previous events
+    if (int rc = local_wait(R, &wx_sim::ev_evcopied, false)) return rc;
+  for (Party &q : R.p) {
+    DeviceScope ds(q.s);
+    if (int rc = rpass(R, q.s, pool_events_pack_mode(q.s, q.s->ev_mine, mode))) return rc;
+  }
+  if (local) {
+    if (int rc = local_record(R, &wx_sim::ev_evpacked)) return rc;
+    if (int rc = local_wait(R, &wx_sim::ev_evpacked, false)) return rc;
+    for (Party &q : R.p) {
+      wx_sim *s = q.s;
+      DeviceScope ds(s);
+      const size_t stride = pool_stride(s);
+      for (Party &o : R.p)
+        if (hipMemcpyAsync(s->ev_all + (size_t)o.rank * stride, o.s->ev_mine, stride, hipMemcpyDefault, xstream(s)) != hipSuccess)
+          return rfail(R, s, WX_E_DEVICE, "device-to-device copy of the status-flip events");
+    }
+    if (int rc = local_record(R, &wx_sim::ev_evcopied)) return rc;
+  } else {
+    RcclApi *a = rccl_api();
+    if (a->GroupStart() != ncclSuccess) return rfail(R, nullptr, WX_E_DEVICE, "ncclGroupStart");
+    for (Party &q : R.p) {
+      DeviceScope ds(q.s);
+      const ncclResult_t r = a->AllGather(q.s->ev_mine, q.s->ev_all, pool_stride(q.s), ncclUint8, q.comm, xstream(q.s));
+      if (r != ncclSuccess) {
+        a->GroupEnd();
+        return rfail(R, q.s, WX_E_DEVICE, "ncclAllGather of the status-flip events: %s", a->GetErrorString(r));
+      }
+    }
+    if (a->GroupEnd() != ncclSuccess) return rfail(R, nullptr, WX_E_DEVICE, "ncclGroupEnd");
+  }
+  for (Party &q : R.p) {
+    DeviceScope ds(q.s);
+    if (int rc = rpass(R, q.s, pool_events_apply_mode(q.s, q.s->ev_all, R.world, pool_stride(q.s), mode))) return rc;
+  }
+  return WX_OK;
+}
+
+// One exchange of every slab of the ring: my left edge -> the left neighbour's right ghosts, my right edge -> the right neighbour's left
+// ghosts; with particles also the droplet pool (status flips unless the exact mode already sent them, edge droplets in the same batch of
+// transfers as the grid halos).
+static int ring_exchange(Ring &R)
+{
+  const int n = (int)R.p.size();
+  if (R.world < 2) return WX_OK;
+  const bool local = R.transport == WX_TRANSPORT_LOCAL;
+  const bool particles = R.p[0].s->pool_remote != nullptr;
+  if (local) // my send buffers are free once both neighbours have copied the previous exchange out of them
+    if (int rc = local_wait(R, &wx_sim::ev_copied, true)) return rc;
+  for (Party &q : R.p) { // (grid-only slabs: on the comm stream, behind the edge strips only)
+    DeviceScope ds(q.s);
+    if (int rc = rpass(R, q.s, wx_halo_pack(q.s, 0, q.s->xsend[0]))) return rc;
+    if (int rc = rpass(R, q.s, wx_halo_pack(q.s, 1, q.s->xsend[1]))) return rc;
+  }
+  if (particles && !R.p[0].s->pool_exact)
+    if (int rc = pool_events_round(R, 2)) return rc;
+  if (particles)
+    for (Party &q : R.p) { // ownership by position; the droplets near my edges become the neighbours' ghost copies
+      wx_sim *s = q.s;
+      DeviceScope ds(s);
+      const int refresh = !s->pool_exact && (s->iter / 600) != ((s->iter - s->since_exchange) / 600); // app.js:5957-5966: every 600 iterations
+      if (int rc = rpass(R, s, wx_pool_edges_pack(s, s->psend[0], s->psend[1], refresh))) return rc;
+    }
+  if (local) {
+    if (int rc = local_record(R, &wx_sim::ev_packed)) return rc;
+    if (int rc = local_wait(R, &wx_sim::ev_packed, true)) return rc;
+    for (int i = 0; i < n; i++) {
+      wx_sim *s = R.p[i].s, *L = R.p[(i + n - 1) % n].s, *Rt = R.p[(i + 1) % n].s;
+      DeviceScope ds(s);
+      bool ok = hipMemcpyAsync(s->xrecv[0], L->xsend[1], s->xbytes, hipMemcpyDefault, xstream(s)) == hipSuccess && // left ghosts <- left neighbour's right edge
+                hipMemcpyAsync(s->xrecv[1], Rt->xsend[0], s->xbytes, hipMemcpyDefault, xstream(s)) == hipSuccess; // right ghosts <- right neighbour's left edge
+      if (ok && particles) {
+        const size_t gb = wx_pool_edge_bytes(s);
+        ok = hipMemcpyAsync(s->precv[0], L->psend[1], gb, hipMemcpyDefault, xstream(s)) == hipSuccess &&
+             hipMemcpyAsync(s->precv[1], Rt->psend[0], gb, hipMemcpyDefault, xstream(s)) == hipSuccess;
+      }
+      if (!ok) return rfail(R, s, WX_E_DEVICE, "device-to-device halo copy of slab %d: %s", i, hipGetErrorString(hipGetLastError()));
+    }
+    if (int rc = local_record(R, &wx_sim::ev_copied)) return rc;
+  } else {
+    // (two ranks: both neighbours are the same peer -- messages between a pair match in order, so what I receive first is the peer's
+    // first send, its LEFT edge, which belongs into my RIGHT ghosts)
+    RcclApi *a = rccl_api();
+    if (a->GroupStart() != ncclSuccess) return rfail(R, nullptr, WX_E_DEVICE, "ncclGroupStart");
+    for (Party &q : R.p) {
+      wx_sim *s = q.s;
+      DeviceScope ds(s);
+      const int left = (q.rank + R.world - 1) % R.world, right = (q.rank + 1) % R.world;
+      hipStream_t st = xstream(s);
+      ncclResult_t r = a->Send(s->xsend[0], s->xbytes, ncclUint8, left, q.comm, st);
+      if (r == ncclSuccess) r = a->Send(s->xsend[1], s->xbytes, ncclUint8, right, q.comm, st);
+      if (r == ncclSuccess) r = a->Recv(s->xrecv[1], s->xbytes, ncclUint8, right, q.comm, st);
+      if (r == ncclSuccess) r = a->Recv(s->xrecv[0], s->xbytes, ncclUint8, left, q.comm, st);
+      if (particles) {
+        const size_t gb = wx_pool_edge_bytes(s);
+        if (r == ncclSuccess) r = a->Send(s->psend[0], gb, ncclUint8, left, q.comm, st);
+        if (r == ncclSuccess) r = a->Send(s->psend[1], gb, ncclUint8, right, q.comm, st);
+        if (r == ncclSuccess) r = a->Recv(s->precv[1], gb, ncclUint8, right, q.comm, st);
+        if (r == ncclSuccess) r = a->Recv(s->precv[0], gb, ncclUint8, left, q.comm, st);
+      }
+      if (r != ncclSuccess) {
+        a->GroupEnd();
+        return rfail(R, s, WX_E_DEVICE, "ncclSend / ncclRecv of slab %d: %s", q.rank, a->GetErrorString(r));
+      }
+    }
+    if (a->GroupEnd() != ncclSuccess) return rfail(R, nullptr, WX_E_DEVICE, "ncclGroupEnd");
+  }
+  for (Party &q : R.p) { // into the ghost columns (grid-only: records the event the next edge strips wait for)
+    wx_sim *s = q.s;
+    DeviceScope ds(s);
+    if (int rc = rpass(R, s, wx_halo_unpack(s, 0, s->xrecv[0]))) return rc;
+    if (int rc = rpass(R, s, wx_halo_unpack(s, 1, s->xrecv[1]))) return rc;
+    if (particles) {
+      if (int rc = rpass(R, s, wx_pool_edges_apply(s, s->precv[0]))) return rc;
+      if (int rc = rpass(R, s, wx_pool_edges_apply(s, s->precv[1]))) return rc;
+      if (int rc = rpass(R, s, wx_slab_period_begin(s))) return rc;
+    }
+    s->since_exchange = 0;
+    s->exchanged = true;
+  }
+  return WX_OK;
+}
+
+// n iterations of every slab of the ring with the exchanges that fall into them
+static int ring_step(Ring &R, int n_iter)
+{
+  wx_sim *s0 = R.p[0].s;
+  if (R.world < 2) {
+    for (Party &q : R.p) {
+      DeviceScope ds(q.s);
+      if (int rc = rpass(R, q.s, wx_step(q.s, n_iter))) return rc;
+    }
+    return WX_OK;
+  }
+  const int ipe = iters_per_exchange(s0);
+  const bool particles = s0->pool_remote != nullptr, exact = particles && s0->pool_exact;
+  for (int done = 0; done < n_iter;) {
+    const int k = std::min(ipe - s0->since_exchange, n_iter - done);
+    if (exact) { // one iteration at a time, each followed by the status flips / lightning requests of all slabs
+      for (int it = 0; it < k; it++) {
+        for (Party &q : R.p) {
+          DeviceScope ds(q.s);
+          if (int rc = rpass(R, q.s, wx_step(q.s, 1))) return rc;
+          q.s->since_exchange += 1;
+        }
+        if (int rc = pool_events_round(R, 1)) return rc;
+      }
+    } else {
+      for (Party &q : R.p) {
+        wx_sim *s = q.s;
+        DeviceScope ds(s);
+        // the iteration before an exchange launches its edge strips first, the one after it its interior strips first (wx_step_overlap;
+        // slabs with particles run in order)
+        unsigned flags = 0;
+        if (!particles) flags = ((s->since_exchange == 0 && s->exchanged) ? WX_OVERLAP_EDGES_LAST : 0u) | (s->since_exchange + k >= ipe ? WX_OVERLAP_EDGES_FIRST : 0u);
+        if (int rc = rpass(R, s, wx_step_overlap(s, k, flags))) return rc;
+        s->since_exchange += k;
+      }
+    }
+    done += k;
+    if (s0->since_exchange >= ipe)
+      if (int rc = ring_exchange(R)) return rc;
+  }
+  return WX_OK;
 }
 
 int wx_comm_unique_id(void *id128)
@@ -144,7 +398,7 @@ int wx_comm_init(wx_sim *s, const void *id128, int rank, int world)
   // global column would lie in the local array twice)
   if (world == 1 && s->halo != 0) return fail(s, WX_E_INVALID, "wx_comm_init: a job of one rank takes a handle without ghost columns (halo 0)");
   if (world > 1)
-    if (int rc = transport_prepare(s)) return rc;
+    if (int rc = transport_prepare(s, world)) return rc;
   if (s->comm) {
     a->CommDestroy((ncclComm_t)s->comm);
     s->comm = nullptr;
@@ -160,61 +414,34 @@ int wx_comm_init(wx_sim *s, const void *id128, int rank, int world)
   return WX_OK;
 }
 
-// ring exchange of one rank: my left edge -> the left neighbour's right ghosts, my right edge -> the right neighbour's left ghosts
+static Ring ring_of(wx_sim *s)
+{
+  Ring R;
+  R.p.push_back(Party{s, (ncclComm_t)s->comm, s->comm_rank});
+  R.world = s->comm_world;
+  R.transport = WX_TRANSPORT_RCCL;
+  return R;
+}
+
+// ring exchange of one rank (all of it enqueued; nothing waits on the host)
 int wx_exchange(wx_sim *s)
 {
   if (!s) return WX_E_INVALID;
   if (!s->comm) return fail(s, WX_E_STATE, "wx_exchange before wx_comm_init");
-  DeviceScope ds(s);
-  if (s->comm_world > 1) {
-    if (int rc = transport_prepare(s)) return rc;
-    if (int rc = wx_halo_pack(s, 0, s->xsend[0])) return rc;
-    if (int rc = wx_halo_pack(s, 1, s->xsend[1])) return rc;
-    RcclApi *a = rccl_api();
-    const int left = (s->comm_rank + s->comm_world - 1) % s->comm_world, right = (s->comm_rank + 1) % s->comm_world;
-    ncclComm_t c = (ncclComm_t)s->comm;
-    // (two ranks: both neighbours are the same peer -- messages between a pair match in order, so what I receive first is the peer's
-    // first send, its LEFT edge, which belongs into my RIGHT ghosts)
-    NCCLCHK(s, a->GroupStart());
-    NCCLCHK(s, a->Send(s->xsend[0], s->xbytes, ncclUint8, left, c, s->comm_stream));
-    NCCLCHK(s, a->Send(s->xsend[1], s->xbytes, ncclUint8, right, c, s->comm_stream));
-    NCCLCHK(s, a->Recv(s->xrecv[1], s->xbytes, ncclUint8, right, c, s->comm_stream));
-    NCCLCHK(s, a->Recv(s->xrecv[0], s->xbytes, ncclUint8, left, c, s->comm_stream));
-    NCCLCHK(s, a->GroupEnd());
-    if (int rc = wx_halo_unpack(s, 0, s->xrecv[0])) return rc;
-    if (int rc = wx_halo_unpack(s, 1, s->xrecv[1])) return rc;
-  }
-  s->since_exchange = 0;
-  s->exchanged = true;
-  return WX_OK;
-}
-
-// the iterations of one call up to the next exchange, with the launch order that overlaps it (see wx_step_overlap)
-static int slab_advance(wx_sim *s, int k, bool lone)
-{
-  const int ipe = iters_per_exchange(s);
-  unsigned flags = 0;
-  if (!lone) flags = ((s->since_exchange == 0 && s->exchanged) ? WX_OVERLAP_EDGES_LAST : 0u) | (s->since_exchange + k >= ipe ? WX_OVERLAP_EDGES_FIRST : 0u);
-  if (int rc = wx_step_overlap(s, k, flags)) return rc;
-  s->since_exchange += k;
-  return WX_OK;
+  if (s->comm_world > 1)
+    if (int rc = transport_prepare(s, s->comm_world)) return rc;
+  Ring R = ring_of(s);
+  return ring_exchange(R);
 }
 
 int wx_slab_step(wx_sim *s, int n_iter)
 {
   if (!s || n_iter < 0) return WX_E_INVALID;
   if (!s->comm) return fail(s, WX_E_STATE, "wx_slab_step before wx_comm_init");
-  DeviceScope ds(s);
-  if (s->comm_world == 1) return wx_step(s, n_iter);
-  const int ipe = iters_per_exchange(s);
-  for (int done = 0; done < n_iter;) {
-    const int k = std::min(ipe - s->since_exchange, n_iter - done);
-    if (int rc = slab_advance(s, k, false)) return rc;
-    done += k;
-    if (s->since_exchange >= ipe)
-      if (int rc = wx_exchange(s)) return rc;
-  }
-  return WX_OK;
+  if (s->comm_world > 1)
+    if (int rc = transport_prepare(s, s->comm_world)) return rc;
+  Ring R = ring_of(s);
+  return ring_step(R, n_iter);
 }
 
 // ---- N slabs in one process ----
@@ -240,6 +467,15 @@ static int gpass(wx_group *g, wx_sim *s, int rc)
 {
   if (rc != WX_OK) g->err = s->err;
   return rc;
+}
+static Ring ring_of(wx_group *g)
+{
+  Ring R;
+  for (size_t i = 0; i < g->slab.size(); i++) R.p.push_back(Party{g->slab[i], g->comms.empty() ? nullptr : g->comms[i], (int)i});
+  R.world = (int)g->slab.size();
+  R.transport = g->transport;
+  R.err = &g->err;
+  return R;
 }
 
 const char *wx_group_last_error(const wx_group *g) { return g ? g->err.c_str() : g_create_error.c_str(); }
@@ -272,8 +508,9 @@ int wx_group_create(int n_slabs, const int *devices, int X_global, int Y, int ha
   if (!out) return WX_E_INVALID;
   *out = nullptr;
   if (n_slabs < 1 || X_global % n_slabs) return gfail(nullptr, WX_E_INVALID, "wx_group_create: X_global = %d is not divisible by %d slabs", X_global, n_slabs);
-  if (n_droplets != 0) return gfail(nullptr, WX_E_INVALID, "wx_group_create: slabs with particles exchange through the host (slab.py) for now");
+  if (n_droplets < 0) return gfail(nullptr, WX_E_INVALID, "wx_group_create: n_droplets < 0");
   if (n_slabs > 1 && halo < WX_SLAB_CONE) return gfail(nullptr, WX_E_INVALID, "wx_group_create: halo >= %d", WX_SLAB_CONE);
+  if (n_slabs > 1 && n_droplets > 0 && WX_SLAB_PERIOD_PARTICLES(halo) < 1) return gfail(nullptr, WX_E_INVALID, "wx_group_create: slabs with particles need halo >= 12");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return gfail(nullptr, WX_E_DEVICE, "no HIP device available: libwxsim has no CPU fallback");
   std::vector<int> dev(n_slabs);
@@ -300,7 +537,7 @@ int wx_group_create(int n_slabs, const int *devices, int X_global, int Y, int ha
       break;
     }
     wx_sim *s = nullptr;
-    rc = wx_create_slab(X_global, Y, i * xo, xo, n_slabs > 1 ? halo : 0, 0, &s);
+    rc = wx_create_slab(X_global, Y, i * xo, xo, n_slabs > 1 ? halo : 0, n_droplets, &s);
     if (rc != WX_OK) break;
     g->slab[i] = s;
     s->rank = i;
@@ -308,9 +545,9 @@ int wx_group_create(int n_slabs, const int *devices, int X_global, int Y, int ha
     if (hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking) != hipSuccess) rc = gfail(nullptr, WX_E_DEVICE, "hipStreamCreate");
     else s->stream = s->own_stream;
     if (rc == WX_OK && n_slabs > 1) {
-      rc = transport_prepare(s);
-      if (rc == WX_OK && (hipEventCreateWithFlags(&s->ev_packed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_copied, hipEventDisableTiming) != hipSuccess))
-        rc = gfail(nullptr, WX_E_DEVICE, "hipEventCreate");
+      rc = transport_prepare(s, n_slabs);
+      for (hipEvent_t *e : {&s->ev_packed, &s->ev_copied, &s->ev_evpacked, &s->ev_evcopied})
+        if (rc == WX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) rc = gfail(nullptr, WX_E_DEVICE, "hipEventCreate");
       if (rc != WX_OK && g_create_error.empty()) g_create_error = s->err;
     }
   }
@@ -320,7 +557,7 @@ int wx_group_create(int n_slabs, const int *devices, int X_global, int Y, int ha
   }
   if (rc == WX_OK && transport == WX_TRANSPORT_LOCAL && n_slabs > 1) // copies between slabs on different devices go directly where the devices allow it
     for (int i = 0; i < n_slabs; i++)
-      for (int nb : {(i + 1) % n_slabs, (i + n_slabs - 1) % n_slabs})
+      for (int nb = 0; nb < n_slabs; nb++)
         if (dev[nb] != dev[i] && hipSetDevice(dev[i]) == hipSuccess && hipDeviceEnablePeerAccess(dev[nb], 0) != hipSuccess) (void)hipGetLastError();
   (void)hipSetDevice(prev);
   if (rc != WX_OK) {
@@ -344,60 +581,13 @@ int wx_group_agree(wx_group *g)
   return WX_OK;
 }
 
-static int group_exchange(wx_group *g)
+// an option on every slab (WX_OPT_SPLAT_ORDER, WX_OPT_POOL_EXACT ...)
+int wx_group_set_option(wx_group *g, int option, int value)
 {
-  const int n = (int)g->slab.size();
-  if (n == 1) return WX_OK;
-  // 1. every slab packs its two edges on its comm stream (behind its edge strips)
-  for (int i = 0; i < n; i++) {
-    wx_sim *s = g->slab[i];
+  if (!g) return WX_E_INVALID;
+  for (wx_sim *s : g->slab) {
     DeviceScope ds(s);
-    if (g->transport == WX_TRANSPORT_LOCAL) { // my send buffers are free once both neighbours have copied the previous exchange out of them
-      for (int nb : {(i + n - 1) % n, (i + 1) % n})
-        if (hipStreamWaitEvent(s->comm_stream, g->slab[nb]->ev_copied, 0) != hipSuccess) return gfail(g, WX_E_DEVICE, "hipStreamWaitEvent");
-    }
-    if (int rc = gpass(g, s, wx_halo_pack(s, 0, s->xsend[0]))) return rc;
-    if (int rc = gpass(g, s, wx_halo_pack(s, 1, s->xsend[1]))) return rc;
-    if (g->transport == WX_TRANSPORT_LOCAL && hipEventRecord(s->ev_packed, s->comm_stream) != hipSuccess) return gfail(g, WX_E_DEVICE, "hipEventRecord");
-  }
-  // 2. the transfers
-  if (g->transport == WX_TRANSPORT_RCCL) {
-    RcclApi *a = rccl_api();
-    if (a->GroupStart() != ncclSuccess) return gfail(g, WX_E_DEVICE, "ncclGroupStart");
-    for (int i = 0; i < n; i++) {
-      wx_sim *s = g->slab[i];
-      DeviceScope ds(s);
-      const int left = (i + n - 1) % n, right = (i + 1) % n;
-      ncclResult_t r = a->Send(s->xsend[0], s->xbytes, ncclUint8, left, g->comms[i], s->comm_stream);
-      if (r == ncclSuccess) r = a->Send(s->xsend[1], s->xbytes, ncclUint8, right, g->comms[i], s->comm_stream);
-      if (r == ncclSuccess) r = a->Recv(s->xrecv[1], s->xbytes, ncclUint8, right, g->comms[i], s->comm_stream);
-      if (r == ncclSuccess) r = a->Recv(s->xrecv[0], s->xbytes, ncclUint8, left, g->comms[i], s->comm_stream);
-      if (r != ncclSuccess) {
-        a->GroupEnd();
-        return gfail(g, WX_E_DEVICE, "ncclSend / ncclRecv of slab %d: %s", i, a->GetErrorString(r));
-      }
-    }
-    if (a->GroupEnd() != ncclSuccess) return gfail(g, WX_E_DEVICE, "ncclGroupEnd");
-  } else {
-    for (int i = 0; i < n; i++) {
-      wx_sim *s = g->slab[i];
-      DeviceScope ds(s);
-      wx_sim *L = g->slab[(i + n - 1) % n], *R = g->slab[(i + 1) % n];
-      if (hipStreamWaitEvent(s->comm_stream, L->ev_packed, 0) != hipSuccess || hipStreamWaitEvent(s->comm_stream, R->ev_packed, 0) != hipSuccess ||
-          hipMemcpyAsync(s->xrecv[0], L->xsend[1], s->xbytes, hipMemcpyDefault, s->comm_stream) != hipSuccess || // left ghosts <- left neighbour's right edge
-          hipMemcpyAsync(s->xrecv[1], R->xsend[0], s->xbytes, hipMemcpyDefault, s->comm_stream) != hipSuccess || // right ghosts <- right neighbour's left edge
-          hipEventRecord(s->ev_copied, s->comm_stream) != hipSuccess)
-        return gfail(g, WX_E_DEVICE, "device-to-device halo copy of slab %d: %s", i, hipGetErrorString(hipGetLastError()));
-    }
-  }
-  // 3. unpack into the ghost columns (records the event the next edge strips wait for)
-  for (int i = 0; i < n; i++) {
-    wx_sim *s = g->slab[i];
-    DeviceScope ds(s);
-    if (int rc = gpass(g, s, wx_halo_unpack(s, 0, s->xrecv[0]))) return rc;
-    if (int rc = gpass(g, s, wx_halo_unpack(s, 1, s->xrecv[1]))) return rc;
-    s->since_exchange = 0;
-    s->exchanged = true;
+    if (int rc = gpass(g, s, wx_set_option(s, option, value))) return rc;
   }
   return WX_OK;
 }
@@ -405,20 +595,17 @@ static int group_exchange(wx_group *g)
 int wx_group_step(wx_group *g, int n_iter)
 {
   if (!g || n_iter < 0) return WX_E_INVALID;
-  const int n = (int)g->slab.size();
-  wx_sim *s0 = g->slab[0];
-  const int ipe = iters_per_exchange(s0);
-  for (int done = 0; done < n_iter;) {
-    const int k = n == 1 ? n_iter - done : std::min(ipe - s0->since_exchange, n_iter - done);
-    for (wx_sim *s : g->slab) {
-      DeviceScope ds(s);
-      if (int rc = gpass(g, s, n == 1 ? wx_step(s, k) : slab_advance(s, k, false))) return rc;
-    }
-    done += k;
-    if (n > 1 && s0->since_exchange >= ipe)
-      if (int rc = group_exchange(g)) return rc;
-  }
-  return WX_OK;
+  Ring R = ring_of(g);
+  return ring_step(R, n_iter);
+}
+
+// brings the droplet pool to the state right after an exchange (every active droplet owned by exactly one slab): what a host
+// calls before it reads the pool of a group inside a period
+int wx_group_exchange(wx_group *g)
+{
+  if (!g) return WX_E_INVALID;
+  Ring R = ring_of(g);
+  return ring_exchange(R);
 }
 
 int wx_group_sync(wx_group *g)

@@ -950,18 +950,18 @@ __global__ void k_pool_events_pack(int n, int rank, int cap, unsigned short *__r
                                    const float4 *__restrict__ fb00)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (exact && i == 0) {
+  if (exact && i == 0) { // exact: 1 = the iteration record (lightning REQUEST), 2 = the period record (this rank's lightning STATE)
     const int at = atomicAdd(hdr, 1);
     if (at < cap) {
       PoolEvent e;
       e.gid = -1;
       e.key = rank;
-      for (int c = 0; c < 4; c++) e.rec[c] = st->px_light[c];
+      for (int c = 0; c < 4; c++) e.rec[c] = exact == 1 ? st->px_light[c] : st->lightning[c];
       e.rec[4] = fb00 ? fb00->x : 0.f;
       e.pad = 0;
       ev[at] = e;
     }
-    st->px_light[0] = st->px_light[1] = st->px_light[2] = st->px_light[3] = 0.f;
+    if (exact == 1) st->px_light[0] = st->px_light[1] = st->px_light[2] = st->px_light[3] = 0.f;
   }
   if (i >= n) return;
   const unsigned f = flips[i], meta = owned_once[i];
@@ -1038,6 +1038,29 @@ __global__ void k_pool_exact_resolve(int n_ranks, size_t stride_bytes, int cap, 
   st->px_count = 0.f;
   if (n[2] < fmaxf(iterNum - 1.0f, 1.0f) || n[2] > iterNum) return; // discard
   for (int c = 0; c < 4; c++) st->lightning[c] = n[c];
+}
+// per-period protocol through the library's transport: every rank's lightning state travels as its period record; the latest strike
+// wins (equal start times: the lower rank), as slab.py's reconcile_lightning does with two all-reduces
+__global__ void k_pool_lightning_latest(int n_ranks, size_t stride_bytes, int cap, const char *__restrict__ bufs, DevState *st)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float best[4] = {0.f, 0.f, 0.f, 0.f};
+  bool have = false;
+  for (int r = 0; r < n_ranks; r++) {
+    const int *hdr = reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
+    const PoolEvent *ev = reinterpret_cast<const PoolEvent *>(bufs + (size_t)r * stride_bytes + POOL_HDR);
+    const int cnt = min(hdr[0], cap);
+    for (int k = 0; k < cnt; k++)
+      if (ev[k].gid < 0) {
+        if (ev[k].rec[2] > 0.f && (!have || ev[k].rec[2] > best[2])) {
+          for (int c = 0; c < 4; c++) best[c] = ev[k].rec[c];
+          have = true;
+        }
+        break;
+      }
+  }
+  if (have)
+    for (int c = 0; c < 4; c++) st->lightning[c] = best[c];
 }
 // inactive records this rank holds (exact mode: all of them, current), into px_count
 __global__ void k_pool_count_inactive(int n, const float *__restrict__ drops, const unsigned char *__restrict__ remote, DevState *st)

@@ -141,6 +141,11 @@ struct wx_sim {
   size_t xbytes = 0;
   hipStream_t own_stream = nullptr, own_comm_stream = nullptr; // streams the library created itself (groups, wx_comm_init)
   hipEvent_t ev_packed = nullptr, ev_copied = nullptr;         // in-process transport: my send buffers are full / my recv copies are done
+  char *ev_mine = nullptr, *ev_all = nullptr;                           // slabs with particles: my status-flip events / everybody's (all-gathered)
+  int ev_world = 0;
+  char *psend[2] = {nullptr, nullptr}, *precv[2] = {nullptr, nullptr}; // ... and the edge droplets to / from the ring neighbours
+  hipEvent_t ev_evpacked = nullptr, ev_evcopied = nullptr;
+  int pool_stride_events = 65536; // events per rank the all-gather of the library's transport carries (fixed stride: no host round trip)
   int since_exchange = 0;         // iterations since the ghost columns were last fresh (upload or exchange)
   bool exchanged = false;         // ... and they came from an exchange (the next step may run its interior strips first)
   int air_from_row = -1;       // lowest row above which every cell is free air (cost model of the row segmentation); -1: to be measured
@@ -1878,15 +1883,23 @@ size_t wx_pool_edge_bytes(const wx_sim *s) { return s && s->pool_remote ? POOL_H
 #define POOL_ONLY(s, what) \
   if (!(s)->pool_remote) return fail((s), WX_E_STATE, what ": not a slab handle with particles")
 
+// mode: 0 = status flips only, 1 = + the iteration record of the exact mode (lightning request, deposit at texel (0,0)), 2 = + the
+// period record of the library's own transport (this rank's lightning state)
+static int pool_events_pack_mode(wx_sim *s, void *dev_buf, int mode);
+static int pool_events_apply_mode(wx_sim *s, const void *dev_bufs, int n_ranks, size_t stride_bytes, int mode);
 int wx_pool_events_pack(wx_sim *s, void *dev_buf)
 {
   if (!s || !dev_buf) return WX_E_INVALID;
   POOL_ONLY(s, "wx_pool_events_pack");
+  return pool_events_pack_mode(s, dev_buf, s->pool_exact ? 1 : 0);
+}
+static int pool_events_pack_mode(wx_sim *s, void *dev_buf, int mode)
+{
   HIPCHK(s, hipMemsetAsync(dev_buf, 0, POOL_HDR, s->stream));
   // (exact mode: + this rank's iteration record; the deposit at the domain's texel (0,0) comes from the rank that owns global column 0)
   hipLaunchKernelGGL(k_pool_events_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->rank, s->pool_event_cap, s->pool_flips, s->pool_owned,
-                     s->drops[0], (int *)dev_buf, (PoolEvent *)((char *)dev_buf + POOL_HDR), s->state, s->pool_exact,
-                     (s->pool_exact && s->x0 == 0) ? s->fb + s->halo : nullptr);
+                     s->drops[0], (int *)dev_buf, (PoolEvent *)((char *)dev_buf + POOL_HDR), s->state, mode,
+                     (mode == 1 && s->x0 == 0) ? s->fb + s->halo : nullptr);
   HIPCHK(s, hipGetLastError());
   return WX_OK;
 }
@@ -1895,6 +1908,10 @@ int wx_pool_events_apply(wx_sim *s, const void *dev_bufs, int n_ranks, size_t st
 {
   if (!s || !dev_bufs || n_ranks < 1) return WX_E_INVALID;
   POOL_ONLY(s, "wx_pool_events_apply");
+  return pool_events_apply_mode(s, dev_bufs, n_ranks, stride_bytes, s->pool_exact ? 1 : 0);
+}
+static int pool_events_apply_mode(wx_sim *s, const void *dev_bufs, int n_ranks, size_t stride_bytes, int mode)
+{
   const size_t stride = stride_bytes ? stride_bytes : wx_pool_event_bytes(s);
   if (stride < (size_t)POOL_HDR || stride > wx_pool_event_bytes(s)) return fail(s, WX_E_INVALID, "wx_pool_events_apply: stride %zu outside 16 .. %zu", stride, wx_pool_event_bytes(s));
   const dim3 grid(64, n_ranks), block(256);
@@ -1902,10 +1919,11 @@ int wx_pool_events_apply(wx_sim *s, const void *dev_bufs, int n_ranks, size_t st
   const int cap = (int)((stride - POOL_HDR) / sizeof(PoolEvent)); // entries a rank's (possibly truncated) buffer holds
   hipLaunchKernelGGL(k_pool_check, dim3(1), dim3(64), 0, s->stream, n_ranks, stride, cap, b, s->state);
   hipLaunchKernelGGL(k_pool_events_best, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best);
-  if (s->pool_exact) HIPCHK(s, hipMemsetAsync(&s->state->pool_retired, 0, 4, s->stream));
-  hipLaunchKernelGGL(k_pool_events_apply, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best, s->rank, s->drops[0], s->pool_remote, s->geo, s->pool_exact,
-                     s->pool_exact ? &s->state->pool_retired : nullptr);
-  if (s->pool_exact && s->exact_pending > 0) { // the iteration that just ran: lightning of the whole domain, the 600-iteration inactive count
+  if (mode == 1) HIPCHK(s, hipMemsetAsync(&s->state->pool_retired, 0, 4, s->stream));
+  hipLaunchKernelGGL(k_pool_events_apply, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best, s->rank, s->drops[0], s->pool_remote, s->geo, mode == 1 ? 1 : 0,
+                     mode == 1 ? &s->state->pool_retired : nullptr);
+  if (mode == 2) hipLaunchKernelGGL(k_pool_lightning_latest, dim3(1), dim3(64), 0, s->stream, n_ranks, stride, cap, b, s->state);
+  if (mode == 1 && s->exact_pending > 0) { // the iteration that just ran: lightning of the whole domain, the 600-iteration inactive count
     const int64_t it = s->iter - 1;
     const int refresh = it % 600 == 0 ? 1 : 0;
     if (refresh) hipLaunchKernelGGL(k_pool_count_inactive, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->drops[0], s->pool_remote, s->state);

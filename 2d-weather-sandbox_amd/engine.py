@@ -35,7 +35,8 @@ EXPORTS = [
     "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait", "wx_set_comm_stream", "wx_step_overlap",
     "wx_set_option", "wx_water_free", "wx_slab_assert_water_free", "wx_tune_placement",
     "wx_comm_unique_id", "wx_comm_init", "wx_exchange", "wx_slab_step", "wx_group_create", "wx_group_destroy", "wx_group_last_error",
-    "wx_group_count", "wx_group_transport", "wx_group_slab", "wx_group_agree", "wx_group_step", "wx_group_sync",
+    "wx_group_count", "wx_group_transport", "wx_group_slab", "wx_group_agree", "wx_group_step", "wx_group_sync", "wx_group_set_option",
+    "wx_group_exchange",
 ]
 
 
@@ -142,6 +143,8 @@ def lib() -> C.CDLL:
     L.wx_group_agree.argtypes = [vp]
     L.wx_group_step.argtypes = [vp, i32]
     L.wx_group_sync.argtypes = [vp]
+    L.wx_group_set_option.argtypes = [vp, i32, i32]
+    L.wx_group_exchange.argtypes = [vp]
     _lib = L
     return L
 
@@ -189,12 +192,12 @@ class Handle:
         self.generation = 0  # bumped whenever device pointers obtained earlier become invalid (tune_placement)
 
     @classmethod
-    def _borrowed(cls, ptr, X_owned: int, Y: int, halo: int, owner) -> "Handle":
+    def _borrowed(cls, ptr, X_owned: int, Y: int, halo: int, owner, n_droplets: int = 0) -> "Handle":
         """A slab of a Group: the group destroys it (``owner`` is kept alive as long as this wrapper is)."""
         self = cls.__new__(cls)
         self._h = C.c_void_p(ptr)
         self._owner = owner
-        self.X_owned, self.Y, self.n_droplets, self.halo = X_owned, Y, 0, halo
+        self.X_owned, self.Y, self.n_droplets, self.halo = X_owned, Y, n_droplets, halo
         self.X = lib().wx_local_width(self._h)
         self.generation = 0
         return self
@@ -473,14 +476,14 @@ class Group:
     """N column slabs of one periodic domain in THIS process (wx_group_*): one handle per slab -- on N devices with RCCL between them,
     or several per device with device-to-device copies -- stepped together with the halo exchange inside the library."""
 
-    def __init__(self, n_slabs: int, X_global: int, Y: int, halo: int = 42, devices=None, transport: int = TRANSPORT_AUTO):
+    def __init__(self, n_slabs: int, X_global: int, Y: int, halo: int = 42, devices=None, transport: int = TRANSPORT_AUTO, n_droplets: int = 0):
         L = lib()
         g = C.c_void_p()
         _apply_env_defaults()
         dev = None
         if devices is not None:
             dev = (C.c_int * n_slabs)(*[int(d) for d in devices])
-        rc = L.wx_group_create(int(n_slabs), dev, int(X_global), int(Y), int(halo), 0, int(transport), C.byref(g))
+        rc = L.wx_group_create(int(n_slabs), dev, int(X_global), int(Y), int(halo), int(n_droplets), int(transport), C.byref(g))
         if rc != 0:
             raise WxError(rc, (L.wx_group_last_error(None) or b"").decode())
         self._g = g
@@ -488,7 +491,8 @@ class Group:
         self.halo = halo if n_slabs > 1 else 0
         self.xo = X_global // n_slabs
         self.transport = L.wx_group_transport(g)
-        self.slabs = [Handle._borrowed(L.wx_group_slab(g, i), self.xo, Y, self.halo, self) for i in range(n_slabs)]
+        self.n_droplets = n_droplets
+        self.slabs = [Handle._borrowed(L.wx_group_slab(g, i), self.xo, Y, self.halo, self, n_droplets) for i in range(n_slabs)]
 
     def _chk(self, rc: int):
         if rc != 0:
@@ -498,12 +502,33 @@ class Group:
         """Global column of every local column of slab i (owned + ghost columns, periodic)."""
         return (i * self.xo - self.halo + np.arange(self.xo + 2 * self.halo)) % self.X
 
-    def upload(self, base, water, wall):
-        """Whole-domain arrays (Y, X, 4) cut into the slabs' local arrays."""
+    def upload(self, base, water, wall, drops=None):
+        """Whole-domain arrays (Y, X, 4) cut into the slabs' local arrays; ``drops`` = the WHOLE droplet pool, handed to every slab."""
         for i, h in enumerate(self.slabs):
             idx = self.columns(i)
-            h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]))
+            h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]), drops)
         self._chk(lib().wx_group_agree(self._g))
+
+    def set_option(self, option: int, value: int):
+        self._chk(lib().wx_group_set_option(self._g, int(option), int(value)))
+
+    def exchange(self):
+        """An exchange now (wx_group_exchange): afterwards every active droplet is owned by exactly one slab."""
+        self._chk(lib().wx_group_exchange(self._g))
+
+    def particles(self) -> np.ndarray:
+        """The whole droplet pool assembled from the slabs (call right after an exchange: inside a period a droplet near an edge is held
+        by two slabs): an active droplet's record comes from the slab that owns it, an inactive one's is the same everywhere."""
+        d = [h.read_particles() for h in self.slabs]
+        if self.n == 1:
+            return d[0]
+        f = np.stack([h.pool_flags() for h in self.slabs])
+        if ((f == 2).sum(0) > 1).any():
+            raise RuntimeError("Group.particles: a droplet is owned by two slabs (call exchange() first)")
+        out = d[0].copy()
+        for k in range(self.n):
+            out[f[k] == 2] = d[k][f[k] == 2]
+        return out
 
     def set_params(self, p: WxParams, initial_T=None, snd_T=None, snd_W=None, snd_Vel=None):
         for h in self.slabs:

@@ -208,12 +208,13 @@ class SlabSim:
                 self._hsend = [torch.empty_like(b, device="cpu") for b in self.send]
                 self._hrecv = [torch.empty_like(b, device="cpu") for b in self.recv]
             self.agree_water_free()
-        # Grid-only slabs on GPUs: the exchange runs INSIDE the library (wx_comm_init / wx_slab_step: pack -> ncclSend / ncclRecv ->
-        # unpack on the handle's comm stream); torch.distributed is then only the launcher and the carrier of the communicator's id.
-        # The host-driven path below stays for slabs with particles and for the gloo transport of the CPU tests.
+        # On GPUs the exchange runs INSIDE the library (wx_comm_init / wx_slab_step: pack -> ncclSend / ncclRecv -> unpack on the handle's
+        # comm stream; with particles also the droplet-pool protocol: ncclAllGather of the status flips with a fixed stride, edge droplets
+        # in the halos' batch); torch.distributed is then only the launcher and the carrier of the communicator's id. The host-driven
+        # path below stays for the gloo transport of the CPU tests (and as the fallback).
         self._native = False
         self.transport = "host-driven (torch.distributed send / recv)"
-        if (world > 1 and not self.particles and hasattr(engine, "comm_init_native") and dist.get_backend() == "nccl"
+        if (world > 1 and hasattr(engine, "comm_init_native") and dist.get_backend() == "nccl"
                 and os.environ.get("WX_SLAB_NATIVE", "1") != "0"):
             # First contact insurance: communicator set-up and one real exchange (harmless right after an upload: the ghosts receive the
             # values they already hold) under a watchdog -- a transport that cannot be initialised falls back to the host-driven
@@ -450,7 +451,9 @@ class SlabSim:
         """The whole droplet pool (n_droplets x 5) assembled on rank 0 (None elsewhere): an active droplet's record comes from the rank
         that has it in its owned columns, an inactive one's is the same on every rank (wx_pool_flags). Host-side, for readback / saves."""
         h = self.handle
-        if self.world > 1 and self._since_exchange != 0:
+        if self.world > 1 and self._native:
+            h.exchange()  # settle ownership: right after an exchange every active droplet has exactly one owner
+        elif self.world > 1 and self._since_exchange != 0:
             # inside a period a droplet can be "owned" by two ranks at once (a phantom spawn from a stale record, resolved by the next
             # exchange): the sum below would then add two records
             raise RuntimeError("gather_particles: call it right after an exchange (step a whole number of exchange periods)")

@@ -270,13 +270,20 @@ function WeatherSim(sf, opts)
     // The domain cut into opts.gpus column slabs, one per GPU (periodic in x like the textures' REPEAT wrap), each with `halo` ghost columns
     // per side; the library exchanges the halos itself (RCCL send / recv between the devices, or device-to-device copies where several
     // slabs share a device) every halo / 6 iterations, overlapped with compute: wx_group_* in include/wxsim.h. Same results as one
-    // handle, bit for bit. The droplet pool is not decomposed on this path yet: particles stay off.
+    // handle, bit for bit. With droplets the pool is PARTITIONED (include/wxsim.h): every slab is handed the whole pool once, an active
+    // droplet is then tracked by the slab that contains it; slab widths and the halo must be multiples of the 64-column splat tile, so
+    // a grid that does not allow that (or opts.particles === false) runs with the particles off and carries the pool through unchanged.
     if (this.X % opts.gpus) throw new Error('the grid width ' + this.X + ' is not divisible by ' + opts.gpus + ' slabs');
-    this.nDroplets = 0;
-    this.savedDroplets = sf.droplets || null; // (written back unchanged: the save format carries X * Y / 25 droplets)
-    this.gui.enablePrecipitation = false;
-    const halo = opts.halo != null ? opts.halo : 42, xo = this.X / opts.gpus, wl = xo + 2 * halo, Y = this.Y, X = this.X;
-    this.group = this.addon.groupCreate(opts.gpus, X, Y, halo, opts.transport || 0);
+    const xo = this.X / opts.gpus, Y = this.Y, X = this.X;
+    const withDrops = this.nDroplets > 0 && opts.particles !== false && this.gui.enablePrecipitation && xo % 64 == 0;
+    const halo = opts.halo != null ? opts.halo : (withDrops ? 64 : 42), wl = xo + 2 * halo;
+    if (withDrops && halo % 64) throw new Error('slabs with particles need a halo that is a multiple of 64 (the splat tile)');
+    this.savedDroplets = sf.droplets || null; // (written back unchanged when the particles are off: the save format carries X * Y / 25 droplets)
+    if (!withDrops) {
+      this.nDroplets = 0;
+      this.gui.enablePrecipitation = false;
+    }
+    this.group = this.addon.groupCreate(opts.gpus, X, Y, halo, opts.transport || 0, this.nDroplets);
     this.slabs = [];
     for (let i = 0; i < opts.gpus; i++) {
       const h = this.addon.groupSlab(this.group, i, Y), x0 = i * xo;
@@ -284,7 +291,7 @@ function WeatherSim(sf, opts)
       for (let c = 0; c < wl; c++) gx[c] = ((x0 - halo + c) % X + X) % X;
       if (sf.columns) {
         const c = sf.columns, pick = function(a) { const o = new a.constructor(wl); for (let k = 0; k < wl; k++) o[k] = a[gx[k]]; return o; };
-        this.addon.setupColumns(h, pick(c.wallRows), pick(c.sea), pick(c.vegNoise), pick(c.snow), c.T_air, c.totalWater, c.cloudWater, null);
+        this.addon.setupColumns(h, pick(c.wallRows), pick(c.sea), pick(c.vegNoise), pick(c.snow), c.T_air, c.totalWater, c.cloudWater, this.nDroplets ? sf.droplets : null);
       } else {
         const cut = function(a) {
           const o = new a.constructor(wl * Y * 4);
@@ -292,7 +299,7 @@ function WeatherSim(sf, opts)
             for (let k = 0; k < wl; k++) o.set(a.subarray((y * X + gx[k]) * 4, (y * X + gx[k]) * 4 + 4), (y * wl + k) * 4);
           return o;
         };
-        this.addon.upload(h, cut(sf.base), cut(sf.water), cut(sf.wall), null);
+        this.addon.upload(h, cut(sf.base), cut(sf.water), cut(sf.wall), this.nDroplets ? sf.droplets : null);
       }
       this.slabs.push({h: h, x0: x0, xo: xo, halo: halo, wl: wl});
     }
@@ -357,7 +364,7 @@ WeatherSim.prototype.frame = function(nIter) {
 WeatherSim.prototype.sync = function() { if (this.slabs) this.addon.groupSync(this.group); else this.addon.sync(this.h); };
 // engine options with no counterpart in app.js: deterministic particle splats (option 1), per-launch checks (option 2), and the
 // search for a fast placement of the handle's planes in device memory (returns [ms before, ms after]; the state is unchanged)
-WeatherSim.prototype.setOption = function(option, value) { (this.slabs ? this.slabs.map(function(sl) { return sl.h; }) : [this.h]).forEach(function(h) { this.addon.setOption(h, option, value); }, this); };
+WeatherSim.prototype.setOption = function(option, value) { if (this.slabs) this.addon.groupSetOption(this.group, option, value); else this.addon.setOption(this.h, option, value); };
 WeatherSim.prototype.tunePlacement = function(tries, itersPerTry) {
   if (this.slabs) throw new Error('tunePlacement: single-handle simulations only');
   return this.addon.tunePlacement(this.h, tries || 6, itersPerTry || 30);
@@ -386,11 +393,21 @@ WeatherSim.prototype.soundingColumn = function(x) { // soundingGraph.draw, app.j
           wall: this.readRect('WALL_DISP', x, 0, 1, this.Y, Int32Array)};
 };
 WeatherSim.prototype.readParticles = function() {
-  return this.nDroplets ? this.addon.readParticles(this.h, 0, this.nDroplets, new Float32Array(this.nDroplets * 5)) : new Float32Array(0);
+  if (!this.nDroplets) return new Float32Array(0);
+  if (!this.slabs) return this.addon.readParticles(this.h, 0, this.nDroplets, new Float32Array(this.nDroplets * 5));
+  // the partitioned pool: right after an exchange every active droplet is owned (flag 2) by exactly one slab, whose record is THE
+  // record; an inactive droplet's record is the same on every slab
+  this.addon.groupExchange(this.group);
+  const n = this.nDroplets, out = this.addon.readParticles(this.slabs[0].h, 0, n, new Float32Array(n * 5));
+  for (const sl of this.slabs) {
+    const d = this.addon.readParticles(sl.h, 0, n, new Float32Array(n * 5)), f = this.addon.poolFlags(sl.h, new Uint8Array(n));
+    for (let i = 0; i < n; i++) if (f[i] == 2) out.set(d.subarray(5 * i, 5 * i + 5), 5 * i);
+  }
+  return out;
 };
 WeatherSim.prototype.toSave = function() { // prepareDownload(): FB0 = base_0, water_0, wall_0 (app.js:6584-6593)
   return {X: this.X, Y: this.Y, base: this.readRect('BASE_CUR', 0, 0, this.X, this.Y), water: this.readRect('WATER_0', 0, 0, this.X, this.Y),
-          wall: this.readRect('WALL_CUR', 0, 0, this.X, this.Y), droplets: this.slabs && this.savedDroplets ? this.savedDroplets : this.readParticles(),
+          wall: this.readRect('WALL_CUR', 0, 0, this.X, this.Y), droplets: this.slabs && !this.nDroplets && this.savedDroplets ? this.savedDroplets : this.readParticles(),
           stations: [], settings: this.gui};
 };
 // display fields of a viewport, copied asynchronously into pinned memory (what the renderer binds, app.js:6081-6219):
@@ -431,14 +448,16 @@ if (require.main === module) {
   const flags = args.filter(function(a) { return a.startsWith('--'); });
   const pos = args.filter(function(a) { return !a.startsWith('--'); });
   if (pos.length < 2) {
-    console.error('usage: node sim_host.js <in.weathersandbox> <iterations> [out.weathersandbox] [--sun-fixed] [--gpus N [--halo H] [--transport rccl|local]]');
+    console.error('usage: node sim_host.js <in.weathersandbox> <iterations> [out.weathersandbox] [--sun-fixed] [--splat-order] [--gpus N [--halo H] [--transport rccl|local] [--exact]]');
     process.exit(2);
   }
   const sf = loadSave(pos[0]);
   const num = function(flag, dflt) { const i = args.indexOf(flag); return i >= 0 ? parseInt(args[i + 1], 10) : dflt; };
   const tr = args.indexOf('--transport') >= 0 ? args[args.indexOf('--transport') + 1] : 'auto';
-  const sim = new WeatherSim(sf, {sunFixed: flags.indexOf('--sun-fixed') >= 0, gpus: num('--gpus', 1), halo: num('--halo', 42),
+  const sim = new WeatherSim(sf, {sunFixed: flags.indexOf('--sun-fixed') >= 0, gpus: num('--gpus', 1), halo: args.indexOf('--halo') >= 0 ? num('--halo', 42) : null,
                                   transport: tr == 'rccl' ? 1 : tr == 'local' ? 2 : 0});
+  if (flags.indexOf('--splat-order') >= 0) sim.setOption(1, 1); // WX_OPT_SPLAT_ORDER: deterministic particle splats
+  if (flags.indexOf('--exact') >= 0 && sim.slabs && sim.nDroplets) sim.setOption(7, 1); // WX_OPT_POOL_EXACT: slabs with particles == one handle, exactly
   const n = parseInt(pos[1], 10);
   const t0 = Date.now();
   let left = n;

@@ -49,6 +49,9 @@ static struct {
   int (*group_agree)(wx_group *);
   int (*group_step)(wx_group *, int);
   int (*group_sync)(wx_group *);
+  int (*group_set_option)(wx_group *, int, int);
+  int (*group_exchange)(wx_group *);
+  int (*pool_flags)(wx_sim *, uint8_t *);
   int (*local_width)(const wx_sim *);
 } L;
 
@@ -77,6 +80,7 @@ typedef struct {
 } wx_slot;
 typedef struct {
   wx_group *g;
+  int32_t N; /* droplets of the pool every slab holds */
 } wx_gslot;
 
 static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv)
@@ -519,18 +523,24 @@ static napi_value throw_group(napi_env env, wx_group *g, int rc, const char *wha
   napi_throw_error(env, NULL, buf);
   return NULL;
 }
-/* groupCreate(nSlabs, Xglobal, Y, halo, transport) -> group   (transport: 0 auto, 1 RCCL, 2 local copies) */
+/* groupCreate(nSlabs, Xglobal, Y, halo, transport[, nDroplets]) -> group   (transport: 0 auto, 1 RCCL, 2 local copies) */
 static napi_value GroupCreate(napi_env env, napi_callback_info info)
 {
-  napi_value a[5];
-  if (get_args(env, info, 5, a)) return NULL;
-  int32_t v[5];
-  for (int i = 0; i < 5; i++) NAPI_CALL(env, napi_get_value_int32(env, a[i], &v[i]));
+  napi_value a[6];
+  size_t argc = 6;
+  NAPI_CALL(env, napi_get_cb_info(env, info, &argc, a, NULL, NULL));
+  if (argc < 5) {
+    napi_throw_type_error(env, NULL, "groupCreate(nSlabs, Xglobal, Y, halo, transport[, nDroplets])");
+    return NULL;
+  }
+  int32_t v[6] = {0, 0, 0, 0, 0, 0};
+  for (size_t i = 0; i < argc && i < 6; i++) NAPI_CALL(env, napi_get_value_int32(env, a[i], &v[i]));
   wx_group *g = NULL;
-  int rc = L.group_create(v[0], NULL, v[1], v[2], v[3], 0, v[4], &g);
+  int rc = L.group_create(v[0], NULL, v[1], v[2], v[3], v[5], v[4], &g);
   if (rc) return throw_group(env, NULL, rc, "wx_group_create");
   wx_gslot *gs = (wx_gslot *)malloc(sizeof(*gs));
   gs->g = g;
+  gs->N = v[5];
   napi_value ext;
   NAPI_CALL(env, napi_create_external(env, gs, finalize_group, NULL, &ext));
   return ext;
@@ -554,7 +564,7 @@ static napi_value GroupSlab(napi_env env, napi_callback_info info)
   slot->s = s;
   slot->X = L.local_width(s);
   slot->Y = Y;
-  slot->N = 0;
+  slot->N = gs->N;
   slot->borrowed = 1;
   napi_value ext;
   NAPI_CALL(env, napi_create_external(env, slot, finalize_handle, NULL, &ext));
@@ -595,6 +605,45 @@ static napi_value GroupStep(napi_env env, napi_callback_info info)
   int rc = L.group_step(gs->g, n);
   if (rc) return throw_group(env, gs->g, rc, "wx_group_step");
   return NULL;
+}
+/* groupSetOption(group, option, value): wx_set_option on every slab */
+static napi_value GroupSetOption(napi_env env, napi_callback_info info)
+{
+  napi_value a[3];
+  if (get_args(env, info, 3, a)) return NULL;
+  wx_gslot *gs = get_group(env, a[0]);
+  if (!gs) return NULL;
+  int32_t o, v;
+  NAPI_CALL(env, napi_get_value_int32(env, a[1], &o));
+  NAPI_CALL(env, napi_get_value_int32(env, a[2], &v));
+  int rc = L.group_set_option(gs->g, o, v);
+  if (rc) return throw_group(env, gs->g, rc, "wx_group_set_option");
+  return NULL;
+}
+/* groupExchange(group): an exchange now -- afterwards every active droplet is owned by exactly one slab */
+static napi_value GroupExchange(napi_env env, napi_callback_info info)
+{
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  wx_gslot *gs = get_group(env, a[0]);
+  if (!gs) return NULL;
+  int rc = L.group_exchange(gs->g);
+  if (rc) return throw_group(env, gs->g, rc, "wx_group_exchange");
+  return NULL;
+}
+/* poolFlags(h, Uint8Array nDroplets) -> the array: 0 tracked by another slab, 1 inactive, 2 active and owned here, 3 ghost copy */
+static napi_value PoolFlags(napi_env env, napi_callback_info info)
+{
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  const wx_slot *sl = s ? get_slot(env, a[0]) : NULL;
+  if (!sl) return NULL;
+  uint8_t *dst = (uint8_t *)typed_at_least(env, a[1], napi_uint8_array, (size_t)sl->N, "poolFlags: Uint8Array, nDroplets");
+  if (!dst) return NULL;
+  int rc = L.pool_flags(s, dst);
+  if (rc) return throw_wx(env, s, rc, "wx_pool_flags");
+  return a[1];
 }
 static napi_value GroupSync(napi_env env, napi_callback_info info)
 {
@@ -659,7 +708,8 @@ static int load_lib(napi_env env)
   SYM(stream_frame, "wx_stream_frame") SYM(stream_wait, "wx_stream_wait") SYM(set_option, "wx_set_option") SYM(tune_placement, "wx_tune_placement")
   SYM(group_create, "wx_group_create") SYM(group_destroy, "wx_group_destroy") SYM(group_last_error, "wx_group_last_error") SYM(group_count, "wx_group_count")
   SYM(group_transport, "wx_group_transport") SYM(group_slab, "wx_group_slab") SYM(group_agree, "wx_group_agree") SYM(group_step, "wx_group_step")
-  SYM(group_sync, "wx_group_sync") SYM(local_width, "wx_local_width")
+  SYM(group_sync, "wx_group_sync") SYM(local_width, "wx_local_width") SYM(group_set_option, "wx_group_set_option") SYM(group_exchange, "wx_group_exchange")
+  SYM(pool_flags, "wx_pool_flags")
 #undef SYM
   return 0;
 }
@@ -679,7 +729,8 @@ static napi_value Init(napi_env env, napi_value exports)
     {"groupCreate", 0, GroupCreate, 0, 0, 0, napi_default, 0}, {"groupSlab", 0, GroupSlab, 0, 0, 0, napi_default, 0},
     {"groupInfo", 0, GroupInfo, 0, 0, 0, napi_default, 0},     {"groupAgree", 0, GroupAgree, 0, 0, 0, napi_default, 0},
     {"groupStep", 0, GroupStep, 0, 0, 0, napi_default, 0},     {"groupSync", 0, GroupSync, 0, 0, 0, napi_default, 0},
-    {"groupDestroy", 0, GroupDestroy, 0, 0, 0, napi_default, 0},
+    {"groupDestroy", 0, GroupDestroy, 0, 0, 0, napi_default, 0}, {"groupSetOption", 0, GroupSetOption, 0, 0, 0, napi_default, 0},
+    {"groupExchange", 0, GroupExchange, 0, 0, 0, napi_default, 0}, {"poolFlags", 0, PoolFlags, 0, 0, 0, napi_default, 0},
   };
   NAPI_CALL(env, napi_define_properties(env, exports, sizeof(d) / sizeof(d[0]), d));
   return exports;

@@ -299,7 +299,7 @@ int wx_lightning_set(wx_sim *s, const float in[4]);
 
 /* ---- the halo exchange inside the library (no reference counterpart: the reference is single-GPU; BASELINE north_star: "halo
  * exchange on RCCL send/recv over xGMI overlapped on a side HIP stream; host code stays in JavaScript"). RCCL is bound at run time
- * (dlopen), so nothing here is needed to run on one GPU. Slabs with particles keep the host-driven exchange of the functions above.
+ * (dlopen), so nothing here is needed to run on one GPU.
  *
  * One rank per process (what `bench.py --gpus N` runs under torchrun, which then only launches the ranks and carries the 128-byte
  * id from rank 0 to the others):
@@ -333,8 +333,16 @@ int wx_group_count(const wx_group *g);
 int wx_group_transport(const wx_group *g);
 wx_sim *wx_group_slab(wx_group *g, int i);
 int wx_group_agree(wx_group *g);            /* after the uploads: wx_water_free of every slab -> wx_slab_assert_water_free on all */
+int wx_group_set_option(wx_group *g, int option, int value); /* wx_set_option on every slab (WX_OPT_SPLAT_ORDER, WX_OPT_POOL_EXACT ...) */
 int wx_group_step(wx_group *g, int n_iter); /* like wx_slab_step, for all slabs; asynchronous */
+int wx_group_exchange(wx_group *g);         /* an exchange now: afterwards every active droplet is owned by exactly one slab (read the pool then) */
 int wx_group_sync(wx_group *g);
+/* Slabs with particles (n_droplets > 0; halo and X_global / n_slabs multiples of 64) on the library's transport: wx_upload hands every
+ * slab the WHOLE pool; wx_exchange / wx_slab_step / wx_group_step then also run the droplet-pool protocol above -- status flips (+ every
+ * rank's lightning state) all-gathered with a fixed stride (65536 events per rank: no host round trip; more flips in one period are
+ * reported as WX_E_STATE by the next blocking call), edge droplets in the same batch of transfers as the grid halos -- every
+ * WX_SLAB_PERIOD_PARTICLES(halo) iterations, in order on the compute stream; with WX_OPT_POOL_EXACT one iteration at a time, each
+ * followed by the all-gather of its flips and lightning requests. */
 
 /* Per-kernel device time from HIP events recorded on the handle's stream around every launch.
  * wx_profile(s, 1) starts collecting, wx_profile_read returns accumulated milliseconds and launch counts
