@@ -11,7 +11,9 @@
 //     box with fewer devices, several slabs per device with device-to-device copies between the slabs' buffers behind the same
 //     calls: "local" transport) -> wx_group_step / wx_group_sync.
 // RCCL is bound at run time (dlopen: the copy the process already holds -- PyTorch ships its own -- else the ROCm one), so the
-// library loads and runs single-GPU without it. Slabs with particles keep the host-driven exchange of slab.py for now.
+// library loads and runs single-GPU without it. Slabs with particles run the partitioned-pool protocol (include/wxsim.h) through the
+// same calls: status flips (+ lightning) all-gathered with a fixed stride -- no host round trip --, edge droplets in the halos' batch of
+// transfers, in order on the compute stream; with WX_OPT_POOL_EXACT one iteration at a time.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
