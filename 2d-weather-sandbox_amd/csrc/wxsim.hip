@@ -1246,6 +1246,7 @@ int wx_set_option(wx_sim *s, int option, int value)
     default: return WX_E_INVALID;
     }
   }
+  DeviceScope dev_scope(s);
   switch (option) {
   case WX_OPT_KERNEL_SET:
     if (int rc = wx_sync(s)) return rc;
@@ -1890,6 +1891,7 @@ static int pool_events_apply_mode(wx_sim *s, const void *dev_bufs, int n_ranks, 
 int wx_pool_events_pack(wx_sim *s, void *dev_buf)
 {
   if (!s || !dev_buf) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   POOL_ONLY(s, "wx_pool_events_pack");
   return pool_events_pack_mode(s, dev_buf, s->pool_exact ? 1 : 0);
 }
@@ -1907,6 +1909,7 @@ static int pool_events_pack_mode(wx_sim *s, void *dev_buf, int mode)
 int wx_pool_events_apply(wx_sim *s, const void *dev_bufs, int n_ranks, size_t stride_bytes)
 {
   if (!s || !dev_bufs || n_ranks < 1) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   POOL_ONLY(s, "wx_pool_events_apply");
   return pool_events_apply_mode(s, dev_bufs, n_ranks, stride_bytes, s->pool_exact ? 1 : 0);
 }
@@ -1939,6 +1942,7 @@ static int pool_events_apply_mode(wx_sim *s, const void *dev_bufs, int n_ranks, 
 int wx_pool_edges_pack(wx_sim *s, void *dev_left, void *dev_right, int refresh_inactive)
 {
   if (!s || !dev_left || !dev_right) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   POOL_ONLY(s, "wx_pool_edges_pack");
   HIPCHK(s, hipMemsetAsync(dev_left, 0, POOL_HDR, s->stream));
   HIPCHK(s, hipMemsetAsync(dev_right, 0, POOL_HDR, s->stream));
@@ -1954,6 +1958,7 @@ int wx_pool_edges_pack(wx_sim *s, void *dev_left, void *dev_right, int refresh_i
 int wx_pool_edges_apply(wx_sim *s, const void *dev_buf)
 {
   if (!s || !dev_buf) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   POOL_ONLY(s, "wx_pool_edges_apply");
   hipLaunchKernelGGL(k_pool_check, dim3(1), dim3(64), 0, s->stream, 1, (size_t)0, s->pool_edge_cap, (const char *)dev_buf, s->state);
   hipLaunchKernelGGL(k_pool_edges_apply, dim3(64), dim3(256), 0, s->stream, s->pool_edge_cap, (const int *)dev_buf, (const PoolRec *)((const char *)dev_buf + POOL_HDR),
@@ -1966,6 +1971,7 @@ int wx_pool_edges_apply(wx_sim *s, const void *dev_buf)
 int wx_pool_flags(wx_sim *s, uint8_t *host_dst)
 {
   if (!s || !host_dst) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   POOL_ONLY(s, "wx_pool_flags");
   unsigned char *d = nullptr;
   if (hipMalloc((void **)&d, (size_t)s->n_drops) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_pool_flags");
@@ -1979,6 +1985,7 @@ int wx_pool_flags(wx_sim *s, uint8_t *host_dst)
 int wx_lightning_get(wx_sim *s, float out[4])
 {
   if (!s || !out) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   HIPCHK(s, hipMemcpyAsync(out, s->state->lightning, 16, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
   return WX_OK;
@@ -1987,6 +1994,7 @@ int wx_lightning_get(wx_sim *s, float out[4])
 int wx_lightning_set(wx_sim *s, const float in[4])
 {
   if (!s || !in) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
   HIPCHK(s, hipMemcpyAsync(s->state->lightning, in, 16, hipMemcpyHostToDevice, s->stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
   return WX_OK;
