@@ -78,8 +78,8 @@ static int iters_per_exchange(const wx_sim *s) { return s->pool_remote ? std::ma
 // the stream the exchange of a slab runs on: its comm stream (grid-only slabs: overlapped with compute), else its compute stream
 // (slabs with particles: the pool exchange needs the finished iteration, so everything stays in order)
 static hipStream_t xstream(const wx_sim *s) { return s->comm_stream ? s->comm_stream : s->stream; }
-// bytes per rank in the all-gather of status-flip events: a fixed stride (no host round trip for the counts); a rank with more
-// flips than fit is reported by the next blocking call (pool_overflow)
+// bytes per rank in the all-gather of status-flip events: a stride every rank knows without a host round trip inside the period
+// (pool_stride_update); a rank with more flips than fit is reported by the next blocking call (pool_overflow)
 static size_t pool_stride(const wx_sim *s)
 {
   const size_t want = (POOL_HDR + sizeof(PoolEvent) * (size_t)(1 + s->pool_stride_events) + 4095) / 4096 * 4096;
@@ -106,8 +106,15 @@ static int transport_prepare(wx_sim *s, int world)
     hipFree(s->ev_all);
     s->ev_mine = s->ev_all = nullptr;
     const size_t eb = wx_pool_event_bytes(s), gb = wx_pool_edge_bytes(s);
-    if (hipMalloc((void **)&s->ev_mine, eb) != hipSuccess || hipMalloc((void **)&s->ev_all, pool_stride(s) * (size_t)world) != hipSuccess)
-      return fail(s, WX_E_NOMEM, "droplet-pool event buffers");
+    if (hipMalloc((void **)&s->ev_mine, eb) != hipSuccess || hipMalloc((void **)&s->ev_all, eb * (size_t)world) != hipSuccess)
+      return fail(s, WX_E_NOMEM, "droplet-pool event buffers: %zu bytes", eb * (size_t)(world + 1));
+    if (!s->ev_seen_host) {
+      HIPCHK(s, hipHostMalloc((void **)&s->ev_seen_host, sizeof(int), hipHostMallocDefault));
+      *s->ev_seen_host = 0;
+      HIPCHK(s, hipEventCreateWithFlags(&s->ev_counted, hipEventDisableTiming));
+    }
+    s->pool_stride_events = 1 << 30; // a new ring: everything until the first counts are in
+    s->count_pending = false;
     for (int i = 0; i < 2; i++) {
       hipFree(s->psend[i]);
       hipFree(s->precv[i]);
@@ -115,9 +122,14 @@ static int transport_prepare(wx_sim *s, int world)
     }
     s->ev_world = world;
   }
-  if (!s->pool_remote && !s->comm_stream) {
+  // the side stream of the exchange; the exact particle mode runs everything in order on the compute stream (wx_set_option may have
+  // switched modes since the last call)
+  const bool in_order = (s->pool_remote && s->pool_exact) || s->exchange_in_order;
+  if (!in_order && !s->comm_stream) {
     if (!s->own_comm_stream) HIPCHK(s, hipStreamCreateWithFlags(&s->own_comm_stream, hipStreamNonBlocking));
     if (int rc = wx_set_comm_stream(s, s->own_comm_stream)) return rc;
+  } else if (in_order && s->comm_stream && s->comm_stream == s->own_comm_stream) {
+    if (int rc = wx_set_comm_stream(s, nullptr)) return rc;
   }
   return WX_OK;
 }
@@ -138,6 +150,11 @@ void transport_release(wx_sim *s)
   hipFree(s->ev_mine);
   hipFree(s->ev_all);
   s->ev_mine = s->ev_all = nullptr;
+  if (s->ev_seen_host) hipHostFree(s->ev_seen_host);
+  s->ev_seen_host = nullptr;
+  if (s->ev_counted) hipEventDestroy(s->ev_counted);
+  s->ev_counted = nullptr;
+  s->count_pending = false;
   s->xbytes = 0;
   for (hipEvent_t *e : {&s->ev_packed, &s->ev_copied, &s->ev_evpacked, &s->ev_evcopied}) {
     if (*e) hipEventDestroy(*e);
@@ -250,6 +267,24 @@ static int pool_events_round(Ring &R, int mode)
   return WX_OK;
 }
 
+// The stride of the coming all-gathers, from the counts the rounds since the last exchange carried: every rank saw the same headers,
+// so every rank arrives at the same number. The only host wait of the protocol, and on something that finished a period ago (the
+// previous exchange's status-flip round); it bounds how far the host runs ahead of the device to one exchange period.
+static int pool_stride_update(Ring &R)
+{
+  for (Party &q : R.p) {
+    wx_sim *s = q.s;
+    if (!s->count_pending) continue;
+    DeviceScope ds(s);
+    if (hipEventSynchronize(s->ev_counted) != hipSuccess) return rfail(R, s, WX_E_DEVICE, "waiting for the status-flip counts: %s", hipGetErrorString(hipGetLastError()));
+    const long long seen = *s->ev_seen_host;
+    s->count_pending = false;
+    if (hipMemsetAsync(&s->state->pool_seen_max, 0, 4, pool_stream(s)) != hipSuccess) return rfail(R, s, WX_E_DEVICE, "hipMemsetAsync");
+    s->pool_stride_events = (int)std::min<long long>(std::max<long long>(65536, 4 * seen), 1 << 30);
+  }
+  return WX_OK;
+}
+
 // One exchange of every slab of the ring: my left edge -> the left neighbour's right ghosts, my right edge -> the right neighbour's left
 // ghosts; with particles also the droplet pool (status flips unless the exact mode already sent them, edge droplets in the same batch of
 // transfers as the grid halos).
@@ -259,6 +294,8 @@ static int ring_exchange(Ring &R)
   if (R.world < 2) return WX_OK;
   const bool local = R.transport == WX_TRANSPORT_LOCAL;
   const bool particles = R.p[0].s->pool_remote != nullptr;
+  if (particles)
+    if (int rc = pool_stride_update(R)) return rc;
   if (local) // my send buffers are free once both neighbours have copied the previous exchange out of them
     if (int rc = local_wait(R, &wx_sim::ev_copied, true)) return rc;
   for (Party &q : R.p) { // (grid-only slabs: on the comm stream, behind the edge strips only)
@@ -364,9 +401,8 @@ static int ring_step(Ring &R, int n_iter)
         wx_sim *s = q.s;
         DeviceScope ds(s);
         // the iteration before an exchange launches its edge strips first, the one after it its interior strips first (wx_step_overlap;
-        // slabs with particles run in order)
-        unsigned flags = 0;
-        if (!particles) flags = ((s->since_exchange == 0 && s->exchanged) ? WX_OVERLAP_EDGES_LAST : 0u) | (s->since_exchange + k >= ipe ? WX_OVERLAP_EDGES_FIRST : 0u);
+        // with particles only the latter: the exchange -- grid, feedback texture and droplet pool -- hides behind the next interior)
+        const unsigned flags = ((s->since_exchange == 0 && s->exchanged) ? WX_OVERLAP_EDGES_LAST : 0u) | (s->since_exchange + k >= ipe ? WX_OVERLAP_EDGES_FIRST : 0u);
         if (int rc = rpass(R, s, wx_step_overlap(s, k, flags))) return rc;
         s->since_exchange += k;
       }
@@ -594,9 +630,21 @@ int wx_group_set_option(wx_group *g, int option, int value)
   return WX_OK;
 }
 
+// (stream roles follow the particle mode, which wx_group_set_option may have changed)
+static int group_prepare(wx_group *g)
+{
+  if (g->slab.size() < 2) return WX_OK;
+  for (wx_sim *s : g->slab) {
+    DeviceScope ds(s);
+    if (int rc = gpass(g, s, transport_prepare(s, (int)g->slab.size()))) return rc;
+  }
+  return WX_OK;
+}
+
 int wx_group_step(wx_group *g, int n_iter)
 {
   if (!g || n_iter < 0) return WX_E_INVALID;
+  if (int rc = group_prepare(g)) return rc;
   Ring R = ring_of(g);
   return ring_step(R, n_iter);
 }
@@ -606,6 +654,7 @@ int wx_group_step(wx_group *g, int n_iter)
 int wx_group_exchange(wx_group *g)
 {
   if (!g) return WX_E_INVALID;
+  if (int rc = group_prepare(g)) return rc;
   Ring R = ring_of(g);
   return ring_exchange(R);
 }

@@ -291,6 +291,7 @@ struct DevState {
                           // although the host asserted a water-free domain (wx_slab_assert_water_free): reported by the next blocking call
   int fix_overflow;       // set by k_wet_fix when more output cells needed the exact path than its list holds (the entry count)
   int pool_overflow;      // set when an exchange buffer of the partitioned droplet pool received more entries than it holds
+  int pool_seen_max;      // largest status-flip count any rank reported since the transport last looked (k_pool_check)
   int pool_retired;       // exact mode: droplets that ended the iteration inactive among this iteration's status flips (k_pool_events_apply)
 };
 
@@ -1144,12 +1145,14 @@ __global__ void k_pool_flags(Geo g, int n, int own_lo, int own_hi, const float *
   }
   out[i] = f;
 }
-__global__ void k_pool_check(int n_bufs, size_t stride_bytes, int cap, const char *__restrict__ bufs, DevState *st)
+// note != 0: also keep the largest entry count seen (what the library's transport sizes the next all-gathers by)
+__global__ void k_pool_check(int n_bufs, size_t stride_bytes, int cap, const char *__restrict__ bufs, DevState *st, int note)
 {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n_bufs) {
     const int cnt = *reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
     if (cnt > cap) atomicMax(&st->pool_overflow, cnt);
+    if (note) atomicMax(&st->pool_seen_max, cnt);
   }
 }
 __global__ void k_inactive_from_count(DevState *st)

@@ -139,13 +139,19 @@ struct wx_sim {
   int comm_rank = 0, comm_world = 1;
   char *xsend[2] = {nullptr, nullptr}, *xrecv[2] = {nullptr, nullptr}; // halo buffers [left, right] of wx_exchange / wx_group_step
   size_t xbytes = 0;
+  bool exchange_in_order = false; // WX_OPT_EXCHANGE_OVERLAP 0: the library's transport keeps the exchange on the compute stream
   hipStream_t own_stream = nullptr, own_comm_stream = nullptr; // streams the library created itself (groups, wx_comm_init)
   hipEvent_t ev_packed = nullptr, ev_copied = nullptr;         // in-process transport: my send buffers are full / my recv copies are done
   char *ev_mine = nullptr, *ev_all = nullptr;                           // slabs with particles: my status-flip events / everybody's (all-gathered)
   int ev_world = 0;
   char *psend[2] = {nullptr, nullptr}, *precv[2] = {nullptr, nullptr}; // ... and the edge droplets to / from the ring neighbours
   hipEvent_t ev_evpacked = nullptr, ev_evcopied = nullptr;
-  int pool_stride_events = 65536; // events per rank the all-gather of the library's transport carries (fixed stride: no host round trip)
+  // events per rank the all-gathers of the library's transport carry: everything at first, then 4 x the largest count the PREVIOUS
+  // period's rounds carried, at least 65536 (pool_stride_update: no host round trip inside a period)
+  int pool_stride_events = 1 << 30;
+  int *ev_seen_host = nullptr; // pinned: pool_seen_max as of the last round
+  hipEvent_t ev_counted = nullptr;
+  bool count_pending = false;
   int since_exchange = 0;         // iterations since the ghost columns were last fresh (upload or exchange)
   bool exchanged = false;         // ... and they came from an exchange (the next step may run its interior strips first)
   int air_from_row = -1;       // lowest row above which every cell is free air (cost model of the row segmentation); -1: to be measured
@@ -1138,7 +1144,9 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
                   n_iter, s->period_j, s->halo, WX_SLAB_PERIOD_PARTICLES(s->halo));
   }
   // overlap needs the kernel that can be launched per strip range; everything else orders the exchange on the compute stream
-  const bool can_split = (fused || (dry && dry_marches(s))) && !precip && s->comm_stream != nullptr && s->halo > 0;
+  // (with particles only the iteration AFTER an exchange splits: precipitation needs the whole grid of its iteration, and the
+  // exchange needs the feedback texture precipitation leaves behind -- so the exchange hides behind the next interior strips)
+  const bool can_split = (fused || (dry && dry_marches(s))) && s->comm_stream != nullptr && s->halo > 0 && !(precip && s->pool_exact);
   if (!can_split) wait_unpacked(s);
   if (!fused && s->light_planar) { // the per-pass / dry kernels take the light textures interleaved (the conversion reads ghost columns)
     wait_unpacked(s);
@@ -1147,7 +1155,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   s->edges_recorded = false;
   for (int it = 0; it < n_iter; it++) {
     int edge_mode = 0;
-    if (can_split) edge_mode = ((flags & WX_OVERLAP_EDGES_LAST) && it == 0 ? 2 : 0) | ((flags & WX_OVERLAP_EDGES_FIRST) && it == n_iter - 1 ? 1 : 0);
+    if (can_split) edge_mode = ((flags & WX_OVERLAP_EDGES_LAST) && it == 0 ? 2 : 0) | ((flags & WX_OVERLAP_EDGES_FIRST) && it == n_iter - 1 && !precip ? 1 : 0);
     if (can_split && it == 0 && !(edge_mode & 2)) wait_unpacked(s);
     int rc;
     if (dry)
@@ -1265,6 +1273,9 @@ int wx_set_option(wx_sim *s, int option, int value)
     if (int rc = wx_sync(s)) return rc;
     s->pool_exact = value != 0;
     s->exact_pending = 0;
+    return WX_OK;
+  case WX_OPT_EXCHANGE_OVERLAP: // (takes effect at the next wx_slab_step / wx_exchange / wx_group_step: transport_prepare)
+    s->exchange_in_order = value == 0;
     return WX_OK;
   case WX_OPT_FIX_CAP:
     if (value < 0) return fail(s, WX_E_INVALID, "wx_set_option: WX_OPT_FIX_CAP >= 0");
@@ -1881,6 +1892,30 @@ int wx_slab_period_begin(wx_sim *s)
 size_t wx_pool_event_bytes(const wx_sim *s) { return s && s->pool_remote ? POOL_HDR + (size_t)s->pool_event_cap * sizeof(PoolEvent) : 0; }
 size_t wx_pool_edge_bytes(const wx_sim *s) { return s && s->pool_remote ? POOL_HDR + (size_t)s->pool_edge_cap * sizeof(PoolRec) : 0; }
 
+// The stream the droplet-pool exchange kernels run on: the side stream when the handle has one (they then overlap with the interior
+// strips of the next iteration, like the grid halos), the compute stream otherwise and always in the exact mode (whose per-iteration
+// rounds need the finished iteration and are needed by the next one).
+static hipStream_t pool_stream(const wx_sim *s) { return s->comm_stream && !s->pool_exact ? s->comm_stream : s->stream; }
+// side stream: the pool kernels read what the iterations enqueued so far leave behind
+static int pool_fence(wx_sim *s, hipStream_t st)
+{
+  if (st == s->stream) return WX_OK;
+  if (!s->edges_recorded) {
+    HIPCHK(s, hipEventRecord(s->ev_edges, s->stream));
+    s->edges_recorded = true;
+  }
+  HIPCHK(s, hipStreamWaitEvent(st, s->ev_edges, 0));
+  return WX_OK;
+}
+// side stream: whatever touches the pool (or the ghost columns) next on the compute stream waits for what was just enqueued
+static int pool_applied(wx_sim *s, hipStream_t st)
+{
+  if (st == s->stream) return WX_OK;
+  HIPCHK(s, hipEventRecord(s->ev_unpacked, st));
+  s->unpack_pending = true;
+  return WX_OK;
+}
+
 #define POOL_ONLY(s, what) \
   if (!(s)->pool_remote) return fail((s), WX_E_STATE, what ": not a slab handle with particles")
 
@@ -1897,9 +1932,11 @@ int wx_pool_events_pack(wx_sim *s, void *dev_buf)
 }
 static int pool_events_pack_mode(wx_sim *s, void *dev_buf, int mode)
 {
-  HIPCHK(s, hipMemsetAsync(dev_buf, 0, POOL_HDR, s->stream));
+  hipStream_t st = pool_stream(s);
+  if (int rc = pool_fence(s, st)) return rc;
+  HIPCHK(s, hipMemsetAsync(dev_buf, 0, POOL_HDR, st));
   // (exact mode: + this rank's iteration record; the deposit at the domain's texel (0,0) comes from the rank that owns global column 0)
-  hipLaunchKernelGGL(k_pool_events_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->rank, s->pool_event_cap, s->pool_flips, s->pool_owned,
+  hipLaunchKernelGGL(k_pool_events_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, st, s->n_drops, s->rank, s->pool_event_cap, s->pool_flips, s->pool_owned,
                      s->drops[0], (int *)dev_buf, (PoolEvent *)((char *)dev_buf + POOL_HDR), s->state, mode,
                      (mode == 1 && s->x0 == 0) ? s->fb + s->halo : nullptr);
   HIPCHK(s, hipGetLastError());
@@ -1918,23 +1955,31 @@ static int pool_events_apply_mode(wx_sim *s, const void *dev_bufs, int n_ranks, 
   const size_t stride = stride_bytes ? stride_bytes : wx_pool_event_bytes(s);
   if (stride < (size_t)POOL_HDR || stride > wx_pool_event_bytes(s)) return fail(s, WX_E_INVALID, "wx_pool_events_apply: stride %zu outside 16 .. %zu", stride, wx_pool_event_bytes(s));
   const dim3 grid(64, n_ranks), block(256);
+  hipStream_t st = pool_stream(s);
+  if (int rc = pool_fence(s, st)) return rc;
   const char *b = (const char *)dev_bufs;
   const int cap = (int)((stride - POOL_HDR) / sizeof(PoolEvent)); // entries a rank's (possibly truncated) buffer holds
-  hipLaunchKernelGGL(k_pool_check, dim3(1), dim3(64), 0, s->stream, n_ranks, stride, cap, b, s->state);
-  hipLaunchKernelGGL(k_pool_events_best, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best);
-  if (mode == 1) HIPCHK(s, hipMemsetAsync(&s->state->pool_retired, 0, 4, s->stream));
-  hipLaunchKernelGGL(k_pool_events_apply, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best, s->rank, s->drops[0], s->pool_remote, s->geo, mode == 1 ? 1 : 0,
+  hipLaunchKernelGGL(k_pool_check, dim3(1), dim3(64), 0, st, n_ranks, stride, cap, b, s->state, 1);
+  if (s->ev_seen_host) { // the library's transport sizes the coming all-gathers by what this one carried (wx_comm.h: pool_stride_update)
+    HIPCHK(s, hipMemcpyAsync(s->ev_seen_host, &s->state->pool_seen_max, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(s, hipEventRecord(s->ev_counted, st));
+    s->count_pending = true;
+  }
+  hipLaunchKernelGGL(k_pool_events_best, grid, block, 0, st, n_ranks, stride, cap, b, s->pool_best);
+  if (mode == 1) HIPCHK(s, hipMemsetAsync(&s->state->pool_retired, 0, 4, st));
+  hipLaunchKernelGGL(k_pool_events_apply, grid, block, 0, st, n_ranks, stride, cap, b, s->pool_best, s->rank, s->drops[0], s->pool_remote, s->geo, mode == 1 ? 1 : 0,
                      mode == 1 ? &s->state->pool_retired : nullptr);
-  if (mode == 2) hipLaunchKernelGGL(k_pool_lightning_latest, dim3(1), dim3(64), 0, s->stream, n_ranks, stride, cap, b, s->state);
+  if (mode == 2) hipLaunchKernelGGL(k_pool_lightning_latest, dim3(1), dim3(64), 0, st, n_ranks, stride, cap, b, s->state);
   if (mode == 1 && s->exact_pending > 0) { // the iteration that just ran: lightning of the whole domain, the 600-iteration inactive count
     const int64_t it = s->iter - 1;
     const int refresh = it % 600 == 0 ? 1 : 0;
-    if (refresh) hipLaunchKernelGGL(k_pool_count_inactive, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, s->drops[0], s->pool_remote, s->state);
-    hipLaunchKernelGGL(k_pool_exact_resolve, dim3(1), dim3(64), 0, s->stream, n_ranks, stride, cap, b, s->state, (float)it, refresh, &s->state->pool_retired);
+    if (refresh) hipLaunchKernelGGL(k_pool_count_inactive, dim3((s->n_drops + 255) / 256), dim3(256), 0, st, s->n_drops, s->drops[0], s->pool_remote, s->state);
+    hipLaunchKernelGGL(k_pool_exact_resolve, dim3(1), dim3(64), 0, st, n_ranks, stride, cap, b, s->state, (float)it, refresh, &s->state->pool_retired);
     s->exact_pending = 0;
   }
-  hipLaunchKernelGGL(k_pool_events_reset, grid, block, 0, s->stream, n_ranks, stride, cap, b, s->pool_best);
+  hipLaunchKernelGGL(k_pool_events_reset, grid, block, 0, st, n_ranks, stride, cap, b, s->pool_best);
   s->pool_check = true;
+  if (int rc = pool_applied(s, st)) return rc;
   HIPCHK(s, hipGetLastError());
   return WX_OK;
 }
@@ -1944,13 +1989,15 @@ int wx_pool_edges_pack(wx_sim *s, void *dev_left, void *dev_right, int refresh_i
   if (!s || !dev_left || !dev_right) return WX_E_INVALID;
   DeviceScope dev_scope(s);
   POOL_ONLY(s, "wx_pool_edges_pack");
-  HIPCHK(s, hipMemsetAsync(dev_left, 0, POOL_HDR, s->stream));
-  HIPCHK(s, hipMemsetAsync(dev_right, 0, POOL_HDR, s->stream));
-  if (refresh_inactive) HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 4, s->stream));
-  hipLaunchKernelGGL(k_pool_edges_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, s->n_drops, s->halo, s->X - s->halo, s->halo, s->pool_edge_cap,
+  hipStream_t st = pool_stream(s);
+  if (int rc = pool_fence(s, st)) return rc;
+  HIPCHK(s, hipMemsetAsync(dev_left, 0, POOL_HDR, st));
+  HIPCHK(s, hipMemsetAsync(dev_right, 0, POOL_HDR, st));
+  if (refresh_inactive) HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 4, st));
+  hipLaunchKernelGGL(k_pool_edges_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, st, s->geo, s->n_drops, s->halo, s->X - s->halo, s->halo, s->pool_edge_cap,
                      s->drops[0], s->pool_remote, (int *)dev_left, (PoolRec *)((char *)dev_left + POOL_HDR), (int *)dev_right,
                      (PoolRec *)((char *)dev_right + POOL_HDR), s->state, refresh_inactive);
-  if (refresh_inactive) hipLaunchKernelGGL(k_inactive_from_count, dim3(1), dim3(1), 0, s->stream, s->state);
+  if (refresh_inactive) hipLaunchKernelGGL(k_inactive_from_count, dim3(1), dim3(1), 0, st, s->state);
   HIPCHK(s, hipGetLastError());
   return WX_OK;
 }
@@ -1960,10 +2007,13 @@ int wx_pool_edges_apply(wx_sim *s, const void *dev_buf)
   if (!s || !dev_buf) return WX_E_INVALID;
   DeviceScope dev_scope(s);
   POOL_ONLY(s, "wx_pool_edges_apply");
-  hipLaunchKernelGGL(k_pool_check, dim3(1), dim3(64), 0, s->stream, 1, (size_t)0, s->pool_edge_cap, (const char *)dev_buf, s->state);
-  hipLaunchKernelGGL(k_pool_edges_apply, dim3(64), dim3(256), 0, s->stream, s->pool_edge_cap, (const int *)dev_buf, (const PoolRec *)((const char *)dev_buf + POOL_HDR),
+  hipStream_t st = pool_stream(s);
+  if (int rc = pool_fence(s, st)) return rc;
+  hipLaunchKernelGGL(k_pool_check, dim3(1), dim3(64), 0, st, 1, (size_t)0, s->pool_edge_cap, (const char *)dev_buf, s->state, 0);
+  hipLaunchKernelGGL(k_pool_edges_apply, dim3(64), dim3(256), 0, st, s->pool_edge_cap, (const int *)dev_buf, (const PoolRec *)((const char *)dev_buf + POOL_HDR),
                      s->drops[0], s->pool_remote);
   s->pool_check = true;
+  if (int rc = pool_applied(s, st)) return rc;
   HIPCHK(s, hipGetLastError());
   return WX_OK;
 }
@@ -1973,6 +2023,7 @@ int wx_pool_flags(wx_sim *s, uint8_t *host_dst)
   if (!s || !host_dst) return WX_E_INVALID;
   DeviceScope dev_scope(s);
   POOL_ONLY(s, "wx_pool_flags");
+  wait_unpacked(s); // (a pool exchange still running on the side stream)
   unsigned char *d = nullptr;
   if (hipMalloc((void **)&d, (size_t)s->n_drops) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_pool_flags");
   hipLaunchKernelGGL(k_pool_flags, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, s->n_drops, s->halo, s->X - s->halo, s->drops[0], s->pool_remote, d);
@@ -1986,6 +2037,7 @@ int wx_lightning_get(wx_sim *s, float out[4])
 {
   if (!s || !out) return WX_E_INVALID;
   DeviceScope dev_scope(s);
+  wait_unpacked(s);
   HIPCHK(s, hipMemcpyAsync(out, s->state->lightning, 16, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
   return WX_OK;
@@ -1995,6 +2047,7 @@ int wx_lightning_set(wx_sim *s, const float in[4])
 {
   if (!s || !in) return WX_E_INVALID;
   DeviceScope dev_scope(s);
+  wait_unpacked(s);
   HIPCHK(s, hipMemcpyAsync(s->state->lightning, in, 16, hipMemcpyHostToDevice, s->stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
   return WX_OK;

@@ -185,6 +185,12 @@ int wx_sync(wx_sim *s);
  *   WX_OPT_SPLAT_ORDER 1 the slabs are then bit-identical to one handle (SURVEY 8e's determinism check); the price is a latency-bound
  *   all-gather of a few KB per iteration. */
 #define WX_OPT_POOL_EXACT 7
+/* WX_OPT_EXCHANGE_OVERLAP (slab handles driven by the library's transport: wx_slab_step / wx_group_step): 1 (default) = pack, transfers
+ *   and unpack run on a side stream of the handle and hide behind the interior strips of the neighbouring iterations (grid-only: the
+ *   iteration before AND after; with particles the iteration after, because precipitation needs its whole iteration and the exchange
+ *   needs precipitation's feedback texture); 0 = everything in order on the compute stream -- same results bit for bit (tests), and
+ *   what the exact particle mode always does. */
+#define WX_OPT_EXCHANGE_OVERLAP 8
 int wx_set_option(wx_sim *s, int option, int value);
 
 /* iterNum global (app.js:440) */
@@ -339,10 +345,12 @@ int wx_group_exchange(wx_group *g);         /* an exchange now: afterwards every
 int wx_group_sync(wx_group *g);
 /* Slabs with particles (n_droplets > 0; halo and X_global / n_slabs multiples of 64) on the library's transport: wx_upload hands every
  * slab the WHOLE pool; wx_exchange / wx_slab_step / wx_group_step then also run the droplet-pool protocol above -- status flips (+ every
- * rank's lightning state) all-gathered with a fixed stride (65536 events per rank: no host round trip; more flips in one period are
- * reported as WX_E_STATE by the next blocking call), edge droplets in the same batch of transfers as the grid halos -- every
- * WX_SLAB_PERIOD_PARTICLES(halo) iterations, in order on the compute stream; with WX_OPT_POOL_EXACT one iteration at a time, each
- * followed by the all-gather of its flips and lightning requests. */
+ * rank's lightning state) all-gathered with a stride every rank derives from the headers of the PREVIOUS period's rounds (the whole
+ * event buffer at first, then 4 x the largest count seen, at least 65536 events: no host round trip inside a period; a burst beyond
+ * that is reported as WX_E_STATE by the next blocking call), edge droplets in the same batch of transfers as the grid halos -- every
+ * WX_SLAB_PERIOD_PARTICLES(halo) iterations, on the handle's side stream behind the interior strips of the next iteration
+ * (WX_OPT_EXCHANGE_OVERLAP); with WX_OPT_POOL_EXACT in order, one iteration at a time, each followed by the all-gather of its flips and
+ * lightning requests. */
 
 /* Per-kernel device time from HIP events recorded on the handle's stream around every launch.
  * wx_profile(s, 1) starts collecting, wx_profile_read returns accumulated milliseconds and launch counts

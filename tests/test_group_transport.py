@@ -159,6 +159,45 @@ def test_group_with_particles_equals_whole_domain(pkg, nslab, exact):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nslab,ndrops", [(4, 6000), (2, 6000), (4, 0)])
+def test_group_exchange_overlap_changes_nothing(pkg, nslab, ndrops):
+    """WX_OPT_EXCHANGE_OVERLAP: the exchange on the handles' side streams (grid-only: behind the interior strips before and after; with
+    particles: grid halos, feedback / deposition texture and the droplet pool behind the interior strips of the NEXT iteration) against
+    the same protocol in order on the compute stream -- every field, the pool and the lightning state bit for bit, at call boundaries
+    inside and at the end of periods (deterministic splat order: the textures are then a pure function of the pool)."""
+    E = pkg.engine
+    X, Y, halo = 512, 128, 64
+    base, water, wall, drops, u = _particle_scene(pkg, X, Y, 6000)
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    gs = []
+    for overlap in (1, 0):
+        g = E.Group(nslab, X, Y, halo=halo, devices=[0] * nslab, transport=E.TRANSPORT_LOCAL, n_droplets=ndrops)
+        g.upload(base, water, wall, drops if ndrops else None)
+        g.set_params(p, u["initial_T"])
+        if ndrops:
+            g.set_option(E.Handle.OPT_SPLAT_ORDER, 1)
+        g.set_option(E.Handle.OPT_EXCHANGE_OVERLAP, overlap)
+        gs.append(g)
+    per = (1 + (halo - 12) // 9) if ndrops else halo // 6
+    fields = ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1") + (("PRECIP_DEP", "PRECIP_FB") if ndrops else ())
+    done = 0
+    for k in (per, 1, per - 1, 2, 3 * per + 1, per - 3, per):
+        for g in gs:
+            g.step(k)
+        done += k
+        for f in fields:
+            assert np.array_equal(gs[0].read(f), gs[1].read(f)), (f, done)
+    if ndrops:
+        for a, b in zip(gs[0].slabs, gs[1].slabs):
+            assert np.array_equal(a.lightning(), b.lightning())
+        d0, d1 = gs[0].particles(), gs[1].particles()
+        assert (d0[:, 2] >= 0).sum() > 500
+        assert np.array_equal(d0, d1)
+    for g in gs:
+        g.close()
+
+
+@pytest.mark.gpu
 def test_rccl_comm_of_one_rank(pkg):
     """wx_comm_unique_id / wx_comm_init with world = 1: RCCL itself is bound (dlopen) and a communicator created on the device -- as much
     of the one-rank-per-process path as a 1-GPU box can execute; wx_slab_step then is wx_step. A lone slab with ghost columns is refused."""
