@@ -1513,9 +1513,11 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
         got = true;
         break;
       }
-      if (rejects.empty()) break;
-      free_set(rejects.front());
-      rejects.erase(rejects.begin());
+      // (never the allocations the handle came with: the confirmation below moves back into them)
+      auto victim = std::find_if(rejects.begin(), rejects.end(), [&](const std::vector<Block> &r) { return !r.empty() && r[0].p != original[0].p; });
+      if (victim == rejects.end()) break;
+      free_set(*victim);
+      rejects.erase(victim);
     }
     if (!got) break; // out of device memory: keep the best so far
     rc = copy_set(s, cand, backup);

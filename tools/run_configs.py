@@ -6,8 +6,11 @@ sys.path.insert(0, ROOT)
 rows = []
 
 def bench(label, args):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-pmc", "--no-north-star"] + args, capture_output=True, text=True).stdout
-    d = json.loads(out.strip().split("\n")[-1])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-pmc", "--no-north-star"] + args, capture_output=True, text=True)
+    try:
+        d = json.loads(r.stdout.strip().split("\n")[-1])
+    except ValueError:
+        sys.exit(f"bench.py {' '.join(args)} printed no JSON line (rc {r.returncode}):\n{r.stderr[-3000:]}")
     rows.append((label, " ".join(args), d["ms_per_step"], d["value"], d["roofline"]["kernels_ms_per_step"]))
 
 # C1: the reference's own, unmodified 100 x 100 test save (inputs of the save100raw golden), 1000 iterations, Python host
