@@ -202,6 +202,56 @@ __global__ __launch_bounds__(BX *BY) void k_emitted(Geo g, Uni u, int x0, int y0
   out[cidx(x, y, g.X)] = half4{__float2half_rn(e.x), __float2half_rn(e.y), __float2half_rn(e.z), __float2half_rn(e.w)};
 }
 
+// ---- device-side terrain generator (wx_setup_terrain): the 1-D part of setupShader.frag:26-61, 72, 74 ----
+// rand / noise of the setup shader in double, operation for operation what weather_sandbox_amd.synth and host/sim_host.js evaluate on
+// the host (the library is built with -ffp-contract=off: no fused multiply-adds, as on the host). One thread per local column; g = its global column.
+__device__ inline double tn_rand(double n) // setupShader.frag:26
+{
+  const double v = sin(n) * 43758.5453123;
+  return v - floor(v);
+}
+__device__ inline double tn_noise(double p) // setupShader.frag:28-33
+{
+  const double fl = floor(p), fc = p - fl;
+  const double a = tn_rand(fl) * (1.0 - fc), b = tn_rand(fl + 1.0) * fc;
+  return a + b - 0.5;
+}
+__global__ void k_terrain_columns(int Xl, int Xg, int col0, int Y, double seed, double height_mult, int snap, double sim_height, int *__restrict__ wall_rows,
+                                  unsigned int *__restrict__ sea, double *__restrict__ veg_noise, float *__restrict__ snow)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= Xl) return;
+  int g = (col0 + x) % Xg;
+  if (g < 0) g += Xg;
+  const int gs = snap > 1 ? g / snap * snap : g; // terrain constant over `snap` columns
+  double h = 0.0;
+  if (height_mult < 0.05) { // all sea (setupShader.frag:44-46)
+    h = 0.0;
+  } else if (height_mult < 0.10) { // all land
+    h = 0.005;
+  } else { // hills / mountains: octaves of value noise (setupShader.frag:52-59)
+    const double var = ((double)gs + 0.5) * 0.001;
+    for (double i = 2.0; i < 1000.0; i *= 1.5) {
+      const double r = tn_rand(seed + i) * 10.0;
+      const double arg = var * i;
+      h += tn_noise(arg + r) * 0.5 / i;
+    }
+    h *= height_mult;
+  }
+  // wall where texCoord.y < texelSize.y or texCoord.y < height: rows below max(1, ceil(h * Y - 0.5)), even thickness, 8 rows of air left
+  long long nrows = (long long)ceil(h * (double)Y - 0.5);
+  if (nrows < 1) nrows = 1;
+  if (snap > 1) nrows = (nrows + snap - 1) / snap * snap;
+  if (nrows > Y - 8) nrows = Y - 8;
+  wall_rows[x] = (int)nrows;
+  sea[x] = h < 1.0 / (double)Y ? 1u : 0u; // setupShader.frag:65
+  const double fx = (double)g + 0.5;
+  const double r0 = tn_rand(seed) * 10.0;
+  veg_noise[x] = tn_noise(fx * 0.01 + r0) * 150.0;                                            // setupShader.frag:72
+  const double sn = (h * sim_height - 2000.0) * 100.0 / 3000.0;                               // setupShader.frag:74: map_rangeC(height_m, 2000, 5000, 0, 100)
+  snow[x] = (float)fmin(fmax(sn, 0.0), 100.0);
+}
+
 // ---- device-side initialiser (wx_setup_columns): the 2-D part of setupShader.frag:63-89 ----
 // Column x is wall below row wall_rows[x] (sea if sea[x], else land), air above; per-row sounding for the air cells.
 __global__ __launch_bounds__(BX *BY) void k_setup_columns(int X, int Y, const int *__restrict__ wall_rows, const unsigned int *__restrict__ sea,

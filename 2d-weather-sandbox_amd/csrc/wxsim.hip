@@ -1041,6 +1041,50 @@ static int reset_after_upload(wx_sim *s, const float *drops)
 
 // Device-side initialiser of a new simulation: what the reference's setup pass draws (setupShader.frag:36-92), filled
 // from the per-column terrain description and the per-row sounding instead of uploading three X*Y textures.
+// device scratch of the setup fill: the column descriptors and the per-row sounding
+struct SetupScratch {
+  char *mem = nullptr;
+  double *veg;
+  int32_t *rows;
+  float *snow, *T, *tot, *cloud;
+  unsigned int *sea;
+};
+static int setup_scratch(wx_sim *s, SetupScratch &q, const char *who)
+{
+  const int X = s->X, Y = s->Y;
+  const size_t bytes = (size_t)X * (4 + 8 + 4 + 4) + (size_t)Y * 12;
+  if (hipMalloc(&q.mem, bytes) != hipSuccess) return fail(s, WX_E_NOMEM, "%s: %zu bytes of device scratch", who, bytes);
+  q.veg = (double *)q.mem;
+  q.rows = (int32_t *)(q.veg + X);
+  q.snow = (float *)(q.rows + X);
+  q.T = q.snow + X;
+  q.tot = q.T + Y;
+  q.cloud = q.tot + Y;
+  q.sea = (unsigned int *)(q.cloud + Y);
+  return WX_OK;
+}
+// descriptors on the device -> textures (k_setup_columns), both buffers of each pair, state reset as after wx_upload
+static int setup_fill(wx_sim *s, SetupScratch &q, const float *T_air, const float *total_water, const float *cloud_water, const float *drops, const char *who)
+{
+  const int X = s->X, Y = s->Y;
+  hipMemcpyAsync(q.T, T_air, (size_t)Y * 4, hipMemcpyHostToDevice, s->stream);
+  hipMemcpyAsync(q.tot, total_water, (size_t)Y * 4, hipMemcpyHostToDevice, s->stream);
+  hipMemcpyAsync(q.cloud, cloud_water, (size_t)Y * 4, hipMemcpyHostToDevice, s->stream);
+  hipLaunchKernelGGL(k_setup_columns, grid2d(s), dim3(BX, BY), 0, s->stream, X, Y, q.rows, q.sea, q.veg, q.snow, q.T, q.tot, q.cloud, s->base[0], s->water[0],
+                     s->wall[0]);
+  const size_t n = ncell(s);
+  hipMemcpyAsync(s->base[1], s->base[0], n * 16, hipMemcpyDeviceToDevice, s->stream);
+  hipMemcpyAsync(s->water[1], s->water[0], n * 16, hipMemcpyDeviceToDevice, s->stream);
+  hipMemcpyAsync(s->wall[1], s->wall[0], n * 4, hipMemcpyDeviceToDevice, s->stream);
+  hipError_t e = hipStreamSynchronize(s->stream); // the caller's arrays may go away now
+  hipFree(q.mem);
+  q.mem = nullptr;
+  if (e != hipSuccess) return fail(s, WX_E_DEVICE, "%s: %s", who, hipGetErrorString(e));
+  s->water_trivial = s->local_water_free = false;
+  s->wall_veg_ok = true; // k_setup_columns clamps the vegetation to 0..127
+  return reset_after_upload(s, drops);
+}
+
 int wx_setup_columns(wx_sim *s, const int32_t *wall_rows, const uint8_t *sea_column, const double *veg_noise, const float *snow,
                      const float *T_air, const float *total_water, const float *cloud_water, const float *drops)
 {
@@ -1052,37 +1096,33 @@ int wx_setup_columns(wx_sim *s, const int32_t *wall_rows, const uint8_t *sea_col
   const int X = s->X, Y = s->Y;
   for (int x = 0; x < X; x++)
     if (wall_rows[x] < 0 || wall_rows[x] > Y) return fail(s, WX_E_RANGE, "wx_setup_columns: wall_rows[%d] = %d outside 0..%d", x, wall_rows[x], Y);
-  // the descriptors live in a device scratch allocation for the duration of the fill
   static_assert(sizeof(double) == 8, "");
-  char *scratch = nullptr;
-  const size_t bytes = (size_t)X * (4 + 8 + 4 + 4) + (size_t)Y * 12;
-  if (hipMalloc(&scratch, bytes) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_setup_columns: %zu bytes of device scratch", bytes);
-  double *d_veg = (double *)scratch;
-  int32_t *d_rows = (int32_t *)(d_veg + X);
-  float *d_snow = (float *)(d_rows + X);
-  float *d_T = d_snow + X, *d_tot = d_T + Y, *d_cloud = d_tot + Y;
-  unsigned int *d_sea = (unsigned int *)(d_cloud + Y);
+  SetupScratch q;
+  if (int rc = setup_scratch(s, q, "wx_setup_columns")) return rc;
   std::vector<unsigned int> sea32(X);
   for (int x = 0; x < X; x++) sea32[x] = sea_column[x] ? 1u : 0u;
-  hipMemcpyAsync(d_veg, veg_noise, (size_t)X * 8, hipMemcpyHostToDevice, s->stream);
-  hipMemcpyAsync(d_rows, wall_rows, (size_t)X * 4, hipMemcpyHostToDevice, s->stream);
-  hipMemcpyAsync(d_snow, snow, (size_t)X * 4, hipMemcpyHostToDevice, s->stream);
-  hipMemcpyAsync(d_T, T_air, (size_t)Y * 4, hipMemcpyHostToDevice, s->stream);
-  hipMemcpyAsync(d_tot, total_water, (size_t)Y * 4, hipMemcpyHostToDevice, s->stream);
-  hipMemcpyAsync(d_cloud, cloud_water, (size_t)Y * 4, hipMemcpyHostToDevice, s->stream);
-  hipMemcpyAsync(d_sea, sea32.data(), (size_t)X * 4, hipMemcpyHostToDevice, s->stream);
-  hipLaunchKernelGGL(k_setup_columns, grid2d(s), dim3(BX, BY), 0, s->stream, X, Y, d_rows, d_sea, d_veg, d_snow, d_T, d_tot, d_cloud, s->base[0],
-                     s->water[0], s->wall[0]);
-  const size_t n = ncell(s);
-  hipMemcpyAsync(s->base[1], s->base[0], n * 16, hipMemcpyDeviceToDevice, s->stream);
-  hipMemcpyAsync(s->water[1], s->water[0], n * 16, hipMemcpyDeviceToDevice, s->stream);
-  hipMemcpyAsync(s->wall[1], s->wall[0], n * 4, hipMemcpyDeviceToDevice, s->stream);
-  hipError_t e = hipStreamSynchronize(s->stream); // sea32 and the caller's arrays may go away now
-  hipFree(scratch);
-  if (e != hipSuccess) return fail(s, WX_E_DEVICE, "wx_setup_columns: %s", hipGetErrorString(e));
-  s->water_trivial = s->local_water_free = false;
-  s->wall_veg_ok = true; // k_setup_columns clamps the vegetation to 0..127
-  return reset_after_upload(s, drops);
+  hipMemcpyAsync(q.veg, veg_noise, (size_t)X * 8, hipMemcpyHostToDevice, s->stream);
+  hipMemcpyAsync(q.rows, wall_rows, (size_t)X * 4, hipMemcpyHostToDevice, s->stream);
+  hipMemcpyAsync(q.snow, snow, (size_t)X * 4, hipMemcpyHostToDevice, s->stream);
+  hipMemcpyAsync(q.sea, sea32.data(), (size_t)X * 4, hipMemcpyHostToDevice, s->stream);
+  return setup_fill(s, q, T_air, total_water, cloud_water, drops, "wx_setup_columns"); // (synchronises: sea32 stays alive until then)
+}
+
+int wx_setup_terrain(wx_sim *s, double seed, double height_mult, int snap, double sim_height, const float *T_air, const float *total_water,
+                     const float *cloud_water, const float *drops)
+{
+  if (!s) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
+  if (!T_air || !total_water || !cloud_water) return fail(s, WX_E_INVALID, "wx_setup_terrain: NULL sounding array");
+  if (snap < 1 || !(sim_height > 0.0) || !(height_mult >= 0.0) || !(seed == seed))
+    return fail(s, WX_E_INVALID, "wx_setup_terrain: snap >= 1, sim_height > 0, height_mult >= 0 (got snap=%d sim_height=%g height_mult=%g seed=%g)", snap, sim_height, height_mult, seed);
+  if (s->Y < 16) return fail(s, WX_E_INVALID, "wx_setup_terrain: at least 16 rows (the terrain leaves 8 rows of air)");
+  if (int rc = drain_comm(s)) return rc;
+  SetupScratch q;
+  if (int rc = setup_scratch(s, q, "wx_setup_terrain")) return rc;
+  hipLaunchKernelGGL(k_terrain_columns, dim3((s->X + 255) / 256), dim3(256), 0, s->stream, s->X, s->Xg, s->x0 - s->halo, s->Y, seed, height_mult, snap, sim_height, q.rows,
+                     q.sea, q.veg, q.snow);
+  return setup_fill(s, q, T_air, total_water, cloud_water, drops, "wx_setup_terrain");
 }
 
 int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const float *sounding_T, const float *sounding_W,

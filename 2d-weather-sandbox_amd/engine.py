@@ -31,7 +31,7 @@ EXPORTS = [
     "wx_step", "wx_sync", "wx_get_iter", "wx_set_iter", "wx_read_rect", "wx_read_particles", "wx_set_stream",
     "wx_device_ptr", "wx_local_width", "wx_halo_bytes", "wx_halo_pack", "wx_halo_unpack", "wx_profile",
     "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_pool_event_bytes",
-    "wx_pool_edge_bytes", "wx_pool_events_pack", "wx_pool_events_apply", "wx_pool_edges_pack", "wx_pool_edges_apply", "wx_pool_flags", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns",
+    "wx_pool_edge_bytes", "wx_pool_events_pack", "wx_pool_events_apply", "wx_pool_edges_pack", "wx_pool_edges_apply", "wx_pool_flags", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns", "wx_setup_terrain",
     "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait", "wx_set_comm_stream", "wx_step_overlap",
     "wx_set_option", "wx_water_free", "wx_slab_assert_water_free", "wx_tune_placement",
     "wx_comm_unique_id", "wx_comm_init", "wx_exchange", "wx_slab_step", "wx_group_create", "wx_group_destroy", "wx_group_last_error",
@@ -119,6 +119,7 @@ def lib() -> C.CDLL:
     L.wx_lightning_get.argtypes = [vp, vp]
     L.wx_lightning_set.argtypes = [vp, vp]
     L.wx_setup_columns.argtypes = [vp] + [vp] * 8
+    L.wx_setup_terrain.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_double] + [vp] * 4
     L.wx_stream_bytes.argtypes = [i32, i32]
     L.wx_stream_bytes.restype = C.c_size_t
     L.wx_host_alloc.argtypes = [C.c_size_t]
@@ -393,6 +394,23 @@ class Handle:
                 raise ValueError("setup_columns: drops must be (n_droplets, 5) float32")
             dp = drops.ctypes.data_as(C.c_void_p)
         self._chk(lib().wx_setup_columns(self._h, *[a.ctypes.data_as(C.c_void_p) for a in arrs], dp))
+
+    def setup_terrain(self, sounding, seed: float = 0.5, height_mult: float = 0.3, snap: int = 2, sim_height: float = 12000.0, drops=None):
+        """New simulation generated entirely on the device (wx_setup_terrain): ``sounding`` = the per-row arrays of
+        ``synth.sounding_rows`` (or any dict with T_air / total_water / cloud_water), terrain from the setup shader's noise."""
+        arrs = []
+        for k in ("T_air", "total_water", "cloud_water"):
+            a = np.ascontiguousarray(sounding[k], np.float32)
+            if a.shape != (self.Y,):
+                raise ValueError(f"setup_terrain: {k} has shape {a.shape}, expected ({self.Y},)")
+            arrs.append(a)
+        dp = None
+        if drops is not None:
+            drops = np.ascontiguousarray(drops, np.float32)
+            if drops.shape != (self.n_droplets, 5):
+                raise ValueError("setup_terrain: drops must be (n_droplets, 5) float32")
+            dp = drops.ctypes.data_as(C.c_void_p)
+        self._chk(lib().wx_setup_terrain(self._h, float(seed), float(height_mult), int(snap), float(sim_height), *[a.ctypes.data_as(C.c_void_p) for a in arrs], dp))
 
     # ---- particles on slabs (device pointers; see include/wxsim.h) ----
     def slab_set_rank(self, rank: int):

@@ -69,7 +69,21 @@ def terrain_columns(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: fl
         gcol = (cols[0] + np.arange(cols[1])) % X
         h, nrows = h[gcol], nrows[gcol]
     fx = gcol.astype(np.float64) + 0.5
-    # air: initial sounding (setupShader.frag:78-89)
+    return {
+        "wall_rows": nrows.astype(np.int32), "sea": (h < texY).astype(np.uint8),
+        "veg_noise": (_noise(fx * 0.01 + _rand(seed) * 10.0) * 150.0).astype(np.float64),
+        "snow": np.clip((h * sim_h - 2000.0) * 100.0 / 3000.0, 0.0, 100.0).astype(np.float32),
+        **sounding_rows(Y, gui, cloud_deck),
+    }
+
+
+def sounding_rows(Y: int, gui=None, cloud_deck: bool = False):
+    """Per row: air temperature, total and cloud water of the initial sounding (setupShader.frag:78-89) -- the part of a new
+    simulation that stays on the host when the terrain is generated on the device (``Handle.setup_terrain``)."""
+    gui = params.merge_settings(None) if gui is None else gui
+    sim_h = float(gui["simHeight"])
+    dry_lapse = sim_h * float(gui["dryLapseRate"]) / 1000.0
+    T0 = params.initial_temperature_profile(Y, sim_h, dry_lapse)
     yy = np.arange(Y)
     tcy = (yy + 0.5) / Y
     T_air = T0[:Y].astype(np.float64)
@@ -82,12 +96,7 @@ def terrain_columns(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: fl
         deck = (yy > Y // 4) & (yy < Y // 2)
         cloud = np.where(deck, np.float32(1.5), cloud).astype(np.float32)
         tot = np.where(deck, tot + np.float32(1.5), tot).astype(np.float32)
-    return {
-        "wall_rows": nrows.astype(np.int32), "sea": (h < texY).astype(np.uint8),
-        "veg_noise": (_noise(fx * 0.01 + _rand(seed) * 10.0) * 150.0).astype(np.float64),
-        "snow": np.clip((h * sim_h - 2000.0) * 100.0 / 3000.0, 0.0, 100.0).astype(np.float32),
-        "T_air": T_air, "total_water": tot, "cloud_water": cloud,
-    }
+    return {"T_air": T_air, "total_water": tot, "cloud_water": cloud}
 
 
 def terrain_grid(X: int, Y: int, gui=None, seed: float = 0.5, height_mult: float = 0.3, snap: int = 2, cols=None):

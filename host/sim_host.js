@@ -289,7 +289,10 @@ function WeatherSim(sf, opts)
       const h = this.addon.groupSlab(this.group, i, Y), x0 = i * xo;
       const gx = new Int32Array(wl); // global column of every local one
       for (let c = 0; c < wl; c++) gx[c] = ((x0 - halo + c) % X + X) % X;
-      if (sf.columns) {
+      if (sf.terrain) { // every slab generates its own columns on its own device
+        const c = sf.columns, g = sf.terrain;
+        this.addon.setupTerrain(h, g.seed, g.heightMult, g.snap, this.gui.simHeight, c.T_air, c.totalWater, c.cloudWater, this.nDroplets ? sf.droplets : null);
+      } else if (sf.columns) {
         const c = sf.columns, pick = function(a) { const o = new a.constructor(wl); for (let k = 0; k < wl; k++) o[k] = a[gx[k]]; return o; };
         this.addon.setupColumns(h, pick(c.wallRows), pick(c.sea), pick(c.vegNoise), pick(c.snow), c.T_air, c.totalWater, c.cloudWater, this.nDroplets ? sf.droplets : null);
       } else {
@@ -307,7 +310,10 @@ function WeatherSim(sf, opts)
     this.h = null;
   } else {
     this.h = this.addon.create(this.X, this.Y, this.nDroplets);
-    if (sf.columns) { // new simulation: textures filled on the device from the 1-D descriptors (setupShader.frag)
+    if (sf.terrain) { // new simulation generated entirely on the device (wx_setup_terrain); the host keeps the per-row sounding
+      const c = sf.columns, g = sf.terrain;
+      this.addon.setupTerrain(this.h, g.seed, g.heightMult, g.snap, this.gui.simHeight, c.T_air, c.totalWater, c.cloudWater, this.nDroplets ? sf.droplets : null);
+    } else if (sf.columns) { // ... or the textures filled on the device from 1-D descriptors computed here (setupShader.frag)
       const c = sf.columns;
       this.addon.setupColumns(this.h, c.wallRows, c.sea, c.vegNoise, c.snow, c.T_air, c.totalWater, c.cloudWater, this.nDroplets ? sf.droplets : null);
     } else {
@@ -435,7 +441,9 @@ WeatherSim.newSimulation = function(X, Y, opts) {
   opts = opts || {};
   const gui = mergeSettings(opts.settings || null);
   const nDrops = opts.nDroplets != null ? opts.nDroplets : Math.floor(X * Y / 25); // app.js: one droplet per 25 cells
-  return new WeatherSim({X: X, Y: Y, settings: gui, columns: terrainColumns(X, Y, gui, opts), droplets: nDrops ? initRainDrops(nDrops, opts.rng) : null}, opts);
+  // opts.deviceTerrain: the terrain noise runs on the device too (wx_setup_terrain); the descriptors computed here then only serve as reference
+  const terrain = opts.deviceTerrain ? {seed: opts.seed != null ? opts.seed : 0.5, heightMult: opts.heightMult != null ? opts.heightMult : 0.3, snap: opts.snap != null ? opts.snap : 2} : null;
+  return new WeatherSim({X: X, Y: Y, settings: gui, columns: terrainColumns(X, Y, gui, opts), terrain: terrain, droplets: nDrops ? initRainDrops(nDrops, opts.rng) : null}, opts);
 };
 
 module.exports = {WeatherSim: WeatherSim, initialSimDateTime: initialSimDateTime, advanceSimDateTime: advanceSimDateTime, loadSave: loadSave, decodeSave: decodeSave, encodeSave: encodeSave, mergeSettings: mergeSettings,

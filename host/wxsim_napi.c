@@ -34,6 +34,7 @@ static struct {
   int (*read_particles)(wx_sim *, int, int, float *);
   int (*setup_columns)(wx_sim *, const int32_t *, const uint8_t *, const double *, const float *, const float *, const float *, const float *,
                        const float *);
+  int (*setup_terrain)(wx_sim *, double, double, int, double, const float *, const float *, const float *, const float *);
   size_t (*stream_bytes)(int, int);
   void *(*host_alloc)(size_t);
   void (*host_free)(void *);
@@ -460,6 +461,38 @@ static napi_value SetupColumns(napi_env env, napi_callback_info info)
   return NULL;
 }
 
+/* setupTerrain(h, seed, heightMult, snap, simHeight, Float32Array T_air, totalWater, cloudWater, Float32Array drops | null): a new
+ * simulation generated entirely on the device (wx_setup_terrain: setupShader.frag:26-92) */
+static napi_value SetupTerrain(napi_env env, napi_callback_info info)
+{
+  napi_value a[9];
+  if (get_args(env, info, 9, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  const wx_slot *sl = get_slot(env, a[0]);
+  if (!sl) return NULL;
+  double seed, mult, snap, simh;
+  NAPI_CALL(env, napi_get_value_double(env, a[1], &seed));
+  NAPI_CALL(env, napi_get_value_double(env, a[2], &mult));
+  NAPI_CALL(env, napi_get_value_double(env, a[3], &snap));
+  NAPI_CALL(env, napi_get_value_double(env, a[4], &simh));
+  const size_t ny = (size_t)sl->Y;
+  const float *T = (const float *)typed_at_least(env, a[5], napi_float32_array, ny, "setupTerrain: T_air (Float32Array, Y)");
+  if (!T) return NULL;
+  const float *tot = (const float *)typed_at_least(env, a[6], napi_float32_array, ny, "setupTerrain: totalWater (Float32Array, Y)");
+  if (!tot) return NULL;
+  const float *cloud = (const float *)typed_at_least(env, a[7], napi_float32_array, ny, "setupTerrain: cloudWater (Float32Array, Y)");
+  if (!cloud) return NULL;
+  const float *drops = NULL;
+  if (!is_nullish(env, a[8]) && sl->N > 0) {
+    drops = (const float *)typed_at_least(env, a[8], napi_float32_array, (size_t)sl->N * 5, "setupTerrain: drops (Float32Array, nDroplets*5)");
+    if (!drops) return NULL;
+  }
+  int rc = L.setup_terrain(s, seed, mult, (int)snap, simh, T, tot, cloud, drops);
+  if (rc) return throw_wx(env, s, rc, "wx_setup_terrain");
+  return NULL;
+}
+
 static void finalize_pinned(napi_env env, void *data, void *hint) { L.host_free(data); }
 
 /* streamFrame(h, x, y, w, h) -> ArrayBuffer over pinned host memory that the copies fill asynchronously; streamWait(h)
@@ -704,7 +737,7 @@ static int load_lib(napi_env env)
   SYM(create, "wx_create") SYM(destroy, "wx_destroy") SYM(last_error, "wx_last_error") SYM(abi_version, "wx_abi_version")
   SYM(upload, "wx_upload") SYM(set_params, "wx_set_params") SYM(step, "wx_step") SYM(sync, "wx_sync") SYM(get_iter, "wx_get_iter")
   SYM(set_iter, "wx_set_iter") SYM(read_rect, "wx_read_rect") SYM(read_particles, "wx_read_particles")
-  SYM(setup_columns, "wx_setup_columns") SYM(stream_bytes, "wx_stream_bytes") SYM(host_alloc, "wx_host_alloc") SYM(host_free, "wx_host_free")
+  SYM(setup_columns, "wx_setup_columns") SYM(setup_terrain, "wx_setup_terrain") SYM(stream_bytes, "wx_stream_bytes") SYM(host_alloc, "wx_host_alloc") SYM(host_free, "wx_host_free")
   SYM(stream_frame, "wx_stream_frame") SYM(stream_wait, "wx_stream_wait") SYM(set_option, "wx_set_option") SYM(tune_placement, "wx_tune_placement")
   SYM(group_create, "wx_group_create") SYM(group_destroy, "wx_group_destroy") SYM(group_last_error, "wx_group_last_error") SYM(group_count, "wx_group_count")
   SYM(group_transport, "wx_group_transport") SYM(group_slab, "wx_group_slab") SYM(group_agree, "wx_group_agree") SYM(group_step, "wx_group_step")
@@ -723,7 +756,7 @@ static napi_value Init(napi_env env, napi_value exports)
     {"step", 0, Step, 0, 0, 0, napi_default, 0},           {"sync", 0, Sync, 0, 0, 0, napi_default, 0},
     {"getIter", 0, GetIter, 0, 0, 0, napi_default, 0},     {"setIter", 0, SetIter, 0, 0, 0, napi_default, 0},
     {"readRect", 0, ReadRect, 0, 0, 0, napi_default, 0},   {"readParticles", 0, ReadParticles, 0, 0, 0, napi_default, 0},
-    {"abiVersion", 0, AbiVersion, 0, 0, 0, napi_default, 0}, {"setupColumns", 0, SetupColumns, 0, 0, 0, napi_default, 0},
+    {"abiVersion", 0, AbiVersion, 0, 0, 0, napi_default, 0}, {"setupColumns", 0, SetupColumns, 0, 0, 0, napi_default, 0}, {"setupTerrain", 0, SetupTerrain, 0, 0, 0, napi_default, 0},
     {"streamFrame", 0, StreamFrame, 0, 0, 0, napi_default, 0}, {"streamWait", 0, StreamWait, 0, 0, 0, napi_default, 0},
     {"setOption", 0, SetOption, 0, 0, 0, napi_default, 0},   {"tunePlacement", 0, TunePlacement, 0, 0, 0, napi_default, 0},
     {"groupCreate", 0, GroupCreate, 0, 0, 0, napi_default, 0}, {"groupSlab", 0, GroupSlab, 0, 0, 0, napi_default, 0},

@@ -142,6 +142,16 @@ int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wa
 int wx_setup_columns(wx_sim *s, const int32_t *wall_rows, const uint8_t *sea_column, const double *veg_noise, const float *snow,
                      const float *T_air, const float *total_water, const float *cloud_water, const float *drops);
 
+/* The same with the 1-D part generated on the device too (k_terrain_columns: rand / noise of setupShader.frag:26-33, the octave sum of
+ * :52-59, vegetation noise :72, snow :74 -- in double, operation for operation what the host generators evaluate, so the result equals
+ * wx_setup_columns of weather_sandbox_amd.synth.terrain_columns(X, Y, seed=, height_mult=, snap=) unless the device's sin() differs in
+ * the last bit at a column whose height sits on a row boundary). seed / height_mult: the shader's uniforms (app.js: Math.random() and the
+ * new-simulation dialog); snap: terrain constant over `snap` columns and an even number of rows thick (1 = the shader's raw terrain);
+ * sim_height: simHeight [m]; the three per-row arrays (Y entries) are the initial sounding as for wx_setup_columns. A slab handle
+ * generates its own local columns (global column (x0 - halo + i) mod X_global): no host array scales with the grid. */
+int wx_setup_terrain(wx_sim *s, double seed, double height_mult, int snap, double sim_height, const float *T_air, const float *total_water,
+                     const float *cloud_water, const float *drops);
+
 /* Replaces the uniform pushes (see wx_params) plus the `initial_Tv` / realWorldSounding_* arrays
  * (app.js:5444-5474, 5485-5537). initial_T has Y+1 entries; sounding arrays Y+1 entries or NULL (= 0).
  * Takes effect at the next wx_step. */

@@ -1196,6 +1196,47 @@ def test_device_side_setup_equals_uploaded_grid(pkg, E, X, Y, cols):
         b.setup_columns(dict(desc, snow=desc["snow"][:-1]))
 
 
+@pytest.mark.parametrize("X,Y,cols,seed,mult,snap", [(4096, 256, None, 0.5, 0.3, 2), (1000, 600, None, 0.8371, 0.45, 1), (4096, 256, (4000, 300), 0.5, 0.3, 2),
+                                                     (512, 64, None, 0.2, 0.07, 2), (512, 64, None, 0.2, 0.0, 2), (16384, 512, (16000, 1024), 0.123, 0.9, 4)])
+def test_device_side_terrain_equals_host_generator(pkg, E, X, Y, cols, seed, mult, snap):
+    """wx_setup_terrain (setupShader.frag:26-92 entirely on the device): rand / noise / the octave sum in double on the device
+    against the host generator's descriptors -- wall rows, sea / land, snow and the vegetation byte of every column. The only source of a
+    difference is the last bit of the device's sin() at a column whose height sits exactly on a row boundary, so the textures must be
+    identical on (at least) all but a handful of columns; in practice they are identical, and then so is the run that follows.
+    A slab handle generates its own window of global columns (wrap included)."""
+    S = pkg.synth
+    desc = S.terrain_columns(X, Y, seed=seed, height_mult=mult, snap=snap, cols=cols)
+    Xl = X if cols is None else cols[1]
+    kw = {} if cols is None else dict(X_global=X, x0=cols[0] + 12, halo=12)
+    a = E.Handle(Xl if cols is None else Xl - 24, Y, 0, **kw)
+    b = E.Handle(Xl if cols is None else Xl - 24, Y, 0, **kw)
+    a.setup_columns(desc)
+    gui = pkg.params.merge_settings(None)
+    b.setup_terrain(S.sounding_rows(Y), seed=seed, height_mult=mult, snap=snap, sim_height=float(gui["simHeight"]))
+    fields = ("BASE_CUR", "WATER_CUR", "WATER_0", "WALL_CUR")
+    fa, fb = {f: a.read_rect(f) for f in fields}, {f: b.read_rect(f) for f in fields}
+    differing = np.zeros(Xl, bool)
+    for f in fields:
+        differing |= (fa[f] != fb[f]).any(axis=(0, 2))
+    assert differing.sum() <= max(2, Xl // 2000), (int(differing.sum()), np.flatnonzero(differing)[:10])
+    if mult >= 0.10:
+        assert len(np.unique(desc["wall_rows"])) >= 3  # hills, not a flat line
+    if not differing.any():
+        gui["sunAngle"] = 40.0
+        u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+        u["enablePrecipitation"] = 0
+        p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+        for h in (a, b):
+            h.set_params(p, u["initial_T"])
+            h.step(5)
+        for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0"):
+            assert np.array_equal(a.read_rect(f), b.read_rect(f)), f
+    with pytest.raises(E.WxError):
+        b.setup_terrain(S.sounding_rows(Y), snap=0)
+    with pytest.raises(ValueError):
+        b.setup_terrain({k: v[:-1] for k, v in S.sounding_rows(Y).items()})
+
+
 def test_display_field_streaming(pkg, golden, E):
     """wx_stream_frame: the six display fields of a viewport arrive in one pinned buffer, hold the state
     at the time of the call even though more iterations are enqueued right behind it, and do not disturb the run."""

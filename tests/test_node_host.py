@@ -134,6 +134,28 @@ def test_node_new_simulation_and_streaming(pkg, tmp_path):
 
 @needs_node
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [1, 4])
+def test_node_new_simulation_with_device_terrain(pkg, tmp_path, gpus):
+    """WeatherSim.newSimulation({deviceTerrain: true}): the terrain noise of the setup shader evaluated on the device (wx_setup_terrain; with
+    --gpus N every slab generates its own columns) -- the same save file as the host-side descriptors produce, bit for bit."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    X, Y, n = 1024, 100, 12
+    outs = []
+    for dev in ("true", "false"):
+        out_file = str(tmp_path / f"new_{dev}.weathersandbox")
+        slab = "gpus:%d,halo:12,transport:2," % gpus if gpus > 1 else ""
+        js = ("const H=require('%s'), fs=require('fs');"
+              "const sim=H.WeatherSim.newSimulation(%d,%d,{%ssunFixed:true,deviceTerrain:%s,seed:0.37,heightMult:0.4,settings:{enablePrecipitation:false}});"
+              "sim.frame(%d); fs.writeFileSync('%s', H.encodeSave(sim.toSave())); sim.destroy();" % (os.path.join(ROOT, "host", "sim_host.js"), X, Y, slab, dev, n, out_file))
+        subprocess.check_call([NODE, "-e", js])
+        outs.append(pkg.codec.load(out_file))
+    a, b = outs
+    assert len(np.unique((a.wall[..., 1] == 0).sum(0))) >= 3  # hills (low ones on a 100-row grid)
+    assert np.array_equal(a.base, b.base) and np.array_equal(a.water, b.water) and np.array_equal(a.wall, b.wall)
+
+
+@needs_node
+@pytest.mark.gpu
 def test_addon_rejects_short_arrays(pkg):
     """The N-API shim checks every typed array against the handle's dimensions (X*Y*4, Y+1, X, nDroplets*5) before the
     C ABI reads through the pointer: a short array is a RangeError, a wrong type a TypeError, never an out-of-bounds read."""
