@@ -209,8 +209,8 @@ class SlabSim:
                 self._hrecv = [torch.empty_like(b, device="cpu") for b in self.recv]
             self.agree_water_free()
         # On GPUs the exchange runs INSIDE the library (wx_comm_init / wx_slab_step: pack -> ncclSend / ncclRecv -> unpack on the handle's
-        # comm stream; with particles also the droplet-pool protocol: ncclAllGather of the status flips with a fixed stride, edge droplets
-        # in the halos' batch); torch.distributed is then only the launcher and the carrier of the communicator's id. The host-driven
+        # comm stream; with particles also the droplet-pool protocol: ncclAllGather of the status flips with a stride derived from the previous
+        # period's counts, edge droplets in the halos' batch, all of it behind the interior strips of the next iteration); torch.distributed is then only the launcher and the carrier of the communicator's id. The host-driven
         # path below stays for the gloo transport of the CPU tests (and as the fallback).
         self._native = False
         self.transport = "host-driven (torch.distributed send / recv)"
@@ -240,8 +240,11 @@ class SlabSim:
             if int(ok.item()) == 1:
                 self._native = True
                 self.transport = "in-library RCCL (wx_comm_init / wx_slab_step: ncclSend / ncclRecv on the comm stream)"
-            elif err:
-                print(f"[slab] rank {rank}: in-library transport unavailable ({err[0]}); using the host-driven exchange", flush=True)
+            else:
+                if err:
+                    print(f"[slab] rank {rank}: in-library transport unavailable ({err[0]}); using the host-driven exchange", flush=True)
+                if self.particles:  # wx_comm_init gave the handle a side stream for the pool exchange; the host-driven one runs in order
+                    engine.h.set_comm_stream(0)
 
     def agree_water_free(self):
         """The water-free dry iteration (36 B/cell) is only valid on a slab if NO slab of the domain carries water (ghost columns
