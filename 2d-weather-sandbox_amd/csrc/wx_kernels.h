@@ -404,6 +404,24 @@ __device__ __forceinline__ float det_cbrt(float x)
   return y;
 }
 
+// initRainDrops() (app.js:4901-4913) on the device: every droplet starts inactive, its five fields are random seeds --
+// (r, r, -10 + r, r, r) with r uniform in [0, 1). The reference draws them from Math.random(); here field c of droplet i is a pure
+// function of (seed, i, c) through the shaders' own integer hash (common.glsl:103-111), 24 random bits each, so every slab of a
+// decomposed domain generates the same pool and a numpy restatement reproduces it bit for bit (tests).
+__global__ void k_init_droplets(int n, uint32_t seed, float *__restrict__ d0, float *__restrict__ d1)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    const uint32_t h = hash_u32(seed + hash_u32((uint32_t)i * 5u + (uint32_t)c));
+    float r = (float)(h >> 8) * (1.0f / 16777216.0f);
+    if (c == 2) r = -10.0f + r;
+    d0[(size_t)i * 5 + c] = r;
+    d1[(size_t)i * 5 + c] = r;
+  }
+}
+
 // texel of the LOCAL array that holds global texture coordinate (u, v); the column may lie outside the local array
 // (>= g.X) on slab handles -- callers check local_col() first
 __device__ __forceinline__ int local_col(const Geo &g, float u_)

@@ -992,6 +992,35 @@ int wx_upload(wx_sim *s, const float *base, const float *water, const int8_t *wa
   return reset_after_upload(s, drops);
 }
 
+// partitioned pool of a slab handle: every rank was handed the whole pool; keep what lies in the local array (owned + ghost columns)
+static int pool_reset(wx_sim *s)
+{
+  if (!s->pool_remote) return WX_OK;
+  HIPCHK(s, hipMemsetAsync(s->pool_remote, 0, (size_t)s->n_drops, s->stream));
+  HIPCHK(s, hipMemsetAsync(s->pool_owned, 0, (size_t)s->n_drops, s->stream));
+  HIPCHK(s, hipMemsetAsync(s->pool_flips, 0, (size_t)s->n_drops * 2, s->stream));
+  hipLaunchKernelGGL(k_pool_edges_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, s->n_drops, 0, s->X, 0, 0, s->drops[0], s->pool_remote,
+                     nullptr, nullptr, nullptr, nullptr, s->state, 0);
+  HIPCHK(s, hipGetLastError());
+  return WX_OK;
+}
+
+// initRainDrops() on the device (k_init_droplets): a fresh, all-inactive pool from a seed; the grid is untouched
+int wx_init_droplets(wx_sim *s, uint32_t seed)
+{
+  if (!s) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
+  if (s->n_drops <= 0) return fail(s, WX_E_STATE, "wx_init_droplets: the handle has no droplets");
+  if (int rc = drain_comm(s)) return rc;
+  hipLaunchKernelGGL(k_init_droplets, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->n_drops, seed, s->drops[0], s->drops[1]);
+  HIPCHK(s, hipGetLastError());
+  if (int rc = pool_reset(s)) return rc;
+  HIPCHK(s, hipStreamSynchronize(s->stream));
+  s->period_j = 0;
+  s->exact_pending = 0;
+  return WX_OK;
+}
+
 // everything wx_upload resets besides the three grids (shared with wx_setup_columns)
 static int reset_after_upload(wx_sim *s, const float *drops)
 {
@@ -1006,14 +1035,8 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 16, s->stream));
   HIPCHK(s, hipMemsetAsync(s->dep, 0, n * 8, s->stream));
   HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
-  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 40, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow, pool_overflow, pool_retired
-  if (s->pool_remote) { // partitioned pool: every rank was handed the whole pool; keep what lies in the local array (owned + ghost columns)
-    HIPCHK(s, hipMemsetAsync(s->pool_remote, 0, (size_t)s->n_drops, s->stream));
-    HIPCHK(s, hipMemsetAsync(s->pool_owned, 0, (size_t)s->n_drops, s->stream));
-    HIPCHK(s, hipMemsetAsync(s->pool_flips, 0, (size_t)s->n_drops * 2, s->stream));
-    hipLaunchKernelGGL(k_pool_edges_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, s->stream, s->geo, s->n_drops, 0, s->X, 0, 0, s->drops[0], s->pool_remote,
-                       nullptr, nullptr, nullptr, nullptr, s->state, 0);
-  }
+  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 44, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow, pool_overflow, pool_seen_max, pool_retired
+  if (int rc = pool_reset(s)) return rc;
   if (s->sg.acc4) {
     HIPCHK(s, hipMemsetAsync(s->sg.acc4, 0, (size_t)s->sg.AP * s->sg.AH * 16, s->stream));
     HIPCHK(s, hipMemsetAsync(s->sg.acc2, 0, (size_t)s->sg.AP * s->sg.AH * 8, s->stream));

@@ -195,3 +195,25 @@ def add_cloud_deck(water: np.ndarray, wall: np.ndarray) -> None:
     deck = (wall[..., 1] != 0) & (yy > Y // 4) & (yy < Y // 2)
     water[..., 1] = np.where(deck, 1.5, water[..., 1]).astype(np.float32)
     water[..., 0] = np.where(deck, water[..., 0] + 1.5, water[..., 0]).astype(np.float32)
+
+
+def _hash_u32(x: np.ndarray) -> np.ndarray:
+    # common.glsl:103-111 on uint32 arrays (wrap-around arithmetic)
+    x = x.astype(np.uint32)
+    x = x + (x << np.uint32(10))
+    x = x ^ (x >> np.uint32(6))
+    x = x + (x << np.uint32(3))
+    x = x ^ (x >> np.uint32(11))
+    x = x + (x << np.uint32(15))
+    return x
+
+
+def init_rain_drops_hashed(n: int, seed: int = 1) -> np.ndarray:
+    """The pool ``Handle.init_droplets(seed)`` (wx_init_droplets) generates on the device, restated: field c of droplet i = 24 bits
+    of hash(seed + hash(5 i + c)); (r, r, -10 + r, r, r) as initRainDrops() lays them out (app.js:4901-4913)."""
+    with np.errstate(over="ignore"):
+        idx = (np.arange(n, dtype=np.uint32)[:, None] * np.uint32(5) + np.arange(5, dtype=np.uint32)[None, :]).astype(np.uint32)
+        h = _hash_u32(np.uint32(seed & 0xFFFFFFFF) + _hash_u32(idx))
+    r = (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    r[:, 2] = np.float32(-10.0) + r[:, 2]
+    return r

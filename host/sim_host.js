@@ -262,7 +262,7 @@ function WeatherSim(sf, opts)
   this.X = sf.X;
   this.Y = sf.Y;
   this.gui = mergeSettings(sf.settings);
-  this.nDroplets = sf.droplets ? Math.floor(sf.droplets.length / 5) : 0;
+  this.nDroplets = sf.droplets ? Math.floor(sf.droplets.length / 5) : (sf.dropletSeed != null ? (sf.nDroplets | 0) : 0);
   this.opts = opts;
   this.manualSun = opts.sunFixed ? this.gui.sunAngle : null; // updateSunlight('MANUAL_ANGLE')
   this.slabs = null;
@@ -304,6 +304,7 @@ function WeatherSim(sf, opts)
         };
         this.addon.upload(h, cut(sf.base), cut(sf.water), cut(sf.wall), this.nDroplets ? sf.droplets : null);
       }
+      if (sf.dropletSeed != null && this.nDroplets) this.addon.initDroplets(h, sf.dropletSeed >>> 0); // the same pool on every slab
       this.slabs.push({h: h, x0: x0, xo: xo, halo: halo, wl: wl});
     }
     this.addon.groupAgree(this.group);
@@ -319,6 +320,7 @@ function WeatherSim(sf, opts)
     } else {
       this.addon.upload(this.h, sf.base, sf.water, sf.wall, this.nDroplets ? sf.droplets : null);
     }
+    if (sf.dropletSeed != null && this.nDroplets) this.addon.initDroplets(this.h, sf.dropletSeed >>> 0);
   }
   // startSimulation(): clock from month / timeOfDay (app.js:3902)
   const m = this.gui.month;
@@ -441,9 +443,11 @@ WeatherSim.newSimulation = function(X, Y, opts) {
   opts = opts || {};
   const gui = mergeSettings(opts.settings || null);
   const nDrops = opts.nDroplets != null ? opts.nDroplets : Math.floor(X * Y / 25); // app.js: one droplet per 25 cells
+  // opts.dropletSeed (an integer): the droplet pool is generated on the device as well (wx_init_droplets), identically on every slab
   // opts.deviceTerrain: the terrain noise runs on the device too (wx_setup_terrain); the descriptors computed here then only serve as reference
   const terrain = opts.deviceTerrain ? {seed: opts.seed != null ? opts.seed : 0.5, heightMult: opts.heightMult != null ? opts.heightMult : 0.3, snap: opts.snap != null ? opts.snap : 2} : null;
-  return new WeatherSim({X: X, Y: Y, settings: gui, columns: terrainColumns(X, Y, gui, opts), terrain: terrain, droplets: nDrops ? initRainDrops(nDrops, opts.rng) : null}, opts);
+  return new WeatherSim({X: X, Y: Y, settings: gui, columns: terrainColumns(X, Y, gui, opts), terrain: terrain, nDroplets: nDrops, dropletSeed: opts.dropletSeed != null ? opts.dropletSeed : null,
+                         droplets: nDrops && opts.dropletSeed == null ? initRainDrops(nDrops, opts.rng) : null}, opts);
 };
 
 module.exports = {WeatherSim: WeatherSim, initialSimDateTime: initialSimDateTime, advanceSimDateTime: advanceSimDateTime, loadSave: loadSave, decodeSave: decodeSave, encodeSave: encodeSave, mergeSettings: mergeSettings,

@@ -35,6 +35,7 @@ static struct {
   int (*setup_columns)(wx_sim *, const int32_t *, const uint8_t *, const double *, const float *, const float *, const float *, const float *,
                        const float *);
   int (*setup_terrain)(wx_sim *, double, double, int, double, const float *, const float *, const float *, const float *);
+  int (*init_droplets)(wx_sim *, uint32_t);
   size_t (*stream_bytes)(int, int);
   void *(*host_alloc)(size_t);
   void (*host_free)(void *);
@@ -493,6 +494,20 @@ static napi_value SetupTerrain(napi_env env, napi_callback_info info)
   return NULL;
 }
 
+/* initDroplets(h, seed): initRainDrops() on the device (wx_init_droplets) */
+static napi_value InitDroplets(napi_env env, napi_callback_info info)
+{
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  uint32_t seed;
+  NAPI_CALL(env, napi_get_value_uint32(env, a[1], &seed));
+  int rc = L.init_droplets(s, seed);
+  if (rc) return throw_wx(env, s, rc, "wx_init_droplets");
+  return NULL;
+}
+
 static void finalize_pinned(napi_env env, void *data, void *hint) { L.host_free(data); }
 
 /* streamFrame(h, x, y, w, h) -> ArrayBuffer over pinned host memory that the copies fill asynchronously; streamWait(h)
@@ -737,7 +752,7 @@ static int load_lib(napi_env env)
   SYM(create, "wx_create") SYM(destroy, "wx_destroy") SYM(last_error, "wx_last_error") SYM(abi_version, "wx_abi_version")
   SYM(upload, "wx_upload") SYM(set_params, "wx_set_params") SYM(step, "wx_step") SYM(sync, "wx_sync") SYM(get_iter, "wx_get_iter")
   SYM(set_iter, "wx_set_iter") SYM(read_rect, "wx_read_rect") SYM(read_particles, "wx_read_particles")
-  SYM(setup_columns, "wx_setup_columns") SYM(setup_terrain, "wx_setup_terrain") SYM(stream_bytes, "wx_stream_bytes") SYM(host_alloc, "wx_host_alloc") SYM(host_free, "wx_host_free")
+  SYM(setup_columns, "wx_setup_columns") SYM(setup_terrain, "wx_setup_terrain") SYM(init_droplets, "wx_init_droplets") SYM(stream_bytes, "wx_stream_bytes") SYM(host_alloc, "wx_host_alloc") SYM(host_free, "wx_host_free")
   SYM(stream_frame, "wx_stream_frame") SYM(stream_wait, "wx_stream_wait") SYM(set_option, "wx_set_option") SYM(tune_placement, "wx_tune_placement")
   SYM(group_create, "wx_group_create") SYM(group_destroy, "wx_group_destroy") SYM(group_last_error, "wx_group_last_error") SYM(group_count, "wx_group_count")
   SYM(group_transport, "wx_group_transport") SYM(group_slab, "wx_group_slab") SYM(group_agree, "wx_group_agree") SYM(group_step, "wx_group_step")
@@ -756,7 +771,7 @@ static napi_value Init(napi_env env, napi_value exports)
     {"step", 0, Step, 0, 0, 0, napi_default, 0},           {"sync", 0, Sync, 0, 0, 0, napi_default, 0},
     {"getIter", 0, GetIter, 0, 0, 0, napi_default, 0},     {"setIter", 0, SetIter, 0, 0, 0, napi_default, 0},
     {"readRect", 0, ReadRect, 0, 0, 0, napi_default, 0},   {"readParticles", 0, ReadParticles, 0, 0, 0, napi_default, 0},
-    {"abiVersion", 0, AbiVersion, 0, 0, 0, napi_default, 0}, {"setupColumns", 0, SetupColumns, 0, 0, 0, napi_default, 0}, {"setupTerrain", 0, SetupTerrain, 0, 0, 0, napi_default, 0},
+    {"abiVersion", 0, AbiVersion, 0, 0, 0, napi_default, 0}, {"setupColumns", 0, SetupColumns, 0, 0, 0, napi_default, 0}, {"setupTerrain", 0, SetupTerrain, 0, 0, 0, napi_default, 0}, {"initDroplets", 0, InitDroplets, 0, 0, 0, napi_default, 0},
     {"streamFrame", 0, StreamFrame, 0, 0, 0, napi_default, 0}, {"streamWait", 0, StreamWait, 0, 0, 0, napi_default, 0},
     {"setOption", 0, SetOption, 0, 0, 0, napi_default, 0},   {"tunePlacement", 0, TunePlacement, 0, 0, 0, napi_default, 0},
     {"groupCreate", 0, GroupCreate, 0, 0, 0, napi_default, 0}, {"groupSlab", 0, GroupSlab, 0, 0, 0, napi_default, 0},

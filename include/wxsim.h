@@ -152,6 +152,13 @@ int wx_setup_columns(wx_sim *s, const int32_t *wall_rows, const uint8_t *sea_col
 int wx_setup_terrain(wx_sim *s, double seed, double height_mult, int snap, double sim_height, const float *T_air, const float *total_water,
                      const float *cloud_water, const float *drops);
 
+/* initRainDrops() (app.js:4901-4913) on the device: a fresh pool of inactive droplets whose five fields are random seeds, (r, r, -10 + r,
+ * r, r) with r in [0, 1). Field c of droplet i = 24 bits of hash(seed + hash(5 i + c)) with the shaders' integer hash (common.glsl:103-111):
+ * a pure function of the seed, so every slab of a decomposed domain generates the same pool (the partitioned pool wants the WHOLE pool
+ * on every slab) and no host array scales with the droplet count. The grid is untouched; the pool bookkeeping of slab handles is reset
+ * as after wx_upload. */
+int wx_init_droplets(wx_sim *s, uint32_t seed);
+
 /* Replaces the uniform pushes (see wx_params) plus the `initial_Tv` / realWorldSounding_* arrays
  * (app.js:5444-5474, 5485-5537). initial_T has Y+1 entries; sounding arrays Y+1 entries or NULL (= 0).
  * Takes effect at the next wx_step. */

@@ -1237,6 +1237,47 @@ def test_device_side_terrain_equals_host_generator(pkg, E, X, Y, cols, seed, mul
         b.setup_terrain({k: v[:-1] for k, v in S.sounding_rows(Y).items()})
 
 
+def test_device_side_droplet_pool(pkg, E):
+    """wx_init_droplets (initRainDrops app.js:4901-4913 on the device): the pool is a pure function of the seed through
+    the shaders' integer hash -- bit-identical to the numpy restatement, identical on a slab handle, all droplets inactive with seeds in
+    [0, 1), different seeds give different pools, and a run started from it equals a run started from the uploaded restatement."""
+    S = pkg.synth
+    X, Y, N = 512, 128, 5000
+    ref = S.init_rain_drops_hashed(N, seed=77)
+    assert ref.shape == (N, 5) and (ref[:, 2] < -9.0).all() and (ref[:, 2] >= -10.0).all()
+    assert (ref[:, [0, 1, 3, 4]] >= 0).all() and (ref[:, [0, 1, 3, 4]] < 1).all()
+    assert abs(float(ref[:, 0].mean()) - 0.5) < 0.02 and len(np.unique(ref[:, 0])) > 0.99 * N
+    base, water, wall = S.terrain_grid(X, Y)
+    S.add_cloud_deck(water, wall)
+    gui = pkg.params.merge_settings(None)
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 1
+    u["inactiveDroplets"] = float(N)
+    u["spawnChanceMult"] = 5e-3
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    a, b = E.Handle(X, Y, N), E.Handle(X, Y, N)
+    a.upload(base, water, wall, ref)
+    b.upload(base, water, wall, S.init_rain_drops(N))
+    b.init_droplets(77)
+    assert np.array_equal(b.read_particles(), ref)
+    for h in (a, b):
+        h.set_params(p, u["initial_T"])
+        h.set_option(h.OPT_SPLAT_ORDER, 1)
+        h.step(12)
+    da, db = a.read_particles(), b.read_particles()
+    assert (da[:, 2] >= 0).sum() > 20  # droplets spawned from the hashed seeds
+    assert np.array_equal(da, db) and np.array_equal(a.read_rect("BASE_CUR"), b.read_rect("BASE_CUR"))
+    b.init_droplets(78)
+    assert not np.array_equal(b.read_particles(), ref)
+    sl = E.Handle(256, Y, N, X_global=X, x0=64, halo=64)
+    sl.upload(base[:, :384], water[:, :384], wall[:, :384], None)
+    sl.init_droplets(77)
+    assert np.array_equal(sl.read_particles(), ref)  # (all inactive: every slab holds every inactive record)
+    g = E.Handle(X, Y, 0)
+    with pytest.raises(E.WxError):
+        g.init_droplets(1)
+
+
 def test_display_field_streaming(pkg, golden, E):
     """wx_stream_frame: the six display fields of a viewport arrive in one pinned buffer, hold the state
     at the time of the call even though more iterations are enqueued right behind it, and do not disturb the run."""

@@ -156,6 +156,38 @@ def test_node_new_simulation_with_device_terrain(pkg, tmp_path, gpus):
 
 @needs_node
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [1, 4])
+def test_node_new_simulation_with_device_droplets(pkg, gpus):
+    """WeatherSim.newSimulation({dropletSeed}): the droplet pool generated on the device (wx_init_droplets), identically on every slab of a
+    decomposed domain -- what readParticles assembles equals the numpy restatement of the generator, before and (particles running)
+    consistent after a few iterations: the same droplets are active on one handle and on four slabs in exact mode."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    X, Y, N = 1024, 128, 4096
+    slab = "gpus:%d,halo:64,transport:2," % gpus if gpus > 1 else ""
+    js = ("const H=require('%s');"
+          "const sim=H.WeatherSim.newSimulation(%d,%d,{%ssunFixed:true,deviceTerrain:true,nDroplets:%d,dropletSeed:1234});"
+          "const d0=Array.from(sim.readParticles()); sim.setOption(1,1); if (sim.slabs) sim.setOption(7,1); sim.frame(8);"
+          "const d1=Array.from(sim.readParticles()); console.log(JSON.stringify({d0:d0,d1:d1})); sim.destroy();"
+          % (os.path.join(ROOT, "host", "sim_host.js"), X, Y, slab, N))
+    info = json.loads(subprocess.check_output([NODE, "-e", js]).decode().strip().split("\n")[-1])
+    ref = pkg.synth.init_rain_drops_hashed(N, 1234)
+    assert np.array_equal(np.asarray(info["d0"], np.float32).reshape(N, 5), ref)
+    d1 = np.asarray(info["d1"], np.float32).reshape(N, 5)
+    assert np.isfinite(d1).all()
+    # the same run on one Python handle (deterministic splat order): the JS host on one handle / on four exact slabs must match it
+    gui = pkg.params.merge_settings(None)
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    h = pkg.engine.Handle(X, Y, N)
+    h.setup_terrain(pkg.synth.sounding_rows(Y), sim_height=float(gui["simHeight"]))
+    h.init_droplets(1234)
+    h.set_option(h.OPT_SPLAT_ORDER, 1)
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    h.step(8)
+    assert np.array_equal(h.read_particles(), d1)
+
+
+@needs_node
+@pytest.mark.gpu
 def test_addon_rejects_short_arrays(pkg):
     """The N-API shim checks every typed array against the handle's dimensions (X*Y*4, Y+1, X, nDroplets*5) before the
     C ABI reads through the pointer: a short array is a RangeError, a wrong type a TypeError, never an out-of-bounds read."""
