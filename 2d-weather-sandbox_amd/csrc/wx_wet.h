@@ -1219,6 +1219,18 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row, int bands_mode
   int rounds = WX_WET_ROUNDS, minrows = 24; // (narrow slabs: 2144x2048 runs 17 % faster with 30-row unit segments + tail than with equal 32-row ones)
   const double alpha = wet_alpha();
   if (const char *e = wx_tune_env("WX_WET_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
+  // Grids that cannot fill the chip with 24-row segments (the reference's own sizes, 100 x 100 ... 2048 x 512): a wave's row steps
+  // are serial, so parallelism is worth more than the 8 redundant warm-up rows of a segment -- rows per segment that fill the chip
+  // once, at least 4 (2 while there is less than one wave per CU). 100x100: 64 -> 21 us per iteration, 1024x512: 87 -> 39,
+  // 2048x512: 86 -> 51; from 4096x1024 on nothing changes (profiles/r04_small_grid_segments.txt).
+  {
+    const long long cap = wet_capacity(), per_row_set = (long long)w.n_strips * (bands ? 8 : 1);
+    auto waves_at = [&](int m) { return per_row_set * ((Y + m - 1) / m); };
+    if (waves_at(minrows) < cap) {
+      const int fill = (int)(per_row_set * Y / cap), floor_rows = waves_at(4) <= 256 ? 2 : 4;
+      minrows = std::max(floor_rows, std::min(minrows, fill));
+    }
+  }
   if (const char *e = wx_tune_env("WX_WET_MINROWS")) minrows = atoi(e) > 0 ? atoi(e) : minrows;
   // workgroups per segment: 8 XCD column blocks x ceil(strips of the block / waves per workgroup); the device holds capacity / WPB
   const int wg_per_seg = bands ? 8 * ((w.n_strips + WX_WET_WPB - 1) / WX_WET_WPB) : 8 * (((w.n_strips + 7) / 8 + WX_WET_WPB - 1) / WX_WET_WPB);
