@@ -342,6 +342,7 @@ struct DevState {
   int fix_overflow;       // set by k_wet_fix when more output cells needed the exact path than its list holds (the entry count)
   int pool_overflow;      // set when an exchange buffer of the partitioned droplet pool received more entries than it holds
   int pool_seen_max;      // largest status-flip count any rank reported since the transport last looked (k_pool_check)
+  int fastest_bits;       // float bits of the largest |velocity component| that took a cell to the exact path (marching wet kernel)
   int pool_retired;       // exact mode: droplets that ended the iteration inactive among this iteration's status flips (k_pool_events_apply)
 };
 

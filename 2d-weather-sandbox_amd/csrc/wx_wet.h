@@ -133,6 +133,7 @@ struct WetFixList {
   int2 *cells;
   int cap;
   const int *hint_host; // (host address of the same word)
+  int *fastest; // bit pattern of the largest |velocity component| [cells / iteration] that sent a cell to this list (wx_fastest_velocity)
   int *hint; // host-visible word (pinned, mapped): the fix pass leaves the length of the list it consumed here; the host looks at it
              // (stale, never waited for) to size the NEXT fix launches -- a launch over the whole chip costs 10 us to find an empty list
 };
@@ -815,6 +816,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #ifdef WX_ABL_NOFIX // (timing-only ablation builds produce garbage velocities: keep them from flooding the exact path)
           n_add = 0;
 #endif
+          if (fix.fastest) atomicMax(fix.fastest, __float_as_int(m)); // (m >= 0.9 or NaN: the bit patterns of positive floats order like ints)
           if (n_add) {
             int at = atomicAdd(fix.count, n_add);
             if (at + n_add <= fix.cap) {

@@ -633,7 +633,7 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
   }
   {
     ProfScope ps(s, K_MARCH_WET);
-    const WetFixList fix{s->fix_count, s->fix_cells, s->fix_cap, s->fix_hint_host, s->fix_hint_dev};
+    const WetFixList fix{s->fix_count, s->fix_cells, s->fix_cap, s->fix_hint_host, &s->state->fastest_bits, s->fix_hint_dev};
     // one launch group: marching kernel over a strip range (or two) -> the fix pass over what it recorded (leaves the list empty)
     auto group = [&](int lo0, int cnt0, int lo1 = 0, int cnt1 = 0) {
       launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, fix, opt_out, s->stream, lo0, cnt0);
@@ -1035,7 +1035,7 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 16, s->stream));
   HIPCHK(s, hipMemsetAsync(s->dep, 0, n * 8, s->stream));
   HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
-  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 44, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow, pool_overflow, pool_seen_max, pool_retired
+  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 48, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow, pool_overflow, pool_seen_max, fastest_bits, pool_retired
   if (int rc = pool_reset(s)) return rc;
   if (s->sg.acc4) {
     HIPCHK(s, hipMemsetAsync(s->sg.acc4, 0, (size_t)s->sg.AP * s->sg.AH * 16, s->stream));
@@ -1635,6 +1635,19 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
   if (ms_after) *ms_after = best_ms;
   if (rc != WX_OK && s->err.empty()) s->err = "wx_tune_placement: device error";
   return rc;
+}
+
+// largest |velocity component| that sent a cell to the exact path since the last call (0: none reached 0.9); resets it
+int wx_fastest_velocity(wx_sim *s, float *cells_per_iteration)
+{
+  if (!s || !cells_per_iteration) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
+  int bits = 0;
+  HIPCHK(s, hipMemcpyAsync(&bits, &s->state->fastest_bits, 4, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(s, hipMemsetAsync(&s->state->fastest_bits, 0, 4, s->stream));
+  HIPCHK(s, hipStreamSynchronize(s->stream));
+  memcpy(cells_per_iteration, &bits, 4);
+  return WX_OK;
 }
 
 int wx_water_free(const wx_sim *s) { return s && s->local_water_free ? 1 : 0; }

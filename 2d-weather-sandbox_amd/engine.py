@@ -31,7 +31,7 @@ EXPORTS = [
     "wx_step", "wx_sync", "wx_get_iter", "wx_set_iter", "wx_read_rect", "wx_read_particles", "wx_set_stream",
     "wx_device_ptr", "wx_local_width", "wx_halo_bytes", "wx_halo_pack", "wx_halo_unpack", "wx_profile",
     "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_pool_event_bytes",
-    "wx_pool_edge_bytes", "wx_pool_events_pack", "wx_pool_events_apply", "wx_pool_edges_pack", "wx_pool_edges_apply", "wx_pool_flags", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns", "wx_setup_terrain", "wx_init_droplets",
+    "wx_pool_edge_bytes", "wx_pool_events_pack", "wx_pool_events_apply", "wx_pool_edges_pack", "wx_pool_edges_apply", "wx_pool_flags", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns", "wx_setup_terrain", "wx_init_droplets", "wx_fastest_velocity",
     "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait", "wx_set_comm_stream", "wx_step_overlap",
     "wx_set_option", "wx_water_free", "wx_slab_assert_water_free", "wx_tune_placement",
     "wx_comm_unique_id", "wx_comm_init", "wx_exchange", "wx_slab_step", "wx_group_create", "wx_group_destroy", "wx_group_last_error",
@@ -120,6 +120,7 @@ def lib() -> C.CDLL:
     L.wx_lightning_set.argtypes = [vp, vp]
     L.wx_setup_columns.argtypes = [vp] + [vp] * 8
     L.wx_init_droplets.argtypes = [vp, C.c_uint32]
+    L.wx_fastest_velocity.argtypes = [vp, C.POINTER(C.c_float)]
     L.wx_setup_terrain.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_double] + [vp] * 4
     L.wx_stream_bytes.argtypes = [i32, i32]
     L.wx_stream_bytes.restype = C.c_size_t
@@ -412,6 +413,12 @@ class Handle:
                 raise ValueError("setup_terrain: drops must be (n_droplets, 5) float32")
             dp = drops.ctypes.data_as(C.c_void_p)
         self._chk(lib().wx_setup_terrain(self._h, float(seed), float(height_mult), int(snap), float(sim_height), *[a.ctypes.data_as(C.c_void_p) for a in arrs], dp))
+
+    def fastest_velocity(self) -> float:
+        """Largest |velocity component| [cells / iteration] the exact path of the marching wet kernel saw since the last call (0: none >= 0.9)."""
+        v = C.c_float(0)
+        self._chk(lib().wx_fastest_velocity(self._h, C.byref(v)))
+        return float(v.value)
 
     def init_droplets(self, seed: int = 1):
         """initRainDrops() on the device (wx_init_droplets): a fresh all-inactive pool, a pure function of the seed."""

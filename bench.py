@@ -487,7 +487,13 @@ def main():
     prof_steps = a.steps if profile_inline else 16
     flow1 = devtools.flow_stats(stepper)
     verify = "n/a (single rank)" if world == 1 else "not requested"
+    # largest |velocity component| the exact path of the wet kernel saw during the run (0: nothing reached 0.9 cells / iteration). On
+    # slabs the halo width assumes |v| < 1: a larger value means the decomposed run may differ from the undecomposed one near slab edges
+    fastest = stepper.fastest_velocity() if a.workload == "wet" else 0.0
     if world > 1:
+        tf = torch.tensor([fastest], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+        fastest = float(tf.item())
         t = torch.tensor([dt], device="cuda", dtype=torch.float64) if dist.get_backend() == "nccl" else torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -577,7 +583,7 @@ def main():
             "config": {"workload": wl, "grid": [X, Y], "decomposition": deco, "iteration_algorithmic_bytes_per_cell": A,
                        "frame": a.frame, "flow_std": a.flow, "flow_kind": a.flow_kind},
             "ranks_seen": ranks_seen, "verify": verify, "placement": placement, "transport": getattr(drv, "transport", None) if drv is not None else None,
-            "flow": {"start_of_warmup": flow0, "end_of_timed_region": flow1},
+            "flow": {"start_of_warmup": flow0, "end_of_timed_region": flow1, "fastest_velocity_on_the_exact_path": fastest},
             "iteration_roofline_frac_A_wet": cells * a.steps * A / dt / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roof,
         }

@@ -369,6 +369,14 @@ int wx_group_sync(wx_group *g);
  * (WX_OPT_EXCHANGE_OVERLAP); with WX_OPT_POOL_EXACT in order, one iteration at a time, each followed by the all-gather of its flips and
  * lightning requests. */
 
+/* The largest |velocity component| [cells / iteration] among the cells the marching wet kernel handed to its exact path (back-traces
+ * of 0.9 cells and more) since the last call; 0 if there was none; NaN if a velocity was NaN. Resets the value; synchronises the
+ * handle's stream. Whole-domain handles are exact at any speed. On SLAB handles the halo width assumes |v| < 1 (the advection reaches
+ * 1 + ceil|v| columns: 6 columns per iteration in all, WX_SLAB_CONE): a value >= 1 says that cells near a slab edge may have used ghost
+ * columns that were no longer valid in the last iterations of a period, i.e. the slabs may differ from the undecomposed run there
+ * (the simulation itself is as valid as the reference's at such speeds; bench.py --verify measures the difference). */
+int wx_fastest_velocity(wx_sim *s, float *cells_per_iteration);
+
 /* Per-kernel device time from HIP events recorded on the handle's stream around every launch.
  * wx_profile(s, 1) starts collecting, wx_profile_read returns accumulated milliseconds and launch counts
  * for up to `cap` kernels (names via wx_kernel_name) and resets the accumulators. */

@@ -343,12 +343,23 @@ def test_fast_cells_exact_path_vs_oracle(pkg, oracle, E, monkeypatch, X, Y, band
     u["enablePrecipitation"] = 0
     h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
     assert (np.abs(base[..., :2]).max(-1) >= 0.9).sum() > 300
+    assert h.fastest_velocity() == 0.0  # nothing ran yet
     for n in (1, 2, 4):
         h.step(n)
         o.step(n)
         _assert_grid_equal(h, o)
+        if n == 1:  # wx_fastest_velocity: the planted fast cells went through the exact path (post-boundary values: the pressure step has already taken the edge off the 3.1-cell spikes)
+            assert 1.2 < h.fastest_velocity() < 4.5
+            assert h.fastest_velocity() == 0.0  # ... and reading it resets it
     h.sync()
     h.close()
+    calm, _, _ = pkg.synth.terrain_grid(X, Y)
+    c = E.Handle(X, Y, 0)
+    c.upload(calm, water, wall)
+    c.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    c.step(5)
+    assert c.fastest_velocity() == 0.0  # a fluid at rest never enters the exact path
+    c.close()
 
 
 def test_fix_pass_sized_for_an_empty_list_meets_fast_cells(pkg, oracle, E, monkeypatch):
