@@ -1782,6 +1782,7 @@ int wx_read_particles(wx_sim *s, int first, int count, float *dst)
   DeviceScope dev_scope(s);
   if (first < 0 || count < 0 || first + count > s->n_drops) return fail(s, WX_E_RANGE, "wx_read_particles: [%d, %d) outside 0..%d", first, first + count, s->n_drops);
   if (count == 0) return WX_OK;
+  wait_unpacked(s); // (a pool exchange still running on the side stream)
   HIPCHK(s, hipMemcpyAsync(dst, s->drops[s->drop_cur] + 5 * (size_t)first, (size_t)count * 20, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
   return WX_OK;
