@@ -198,6 +198,51 @@ def test_group_exchange_overlap_changes_nothing(pkg, nslab, ndrops):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("exact", [True, False])
+def test_group_start_up_burst_of_status_flips(pkg, exact):
+    """The start-up burst: a large all-inactive pool over a cloud deck with a high spawn chance flips more droplets in its first period
+    than the steady-state stride of the status-flip all-gather holds (65 536 events). The transport carries the whole event buffer until
+    it has seen the counts of a period, then 4 x the largest count (pool_stride_update): nothing is lost -- in exact mode the two slabs
+    stay bit-identical to one handle through the burst and after it; the default protocol ends without an overflow report."""
+    E = pkg.engine
+    X, Y, halo, N = 512, 128, 64, 800000
+    base, water, wall, _, u = _particle_scene(pkg, X, Y, 6000)
+    drops = pkg.synth.init_rain_drops_hashed(N, 9)
+    u["inactiveDroplets"] = 1000.0  # (the normaliser of the spawn chance: every probe that lands in cloud spawns)
+    u["spawnChanceMult"] = 2.0
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    g = E.Group(2, X, Y, halo=halo, devices=[0, 0], transport=E.TRANSPORT_LOCAL, n_droplets=N)
+    g.upload(base, water, wall, drops)
+    g.set_params(p, u["initial_T"])
+    g.set_option(E.Handle.OPT_SPLAT_ORDER, 1)
+    g.set_option(E.Handle.OPT_POOL_EXACT, 1 if exact else 0)
+    per = 1 + (halo - 12) // 9
+    whole = None
+    if exact:
+        whole = E.Handle(X, Y, N)
+        whole.upload(base, water, wall, drops)
+        whole.set_params(p, u["initial_T"])
+        whole.set_option(whole.OPT_SPLAT_ORDER, 1)
+    for k in (1, per - 1, per, 2 * per):
+        g.step(k)
+        g.sync()  # (an overflow of an exchange buffer would be reported here)
+        if whole is not None:
+            whole.step(k)
+            if k == 1:  # the premise: ONE iteration flips more droplets per slab than the steady-state stride holds
+                flipped = int((whole.read_particles()[:, 2] >= 0).sum())
+                assert flipped > 2 * 65536 * 1.2, flipped
+    d = g.particles()
+    active = int((d[:, 2] >= 0).sum())
+    assert active > 70000, active  # more flips than the steady-state stride holds, most of them in the first period
+    if whole is not None:
+        assert np.array_equal(d, whole.read_particles())
+        for f in ("BASE_CUR", "WATER_CUR", "PRECIP_DEP"):
+            assert np.array_equal(g.read(f), whole.read_rect(f)), f
+        whole.close()
+    g.close()
+
+
+@pytest.mark.gpu
 def test_rccl_comm_of_one_rank(pkg):
     """wx_comm_unique_id / wx_comm_init with world = 1: RCCL itself is bound (dlopen) and a communicator created on the device -- as much
     of the one-rank-per-process path as a 1-GPU box can execute; wx_slab_step then is wx_step. A lone slab with ghost columns is refused."""
