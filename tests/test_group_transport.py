@@ -109,7 +109,7 @@ def _particle_scene(pkg, X, Y, N, seed=4):
 @pytest.mark.gpu
 @pytest.mark.parametrize("nslab,exact", [(2, False), (4, False), (4, True)])
 def test_group_with_particles_equals_whole_domain(pkg, nslab, exact):
-    """Slabs with particles on the library's transport (wx_group_step: status flips + lightning all-gathered with a fixed stride, edge
+    """Slabs with particles on the library's transport (wx_group_step: status flips + lightning all-gathered with a stride every rank derives from the previous counts, edge
     droplets in the halos' batch, no host round trip): with the deterministic splat order and WX_OPT_POOL_EXACT the group is
     BIT-IDENTICAL to one handle -- pool, feedback, deposition, lightning, every field, checked after calls that end inside and at the
     end of exchange periods; with the per-period protocol the same droplets are active at the end of whole periods and the fields agree
