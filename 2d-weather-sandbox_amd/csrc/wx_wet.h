@@ -36,13 +36,14 @@
 #include "wx_cells.h"
 #include "wx_tile.h"
 #include <cstddef>
+#include <type_traits>
 #include <cstdlib>
 #include <algorithm>
 
 namespace wx {
 
 #ifndef WX_WET_MINWAVES
-#define WX_WET_MINWAVES 3
+#define WX_WET_MINWAVES 4
 #endif
 #ifndef WX_WET_UNI_COPY
 #define WX_WET_UNI_COPY 0
@@ -253,16 +254,17 @@ constexpr int WOUT = 56;          // output columns per wave: lanes 4 .. 59
 constexpr int WLO = 4;            // first output lane
 constexpr int WPAD = 1;           // never-written pad entry on each side of a ring row (lane -1 / lane 64 reads land there)
 constexpr int WRW = 64 + 2 * WPAD;
-constexpr int WD = 6;             // rows r-5 .. r of the base / wall planes: slot = row mod 6
-constexpr int WQ = 3;             // rows r-5 .. r-3 of the post-boundary water planes: slot = row mod 3
+constexpr int WQ = 3;             // rows r-5 .. r-3 of the post-boundary base / wall / water planes: slot = row mod 3 (round 4: rows
+                                  // r-2 .. r are carried in registers until the boundary stage needs their horizontal neighbours --
+                                  // the ring is what bounds the occupancy: 50 -> 35 plane-rows = 3 -> 4 waves per SIMD)
 constexpr int WL = 4;             // rows r-5 .. r-2 of the source light planes: slot = row & 3
 struct WetRing {
-  float P[WD][WRW], T[WD][WRW], vx[WD][WRW], vy[WD][WRW];
-  char4 wl[WD][WRW];
+  float P[WQ][WRW], T[WQ][WRW], vx[WQ][WRW], vy[WQ][WRW];
+  char4 wl[WQ][WRW];
   float qx[WQ][WRW], qy[WQ][WRW], qz[WQ][WRW], qw[WQ][WRW];
   float lx[WL][WRW], lw[WL][WRW]; // sunlight and upward IR of the source light texture
 };
-static_assert(sizeof(WetRing) == (5 * WD + 4 * WQ + 2 * WL) * WRW * 4, "ring layout");
+static_assert(sizeof(WetRing) == (5 * WQ + 4 * WQ + 2 * WL) * WRW * 4, "ring layout");
 
 // whole-wave shifts: lane i <- lane i-1 / lane i+1; the edge lane keeps its own value
 __device__ __forceinline__ float wave_from_left(float v)
@@ -291,7 +293,9 @@ __device__ __forceinline__ char4 unpack_wall(int w)
 // texels of the row above and the horizontal wall neighbours in the ring
 struct MWBoundaryAcc {
   const WetRing &rg;
-  int li, o0, o1;          // ring column; in-plane offsets of ring rows yb and yb+1
+  int li, o0;              // ring column; in-plane offset of ring row yb (its pre-boundary T and wall: the horizontal neighbours)
+  float vxU, TU;           // row above: velocity-pass vx, T (carried registers)
+  char4 wU;
   float4 b00, q00, qU;     // velocity output / pre-boundary water of the own cell; pre-boundary water of the cell above
   char4 w00, wD;
   float vxD, TD, qzD, qwD; // row below: velocity-pass vx, pre-boundary T, soil moisture / snow of the pre-boundary water
@@ -305,7 +309,7 @@ struct MWBoundaryAcc {
   __device__ __forceinline__ float4 base(int dx, int dy) const
   {
     if (dx == 0 && dy == 0) return b00;
-    if (dy == 1) return make_float4((&rg.vx[0][0])[o1 + li], 0.f, 0.f, (&rg.T[0][0])[o1 + li]);
+    if (dy == 1) return make_float4(vxU, 0.f, 0.f, TU);
     if (dy == -1) return make_float4(vxD, 0.f, 0.f, TD);
     return make_float4(0.f, 0.f, 0.f, (&rg.T[0][0])[o0 + li + dx]); // (+-1, 0): temperature of the neighbouring sea cell
   }
@@ -320,7 +324,7 @@ struct MWBoundaryAcc {
   {
     if (dx == 0 && dy == 0) return w00;
     if (dy == -1) return wD;
-    if (dy == 1) return (&rg.wl[0][0])[o1 + li];
+    if (dy == 1) return wU;
     return (&rg.wl[0][0])[o0 + li + dx];
   }
   __device__ __forceinline__ float2 vort(int dx, int dy) const
@@ -341,7 +345,7 @@ struct MWBoundaryAcc {
 struct MWAdvAcc {
   const WetRing &rg;
   int li;
-  int ob[3], oq[3]; // in-plane offsets of rows ya-1, ya, ya+1 in the base planes / the water planes (wave-uniform)
+  int ob[3]; // in-plane offsets of rows ya-1, ya, ya+1 (wave-uniform; the base / wall and the water planes share their slots)
   __device__ __forceinline__ float4 base(int dx, int dy) const
   {
     const int o = ob[dy + 1] + li + dx;
@@ -352,7 +356,7 @@ struct MWAdvAcc {
   __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return wall(dx, dy); }
   __device__ __forceinline__ float4 water_off(int dx, int dy) const
   {
-    const int o = oq[dy + 1] + li + dx;
+    const int o = ob[dy + 1] + li + dx;
     return make_float4((&rg.qx[0][0])[o], (&rg.qy[0][0])[o], (&rg.qz[0][0])[o], (&rg.qw[0][0])[o]);
   }
 };
@@ -376,7 +380,8 @@ __device__ __forceinline__ MWFp make_fp(const MWAdvAcc &a, int dx0, int dy0)
 {
   const bool lo = dy0 < 0; // dy0 is -1 or 0 for every cell that takes this path
   const int c = a.li + dx0;
-  return MWFp{a.rg, (lo ? a.ob[0] : a.ob[1]) + c, (lo ? a.ob[1] : a.ob[2]) + c, (lo ? a.oq[0] : a.oq[1]) + c, (lo ? a.oq[1] : a.oq[2]) + c};
+  const int o0 = (lo ? a.ob[0] : a.ob[1]) + c, o1 = (lo ? a.ob[1] : a.ob[2]) + c;
+  return MWFp{a.rg, o0, o1, o0, o1};
 }
 
 // lighting stage, row y (an OUTPUT row: unwrapped == wrapped row index); ring row k of the light planes holds texture row clamp(k)
@@ -536,6 +541,10 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   int w_prev = 0;
   float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);                        // pre-boundary water row r-3
   float v1x = 0.f, v1y = 0.f;                                         // velocity row r-2
+  float p2 = 0.f, t2 = 0.f;                                           // P, T of row r-2 (unchanged by the velocity pass)
+  int w2 = 0;                                                         // wall row r-2 (raw dword)
+  float v3x = 0.f, v3y = 0.f, p3 = 0.f, t3 = 0.f;                     // velocity output of row r-3: what the boundary stage starts from
+  int w3 = 0;
   float c1 = 0.f, c2 = 0.f;                                           // curl rows r-3, r-4
   float vfDx = 0.f;                                                   // vortForce.x row r-4
   float TD = 0.f, vxD = 0.f, qzD = 0.f, qwD = 0.f;                    // pre-boundary values of row r-4 (see MWBoundaryAcc)
@@ -565,7 +574,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     pf_b = ld_row(in.base + e, lo16);
     pf_w = ld_row(WX_WALL_RAW + e, lo4);
   }
-  int s0 = (r + 12) % WD, sq3 = (r - 3 + 12) % WQ; // ring slots of row r (base / wall planes) and of row r-3 (water planes)
+  int sq3 = (r - 3 + 12) % WQ; // ring slot of row r-3 (base / wall / water planes)
   // wrapped (REPEAT) row indices of rows r+1, r-1 .. r-4, advanced by one per step (a general modulo costs ~20 scalar instructions)
   int yw_p1 = wrapmod(r + 1, Y), yw_m1 = wrapmod(r - 1, Y), yw_m2 = wrapmod(r - 2, Y), yw_m3 = wrapmod(r - 3, Y), yw_m4 = wrapmod(r - 4, Y);
 #if WX_WET_PRIO_ROTATE
@@ -573,7 +582,12 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   const int prio_phase = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
 #endif
   int t = 0;
-  auto step = [&]() __attribute__((always_inline)) {
+  // WARM: one of the first eight steps of the segment, in which the stages come alive one after the other (t >= ...); the steady-state
+  // instantiation has none of those wave-uniform branches -- every one of them is a control-flow merge at which the carried values of
+  // both paths meet, i.e. a bundle of v_mov copies per step (a third of the loop's vector instructions were v_mov_b32)
+#define WX_T_GE(n) (!WARM || t >= (n))
+  auto step = [&](auto warm_tag) __attribute__((always_inline)) {
+    constexpr bool WARM = decltype(warm_tag)::value;
 #if WX_WET_PRIO_ROTATE
     { // the SIMD issues the OLDEST ready wave first: without this the first-dispatched waves run ~30 % faster than the last ones
       const int pr = (t + prio_phase) % 3;
@@ -597,15 +611,15 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #ifdef WX_STAGE_MARKS
     asm volatile("; @@ring");
 #endif
-    // ---- row r enters the ring: P, T and wall (velocity leaves them unchanged); light row r-2 ----
+    // ---- row r-3 enters the ring with its pre-boundary T and wall (what the boundary stage reads of its horizontal neighbours; the
+    //      slot was row r-6's, last read by the previous step's advection); light row r-2 ----
     // Ahead of the prefetch: behind it (and behind the deferred stores) the compiler puts an s_waitcnt vmcnt in front of these LDS
     // writes that waits for the loads just issued -- a memory latency per step (5 % of the feedback instantiation,
     // profiles/r02_particles_ring_first.txt; the other one shows the same wait as soon as the stores lose their address copies).
     auto ring_in = [&]() {
-      const int o = s0 * WRW + li;
-      (&rg.P[0][0])[o] = b_cur.z;
-      (&rg.T[0][0])[o] = b_cur.w;
-      (&rg.wl[0][0])[o] = w_cur;
+      const int o = sq3 * WRW + li;
+      (&rg.T[0][0])[o] = t3;
+      (&rg.wl[0][0])[o] = unpack_wall(w3);
       rg.lx[(r - 2 + 8) & (WL - 1)][li] = lx_cur;
       rg.lw[(r - 2 + 8) & (WL - 1)][li] = lzw_cur.y;
     };
@@ -623,7 +637,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         pf_b = ld_row(in.base + e, lo16);
         pf_w = ld_row(WX_WALL_RAW + e, lo4);
       }
-      if (WX_WET_SKIP_LOADS != 1 || t >= 2) { // (the first warm-up steps of a segment only feed velocity / curl: no water, no light yet)
+      if (WX_WET_SKIP_LOADS != 1 || WX_T_GE(2)) { // (the first warm-up steps of a segment only feed velocity / curl: no water, no light yet)
         const int rl = r - 1;
         const size_t ew = (size_t)yw_m1 * X;
         pf_q = ld_row(in.water + ew, lo16);
@@ -700,20 +714,17 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #endif
     // ---- velocity of row r-1 ----
     float v0x = 0.f, v0y = 0.f;
-    if (t >= 1) {
+    if (WX_T_GE(1)) {
       const float4 v = velocity_cell(u, b_prev, wave_from_right(b_prev.z), b_cur.z, unpack_wall(w_prev).y);
       v0x = v.x;
       v0y = v.y;
-      const int o = ring_back(s0, 1, WD) * WRW + li;
-      (&rg.vx[0][0])[o] = v0x;
-      (&rg.vy[0][0])[o] = v0y;
     }
 #ifdef WX_STAGE_MARKS
     asm volatile("; @@curlvort");
 #endif
     // ---- curl of row r-2, vortForce of row r-3 (registers + wave shifts only) ----
     float c0 = 0.f;
-    if (t >= 2) {
+    if (WX_T_GE(2)) {
       c0 = curl_cell(v1x, v1y, wave_from_right(v1y), v0x);
       if (OPT_OUT) {
         const int yc = r - 2;
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       }
     }
     float2 vf = make_float2(0.f, 0.f);
-    if (t >= 4) vf = vorticity_cell(c1, wave_from_left(c1), wave_from_right(c1), c2, c0);
+    if (WX_T_GE(4)) vf = vorticity_cell(c1, wave_from_left(c1), wave_from_right(c1), c2, c0);
     const float vfLy = wave_from_left(vf.y);
     float qzL = 0.f, qwL = 0.f, qzR = 0.f, qwR = 0.f;
     if (smooth_iter) { // (wave-uniform) soil moisture / snow smoothing between surface cells: the neighbours' water texels
@@ -736,14 +747,14 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     asm volatile("; @@boundary");
 #endif
     // ---- boundary of row yb = r-3, written back in place ----
-    if (t >= 4) {
-      const int ob0 = ring_back(s0, 3, WD) * WRW, ob1 = ring_back(s0, 2, WD) * WRW;
-      const float4 b00 = make_float4((&rg.vx[0][0])[ob0 + li], (&rg.vy[0][0])[ob0 + li], (&rg.P[0][0])[ob0 + li], (&rg.T[0][0])[ob0 + li]);
-      const char4 w00 = (&rg.wl[0][0])[ob0 + li];
-      if (t >= 5) {
+    if (WX_T_GE(4)) {
+      const int ob0 = sq3 * WRW;
+      const float4 b00 = make_float4(v3x, v3y, p3, t3);
+      const char4 w00 = unpack_wall(w3);
+      if (WX_T_GE(5)) {
         const int yb = yw_m3;
         const bool top = yb + 1 > Y - 1; // light_0 is CLAMP_TO_EDGE in y: the row "above" the top row is the top row itself
-        MWBoundaryAcc a{rg, li, ob0, ob1, b00, q1, q_up, w00, wD, vxD, TD, qzD, qwD, qzL, qwL, qzR, qwR, vf, vfLy, vfDx,
+        MWBoundaryAcc a{rg, li, ob0, v1x, t2, unpack_wall(w2), b00, q1, q_up, w00, wD, vxD, TD, qzD, qwD, qzL, qwL, qzR, qwR, vf, vfLy, vfDx,
                         l0x1, l0y1, top ? l0x1 : l0x_cur, top ? l0y1 : l0y_cur, fb_cur, dep_cur, HAS_FB && fb_cur_have};
         float4 bb, bq;
         char4 bwl;
@@ -763,6 +774,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         wave_fence(); // every lane has read its neighbours' pre-boundary values
         (&rg.vx[0][0])[ob0 + li] = bb.x;
         (&rg.vy[0][0])[ob0 + li] = bb.y;
+        (&rg.P[0][0])[ob0 + li] = bb.z;
         (&rg.T[0][0])[ob0 + li] = bb.w;
         (&rg.wl[0][0])[ob0 + li] = bwl;
         const int oq = sq3 * WRW + li;
@@ -792,12 +804,11 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     asm volatile("; @@advection");
 #endif
     // ---- advection of row ya = r-4 ----
-    if (t >= 7) {
+    if (WX_T_GE(7)) {
       const int ya = yw_m4;
       float4 ab, aw;
       char4 awl;
-      MWAdvAcc a{rg, li, {ring_back(s0, 5, WD) * WRW, ring_back(s0, 4, WD) * WRW, ring_back(s0, 3, WD) * WRW},
-                 {ring_back(sq3, 2, WQ) * WRW, ring_back(sq3, 1, WQ) * WRW, sq3 * WRW}};
+      MWAdvAcc a{rg, li, {ring_back(sq3, 2, WQ) * WRW, ring_back(sq3, 1, WQ) * WRW, sq3 * WRW}};
       bool fast = true;
       if (h_big & 7u) { // wave-uniform: some velocity of rows ya-1 .. ya+1 is large -> per-lane test of the eight that matter
         const float *vxp = &rg.vx[0][0], *vyp = &rg.vy[0][0];
@@ -857,7 +868,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #endif
       // ---- pressure + lighting of row ya: kept in registers, stored at the top of the next step ----
       const float vx_l = wave_from_left(ab.x);
-      if (t >= 8) {
+      if (WX_T_GE(8)) {
         st_p = pressure_cell(ab, vx_l, adv_vy_prev, adv_T_prev, adv_w_prev.x, adv_w_prev.y);
         MWLightAcc la{rg, li, ab.w, adv_T_prev, lz1, aw, awl};
 #ifdef WX_ABL_NOLIGHT
@@ -881,6 +892,14 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     asm volatile("; @@rotate");
 #endif
     // ---- rotate the carried rows ----
+    v3x = v1x;
+    v3y = v1y;
+    p3 = p2;
+    t3 = t2;
+    w3 = w2;
+    p2 = b_prev.z;
+    t2 = b_prev.w;
+    w2 = w_prev;
     b_prev = b_cur;
     w_prev = w_raw;
     q1 = q_up;
@@ -896,7 +915,6 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     WX_H_ROT(h_nowall);
     WX_H_ROT(h_zw0);
     WX_H_ROT(h_near);
-    s0 = s0 + 1 == WD ? 0 : s0 + 1;
     sq3 = sq3 + 1 == WQ ? 0 : sq3 + 1;
     yw_m4 = yw_m3;
     yw_m3 = yw_m2;
@@ -904,26 +922,29 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     yw_m1 = yw_m1 + 1 == Y ? 0 : yw_m1 + 1;
     yw_p1 = yw_p1 + 1 == Y ? 0 : yw_p1 + 1;
   };
+  // (a segment has at least one row: at least nine steps)
+  for (; t < 8; r++, t++) step(std::true_type{});
   if (WX_WET_UNROLL2 && !HAS_FB && !OPT_OUT) {
     // two steps per loop iteration: the values carried from step to step (prefetched rows, the previous rows' registers, the deferred
     // stores) change registers between the two copies instead of being moved: -1.4 % without feedback loads; WITH them (particles on)
     // the doubled loop is 4-6 % slower, and the display-writing one (every tenth iteration) loses 2-8 %: only the plain instantiation
     // is doubled (profiles/r03_unroll_variants.txt)
     for (; r <= y_hi + 3;) {
-      step();
-      r++, t++;
+      step(std::false_type{});
+      r++;
       if (r > y_hi + 3) break;
-      step();
-      r++, t++;
+      step(std::false_type{});
+      r++;
 #if WX_WET_UNROLL2 >= 3
       if (r > y_hi + 3) break;
-      step();
-      r++, t++;
+      step(std::false_type{});
+      r++;
 #endif
     }
   } else {
-    for (; r <= y_hi + 3; r++, t++) step();
+    for (; r <= y_hi + 3; r++) step(std::false_type{});
   }
+#undef WX_T_GE
   // ---- the last row ----
   if (st_valid && lane_out) {
     const size_t e = (size_t)(y_hi - 1) * X;
@@ -1264,8 +1285,13 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row, int bands_mode
       if (bands) { // unit segments of about 64 rows
         const int by_rows = (int)(Y / 64.0 + 0.5) - 1;
         n_full = n_full > by_rows ? n_full : by_rows;
+        // ... and not below ~52 while the launch still holds well over one round of waves: at four waves per SIMD the rounds rule
+        // alone asks for 5 x 44 rows + tail at 16384 x 2048; 4 x 52 + 1/2 + 1/4 + 1/8 is 1.3 % faster on one placement
+        // (profiles/r04_ring_diet.txt). Narrow slabs stay with the short segments that fill the chip.
+        const int by_unit = (int)(Y / 52.0 - 0.875 + 0.5);
+        if (n_full > by_unit && by_unit >= 1 && (long long)w.n_strips * 8 * (by_unit + 3) >= 2LL * wet_capacity()) n_full = by_unit;
       }
-      const int n8 = bands ? (n_full >= 6 ? 1 : 0) : c - 1; // segments of weight 1/8
+      const int n8 = bands ? (n_full >= 4 ? 1 : 0) : c - 1; // segments of weight 1/8
       const int n = n_full + 2 * c + n8;
       const double units = n_full + c * 0.5 + c * 0.25 + n8 * 0.125;
       if (n_full >= 1 && n <= WMAXSEG && Y / units >= minrows) {
