@@ -593,7 +593,11 @@ __device__ __forceinline__ float smoothstepf(float e0, float e1, float x)
 // of the post-boundary water are zero in every texel the footprints can reach -- free air without rain, snow or smoke, i.e. most of
 // the sky. Their interpolations are then 0 + t * (0 - 0) = 0 for the finite weights of this path, so they are not evaluated (one
 // footprint, eight taps and six lerps less).
-template <bool NO_WATER = false, bool NO_WALL = false, bool NO_ZW = false, class UT, class FP, class A>
+// QUIET (launch-uniform, established by the host): no brush input and no airplane event in this iteration (userInputType < 1,
+// airplaneValues[3] in [0, 0.9]) -- the two sections are not compiled in: they are uniform branches that are never taken in a running
+// simulation, but every one of them is a merge point of the cell's whole state (base, water, wall), i.e. copies and scalar tests on
+// the common path.
+template <bool NO_WATER = false, bool NO_WALL = false, bool NO_ZW = false, bool QUIET = false, class UT, class FP, class A>
 __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const FP initial_T, const FP snd_T, const FP snd_W, const FP snd_Vel, int x, int y,
                                                const A &a, float4 &base_out,
                                                float4 &water_out, char4 &wall_out)
@@ -756,7 +760,7 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
   }
 
   // USER INPUT :229-401
-  if (u.userInputType >= 1) {
+  if (!QUIET && u.userInputType >= 1) {
     bool inBrush = false;
     float weight = 1.0f;
     const float brushR = u.userInputValues[3] * a_texY;
@@ -868,7 +872,7 @@ __device__ __forceinline__ void advection_cell(const UT &u, const Geo &g, const 
   if (wl[DISTANCE] == 0) w.x = (wl[TYPE] == WALLTYPE_WATER) ? 1002.0f : 1001.0f; // :403-409
 
   // airplane :415-457 (only when the host set a dump (<0) or crash (>0.9) flag)
-  if (u.airplaneValues[3] < 0.0f || u.airplaneValues[3] > 0.9f) {
+  if (!QUIET && (u.airplaneValues[3] < 0.0f || u.airplaneValues[3] > 0.9f)) {
     float vpx, vpy = u.airplaneValues[1] - tcy;
     if (u.wrapHorizontally)
       vpx = absHorizontalDist(u.airplaneValues[0], tcx);

@@ -353,13 +353,14 @@ struct DevState {
 struct SplatGrid {
   float4 *acc4;  // (mass, heat, vapor, -) deposits, pitch AP
   float2 *acc2;  // (rain, snow) deposits
-  unsigned char *dirty;   // per 64x16 tile of the accumulation grid: holds deposits
-  unsigned char *fb_zero; // per 64x16 tile of the feedback texture: known to be all zero
+  unsigned char *dirty;   // per 64x16 tile t of the accumulation grid: [t] holds deposits; [T + t] holds (rain, snow) deposits too
+                          // (T = TXn * TYn; only droplets that reach the ground deposit there: a small part of the tiles)
+  unsigned char *fb_zero; // per 64x16 tile t of the textures: [2t] feedback known to be all zero, [2t + 1] deposition known to be
   int AP, AH;    // pitch (>= X+1) and rows (>= Y+1) of the accumulation grid
   int TXn, TYn;  // tiles per row / column
-  // work lists of one iteration (k_splat_classify): work[4*par + {0,1,2}] = number of texture tiles to box-sum, texture tiles to
-  // zero, accumulation tiles to clear (par = iteration parity: the kernel that fills one set of counters resets the other);
-  // the lists follow at work[8 + k*TXn*TYn], k = 0, 1, 2
+  // work lists of one iteration (k_splat_classify): work[8*par + {0,1,2,3,4}] = number of feedback tiles to box-sum, feedback tiles
+  // to zero, accumulation tiles to clear, deposition tiles to box-sum, deposition tiles to zero (par = iteration parity: the kernel
+  // that fills one set of counters resets the other); the lists follow at work[16 + k*TXn*TYn], k = 0 .. 4
   int *work;
 };
 constexpr int STX = 64, STY = 16; // splat tile
@@ -696,10 +697,16 @@ __device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const 
   atomic_add_f(f + 0, feedback[0]);
   atomic_add_f(f + 1, feedback[1]);
   atomic_add_f(f + 2, feedback[2]);
-  float *d = reinterpret_cast<float *>(sg.acc2 + ai);
-  atomic_add_f(d + 0, deposition[0]);
-  atomic_add_f(d + 1, deposition[1]);
-  sg.dirty[(r / STY) * sg.TXn + (q / STX)] = 1;
+  const int tile = (r / STY) * sg.TXn + (q / STX);
+  sg.dirty[tile] = 1;
+  // (rain, snow): only a droplet that reaches the ground deposits -- adding the zeros of all the others would be two more atomics
+  // per droplet and, worse, would make every tile under a cloud a deposition tile to box-sum, write and clear (x + 0 == x: same sums)
+  if (deposition[0] != 0.0f || deposition[1] != 0.0f) {
+    float *d = reinterpret_cast<float *>(sg.acc2 + ai);
+    atomic_add_f(d + 0, deposition[0]);
+    atomic_add_f(d + 1, deposition[1]);
+    sg.dirty[sg.TXn * sg.TYn + tile] = 1;
+  }
   return false;
 }
 
@@ -748,9 +755,12 @@ __global__ __launch_bounds__(256) void k_splat_runs(int n, const int *__restrict
     return;
   }
   sg.acc4[k] = make_float4(a[0], a[1], a[2], 0.f);
-  sg.acc2[k] = make_float2(a[3], a[4]);
-  const int r = k / sg.AP, q = k - r * sg.AP;
-  sg.dirty[(r / STY) * sg.TXn + (q / STX)] = 1;
+  const int r = k / sg.AP, q = k - r * sg.AP, tile = (r / STY) * sg.TXn + (q / STX);
+  sg.dirty[tile] = 1;
+  if (a[3] != 0.0f || a[4] != 0.0f) { // (as in precip_droplet: a run that deposits no rain / snow leaves the zero that is there)
+    sg.acc2[k] = make_float2(a[3], a[4]);
+    sg.dirty[sg.TXn * sg.TYn + tile] = 1;
+  }
 }
 
 // 12x12 box sum of the deposits -> precipitationFeedbackTexture (RGBA32F) + precipitationDepositionTexture (RG32F).
@@ -767,23 +777,31 @@ __global__ __launch_bounds__(256) void k_splat_runs(int n, const int *__restrict
 __global__ __launch_bounds__(256) void k_splat_classify(int X, int Y, SplatGrid sg, int mailbox, int par)
 {
   const int T = sg.TXn * sg.TYn, t = blockIdx.x * blockDim.x + threadIdx.x;
-  int *cnt = sg.work + 4 * par;
-  if (t == 0) sg.work[4 * (par ^ 1)] = sg.work[4 * (par ^ 1) + 1] = sg.work[4 * (par ^ 1) + 2] = 0;
+  int *cnt = sg.work + 8 * par;
+  if (t == 0)
+    for (int k = 0; k < 5; k++) sg.work[8 * (par ^ 1) + k] = 0;
   if (t >= T) return;
   const int tby = t / sg.TXn, tbx = t - tby * sg.TXn;
-  if (sg.dirty[t]) sg.work[8 + 2 * T + atomicAdd(&cnt[2], 1)] = t;
+  if (sg.dirty[t]) sg.work[16 + 2 * T + atomicAdd(&cnt[2], 1)] = t;
   if (tbx * STX >= X || tby * STY >= Y) return; // (the accumulation grid is one anchor wider / higher than the texture)
-  int a = 0;
+  int a = 0, a2 = 0;
   for (int dy = -1; dy <= 1; dy++)
     for (int dx = -1; dx <= 1; dx++) {
       const int ax = tbx + dx, ay = tby + dy;
-      if (ax >= 0 && ay >= 0 && ax < sg.TXn && ay < sg.TYn) a |= sg.dirty[ay * sg.TXn + ax];
+      if (ax >= 0 && ay >= 0 && ax < sg.TXn && ay < sg.TYn) {
+        a |= sg.dirty[ay * sg.TXn + ax];
+        a2 |= sg.dirty[T + ay * sg.TXn + ax];
+      }
     }
   const bool corner = mailbox && t == 0;
   if (a)
-    sg.work[8 + atomicAdd(&cnt[0], 1)] = t;
-  else if (!sg.fb_zero[t] || corner)
-    sg.work[8 + T + atomicAdd(&cnt[1], 1)] = t;
+    sg.work[16 + atomicAdd(&cnt[0], 1)] = t;
+  else if (!sg.fb_zero[2 * t] || corner)
+    sg.work[16 + T + atomicAdd(&cnt[1], 1)] = t;
+  if (a2)
+    sg.work[16 + 3 * T + atomicAdd(&cnt[3], 1)] = t;
+  else if (!sg.fb_zero[2 * t + 1])
+    sg.work[16 + 4 * T + atomicAdd(&cnt[4], 1)] = t;
 }
 
 // One (tile, texture) work item: KIND 0 = the feedback texture from the three used channels of acc4, KIND 1 = the deposition texture
@@ -902,21 +920,24 @@ __global__ __launch_bounds__(256, 4) void k_splat_box(int X, int Y, SplatGrid sg
   constexpr int WH = STY + 11, PW = 77; // (pitch 77: the 4 rows x 8 runs a half-wave reads in the horizontal pass hit 32 banks)
   __shared__ float pl[3][WH][PW];
   const int tid = threadIdx.x;
-  const int T = sg.TXn * sg.TYn, n_box = sg.work[4 * par], n_zero = sg.work[4 * par + 1];
+  const int T = sg.TXn * sg.TYn, n_box = sg.work[8 * par], n_zero = sg.work[8 * par + 1], n_box2 = sg.work[8 * par + 3], n_zero2 = sg.work[8 * par + 4];
   const int cx = tid & 63, cyg = tid >> 6;
   // items: (tile, texture) for the tiles to box-sum, then the tiles to zero, dealt out round-robin. The launch must not hold more
   // workgroups than the chip does at once (splat_box_grid): with 2048 of them on a chip that holds 1536, the 512 of the second round
   // started their twelve items when the first round had finished. (Handing the items out through an atomic counter instead costs more
   // than it balances: 24 000 returning atomics on one address serialise, 0.37 instead of 0.25 ms.)
-  for (int wi = blockIdx.x; wi < 2 * n_box + n_zero; wi += gridDim.x) {
-    const bool any_dirty = wi < 2 * n_box;
-    const int tile = any_dirty ? sg.work[8 + (wi >> 1)] : sg.work[8 + T + (wi - 2 * n_box)];
+  // items: feedback tiles to box-sum, deposition tiles to box-sum (few: only where droplets reach the ground), feedback tiles to
+  // zero, deposition tiles to zero
+  const int e0 = n_box, e1 = e0 + n_box2, e2 = e1 + n_zero, e3 = e2 + n_zero2;
+  for (int wi = blockIdx.x; wi < e3; wi += gridDim.x) {
+    const int kind = wi < e0 ? 0 : (wi < e1 ? 1 : (wi < e2 ? 2 : 3));
+    const int tile = kind == 0 ? sg.work[16 + wi] : (kind == 1 ? sg.work[16 + 3 * T + (wi - e0)] : (kind == 2 ? sg.work[16 + T + (wi - e1)] : sg.work[16 + 4 * T + (wi - e2)]));
     const int tby = tile / sg.TXn, tbx = tile - tby * sg.TXn;
     const int x0 = tbx * STX, y0 = tby * STY;
     const bool corner = mailbox && (tbx == 0 && tby == 0);
     const bool right = seam > 0 && x0 >= seam;
     const int qmin = right ? seam : 0, qmax = (seam > 0 && !right) ? seam : X, qshift = right ? 1 : 0;
-    if (!any_dirty) { // the texture tile holds the feedback of an earlier iteration (or the mailbox texels): zero it
+    if (kind == 2) { // the texture tile holds the feedback of an earlier iteration (or the mailbox texels): zero it
       for (int k = 0; k < STY / 4; k++) {
         const int x = x0 + cx, y = y0 + cyg + 4 * k;
         if (x < X && y < Y) {
@@ -924,15 +945,21 @@ __global__ __launch_bounds__(256, 4) void k_splat_box(int X, int Y, SplatGrid sg
           if (corner && y == 0 && x == 0) v.x = st->px_count;
           if (corner && y == 0 && x == 1) v = make_float4(st->px_light[0], st->px_light[1], st->px_light[2], st->px_light[3]);
           fb[(size_t)y * X + x] = v;
-          dep[(size_t)y * X + x] = make_float2(0.f, 0.f);
         }
       }
-      if (tid == 0) sg.fb_zero[tile] = corner ? 0 : 1;
-    } else if ((wi & 1) == 0) {
+      if (tid == 0) sg.fb_zero[2 * tile] = corner ? 0 : 1;
+    } else if (kind == 3) { // ... the deposition of an earlier iteration
+      for (int k = 0; k < STY / 4; k++) {
+        const int x = x0 + cx, y = y0 + cyg + 4 * k;
+        if (x < X && y < Y) dep[(size_t)y * X + x] = make_float2(0.f, 0.f);
+      }
+      if (tid == 0) sg.fb_zero[2 * tile + 1] = 1;
+    } else if (kind == 0) {
       splat_box_tile<0>(pl, X, Y, sg, st, fb, dep, x0, y0, qmin, qmax, qshift, corner);
-      if (tid == 0) sg.fb_zero[tile] = 0;
+      if (tid == 0) sg.fb_zero[2 * tile] = 0;
     } else {
       splat_box_tile<1>(pl, X, Y, sg, st, fb, dep, x0, y0, qmin, qmax, qshift, corner);
+      if (tid == 0) sg.fb_zero[2 * tile + 1] = 0;
     }
   }
 }
@@ -961,19 +988,21 @@ inline int splat_box_grid()
 // zero the accumulation tiles that hold deposits (after k_splat_box consumed them)
 __global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg, int par)
 {
-  const int T = sg.TXn * sg.TYn, n = sg.work[4 * par + 2];
+  const int T = sg.TXn * sg.TYn, n = sg.work[8 * par + 2];
   for (int wi = blockIdx.x; wi < n; wi += gridDim.x) {
-    const int tile = sg.work[8 + 2 * T + wi];
+    const int tile = sg.work[16 + 2 * T + wi];
+    const bool rain = sg.dirty[T + tile] != 0; // (uniform; the flag is reset below, behind the barrier)
     const int tby = tile / sg.TXn, tbx = tile - tby * sg.TXn;
     const int x0 = tbx * STX, y0 = tby * STY;
     for (int i = threadIdx.x; i < STX * STY; i += 256) {
       const int q = x0 + (i & 63), r = y0 + (i >> 6);
       if (q < sg.AP && r < sg.AH) {
         sg.acc4[(size_t)r * sg.AP + q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        sg.acc2[(size_t)r * sg.AP + q] = make_float2(0.f, 0.f);
+        if (rain) sg.acc2[(size_t)r * sg.AP + q] = make_float2(0.f, 0.f);
       }
     }
-    if (threadIdx.x == 0) sg.dirty[tile] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) sg.dirty[tile] = sg.dirty[T + tile] = 0;
   }
 }
 

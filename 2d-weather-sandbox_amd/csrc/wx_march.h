@@ -100,7 +100,8 @@ __device__ __forceinline__ void march_fence()
 #ifndef WX_MARCH_UNROLL
 #define WX_MARCH_UNROLL 1 // row steps per loop iteration. 2: 1.08 instead of 0.95 ms at 32768x4096 (more registers, fewer waves per SIMD), unlike k_march_wet
 #endif
-template <bool WRITE_DISP, bool WRITE_WALL>
+// QUIET: no brush input, no airplane event in this iteration (see advection_cell)
+template <bool WRITE_DISP, bool WRITE_WALL, bool QUIET>
 __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u_arg, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows,
                                                                      int n_full, int n_half, int band_h, int n_seg, int strip_lo
 #ifdef WX_MARCH_TIMING
@@ -237,10 +238,10 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
           MDryAcc a{rg, l1, yc};
 #if WX_MARCH_AIR
           if (nw1 & nw2 & nw3) // (wave-uniform) no wall cell in the three rows the footprints reach: plain interpolation, no wall branch
-            advection_cell<true, true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
+            advection_cell<true, true, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
           else
 #endif
-            advection_cell<true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
+            advection_cell<true, false, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
         } else { // exact out-of-line path (velocity recomputed from global memory)
           const AdvOut o = advection_cell_dry_global(ctx, in, false, col, y);
           ab = o.b;
@@ -309,7 +310,7 @@ inline int march_capacity()
   if (!capacity) {
     int dev = 0, ncu = 0, nb = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_dry<false, true>, 64, 0) != hipSuccess || ncu <= 0 || nb <= 0)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_dry<false, false, true>, 64, 0) != hipSuccess || ncu <= 0 || nb <= 0)
       capacity = 256 * 4 * WX_MARCH_MINWAVES;
     else
       capacity = ncu * nb;
@@ -366,15 +367,19 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
   static unsigned long long *cyc = nullptr;
   static int calls = 0;
   if (!cyc && hipMalloc((void **)&cyc, 16 * (size_t)n_strips_all * n_seg) != hipSuccess) return;
-#define WX_LAUNCH_M(D, W) hipLaunchKernelGGL((k_march_dry<D, W>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, cyc)
+#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, cyc)
 #else
-#define WX_LAUNCH_M(D, W) hipLaunchKernelGGL((k_march_dry<D, W>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo)
+#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo)
 #endif
+  const bool quiet = !(u.userInputType >= 1) && !(u.airplaneValues[3] < 0.0f || u.airplaneValues[3] > 0.9f);
+#define WX_LAUNCH_MQ(D, W) \
+  do { if (quiet) WX_LAUNCH_M(D, W, true); else WX_LAUNCH_M(D, W, false); } while (0)
   if (write_disp) {
-    if (write_wall) WX_LAUNCH_M(true, true); else WX_LAUNCH_M(true, false);
+    if (write_wall) WX_LAUNCH_MQ(true, true); else WX_LAUNCH_MQ(true, false);
   } else {
-    if (write_wall) WX_LAUNCH_M(false, true); else WX_LAUNCH_M(false, false);
+    if (write_wall) WX_LAUNCH_MQ(false, true); else WX_LAUNCH_MQ(false, false);
   }
+#undef WX_LAUNCH_MQ
 #undef WX_LAUNCH_M
 #ifdef WX_MARCH_TIMING
   if (++calls == 40) { // per segment: start / end relative to the first wave of its XCD band, duration (shader clock cycles)

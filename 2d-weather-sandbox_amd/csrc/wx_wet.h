@@ -91,6 +91,12 @@ namespace wx {
 #ifndef WX_WET_UNROLL2
 #define WX_WET_UNROLL2 1 // two row steps per loop iteration (measured -1.2 .. -1.6 % at 16384x2048: fewer register moves for the carried values)
 #endif
+#ifndef WX_WET_UNROLL2_FB
+#define WX_WET_UNROLL2_FB 0
+#endif
+#ifndef WX_WET_UNROLL2_OPT
+#define WX_WET_UNROLL2_OPT 0
+#endif
 #ifndef WX_WET_AIR
 #define WX_WET_AIR 1 // wave-uniform free-air instantiations of the boundary / advection / lighting stages
 #endif
@@ -109,7 +115,7 @@ struct WetIn {
   LightPlanesC lsrc;    // source of this iteration's lighting pass (light_0 or light_1)
   const float4 *fb;     // precipitation feedback / deposition, or NULL when known to be zero
   const float2 *dep;
-  const unsigned char *fb_zero; // per 64x16 tile: feedback AND deposition all zero there (may be NULL)
+  const unsigned char *fb_zero; // per 64x16 tile t: [2t] feedback all zero there, [2t + 1] deposition all zero there (may be NULL)
   const float4 *zero_row;       // one row (X texels) of zeros: what rows of all-zero tiles are "loaded" from
   int fb_txn;
 };
@@ -465,7 +471,8 @@ struct WetSegs {
   int bands;              // experimental (WX_WET_BANDS=1): XCD k takes the row band [k*Y/8, (k+1)*Y/8) of ALL strips; start[] is relative to it
   int start[WMAXSEG + 1];
 };
-template <bool OPT_OUT, bool HAS_FB>
+// QUIET: no brush input and no airplane event in this iteration (the host looks at the uniforms): advection_cell without those sections.
+template <bool OPT_OUT, bool HAS_FB, bool QUIET>
 __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in_arg, WetOut out_arg,
                                                                     WetFixList fix, int n_strips, int strip_lo,
                                                                     int n_strips_all, WetSegs segs)
@@ -535,8 +542,8 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   float2 pf_lzw = make_float2(0.f, 0.f);                              // source IR fluxes row r-2
   float4 pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);                     // feedback / deposition row r-3 (HAS_FB)
   float2 pf_dep = make_float2(0.f, 0.f);
-  bool fb_have = false;                                               // wave-uniform: the tile(s) of that row hold feedback
-  unsigned char pf_flag = 1;                                          // "feedback tile is all zero" flag of the row prefetched next
+  bool fb_have = false, dep_have = false;                             // wave-uniform: the tile(s) of that row hold feedback / deposition
+  unsigned short pf_flag = 0x0101;                                    // "feedback | deposition tile is all zero" flags (low | high byte) of the row prefetched next
   float4 b_prev = make_float4(0.f, 0.f, 0.f, 0.f);                    // base_0 row r-1
   int w_prev = 0;
   float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);                        // pre-boundary water row r-3
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     const float2 lzw_cur = pf_lzw;
     const float4 fb_cur = pf_fb;                   // feedback row r-3
     const float2 dep_cur = pf_dep;
-    const bool fb_cur_have = fb_have;
+    const bool fb_cur_have = fb_have || dep_have;
     // (the feedback texel's fourth channel is never read: without this "use" the register allocator hands its register to another
     // value while the 16-byte load that also writes it is still in flight, and overwriting it then costs a wait for that load)
     if (HAS_FB) asm volatile("" ::"v"(fb_cur.w));
@@ -655,9 +662,10 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       if (HAS_FB) {
         // does any of the (up to three) 64x16 tiles under this strip hold feedback in row r-2? The flag byte was loaded one step
         // ago (pf_flag), so the vote costs no wait of its own
-        fb_have = __any(pf_flag == 0);
+        fb_have = __any((pf_flag & 0xffu) == 0);
+        dep_have = __any((pf_flag >> 8) == 0); // (only droplets that reach the ground deposit: few tiles)
 #if defined(WX_ABL_FB_NOFLAG) || defined(WX_ABL_FB_NOLOAD)
-        fb_have = false; // (timing experiments only: wrong results)
+        fb_have = dep_have = false; // (timing experiments only: wrong results)
 #endif
 #ifdef WX_ABL_FB_NOLOAD
         pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #if WX_WET_FB_COND
           if (fb_have) {
             pf_fb = ld_row(in.fb + e, lo16);
-            pf_dep = ld_row((!WX_WET_DEP_NEAR || (h_near & 4u)) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
+            pf_dep = ld_row((dep_have && (!WX_WET_DEP_NEAR || (h_near & 4u))) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
           } else {
             pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);
             pf_dep = make_float2(0.f, 0.f);
@@ -679,12 +687,12 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
           pf_fb = ld_row(fb_have ? in.fb + e : in.zero_row, lo16);
           // (the deposition texture is only read by surface wall cells, boundaryShader.frag:390-475: rows without a cell at or next to
           // a wall take it from the row of zeros too)
-          pf_dep = ld_row((fb_have && (!WX_WET_DEP_NEAR || (h_near & 4u))) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
+          pf_dep = ld_row((dep_have && (!WX_WET_DEP_NEAR || (h_near & 4u))) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
 #endif
         }
 #endif
 #if !defined(WX_ABL_FB_NOFLAG) && !defined(WX_ABL_FB_NOLOAD)
-        pf_flag = in.fb_zero != nullptr ? in.fb_zero[(yw_m1 >> 4) * in.fb_txn + (col >> 6)] : 0; // row r-1, voted on next step
+        pf_flag = in.fb_zero != nullptr ? reinterpret_cast<const unsigned short *>(in.fb_zero)[(yw_m1 >> 4) * in.fb_txn + (col >> 6)] : (unsigned short)0; // row r-1, voted on next step
 #endif
       }
     }
@@ -848,15 +856,15 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #ifdef WX_STAGE_MARKS
             asm volatile("; @@advair");
 #endif
-            advection_cell<false, true, true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
+            advection_cell<false, true, true, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
 #ifdef WX_STAGE_MARKS
             asm volatile("; @@advairend");
 #endif
           }
           else
-            advection_cell<false, true>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
+            advection_cell<false, true, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
         } else {
-          advection_cell<false, false>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
+          advection_cell<false, false, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, ya, a, ab, aw, awl);
         }
       } else { // placeholder (the post-boundary texel): this cell and the two it feeds are recomputed after the loop
         ab = a.base(0, 0);
@@ -924,7 +932,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   };
   // (a segment has at least one row: at least nine steps)
   for (; t < 8; r++, t++) step(std::true_type{});
-  if (WX_WET_UNROLL2 && !HAS_FB && !OPT_OUT) {
+  if (WX_WET_UNROLL2 && (WX_WET_UNROLL2_FB || !HAS_FB) && (WX_WET_UNROLL2_OPT || !OPT_OUT)) {
     // two steps per loop iteration: the values carried from step to step (prefetched rows, the previous rows' registers, the deferred
     // stores) change registers between the two copies instead of being moved: -1.4 % without feedback loads; WITH them (particles on)
     // the doubled loop is 4-6 % slower, and the display-writing one (every tenth iteration) loses 2-8 %: only the plain instantiation
@@ -1200,7 +1208,7 @@ inline int wet_capacity()
   if (!capacity) {
     int dev = 0, ncu = 0, nb = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_wet<false, false>, 64 * WX_WET_WPB, 0) != hipSuccess || ncu <= 0 || nb <= 0) {
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march_wet<false, false, true>, 64 * WX_WET_WPB, 0) != hipSuccess || ncu <= 0 || nb <= 0) {
       capacity = 256 * 4 * WX_WET_MINWAVES;
     } else {
       // the occupancy API can answer one workgroup per CU too many (MI355X_MICROARCH.md, "Residency"): bound it by what the kernel's own
@@ -1208,7 +1216,7 @@ inline int wet_capacity()
       // WX_WET_WPB waves, one per SIMD
       hipFuncAttributes fa;
       int by_regs = nb, by_lds = nb;
-      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_march_wet<false, false>)) == hipSuccess) {
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_march_wet<false, false, true>)) == hipSuccess) {
         if (fa.numRegs > 0) by_regs = (512 / (((fa.numRegs + 7) / 8) * 8)) * 4 / WX_WET_WPB;
         if (fa.sharedSizeBytes > 0) by_lds = (int)(163840 / fa.sharedSizeBytes);
         if (wx_tune_env("WX_MARCH_DEBUG")) fprintf(stderr, "[wx_wet] numRegs=%d lds=%zu: blocks/CU by registers %d, by LDS %d, occupancy API %d\n", fa.numRegs, fa.sharedSizeBytes, by_regs, by_lds, nb);
@@ -1333,7 +1341,7 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row, int bands_mode
 }
 
 inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, const WetFixList &fix,
-                             bool opt_out, hipStream_t stream, int strip_lo = 0, int strip_count = -1)
+                             bool opt_out, bool quiet, hipStream_t stream, int strip_lo = 0, int strip_count = -1)
 {
   const int ns = strip_count < 0 ? w.n_strips : strip_count;
   if (ns <= 0) return;
@@ -1346,13 +1354,16 @@ inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *c
     dbg = false;
   }
   const bool has_fb = in.fb != nullptr;
-#define WX_LAUNCH_W(O, F) \
-  hipLaunchKernelGGL((k_march_wet<O, F>), grid, dim3(64 * WX_WET_WPB), 0, stream, ctx, iterNum, in, out, fix, ns, strip_lo, w.n_strips, w.segs)
+#define WX_LAUNCH_W(O, F, Q) \
+  hipLaunchKernelGGL((k_march_wet<O, F, Q>), grid, dim3(64 * WX_WET_WPB), 0, stream, ctx, iterNum, in, out, fix, ns, strip_lo, w.n_strips, w.segs)
+#define WX_LAUNCH_WQ(O, F) \
+  do { if (quiet) WX_LAUNCH_W(O, F, true); else WX_LAUNCH_W(O, F, false); } while (0)
   if (opt_out) {
-    if (has_fb) WX_LAUNCH_W(true, true); else WX_LAUNCH_W(true, false);
+    if (has_fb) WX_LAUNCH_WQ(true, true); else WX_LAUNCH_WQ(true, false);
   } else {
-    if (has_fb) WX_LAUNCH_W(false, true); else WX_LAUNCH_W(false, false);
+    if (has_fb) WX_LAUNCH_WQ(false, true); else WX_LAUNCH_WQ(false, false);
   }
+#undef WX_LAUNCH_WQ
 #undef WX_LAUNCH_W
 }
 

@@ -635,9 +635,11 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
     ProfScope ps(s, K_MARCH_WET);
     const WetFixList fix{s->fix_count, s->fix_cells, s->fix_cap, s->fix_hint_host, &s->state->fastest_bits, s->fix_hint_dev};
     // one launch group: marching kernel over a strip range (or two) -> the fix pass over what it recorded (leaves the list empty)
+    // no brush input, no airplane event (the common case: a running simulation): the instantiation without those sections
+    const bool quiet = !(s->uni.userInputType >= 1) && !(s->uni.airplaneValues[3] < 0.0f || s->uni.airplaneValues[3] > 0.9f);
     auto group = [&](int lo0, int cnt0, int lo1 = 0, int cnt1 = 0) {
-      launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, fix, opt_out, s->stream, lo0, cnt0);
-      if (cnt1 > 0) launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, fix, opt_out, s->stream, lo1, cnt1);
+      launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, fix, opt_out, quiet, s->stream, lo0, cnt0);
+      if (cnt1 > 0) launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, fix, opt_out, quiet, s->stream, lo1, cnt1);
       launch_wet_fix((float)s->iter, s->full_ctx, in, out, fix, &s->state->fix_overflow, opt_out, s->stream);
     };
     // edge strips: every output column wx_halo_pack reads ([halo, 2*halo) and its mirror) and every strip that reads ghost columns
@@ -838,9 +840,9 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
     sg.TYn = (Y + 1 + STY - 1) / STY;
     rc = dalloc(s, &sg.acc4, (size_t)sg.AP * sg.AH);
     if (rc == WX_OK) rc = dalloc(s, &sg.acc2, (size_t)sg.AP * sg.AH);
-    if (rc == WX_OK) rc = dalloc(s, &sg.dirty, (size_t)sg.TXn * sg.TYn);
-    if (rc == WX_OK) rc = dalloc(s, &sg.fb_zero, (size_t)sg.TXn * sg.TYn);
-    if (rc == WX_OK) rc = dalloc(s, &sg.work, 8 + 3 * (size_t)sg.TXn * sg.TYn);
+    if (rc == WX_OK) rc = dalloc(s, &sg.dirty, 2 * (size_t)sg.TXn * sg.TYn);   // [t]: deposits, [T + t]: rain / snow deposits
+    if (rc == WX_OK) rc = dalloc(s, &sg.fb_zero, 2 * (size_t)sg.TXn * sg.TYn); // [2t]: feedback tile zero, [2t + 1]: deposition tile zero
+    if (rc == WX_OK) rc = dalloc(s, &sg.work, 16 + 5 * (size_t)sg.TXn * sg.TYn);
     if (rc == WX_OK && halo > 0) rc = dalloc(s, &s->pool_remote, (size_t)n_droplets);
     if (rc == WX_OK && halo > 0) rc = dalloc(s, &s->pool_owned, (size_t)n_droplets);
     if (rc == WX_OK && halo > 0) rc = dalloc(s, &s->pool_flips, (size_t)n_droplets);
@@ -1040,9 +1042,9 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   if (s->sg.acc4) {
     HIPCHK(s, hipMemsetAsync(s->sg.acc4, 0, (size_t)s->sg.AP * s->sg.AH * 16, s->stream));
     HIPCHK(s, hipMemsetAsync(s->sg.acc2, 0, (size_t)s->sg.AP * s->sg.AH * 8, s->stream));
-    HIPCHK(s, hipMemsetAsync(s->sg.dirty, 0, (size_t)s->sg.TXn * s->sg.TYn, s->stream));
-    HIPCHK(s, hipMemsetAsync(s->sg.fb_zero, 1, (size_t)s->sg.TXn * s->sg.TYn, s->stream));
-    HIPCHK(s, hipMemsetAsync(s->sg.work, 0, 32, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->sg.dirty, 0, 2 * (size_t)s->sg.TXn * s->sg.TYn, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->sg.fb_zero, 1, 2 * (size_t)s->sg.TXn * s->sg.TYn, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->sg.work, 0, 64, s->stream));
     s->splat_par = 0;
   }
   HIPCHK(s, hipStreamSynchronize(s->stream)); // the caller keeps ownership of the host arrays
@@ -1293,7 +1295,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
     } else if (s->fb_dirty) { // particles were switched off: the reference's clear leaves both textures zero
       hipMemsetAsync(s->fb, 0, n * 16, s->stream);
       hipMemsetAsync(s->dep, 0, n * 8, s->stream);
-      if (s->sg.fb_zero) hipMemsetAsync(s->sg.fb_zero, 1, (size_t)s->sg.TXn * s->sg.TYn, s->stream);
+      if (s->sg.fb_zero) hipMemsetAsync(s->sg.fb_zero, 1, 2 * (size_t)s->sg.TXn * s->sg.TYn, s->stream);
       s->fb_dirty = false;
     }
     s->iter++;
@@ -1565,6 +1567,11 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
   std::vector<Block> best = original;
   best_ms = first_ms;
   if (dbg) fprintf(stderr, "[wx_tune_placement] current allocations (%zu blocks, %zu MB): %.4f ms / iteration\n", original.size(), total >> 20, first_ms);
+  if (dbg && wx_tune_env("WX_TUNE_DEBUG")[0] == '2') {
+    fprintf(stderr, "[wx_tune_blocks] 0 %.4f", first_ms);
+    for (const Block &b : original) fprintf(stderr, " %llx:%zu", (unsigned long long)(uintptr_t)b.p, b.bytes >> 20);
+    fprintf(stderr, "\n");
+  }
   // Rejected candidates stay allocated while there is room: freed memory is handed straight back by the next hipMalloc (same
   // memory, nothing learned). They are released at the end, or earlier when device memory runs short.
   std::vector<std::vector<Block>> rejects;
@@ -1590,6 +1597,11 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
     if (rc == WX_OK) rc = probe(&ms);
     snap_put(s, snap);
     if (dbg) fprintf(stderr, "[wx_tune_placement] candidate %d (first plane at %p): %.4f ms / iteration\n", t, (void *)(cand.size() > 1 ? cand[1].p : cand[0].p), ms);
+    if (dbg && wx_tune_env("WX_TUNE_DEBUG")[0] == '2') {
+      fprintf(stderr, "[wx_tune_blocks] %d %.4f", t, ms);
+      for (const Block &b : cand) fprintf(stderr, " %llx:%zu", (unsigned long long)(uintptr_t)b.p, b.bytes >> 20);
+      fprintf(stderr, "\n");
+    }
     if (rc == WX_OK && ms < best_ms) {
       rejects.push_back(best);
       best = cand;
@@ -1946,7 +1958,7 @@ int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
     s->unpack_pending = true;
   }
   if (s->pool_remote) { // the ghost tiles of the feedback texture now hold a neighbour's values: nothing is "known zero" any more
-    hipMemsetAsync(s->sg.fb_zero, 0, (size_t)s->sg.TXn * s->sg.TYn, s->stream);
+    hipMemsetAsync(s->sg.fb_zero, 0, 2 * (size_t)s->sg.TXn * s->sg.TYn, s->stream);
     s->fb_dirty = true;
   }
   HIPCHK(s, hipGetLastError());
