@@ -17,7 +17,7 @@ struct GridPtrs {
   const char4 *wall;
   const float2 *vort;
   const float4 *light;
-  const float4 *fb;
+  const float3 *fb; // (mass, heat, vapour): the reference's fourth channel is never written except at its mailbox texel (1,0)
   const float2 *dep;
 };
 
@@ -77,7 +77,12 @@ struct GBoundaryAcc {
   __device__ __forceinline__ float light_x0() const { return light(0).x; }
   __device__ __forceinline__ float2 light_xy_up() const { const float4 l = light(1); return make_float2(l.x, l.y); }
   __device__ __forceinline__ bool has_fb() const { return p.fb != nullptr; }
-  __device__ __forceinline__ float4 fb() const { return p.fb ? p.fb[cidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ float4 fb() const
+  {
+    if (!p.fb) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float3 v = p.fb[cidx(x, y, X)];
+    return make_float4(v.x, v.y, v.z, 0.f);
+  }
   __device__ __forceinline__ float2 dep() const { return p.dep ? p.dep[cidx(x, y, X)] : make_float2(0.f, 0.f); }
 };
 
@@ -344,6 +349,8 @@ struct DevState {
   int pool_seen_max;      // largest status-flip count any rank reported since the transport last looked (k_pool_check)
   int fastest_bits;       // float bits of the largest |velocity component| that took a cell to the exact path (marching wet kernel)
   int pool_retired;       // exact mode: droplets that ended the iteration inactive among this iteration's status flips (k_pool_events_apply)
+  float mailbox_w;        // fourth channel of the feedback texture's texel (1,0) -- the only texel whose alpha the reference ever writes (the
+                          // lightning request's fourth component): the texture itself is stored with three channels (k_lightning keeps it)
 };
 
 // Splat accumulation: a 12x12 point sprite anchored at pixel (i0,j0) adds the same value to pixels
@@ -351,7 +358,7 @@ struct DevState {
 // accumulation grid and a 12x12 box sum (k_splat_box) produces the feedback / deposition textures.
 // Anchor range: i0 = ceil(xw - 6.5) in [-6, X-6]  ->  column q = i0 + 6 in [0, X]; rows likewise.
 struct SplatGrid {
-  float4 *acc4;  // (mass, heat, vapor, -) deposits, pitch AP
+  float3 *acc3;  // (mass, heat, vapor) deposits, pitch AP (12-byte anchors: the fourth channel of the reference's blend target is never used)
   float2 *acc2;  // (rain, snow) deposits
   unsigned char *dirty;   // per 64x16 tile t of the accumulation grid: [t] holds deposits; [T + t] holds (rain, snow) deposits too
                           // (T = TXn * TYn; only droplets that reach the ground deposit there: a small part of the tiles)
@@ -693,7 +700,7 @@ __device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const 
 #if WX_ABL_PRECIP & 2
   return false;
 #endif
-  float *f = reinterpret_cast<float *>(sg.acc4 + ai);
+  float *f = reinterpret_cast<float *>(sg.acc3 + ai);
   atomic_add_f(f + 0, feedback[0]);
   atomic_add_f(f + 1, feedback[1]);
   atomic_add_f(f + 2, feedback[2]);
@@ -754,7 +761,7 @@ __global__ __launch_bounds__(256) void k_splat_runs(int n, const int *__restrict
     for (int c = 0; c < 4; c++) st->px_light[c] += a[c];
     return;
   }
-  sg.acc4[k] = make_float4(a[0], a[1], a[2], 0.f);
+  sg.acc3[k] = make_float3(a[0], a[1], a[2]);
   const int r = k / sg.AP, q = k - r * sg.AP, tile = (r / STY) * sg.TXn + (q / STX);
   sg.dirty[tile] = 1;
   if (a[3] != 0.0f || a[4] != 0.0f) { // (as in precip_droplet: a run that deposits no rain / snow leaves the zero that is there)
@@ -804,19 +811,19 @@ __global__ __launch_bounds__(256) void k_splat_classify(int X, int Y, SplatGrid 
     sg.work[16 + 4 * T + atomicAdd(&cnt[4], 1)] = t;
 }
 
-// One (tile, texture) work item: KIND 0 = the feedback texture from the three used channels of acc4, KIND 1 = the deposition texture
+// One (tile, texture) work item: KIND 0 = the feedback texture from acc3, KIND 1 = the deposition texture
 // from acc2. Splitting a tile by texture brings the staging buffer from 41 to 25 KB (6 instead of 3 workgroups per CU: the kernel
 // is latency-bound between its load, sum and store phases) and doubles the number of independent items.
 template <int KIND>
 __device__ __forceinline__ void splat_box_tile(float (*pl)[STY + 11][77], int X, int Y, const SplatGrid &sg, const DevState *__restrict__ st,
-                                               float4 *__restrict__ fb, float2 *__restrict__ dep, int x0, int y0, int qmin, int qmax, int qshift, bool corner)
+                                               float3 *__restrict__ fb, float2 *__restrict__ dep, int x0, int y0, int qmin, int qmax, int qshift, bool corner)
 {
   constexpr int WW = STX + 11, WH = STY + 11, NCH = KIND == 0 ? 3 : 2;
   const int tid = threadIdx.x;
   // stage the deposit window (zero outside the accumulation grid). All loads of a thread are issued before the first LDS write:
   // as a rolled loop this was load -> wait -> write eight times in a row, i.e. eight memory latencies per tile.
   constexpr int NST = (WW * WH + 255) / 256;
-  float4 v4[KIND == 0 ? NST : 1];
+  float3 v4[KIND == 0 ? NST : 1];
   float2 v2[KIND == 0 ? 1 : NST];
 #pragma unroll
   for (int k = 0; k < NST; k++) {
@@ -824,8 +831,8 @@ __device__ __forceinline__ void splat_box_tile(float (*pl)[STY + 11][77], int X,
     const int q = x0 - 5 + lx, r = y0 - 5 + ly;
     const bool inside = i < WW * WH && q >= qmin && r >= 0 && q <= qmax && r <= Y;
     if (KIND == 0) {
-      v4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (inside) v4[k] = sg.acc4[(size_t)r * sg.AP + q + qshift];
+      v4[k] = make_float3(0.f, 0.f, 0.f);
+      if (inside) v4[k] = sg.acc3[(size_t)r * sg.AP + q + qshift];
     } else {
       v2[k] = make_float2(0.f, 0.f);
       if (inside) v2[k] = sg.acc2[(size_t)r * sg.AP + q + qshift];
@@ -897,13 +904,12 @@ __device__ __forceinline__ void splat_box_tile(float (*pl)[STY + 11][77], int X,
     const int ry = cyg + 4 * k, x = x0 + cx, y = y0 + ry;
     if (x < X && y < Y) {
       if (KIND == 0) {
-        float4 v = make_float4(pl[0][ry][cx], pl[1][ry][cx], pl[2][ry][cx], 0.f);
+        float3 v = make_float3(pl[0][ry][cx], pl[1][ry][cx], pl[2][ry][cx]);
         if (corner && y == 0 && x == 0) v.x += st->px_count;
-        if (corner && y == 0 && x == 1) {
+        if (corner && y == 0 && x == 1) { // (the fourth component of the request: DevState::mailbox_w, k_lightning)
           v.x += st->px_light[0];
           v.y += st->px_light[1];
           v.z += st->px_light[2];
-          v.w += st->px_light[3];
         }
         fb[(size_t)y * X + x] = v;
       } else {
@@ -914,7 +920,7 @@ __device__ __forceinline__ void splat_box_tile(float (*pl)[STY + 11][77], int X,
   __syncthreads(); // (the next item re-uses the staging buffer)
 }
 
-__global__ __launch_bounds__(256, 4) void k_splat_box(int X, int Y, SplatGrid sg, const DevState *__restrict__ st, float4 *__restrict__ fb,
+__global__ __launch_bounds__(256, 4) void k_splat_box(int X, int Y, SplatGrid sg, const DevState *__restrict__ st, float3 *__restrict__ fb,
                                                    float2 *__restrict__ dep, int seam, int mailbox, int par)
 {
   constexpr int WH = STY + 11, PW = 77; // (pitch 77: the 4 rows x 8 runs a half-wave reads in the horizontal pass hit 32 banks)
@@ -941,9 +947,9 @@ __global__ __launch_bounds__(256, 4) void k_splat_box(int X, int Y, SplatGrid sg
       for (int k = 0; k < STY / 4; k++) {
         const int x = x0 + cx, y = y0 + cyg + 4 * k;
         if (x < X && y < Y) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          float3 v = make_float3(0.f, 0.f, 0.f);
           if (corner && y == 0 && x == 0) v.x = st->px_count;
-          if (corner && y == 0 && x == 1) v = make_float4(st->px_light[0], st->px_light[1], st->px_light[2], st->px_light[3]);
+          if (corner && y == 0 && x == 1) v = make_float3(st->px_light[0], st->px_light[1], st->px_light[2]);
           fb[(size_t)y * X + x] = v;
         }
       }
@@ -997,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg,
     for (int i = threadIdx.x; i < STX * STY; i += 256) {
       const int q = x0 + (i & 63), r = y0 + (i >> 6);
       if (q < sg.AP && r < sg.AH) {
-        sg.acc4[(size_t)r * sg.AP + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sg.acc3[(size_t)r * sg.AP + q] = make_float3(0.f, 0.f, 0.f);
         if (rain) sg.acc2[(size_t)r * sg.AP + q] = make_float2(0.f, 0.f);
       }
     }
@@ -1009,14 +1015,16 @@ __global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg,
 // lightningLocationShader.frag:24-38 + the 600-iteration inactive count (app.js:5957-5966), one thread
 // (slab handles: the mailbox texels are not part of the local feedback texture -- the request is taken from the
 // accumulator directly, the inactive count is refreshed by wx_pool_edges_pack)
-__global__ void k_lightning(float iterNum, int refresh_inactive, const float4 *__restrict__ fb, DevState *st, int mailbox, int defer)
+__global__ void k_lightning(float iterNum, int refresh_inactive, const float3 *__restrict__ fb, DevState *st, int mailbox, int defer)
 {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (defer) { // exact slabs: the request stays in px_light until the ranks have summed theirs (k_pool_exact_resolve)
     st->px_count = 0.f;
     return;
   }
-  const float4 n = mailbox ? fb[1] : make_float4(st->px_light[0], st->px_light[1], st->px_light[2], st->px_light[3]); // texel (1,0)
+  // texel (1,0); its fourth channel (0 + the request's, as the blend unit adds it to the cleared texture) lives in the state
+  const float4 n = mailbox ? make_float4(fb[1].x, fb[1].y, fb[1].z, 0.0f + st->px_light[3]) : make_float4(st->px_light[0], st->px_light[1], st->px_light[2], st->px_light[3]);
+  if (mailbox) st->mailbox_w = n.w;
   st->px_count = 0.f; // consumed by k_splat_box
   st->px_light[0] = st->px_light[1] = st->px_light[2] = st->px_light[3] = 0.f;
   if (refresh_inactive && mailbox) st->inactiveDroplets = fb[0].x;
@@ -1046,7 +1054,7 @@ constexpr int POOL_HDR = 16;
 // the inactive count, app.js:5957-5966; NULL on ranks that do not own global column 0)
 __global__ void k_pool_events_pack(int n, int rank, int cap, unsigned short *__restrict__ flips, unsigned char *__restrict__ owned_once,
                                    const float *__restrict__ drops, int *__restrict__ hdr, PoolEvent *__restrict__ ev, DevState *st, int exact,
-                                   const float4 *__restrict__ fb00)
+                                   const float3 *__restrict__ fb00)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (exact && i == 0) { // exact: 1 = the iteration record (lightning REQUEST), 2 = the period record (this rank's lightning STATE)
@@ -1268,7 +1276,7 @@ struct HaloPtrs {
   LightPlanes lp0, lp1; // used instead of light0 / light1 while the light texture is stored as planes (lp0.x != nullptr);
                         // the BUFFER always carries interleaved RGBA texels
   char4 *wall;
-  float4 *fb;  // particle feedback / deposition textures: exchanged only on handles that carry particles
+  float3 *fb;  // particle feedback / deposition textures: exchanged only on handles that carry particles (the BUFFER carries RGBA texels)
   float2 *dep; // buffer layout then: [4 x h*Y float4][fb h*Y float4][dep h*Y float2][wall h*Y char4]
 };
 __global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, int x_start, float4 *buf16, float2 *buf8, char4 *buf4)
@@ -1289,7 +1297,8 @@ __global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, int x_start, float4
     }
     buf4[i] = f.wall[s];
     if (f.fb) {
-      buf16[4 * n + i] = f.fb[s];
+      const float3 v = f.fb[s];
+      buf16[4 * n + i] = make_float4(v.x, v.y, v.z, 0.f);
       buf8[i] = f.dep[s];
     }
   }
@@ -1323,7 +1332,8 @@ __global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, int x_start, cons
     }
     f.wall[s] = buf4[i];
     if (f.fb) {
-      f.fb[s] = buf16[4 * n + i];
+      const float4 v = buf16[4 * n + i];
+      f.fb[s] = make_float3(v.x, v.y, v.z);
       f.dep[s] = buf8[i];
     }
   }

@@ -113,7 +113,7 @@ struct WetIn {
   const float4 *water;  // water_1: post-advection water of the previous iteration
   LightPlanesC l0;      // lightTexture_0 (what boundaryShader samples)
   LightPlanesC lsrc;    // source of this iteration's lighting pass (light_0 or light_1)
-  const float4 *fb;     // precipitation feedback / deposition, or NULL when known to be zero
+  const float3 *fb;     // precipitation feedback (three channels) / deposition, or NULL when known to be zero
   const float2 *dep;
   const unsigned char *fb_zero; // per 64x16 tile t: [2t] feedback all zero there, [2t + 1] deposition all zero there (may be NULL)
   const float4 *zero_row;       // one row (X texels) of zeros: what rows of all-zero tiles are "loaded" from
@@ -186,7 +186,12 @@ struct GWetRecomputeAcc {
     return make_float2(in_.l0.x[i], in_.l0.y[i]);
   }
   __device__ __forceinline__ bool has_fb() const { return in_.fb != nullptr; }
-  __device__ __forceinline__ float4 fb() const { return in_.fb ? in_.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ float4 fb() const
+  {
+    if (!in_.fb) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float3 v = in_.fb[fidx(x, y, X)];
+    return make_float4(v.x, v.y, v.z, 0.f);
+  }
   __device__ __forceinline__ float2 dep() const { return in_.dep ? in_.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
 };
 struct BOut {
@@ -529,6 +534,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   const int col = wrapmod(c_out, X);           // column this lane loads / computes
   const bool lane_out = lane >= WLO && lane < WLO + WOUT && c_out < X;
   unsigned lo4 = (unsigned)col * 4u, lo8 = (unsigned)col * 8u, lo16 = (unsigned)col * 16u; // byte offsets of the loaded column
+  unsigned lo12 = (unsigned)col * 12u; // (feedback texels)
   unsigned so4 = lane_out ? (unsigned)c_out * 4u : 0u, so8 = so4 * 2u, so16 = so4 * 4u;    // ... of the stored column
   const int y_lo = band_lo + segs.start[seg], y_hi = min(band_lo + segs.start[seg + 1], band_hi);
   if (y_lo >= y_hi) return;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   int pf_w;                                                          // wall row r (raw dword)
   float pf_lx = 0.f, pf_l0x = 0.f, pf_l0y = 0.f;                      // source sunlight, light_0 sunlight / net heating, row r-2
   float2 pf_lzw = make_float2(0.f, 0.f);                              // source IR fluxes row r-2
-  float4 pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);                     // feedback / deposition row r-3 (HAS_FB)
+  float3 pf_fb = make_float3(0.f, 0.f, 0.f);                          // feedback / deposition row r-3 (HAS_FB)
   float2 pf_dep = make_float2(0.f, 0.f);
   bool fb_have = false, dep_have = false;                             // wave-uniform: the tile(s) of that row hold feedback / deposition
   unsigned short pf_flag = 0x0101;                                    // "feedback | deposition tile is all zero" flags (low | high byte) of the row prefetched next
@@ -607,12 +613,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     int w_raw = pf_w;
     const float lx_cur = pf_lx, l0x_cur = pf_l0x, l0y_cur = pf_l0y; // light row r-2
     const float2 lzw_cur = pf_lzw;
-    const float4 fb_cur = pf_fb;                   // feedback row r-3
+    const float4 fb_cur = make_float4(pf_fb.x, pf_fb.y, pf_fb.z, 0.f); // feedback row r-3
     const float2 dep_cur = pf_dep;
     const bool fb_cur_have = fb_have || dep_have;
-    // (the feedback texel's fourth channel is never read: without this "use" the register allocator hands its register to another
-    // value while the 16-byte load that also writes it is still in flight, and overwriting it then costs a wait for that load)
-    if (HAS_FB) asm volatile("" ::"v"(fb_cur.w));
     asm volatile("" : "+v"(w_raw)); // keeps the byte unpacking on this side of the prefetch
     const char4 w_cur = unpack_wall(w_raw);
 #ifdef WX_STAGE_MARKS
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         fb_have = dep_have = false; // (timing experiments only: wrong results)
 #endif
 #ifdef WX_ABL_FB_NOLOAD
-        pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);
+        pf_fb = make_float3(0.f, 0.f, 0.f);
         pf_dep = make_float2(0.f, 0.f);
 #else
         {
@@ -677,14 +680,14 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
           const size_t e = (size_t)yw_m2 * X;
 #if WX_WET_FB_COND
           if (fb_have) {
-            pf_fb = ld_row(in.fb + e, lo16);
+            pf_fb = ld_row(in.fb + e, lo12);
             pf_dep = ld_row((dep_have && (!WX_WET_DEP_NEAR || (h_near & 4u))) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
           } else {
-            pf_fb = make_float4(0.f, 0.f, 0.f, 0.f);
+            pf_fb = make_float3(0.f, 0.f, 0.f);
             pf_dep = make_float2(0.f, 0.f);
           }
 #else
-          pf_fb = ld_row(fb_have ? in.fb + e : in.zero_row, lo16);
+          pf_fb = ld_row(fb_have ? in.fb + e : reinterpret_cast<const float3 *>(in.zero_row), lo12);
           // (the deposition texture is only read by surface wall cells, boundaryShader.frag:390-475: rows without a cell at or next to
           // a wall take it from the row of zeros too)
           pf_dep = ld_row((dep_have && (!WX_WET_DEP_NEAR || (h_near & 4u))) ? in.dep + e : reinterpret_cast<const float2 *>(in.zero_row), lo8);
@@ -1062,7 +1065,12 @@ struct WetStageBoundaryAcc { // the interface of GWetRecomputeAcc, served from t
     return make_float2(in_.l0.x[i], in_.l0.y[i]);
   }
   __device__ __forceinline__ bool has_fb() const { return in_.fb != nullptr; }
-  __device__ __forceinline__ float4 fb() const { return in_.fb ? in_.fb[fidx(x, y, X)] : make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ float4 fb() const
+  {
+    if (!in_.fb) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float3 v = in_.fb[fidx(x, y, X)];
+    return make_float4(v.x, v.y, v.z, 0.f);
+  }
   __device__ __forceinline__ float2 dep() const { return in_.dep ? in_.dep[fidx(x, y, X)] : make_float2(0.f, 0.f); }
 };
 // the 8 x 8 patch of post-boundary texels around (cx, cy), all 64 lanes of the wave

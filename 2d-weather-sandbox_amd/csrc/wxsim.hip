@@ -110,7 +110,8 @@ struct wx_sim {
   char4 *wall[2] = {nullptr, nullptr};
   float *curl = nullptr;
   float2 *vort = nullptr, *dep = nullptr;
-  float4 *fb = nullptr;
+  float3 *fb = nullptr;      // precipitationFeedbackTexture stored with its three used channels (12-byte texels); RGBA on demand: fb_rgba
+  float4 *fb_rgba = nullptr; // (not in the placement blocks: allocated by the first reader of WX_FIELD_PRECIP_FB)
   float *drops[2] = {nullptr, nullptr};
   float *initial_T = nullptr, *snd_T = nullptr, *snd_W = nullptr, *snd_Vel = nullptr;
   DevState *state = nullptr;
@@ -838,7 +839,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
     sg.AH = Y + 8;
     sg.TXn = (s->X + 2 + STX - 1) / STX; // anchors 0 .. X (+1 right of a seam)
     sg.TYn = (Y + 1 + STY - 1) / STY;
-    rc = dalloc(s, &sg.acc4, (size_t)sg.AP * sg.AH);
+    rc = dalloc(s, &sg.acc3, (size_t)sg.AP * sg.AH);
     if (rc == WX_OK) rc = dalloc(s, &sg.acc2, (size_t)sg.AP * sg.AH);
     if (rc == WX_OK) rc = dalloc(s, &sg.dirty, 2 * (size_t)sg.TXn * sg.TYn);   // [t]: deposits, [T + t]: rain / snow deposits
     if (rc == WX_OK) rc = dalloc(s, &sg.fb_zero, 2 * (size_t)sg.TXn * sg.TYn); // [2t]: feedback tile zero, [2t + 1]: deposition tile zero
@@ -906,6 +907,8 @@ void wx_destroy(wx_sim *s)
   hipFree(s->emitted);
   dfree(s, s->vort);
   dfree(s, s->fb);
+  if (s->fb_rgba) hipFree(s->fb_rgba);
+  s->fb_rgba = nullptr;
   dfree(s, s->dep);
   dfree(s, s->initial_T);
   dfree(s, s->snd_T);
@@ -938,7 +941,7 @@ void wx_destroy(wx_sim *s)
   hipFree(s->fix_cells);
   if (s->fix_hint_host) hipHostFree(s->fix_hint_host);
   dfree(s, s->water[2]);
-  dfree(s, s->sg.acc4);
+  dfree(s, s->sg.acc3);
   dfree(s, s->sg.acc2);
   dfree(s, s->sg.dirty);
   dfree(s, s->sg.fb_zero);
@@ -1034,13 +1037,13 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   }
   HIPCHK(s, hipMemsetAsync(s->curl, 0, n * 4, s->stream));
   HIPCHK(s, hipMemsetAsync(s->vort, 0, n * 8, s->stream));
-  HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 16, s->stream));
+  HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 12, s->stream));
   HIPCHK(s, hipMemsetAsync(s->dep, 0, n * 8, s->stream));
   HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
-  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 48, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow, pool_overflow, pool_seen_max, fastest_bits, pool_retired
+  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 52, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow, pool_overflow, pool_seen_max, fastest_bits, pool_retired, mailbox_w
   if (int rc = pool_reset(s)) return rc;
-  if (s->sg.acc4) {
-    HIPCHK(s, hipMemsetAsync(s->sg.acc4, 0, (size_t)s->sg.AP * s->sg.AH * 16, s->stream));
+  if (s->sg.acc3) {
+    HIPCHK(s, hipMemsetAsync(s->sg.acc3, 0, (size_t)s->sg.AP * s->sg.AH * 12, s->stream));
     HIPCHK(s, hipMemsetAsync(s->sg.acc2, 0, (size_t)s->sg.AP * s->sg.AH * 8, s->stream));
     HIPCHK(s, hipMemsetAsync(s->sg.dirty, 0, 2 * (size_t)s->sg.TXn * s->sg.TYn, s->stream));
     HIPCHK(s, hipMemsetAsync(s->sg.fb_zero, 1, 2 * (size_t)s->sg.TXn * s->sg.TYn, s->stream));
@@ -1293,7 +1296,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       if (s->pool_remote) s->period_j++;
       if (s->pool_remote && s->pool_exact) s->exact_pending++;
     } else if (s->fb_dirty) { // particles were switched off: the reference's clear leaves both textures zero
-      hipMemsetAsync(s->fb, 0, n * 16, s->stream);
+      hipMemsetAsync(s->fb, 0, n * 12, s->stream);
       hipMemsetAsync(s->dep, 0, n * 8, s->stream);
       if (s->sg.fb_zero) hipMemsetAsync(s->sg.fb_zero, 1, 2 * (size_t)s->sg.TXn * s->sg.TYn, s->stream);
       s->fb_dirty = false;
@@ -1689,6 +1692,27 @@ int wx_set_iter(wx_sim *s, int64_t iter)
   return WX_OK;
 }
 
+// precipitationFeedbackTexture as the RGBA32F texture the reference holds: three stored channels + alpha
+__global__ void k_fb_to_rgba(size_t n, const float3 *__restrict__ fb, float4 *__restrict__ out, const DevState *__restrict__ st, int mailbox)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float3 v = fb[i];
+    out[i] = make_float4(v.x, v.y, v.z, (mailbox && i == 1) ? st->mailbox_w : 0.0f);
+  }
+}
+static int fb_to_rgba(wx_sim *s)
+{
+  const size_t n = ncell(s);
+  if (!s->fb_rgba && hipMalloc((void **)&s->fb_rgba, n * sizeof(float4)) != hipSuccess) {
+    (void)hipGetLastError();
+    s->fb_rgba = nullptr;
+    s->err = "WX_FIELD_PRECIP_FB: no device memory for the RGBA copy of the feedback texture";
+    return WX_E_NOMEM;
+  }
+  hipLaunchKernelGGL(k_fb_to_rgba, dim3(2048), dim3(256), 0, s->stream, n, s->fb, s->fb_rgba, s->state, s->pool_remote ? 0 : 1);
+  return hipGetLastError() == hipSuccess ? WX_OK : WX_E_DEVICE;
+}
+
 static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int *elem)
 {
   switch (field) {
@@ -1703,7 +1727,9 @@ static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int
   case WX_FIELD_LIGHT_1: light_to_rgba(s); *ptr = s->light[1]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_CURL: *ptr = s->curl; *channels = 1; *elem = 4; return 0;
   case WX_FIELD_VORT: *ptr = s->vort; *channels = 2; *elem = 4; return 0;
-  case WX_FIELD_PRECIP_FB: *ptr = s->fb; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_PRECIP_FB: // stored with three channels; the RGBA texture (alpha: 0, the lightning request's fourth component at texel (1,0)) is made here
+    if (fb_to_rgba(s)) return -1;
+    *ptr = s->fb_rgba; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_PRECIP_DEP: *ptr = s->dep; *channels = 2; *elem = 4; return 0;
   default: return -1;
   }
