@@ -1693,27 +1693,34 @@ int wx_set_iter(wx_sim *s, int64_t iter)
 }
 
 // precipitationFeedbackTexture as the RGBA32F texture the reference holds: three stored channels + alpha
-__global__ void k_fb_to_rgba(size_t n, const float3 *__restrict__ fb, float4 *__restrict__ out, const DevState *__restrict__ st, int mailbox)
+__global__ void k_fb_to_rgba(size_t first, size_t n, const float3 *__restrict__ fb, float4 *__restrict__ out, const DevState *__restrict__ st, int mailbox)
 {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < first + n; i += (size_t)gridDim.x * blockDim.x) {
     const float3 v = fb[i];
     out[i] = make_float4(v.x, v.y, v.z, (mailbox && i == 1) ? st->mailbox_w : 0.0f);
   }
 }
-static int fb_to_rgba(wx_sim *s)
+static int fb_to_rgba(wx_sim *s, int y0, int h) // rows [y0, y0 + h) (h <= 0: the whole texture)
 {
   const size_t n = ncell(s);
+  if (h <= 0 || y0 < 0 || y0 + h > s->Y) {
+    y0 = 0;
+    h = s->Y;
+  }
   if (!s->fb_rgba && hipMalloc((void **)&s->fb_rgba, n * sizeof(float4)) != hipSuccess) {
     (void)hipGetLastError();
     s->fb_rgba = nullptr;
     s->err = "WX_FIELD_PRECIP_FB: no device memory for the RGBA copy of the feedback texture";
     return WX_E_NOMEM;
   }
-  hipLaunchKernelGGL(k_fb_to_rgba, dim3(2048), dim3(256), 0, s->stream, n, s->fb, s->fb_rgba, s->state, s->pool_remote ? 0 : 1);
+  const size_t cells = (size_t)h * s->X;
+  hipLaunchKernelGGL(k_fb_to_rgba, dim3((unsigned)std::min<size_t>(2048, (cells + 255) / 256)), dim3(256), 0, s->stream, (size_t)y0 * s->X, cells, s->fb, s->fb_rgba, s->state,
+                     s->pool_remote ? 0 : 1);
   return hipGetLastError() == hipSuccess ? WX_OK : WX_E_DEVICE;
 }
 
-static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int *elem)
+// (y0, h: the rows a reader is going to look at -- fields that are made on demand are only made there)
+static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int *elem, int y0 = 0, int h = 0)
 {
   switch (field) {
   case WX_FIELD_BASE_CUR: *ptr = s->base[0]; *channels = 4; *elem = 4; return 0;
@@ -1728,7 +1735,7 @@ static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int
   case WX_FIELD_CURL: *ptr = s->curl; *channels = 1; *elem = 4; return 0;
   case WX_FIELD_VORT: *ptr = s->vort; *channels = 2; *elem = 4; return 0;
   case WX_FIELD_PRECIP_FB: // stored with three channels; the RGBA texture (alpha: 0, the lightning request's fourth component at texel (1,0)) is made here
-    if (fb_to_rgba(s)) return -1;
+    if (fb_to_rgba(s, y0, h)) return -1;
     *ptr = s->fb_rgba; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_PRECIP_DEP: *ptr = s->dep; *channels = 2; *elem = 4; return 0;
   default: return -1;
@@ -1793,7 +1800,7 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
   }
   const void *ptr;
   int ch, el;
-  if (field_info(s, field, &ptr, &ch, &el)) return fail(s, WX_E_INVALID, "wx_read_rect: unknown field %d", field);
+  if (field_info(s, field, &ptr, &ch, &el, y, h)) return fail(s, WX_E_INVALID, "wx_read_rect: unknown field %d", field);
   if (w <= 0 || h <= 0 || x < 0 || y < 0 || x + w > s->X || y + h > s->Y)
     return fail(s, WX_E_RANGE, "wx_read_rect: rect (%d,%d %dx%d) outside %dx%d (no wrap)", x, y, w, h, s->X, s->Y);
   const bool is_wall = (el == 1);
@@ -1860,7 +1867,7 @@ int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst)
   size_t texel[6];
   for (int f = 0; f < 6; f++) { // (may enqueue a layout conversion of the light texture on the compute stream)
     int ch, el;
-    if (field_info(s, kStreamFields[f], &ptr[f], &ch, &el)) return fail(s, WX_E_INVALID, "wx_stream_frame: field %d", kStreamFields[f]);
+    if (field_info(s, kStreamFields[f], &ptr[f], &ch, &el, y, h)) return fail(s, WX_E_INVALID, "wx_stream_frame: field %d", kStreamFields[f]);
     texel[f] = (size_t)ch * el;
   }
   { // the seventh block: emittedLight (RGBA16F) of the rectangle, computed now on the compute stream

@@ -86,7 +86,8 @@ enum {
   WX_FIELD_LIGHT_1 = 7,
   WX_FIELD_CURL = 8,       /* R32F */
   WX_FIELD_VORT = 9,       /* RG32F vortForce (an intermediate: only the per-pass kernel set, WX_FUSED=0, stores it) */
-  WX_FIELD_PRECIP_FB = 10, /* RGBA32F precipitationFeedbackTexture */
+  WX_FIELD_PRECIP_FB = 10, /* RGBA32F precipitationFeedbackTexture (stored with its three written channels; alpha -- 0, and the lightning
+                            * request's fourth component at texel (1,0), precipitationShader.vert:135-139 -- is added when the field is read) */
   WX_FIELD_PRECIP_DEP = 11,/* RG32F precipitationDepositionTexture */
   WX_FIELD_LIGHTNING = 12, /* 1x1 RGBA32F lightningDataTexture */
   /* RGBA16F emittedLight: the lighting pass's second render target (app.js:838, 5283, 5294; lightingShader.frag:15, 60-78,
@@ -250,7 +251,9 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
 
 /* ---- plumbing for hosts that own device memory / streams (PyTorch, multi-GPU halo exchange) ---- */
 int wx_set_stream(wx_sim *s, void *hip_stream);     /* NULL = legacy default stream */
-void *wx_device_ptr(wx_sim *s, int field);          /* device address of a field's current storage */
+void *wx_device_ptr(wx_sim *s, int field);          /* device address of a field's current storage; WX_FIELD_LIGHT_0/1, WX_FIELD_EMITTED and
+                                                     * WX_FIELD_PRECIP_FB are stored in another form (planes / on demand / three channels): the
+                                                     * pointer is to the RGBA texture made at the time of the call, valid until the next wx_step */
 int wx_local_width(const wx_sim *s);                /* X_owned + 2*halo */
 /* Halo exchange of the state carried across iterations (base_0, wall_0, water_1, both light textures; with particles also
  * the feedback and deposition textures):
