@@ -1255,7 +1255,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
           sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, s->period_j + 1, s->pool_remote, s->pool_flips, s->pool_owned, s->pool_exact};
           d_in = d_out = s->drops[0]; // the partitioned pool is updated in place
         }
-        static const int precip_wgs = [] { const char *e = wx_tune_env("WX_PRECIP_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+        static const int precip_wgs = [] { const char *e = wx_tune_env("WX_PRECIP_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();
         const int chunks = (s->n_drops + 255) / 256;
         hipLaunchKernelGGL(k_precipitation, dim3(chunks < precip_wgs ? chunks : precip_wgs), dim3(256), 0, s->stream, s->geo, u, s->n_drops, d_in,
                            two_kernel ? s->base[0] : ((fused || dry) ? s->base[2] : s->base[1]), s->water[1], s->state, d_out, s->sg, sp,
