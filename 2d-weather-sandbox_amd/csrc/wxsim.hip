@@ -122,6 +122,7 @@ struct wx_sim {
   float *tdisp = nullptr;   // post-advection temperature for the droplets (marching wet kernel, instead of the whole base_disp)
   bool wall_veg_ok = false; // no negative vegetation byte anywhere (advection would clamp it: the one wall change it can make unasked)
   FullCtx *full_ctx = nullptr;
+  std::vector<void *> alloc_pads;          // (WX_ALLOC_PADS experiment: pads between the planes' allocations)
   float4 *zero_row = nullptr;              // X texels of zeros (marching wet kernel: rows of feedback tiles that are known to be zero)
   // marching wet kernel: output cells fed by a back-trace longer than 0.9 cells, recomputed exactly by k_wet_fix (wx_wet.h)
   int *fix_count = nullptr;
@@ -452,6 +453,15 @@ template <class T> int dalloc(wx_sim *s, T **p, size_t n)
     }
   }
   Block b;
+  if (const char *e = wx_tune_env("WX_ALLOC_PADS")) { // experiment: "a,b,m" = a pad of (a + b * (k mod m)) MB in front of the k-th plane
+    int a = 0, bb = 0, m = 1; // (no pad scheme makes a placement fast: profiles/r04_placement_walk.txt)
+    if (sscanf(e, "%d,%d,%d", &a, &bb, &m) >= 1 && m > 0) {
+      void *pad = nullptr;
+      const size_t mb = (size_t)(a + bb * ((int)s->alloc_pads.size() % m));
+      if (mb > 0 && hipMalloc(&pad, mb << 20) == hipSuccess) s->alloc_pads.push_back(pad);
+      else (void)hipGetLastError();
+    }
+  }
   if (block_alloc(bytes ? bytes : 256, &b) != hipSuccess) return fail(s, WX_E_NOMEM, "%zu bytes of device memory", bytes);
   HIPCHK(s, hipMemset(b.p, 0, b.bytes));
   s->blocks.push_back(b);
@@ -937,6 +947,8 @@ void wx_destroy(wx_sim *s)
   }
   dfree(s, s->full_ctx);
   dfree(s, s->zero_row);
+  for (void *pad : s->alloc_pads) hipFree(pad);
+  s->alloc_pads.clear();
   hipFree(s->fix_count);
   hipFree(s->fix_cells);
   if (s->fix_hint_host) hipHostFree(s->fix_hint_host);
