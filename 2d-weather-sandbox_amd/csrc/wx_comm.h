@@ -126,7 +126,11 @@ static int transport_prepare(wx_sim *s, int world)
   // switched modes since the last call)
   const bool in_order = (s->pool_remote && s->pool_exact) || s->exchange_in_order;
   if (!in_order && !s->comm_stream) {
-    if (!s->own_comm_stream) HIPCHK(s, hipStreamCreateWithFlags(&s->own_comm_stream, hipStreamNonBlocking));
+    if (!s->own_comm_stream) { // highest priority: its small pack / unpack kernels run next to a marching kernel that holds every wave slot
+      int prio_lo = 0, prio_hi = 0;
+      if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+      HIPCHK(s, hipStreamCreateWithPriority(&s->own_comm_stream, hipStreamNonBlocking, prio_hi));
+    }
     if (int rc = wx_set_comm_stream(s, s->own_comm_stream)) return rc;
   } else if (in_order && s->comm_stream && s->comm_stream == s->own_comm_stream) {
     if (int rc = wx_set_comm_stream(s, nullptr)) return rc;
@@ -300,8 +304,7 @@ static int ring_exchange(Ring &R)
     if (int rc = local_wait(R, &wx_sim::ev_copied, true)) return rc;
   for (Party &q : R.p) { // (grid-only slabs: on the comm stream, behind the edge strips only)
     DeviceScope ds(q.s);
-    if (int rc = rpass(R, q.s, wx_halo_pack(q.s, 0, q.s->xsend[0]))) return rc;
-    if (int rc = rpass(R, q.s, wx_halo_pack(q.s, 1, q.s->xsend[1]))) return rc;
+    if (int rc = rpass(R, q.s, wx_halo_pack_both(q.s, q.s->xsend[0], q.s->xsend[1]))) return rc; // (one launch: see HaloBufs)
   }
   if (particles && !R.p[0].s->pool_exact)
     if (int rc = pool_events_round(R, 2)) return rc;
@@ -359,8 +362,7 @@ static int ring_exchange(Ring &R)
   for (Party &q : R.p) { // into the ghost columns (grid-only: records the event the next edge strips wait for)
     wx_sim *s = q.s;
     DeviceScope ds(s);
-    if (int rc = rpass(R, s, wx_halo_unpack(s, 0, s->xrecv[0]))) return rc;
-    if (int rc = rpass(R, s, wx_halo_unpack(s, 1, s->xrecv[1]))) return rc;
+    if (int rc = rpass(R, s, wx_halo_unpack_both(s, s->xrecv[0], s->xrecv[1]))) return rc;
     if (particles) {
       if (int rc = rpass(R, s, wx_pool_edges_apply(s, s->precv[0]))) return rc;
       if (int rc = rpass(R, s, wx_pool_edges_apply(s, s->precv[1]))) return rc;

@@ -1279,9 +1279,20 @@ struct HaloPtrs {
   float3 *fb;  // particle feedback / deposition textures: exchanged only on handles that carry particles (the BUFFER carries RGBA texels)
   float2 *dep; // buffer layout then: [4 x h*Y float4][fb h*Y float4][dep h*Y float2][wall h*Y char4]
 };
-__global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, int x_start, float4 *buf16, float2 *buf8, char4 *buf4)
+// one or both sides per launch (blockIdx.y = slot): x_start / buffers of slot 0 and 1. Both sides in ONE launch matter where the small
+// kernel runs next to a marching kernel that holds every wave slot: a second launch queues behind thousands of workgroups.
+struct HaloBufs {
+  int x_start[2];
+  float4 *buf16[2];
+  float2 *buf8[2];
+  char4 *buf4[2];
+};
+__global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, HaloBufs hb)
 {
-  const int n = h * Y;
+  const int n = h * Y, x_start = hb.x_start[blockIdx.y];
+  float4 *buf16 = hb.buf16[blockIdx.y];
+  float2 *buf8 = hb.buf8[blockIdx.y];
+  char4 *buf4 = hb.buf4[blockIdx.y];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int y = i / h, c = i - y * h;
     const size_t s = cidx(x_start + c, y, X);
@@ -1303,10 +1314,12 @@ __global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, int x_start, float4
     }
   }
 }
-__global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, int x_start, const float4 *buf16, const float2 *buf8, const char4 *buf4,
-                              int *ghost_nontrivial)
+__global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, HaloBufs hb, int *ghost_nontrivial)
 {
-  const int n = h * Y;
+  const int n = h * Y, x_start = hb.x_start[blockIdx.y];
+  const float4 *buf16 = hb.buf16[blockIdx.y];
+  const float2 *buf8 = hb.buf8[blockIdx.y];
+  const char4 *buf4 = hb.buf4[blockIdx.y];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int y = i / h, c = i - y * h;
     const size_t s = cidx(x_start + c, y, X);

@@ -103,7 +103,7 @@ __device__ __forceinline__ void march_fence()
 // QUIET: no brush input, no airplane event in this iteration (see advection_cell)
 template <bool WRITE_DISP, bool WRITE_WALL, bool QUIET>
 __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u_arg, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows,
-                                                                     int n_full, int n_half, int band_h, int n_seg, int strip_lo
+                                                                     int n_full, int n_half, int band_h, int n_seg, int strip_lo, int split_at, int strip_lo2
 #ifdef WX_MARCH_TIMING
                                                                      , unsigned long long *cycles
 #endif
@@ -132,9 +132,11 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
   const int total = n_strips * n_seg, k = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int first = (int)(((long long)k * total) >> 3), count = (int)(((long long)(k + 1) * total) >> 3) - first;
   if (j >= count) return;
-  const int item = first + j, seg = item / n_strips, strip = strip_lo + item - seg * n_strips;
+  const int item = first + j, seg = item / n_strips, sidx = item - seg * n_strips;
+  const int strip = sidx < split_at ? strip_lo + sidx : strip_lo2 + (sidx - split_at); // (two strip ranges in one launch: the edges of a slab)
 #else
-  const int strip = strip_lo + blockIdx.x % n_strips, seg = blockIdx.x / n_strips;
+  const int sidx = blockIdx.x % n_strips, seg = blockIdx.x / n_strips;
+  const int strip = sidx < split_at ? strip_lo + sidx : strip_lo2 + (sidx - split_at);
 #endif
   const int c_out = strip * MOUT + lane - 2;         // output column of this lane (may be >= X in the last strip)
   const int col = wrapmod(c_out, X);                 // column this lane loads / computes
@@ -339,9 +341,10 @@ inline int march_dry_strips(const Geo &g) { return (g.X + MOUT - 1) / MOUT; }
 // strips and the interior separately where a slab overlaps its halo exchange with compute (cf. launch_march_wet). The row
 // segmentation is the one of the whole width, so that every strip is cut the same way whichever launch computes it.
 inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, const DryIn &in, const DryOut &out, bool write_disp, bool write_wall,
-                             hipStream_t stream, int strip_lo = 0, int strip_count = -1)
+                             hipStream_t stream, int strip_lo = 0, int strip_count = -1, int strip_lo2 = 0, int strip_count2 = 0)
 {
-  const int n_strips_all = march_dry_strips(g), n_strips = strip_count < 0 ? n_strips_all : strip_count;
+  const int n_strips_all = march_dry_strips(g), n_first = strip_count < 0 ? n_strips_all : strip_count;
+  const int n_strips = n_first + (strip_count2 > 0 ? strip_count2 : 0);
   if (n_strips <= 0) return;
   int seg_rows = march_seg_rows(n_strips_all, g.Y);
   int n_seg = (g.Y + seg_rows - 1) / seg_rows, n_full = n_seg, n_half = 0, band_h = 0;
@@ -367,9 +370,9 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
   static unsigned long long *cyc = nullptr;
   static int calls = 0;
   if (!cyc && hipMalloc((void **)&cyc, 16 * (size_t)n_strips_all * n_seg) != hipSuccess) return;
-#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, cyc)
+#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, n_first, strip_lo2, cyc)
 #else
-#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo)
+#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, n_first, strip_lo2)
 #endif
   const bool quiet = !(u.userInputType >= 1) && !(u.airplaneValues[3] < 0.0f || u.airplaneValues[3] > 0.9f);
 #define WX_LAUNCH_MQ(D, W) \

@@ -480,7 +480,7 @@ struct WetSegs {
 template <bool OPT_OUT, bool HAS_FB, bool QUIET>
 __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in_arg, WetOut out_arg,
                                                                     WetFixList fix, int n_strips, int strip_lo,
-                                                                    int n_strips_all, WetSegs segs)
+                                                                    int n_strips_all, WetSegs segs, int split_at, int strip_lo2)
 {
   struct KArgs { // layout of the kernel-argument segment up to the pointer structs
     const FullCtx *ctx;
@@ -528,7 +528,10 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   if (j >= gk * n_seg) return;
   const int seg = j / gk, sloc = (j - seg * gk) * WX_WET_WPB + wave;
   if (sloc >= nk) return;
-  const int strip = strip_lo + sk0 + sloc, item = ((bands ? k * n_seg : 0) + seg) * n_strips_all + strip;
+  // (a launch may cover two strip ranges -- the left and the right edge strips of a slab: the first split_at strips start at strip_lo,
+  // the others at strip_lo2)
+  const int sidx = sk0 + sloc;
+  const int strip = sidx < split_at ? strip_lo + sidx : strip_lo2 + (sidx - split_at), item = ((bands ? k * n_seg : 0) + seg) * n_strips_all + strip;
   const int band_lo = bands ? (int)(((long long)k * g.Y) >> 3) : 0, band_hi = bands ? (int)(((long long)(k + 1) * g.Y) >> 3) : g.Y;
   const int c_out = strip * WOUT + lane - WLO; // output column of this lane (may be >= X in the last strip, < 0 in the first)
   const int col = wrapmod(c_out, X);           // column this lane loads / computes
@@ -1348,10 +1351,28 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row, int bands_mode
   return w;
 }
 
-inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, const WetFixList &fix,
-                             bool opt_out, bool quiet, hipStream_t stream, int strip_lo = 0, int strip_count = -1)
+// the same shape with every segment cut in two (segments of fewer than 12 rows stay): for a launch of a few strips that runs NEXT TO a
+// launch that fills the chip -- the edge strips of a slab beside its interior -- and should be done first: half the row steps per wave
+inline WetLaunch wet_shape_halved(const WetLaunch &w)
 {
-  const int ns = strip_count < 0 ? w.n_strips : strip_count;
+  WetLaunch h = w;
+  int n = 0;
+  for (int sg = 0; sg < w.segs.n_seg && n < WMAXSEG - 1; sg++) {
+    const int a = w.segs.start[sg], b = w.segs.start[sg + 1];
+    h.segs.start[n++] = a;
+    if (b - a >= 12) h.segs.start[n++] = a + (b - a) / 2;
+  }
+  if (n >= WMAXSEG) return w;
+  h.segs.start[n] = w.segs.start[w.segs.n_seg];
+  h.segs.n_seg = n;
+  return h;
+}
+
+inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, const WetFixList &fix,
+                             bool opt_out, bool quiet, hipStream_t stream, int strip_lo = 0, int strip_count = -1, int strip_lo2 = 0, int strip_count2 = 0)
+{
+  // (strip_count2 > 0: a second strip range in the same launch -- the two edges of a slab)
+  const int ns1 = strip_count < 0 ? w.n_strips : strip_count, ns = ns1 + (strip_count2 > 0 ? strip_count2 : 0);
   if (ns <= 0) return;
   // 8 XCDs x (workgroups of the largest column block) x segments; surplus workgroups / waves exit at once
   const dim3 grid(8 * (((w.segs.bands ? ns : (ns + 7) / 8) + WX_WET_WPB - 1) / WX_WET_WPB) * w.segs.n_seg);
@@ -1363,7 +1384,7 @@ inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *c
   }
   const bool has_fb = in.fb != nullptr;
 #define WX_LAUNCH_W(O, F, Q) \
-  hipLaunchKernelGGL((k_march_wet<O, F, Q>), grid, dim3(64 * WX_WET_WPB), 0, stream, ctx, iterNum, in, out, fix, ns, strip_lo, w.n_strips, w.segs)
+  hipLaunchKernelGGL((k_march_wet<O, F, Q>), grid, dim3(64 * WX_WET_WPB), 0, stream, ctx, iterNum, in, out, fix, ns, strip_lo, w.n_strips, w.segs, ns1, strip_lo2)
 #define WX_LAUNCH_WQ(O, F) \
   do { if (quiet) WX_LAUNCH_W(O, F, true); else WX_LAUNCH_W(O, F, false); } while (0)
   if (opt_out) {

@@ -134,6 +134,14 @@ struct wx_sim {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_edges = nullptr, ev_unpacked = nullptr; // edge strips of the last iteration done (compute stream) / ghosts written (comm stream)
   bool edges_recorded = false;   // ev_edges was recorded behind the edge strips of the latest iteration
+  // Split iterations (edge strips / interior, wx_step_overlap): the two launch groups read the same inputs and write disjoint columns,
+  // so the edge group -- a handful of strips that cannot fill the chip -- runs on a stream of its own NEXT TO the interior group
+  // instead of in front of it (in order it cost a 2132-column slab +0.045 ms per iteration, profiles/r04_slab_protocol_cost.txt)
+  hipStream_t edge_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int *fix_count2 = nullptr;     // the edge group's own list of exact-path cells (the groups run concurrently)
+  int2 *fix_cells2 = nullptr;
+  int fix_cap2 = 0;
   bool unpack_pending = false;   // ghost columns were unpacked on the comm stream since the compute stream last waited
   // transport inside the library (wx_comm_init / wx_exchange / wx_slab_step; in-process groups: wx_group_*)
   int device = 0;                 // HIP device the handle lives on
@@ -584,6 +592,28 @@ static void wait_unpacked(wx_sim *s)
   s->unpack_pending = false;
 }
 
+// stream / events / second exact-path list of the concurrent edge group (created by the first split iteration)
+static int edge_stream_ready(wx_sim *s, bool need_fix_list)
+{
+  if (!s->edge_stream) {
+    // (highest priority: the handful of edge waves should get the first free slots next to the interior group's thousands -- the
+    // neighbours wait for what they produce)
+    int prio_lo = 0, prio_hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+    HIPCHK(s, hipStreamCreateWithPriority(&s->edge_stream, hipStreamNonBlocking, prio_hi));
+    HIPCHK(s, hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    HIPCHK(s, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+  }
+  if (need_fix_list && !s->fix_count2) {
+    const size_t cap = std::min<size_t>(std::max<size_t>((size_t)s->Y * 8 * 64, 1u << 14), 1u << 20); // (a few strips' worth of cells)
+    if (hipMalloc((void **)&s->fix_count2, 8) != hipSuccess || hipMalloc((void **)&s->fix_cells2, cap * sizeof(int2)) != hipSuccess ||
+        hipMemsetAsync(s->fix_count2, 0, 8, s->stream) != hipSuccess)
+      return fail(s, WX_E_NOMEM, "wx_step: the edge group's exact-path cell list");
+    s->fix_cap2 = (int)cap;
+  }
+  return WX_OK;
+}
+
 // The whole iteration as ONE row-marching kernel (wx_wet.h). Reads base[0], wall[0], water[1], the light_0 planes and the source
 // light planes; writes the other buffer of each pair and swaps the pointers, so that afterwards the usual roles hold again
 // (base[0] / wall[0] = post-pressure state, water[1] = post-advection water, lp[0] / lp[1] = light_0 / light_1 as in the reference).
@@ -648,11 +678,11 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
     // one launch group: marching kernel over a strip range (or two) -> the fix pass over what it recorded (leaves the list empty)
     // no brush input, no airplane event (the common case: a running simulation): the instantiation without those sections
     const bool quiet = !(s->uni.userInputType >= 1) && !(s->uni.airplaneValues[3] < 0.0f || s->uni.airplaneValues[3] > 0.9f);
-    auto group = [&](int lo0, int cnt0, int lo1 = 0, int cnt1 = 0) {
-      launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, fix, opt_out, quiet, s->stream, lo0, cnt0);
-      if (cnt1 > 0) launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, fix, opt_out, quiet, s->stream, lo1, cnt1);
-      launch_wet_fix((float)s->iter, s->full_ctx, in, out, fix, &s->state->fix_overflow, opt_out, s->stream);
+    auto group_on = [&](hipStream_t st, const WetFixList &fl, int lo0, int cnt0, int lo1 = 0, int cnt1 = 0, bool halved = false) {
+      launch_march_wet(halved ? wet_shape_halved(shape) : shape, (float)s->iter, s->full_ctx, in, out, fl, opt_out, quiet, st, lo0, cnt0, lo1, cnt1); // (both ranges in ONE launch)
+      launch_wet_fix((float)s->iter, s->full_ctx, in, out, fl, &s->state->fix_overflow, opt_out, st);
     };
+    auto group = [&](int lo0, int cnt0, int lo1 = 0, int cnt1 = 0) { group_on(s->stream, fix, lo0, cnt0, lo1, cnt1); };
     // edge strips: every output column wx_halo_pack reads ([halo, 2*halo) and its mirror) and every strip that reads ghost columns
     // (a wave records -- and the fix pass rewrites -- only output cells of its own strip: the groups never write each other's columns)
     const int nl = s->halo > 0 ? (2 * s->halo - 1) / WOUT + 1 : 0, nr0 = s->halo > 0 ? (s->X - 2 * s->halo) / WOUT : shape.n_strips;
@@ -660,17 +690,25 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
       if (edge_mode & 2) wait_unpacked(s);
       group(0, -1);
     } else {
-      const bool interior_first = (edge_mode & 2) && s->unpack_pending;
-      if (interior_first) { // ghosts still in flight: everything that does not read them goes first
-        group(nl, nr0 - nl);
-        wait_unpacked(s);
+      // The edge group on its own stream, the interior group on the compute stream, side by side: the edge stream starts behind
+      // everything the compute stream holds so far (and behind the unpack where the ghosts are still in flight), the compute stream
+      // goes on behind both groups. What the comm stream waits for before it packs (ev_edges) is the edge group alone.
+      if (int rc = edge_stream_ready(s, true)) return rc;
+      const WetFixList fix2{s->fix_count2, s->fix_cells2, s->fix_cap2, nullptr, &s->state->fastest_bits, nullptr};
+      hipEventRecord(s->ev_fork, s->stream);
+      hipStreamWaitEvent(s->edge_stream, s->ev_fork, 0);
+      if ((edge_mode & 2) && s->unpack_pending) {
+        hipStreamWaitEvent(s->edge_stream, s->ev_unpacked, 0);
+        s->unpack_pending = false; // (the compute stream joins the edge stream below)
       }
-      group(0, nl, nr0, shape.n_strips - nr0);
-      if (edge_mode & 1) { // the columns the neighbours need are final: let the comm stream pack them while the interior computes
-        hipEventRecord(s->ev_edges, s->stream);
+      group_on(s->edge_stream, fix2, 0, nl, nr0, shape.n_strips - nr0, true); // (half-height segments: done before the interior)
+      if (edge_mode & 1) {
+        hipEventRecord(s->ev_edges, s->edge_stream);
         s->edges_recorded = true;
       }
-      if (!interior_first) group(nl, nr0 - nl);
+      hipEventRecord(s->ev_join, s->edge_stream);
+      group(nl, nr0 - nl);
+      hipStreamWaitEvent(s->stream, s->ev_join, 0);
     }
     s->fix_check = true;
     LAUNCH_CHECK(s, "march_wet");
@@ -730,23 +768,29 @@ int iterate_dry(wx_sim *s, bool write_disp, int edge_mode = 0)
     const int n_strips = march_dry_strips(s->geo);
     // edge strips: every output column wx_halo_pack reads ([halo, 2*halo) and its mirror) and every strip that reads ghost columns
     const int nl = s->halo > 0 ? (2 * s->halo - 1) / MOUT + 1 : 0, nr0 = s->halo > 0 ? (s->X - 2 * s->halo) / MOUT : n_strips;
-    auto launch = [&](int lo, int cnt) { launch_march_dry(s->geo, s->uni, s->full_ctx, in, out, write_disp, !wall_const, s->stream, lo, cnt); };
+    auto launch_on = [&](hipStream_t st, int lo, int cnt, int lo2 = 0, int cnt2 = 0) {
+      launch_march_dry(s->geo, s->uni, s->full_ctx, in, out, write_disp, !wall_const, st, lo, cnt, lo2, cnt2);
+    };
+    auto launch = [&](int lo, int cnt) { launch_on(s->stream, lo, cnt); };
     if (edge_mode == 0 || s->halo == 0 || nl >= nr0) {
       if (edge_mode & 2) wait_unpacked(s);
       launch(0, -1);
-    } else {
-      const bool interior_first = (edge_mode & 2) && s->unpack_pending;
-      if (interior_first) { // ghosts still in flight: everything that does not read them goes first
-        launch(nl, nr0 - nl);
-        wait_unpacked(s);
+    } else { // edge strips and interior side by side (see iterate_march_wet)
+      if (int rc = edge_stream_ready(s, false)) return rc;
+      hipEventRecord(s->ev_fork, s->stream);
+      hipStreamWaitEvent(s->edge_stream, s->ev_fork, 0);
+      if ((edge_mode & 2) && s->unpack_pending) {
+        hipStreamWaitEvent(s->edge_stream, s->ev_unpacked, 0);
+        s->unpack_pending = false;
       }
-      launch(0, nl);
-      launch(nr0, n_strips - nr0);
-      if (edge_mode & 1) { // the columns the neighbours need are final: let the comm stream pack them while the interior computes
-        hipEventRecord(s->ev_edges, s->stream);
+      launch_on(s->edge_stream, 0, nl, nr0, n_strips - nr0); // (both edges in one launch)
+      if (edge_mode & 1) {
+        hipEventRecord(s->ev_edges, s->edge_stream);
         s->edges_recorded = true;
       }
-      if (!interior_first) launch(nl, nr0 - nl);
+      hipEventRecord(s->ev_join, s->edge_stream);
+      launch(nl, nr0 - nl);
+      hipStreamWaitEvent(s->stream, s->ev_join, 0);
     }
     LAUNCH_CHECK(s, "march_dry");
     wall_written = !wall_const;
@@ -934,6 +978,14 @@ void wx_destroy(wx_sim *s)
     hipEventDestroy(s->ev_edges);
     hipEventDestroy(s->ev_unpacked);
   }
+  if (s->edge_stream) {
+    hipStreamSynchronize(s->edge_stream);
+    hipEventDestroy(s->ev_fork);
+    hipEventDestroy(s->ev_join);
+    hipStreamDestroy(s->edge_stream);
+  }
+  hipFree(s->fix_count2);
+  hipFree(s->fix_cells2);
   dfree(s, s->state);
   dfree(s, s->pool_remote);
   dfree(s, s->pool_owned);
@@ -1956,16 +2008,32 @@ static int halo_xstart(const wx_sim *s, int side, bool pack)
   return side == 0 ? 0 : s->X - s->halo;                     // ghost columns
 }
 
-int wx_halo_pack(wx_sim *s, int side, void *dev_buf)
+// sides: dev_buf[k] != NULL packs / unpacks side k (0 = left, 1 = right); both in one launch where both are given
+static HaloBufs halo_bufs(const wx_sim *s, void *const dev_buf[2], bool pack, int *n_slots)
 {
-  if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
+  const int n = s->halo * s->Y;
+  const size_t o8 = (size_t)n * (s->pool_remote ? 80 : 64), o4 = o8 + (s->pool_remote ? (size_t)n * 8 : 0);
+  HaloBufs hb{};
+  int k = 0;
+  for (int side = 0; side < 2; side++) {
+    if (!dev_buf[side]) continue;
+    hb.x_start[k] = halo_xstart(s, side, pack);
+    hb.buf16[k] = (float4 *)dev_buf[side];
+    hb.buf8[k] = (float2 *)((char *)dev_buf[side] + o8);
+    hb.buf4[k] = (char4 *)((char *)dev_buf[side] + o4);
+    k++;
+  }
+  *n_slots = k;
+  return hb;
+}
+static int halo_pack_impl(wx_sim *s, void *const dev_buf[2])
+{
   DeviceScope dev_scope(s);
   if (s->halo == 0) return fail(s, WX_E_STATE, "handle has no halo");
   const int n = s->halo * s->Y;
   const LightPlanes none{nullptr, nullptr, nullptr};
   HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
              s->pool_remote ? s->fb : nullptr, s->pool_remote ? s->dep : nullptr};
-  const size_t o8 = (size_t)n * (s->pool_remote ? 80 : 64), o4 = o8 + (s->pool_remote ? (size_t)n * 8 : 0);
   hipStream_t st = s->stream;
   if (s->comm_stream) { // the packed columns are final behind ev_edges (or, without an edge-first step, behind everything enqueued so far)
     if (!s->edges_recorded) {
@@ -1976,26 +2044,25 @@ int wx_halo_pack(wx_sim *s, int side, void *dev_buf)
     st = s->comm_stream;
   }
   ProfScope ps(s, K_HALO);
-  hipLaunchKernelGGL(k_halo_pack, dim3((n + 255) / 256), dim3(256), 0, st, f, s->X, s->Y, s->halo, halo_xstart(s, side, true),
-                     (float4 *)dev_buf, (float2 *)((char *)dev_buf + o8), (char4 *)((char *)dev_buf + o4));
+  int slots = 0;
+  const HaloBufs hb = halo_bufs(s, dev_buf, true, &slots);
+  hipLaunchKernelGGL(k_halo_pack, dim3((n + 255) / 256, slots), dim3(256), 0, st, f, s->X, s->Y, s->halo, hb);
   HIPCHK(s, hipGetLastError());
   return WX_OK;
 }
-
-int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
+static int halo_unpack_impl(wx_sim *s, void *const dev_buf[2])
 {
-  if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
   DeviceScope dev_scope(s);
   if (s->halo == 0) return fail(s, WX_E_STATE, "handle has no halo");
   const int n = s->halo * s->Y;
   const LightPlanes none{nullptr, nullptr, nullptr};
   HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
              s->pool_remote ? s->fb : nullptr, s->pool_remote ? s->dep : nullptr};
-  const size_t o8 = (size_t)n * (s->pool_remote ? 80 : 64), o4 = o8 + (s->pool_remote ? (size_t)n * 8 : 0);
   hipStream_t st = s->comm_stream ? s->comm_stream : s->stream;
   ProfScope ps(s, K_HALO);
-  hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256), dim3(256), 0, st, f, s->X, s->Y, s->halo, halo_xstart(s, side, false),
-                     (const float4 *)dev_buf, (const float2 *)((const char *)dev_buf + o8), (const char4 *)((const char *)dev_buf + o4),
+  int slots = 0;
+  const HaloBufs hb = halo_bufs(s, dev_buf, false, &slots);
+  hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256, slots), dim3(256), 0, st, f, s->X, s->Y, s->halo, hb,
                      s->water_trivial ? &s->state->ghost_nontrivial : nullptr);
   if (s->water_trivial) s->ghost_check = true;
   if (s->comm_stream) { // whoever touches the ghost columns next on the compute stream waits for this
@@ -2008,6 +2075,30 @@ int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
   }
   HIPCHK(s, hipGetLastError());
   return WX_OK;
+}
+int wx_halo_pack(wx_sim *s, int side, void *dev_buf)
+{
+  if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
+  void *const b[2] = {side == 0 ? dev_buf : nullptr, side == 1 ? dev_buf : nullptr};
+  return halo_pack_impl(s, b);
+}
+int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf)
+{
+  if (!s || !dev_buf || (side != 0 && side != 1)) return WX_E_INVALID;
+  void *const b[2] = {side == 0 ? const_cast<void *>(dev_buf) : nullptr, side == 1 ? const_cast<void *>(dev_buf) : nullptr};
+  return halo_unpack_impl(s, b);
+}
+int wx_halo_pack_both(wx_sim *s, void *dev_left, void *dev_right)
+{
+  if (!s || !dev_left || !dev_right) return WX_E_INVALID;
+  void *const b[2] = {dev_left, dev_right};
+  return halo_pack_impl(s, b);
+}
+int wx_halo_unpack_both(wx_sim *s, const void *dev_left, const void *dev_right)
+{
+  if (!s || !dev_left || !dev_right) return WX_E_INVALID;
+  void *const b[2] = {const_cast<void *>(dev_left), const_cast<void *>(dev_right)};
+  return halo_unpack_impl(s, b);
 }
 
 // ---- particles on slabs: reconciliation of the replicated droplet pool (protocol in slab.py / SlabP) ----

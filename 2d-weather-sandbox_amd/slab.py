@@ -73,7 +73,7 @@ class HipSlabEngine:
         self.h.set_stream(torch.cuda.current_stream(device).cuda_stream)
         self.comm = None
         if n_droplets == 0 and os.environ.get("WX_SLAB_OVERLAP", "1") != "0":
-            self.comm = torch.cuda.Stream(device)
+            self.comm = torch.cuda.Stream(device, priority=-1)  # (its small pack / unpack kernels run next to a marching kernel that holds every wave slot)
             self.h.set_comm_stream(self.comm.cuda_stream)
         self.nbytes = self.h.halo_bytes()
         self._light = None
@@ -161,6 +161,13 @@ class HipSlabEngine:
 
     def unpack(self, side: int, buf: torch.Tensor):
         self.h.halo_unpack(side, buf.data_ptr())
+
+    def pack_both(self, left: torch.Tensor, right: torch.Tensor):
+        """Both edges in ONE launch: a second small kernel would queue behind the marching kernel's thousands of workgroups."""
+        self.h.halo_pack_both(left.data_ptr(), right.data_ptr())
+
+    def unpack_both(self, left: torch.Tensor, right: torch.Tensor):
+        self.h.halo_unpack_both(left.data_ptr(), right.data_ptr())
 
     def step(self, n: int, overlap: int = 0):
         self.h.step(n, overlap)
@@ -275,8 +282,11 @@ class SlabSim:
         e = self.engine
         ctx = e.comm_context() if hasattr(e, "comm_context") else contextlib.nullcontext()
         with ctx:
-            e.pack(0, self.send[0])
-            e.pack(1, self.send[1])
+            if hasattr(e, "pack_both"):
+                e.pack_both(self.send[0], self.send[1])
+            else:
+                e.pack(0, self.send[0])
+                e.pack(1, self.send[1])
             if self.particles and self.exact:  # flips, lightning and the inactive count are current already (exact_events after every iteration)
                 e.pool_edges_pack(self.psend[0], self.psend[1], False)
             elif self.particles:
@@ -327,8 +337,11 @@ class SlabSim:
             if self._stage:
                 for hb, b in zip(hin, inn):
                     b.copy_(hb)
-            e.unpack(0, self.recv[0])  # left ghosts  <- left neighbour's right edge
-            e.unpack(1, self.recv[1])  # right ghosts <- right neighbour's left edge
+            if hasattr(e, "unpack_both"):  # left ghosts <- left neighbour's right edge, right ghosts <- right neighbour's left edge
+                e.unpack_both(self.recv[0], self.recv[1])
+            else:
+                e.unpack(0, self.recv[0])
+                e.unpack(1, self.recv[1])
             if self.particles:
                 e.pool_edges_apply(self.precv[0])
                 e.pool_edges_apply(self.precv[1])

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WX_ABI_VERSION 7
+#define WX_ABI_VERSION 8
 
 /* error codes */
 #define WX_OK 0
@@ -262,6 +262,10 @@ int wx_local_width(const wx_sim *s);                /* X_owned + 2*halo */
 size_t wx_halo_bytes(const wx_sim *s);
 int wx_halo_pack(wx_sim *s, int side, void *dev_buf);
 int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf);
+/* both sides in ONE launch each (ABI 8): next to a marching kernel that holds every wave slot of the chip a second small launch queues
+ * behind thousands of workgroups (profiles/r04_slab_protocol_cost.txt); dev_left / dev_right as side 0 / 1 above */
+int wx_halo_pack_both(wx_sim *s, void *dev_left, void *dev_right);
+int wx_halo_unpack_both(wx_sim *s, const void *dev_left, const void *dev_right);
 /* Overlap of the halo exchange with compute (no reference counterpart; BASELINE north_star: "halo exchange ... overlapped on a
  * side HIP stream"). After wx_set_comm_stream(s, stream) the pack / unpack kernels run on `stream` -- the stream the host also
  * issues its send / recv on -- fenced against the handle's compute stream by events inside the library:

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""What the exchange PROTOCOL costs one rank of an 8-GPU run, measured on one GPU that the slab has to itself: ONE slab of X/8 owned
+columns whose neighbours are itself (a periodic domain X/8 wide + ghost columns; wx_step_overlap with the edge-first / interior-first
+flags, wx_halo_pack / wx_halo_unpack on a comm stream as slab.py issues them -- every launch an N-GPU rank makes, minus the link), against the same slab shape
+stepped as a plain handle (what tools/slab_shapes.py times). Usage: python tools/slab_protocol_cost.py [X_global Y halo reps]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402,F401
+import wxpkg  # noqa: E402
+
+pkg = wxpkg.load_package()
+E = pkg.engine
+from weather_sandbox_amd import devtools  # noqa: E402
+
+XG = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+Y = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+HALO = int(sys.argv[3]) if len(sys.argv) > 3 else 42
+REPS = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+XO = XG // 8
+WORK = os.environ.get("WORKLOAD", "wet")
+
+
+def uniforms():
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 50.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, **({"pass_mask": pkg.params.PASS_DRY} if WORK == "dry" else {}))
+    u["enablePrecipitation"] = 0
+    return u
+
+
+def fill(h, Xg, cols):
+    if WORK == "dry":
+        h.upload(*pkg.synth.dry_grid(Xg, Y, cols=cols))
+    else:
+        h.setup_columns(pkg.synth.terrain_columns(Xg, Y, cols=cols))
+
+
+u = uniforms()
+p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+# (a) the slab as a plain handle: no exchange, one launch group per iteration
+plain = E.Handle(XO, Y, 0, X_global=XG, x0=3 * XO, halo=HALO)
+fill(plain, XG, (3 * XO - HALO, XO + 2 * HALO))
+plain.set_params(p, u["initial_T"])
+devtools.seed_flow(plain, 0.2, Xg=XG, x0=3 * XO)
+# (b) the same shape as a periodic domain of its own: the slab's neighbours are itself -- the whole host-driven protocol of slab.py
+#     (wx_step_overlap flags, pack / unpack on a comm stream), minus the link
+import ctypes  # noqa: E402
+
+
+class SelfExchange:
+    def __init__(self, overlap):
+        self.h = E.Handle(XO, Y, 0, X_global=XO, x0=0, halo=HALO)
+        fill(self.h, XO, (XO - HALO, XO + 2 * HALO))
+        self.h.set_params(p, u["initial_T"])
+        devtools.seed_flow(self.h, 0.2, Xg=XO, x0=0)
+        self.overlap = overlap
+        self.comm = torch.cuda.Stream(priority=-1) if overlap else None
+        if overlap:
+            self.h.set_comm_stream(self.comm.cuda_stream)
+        nb = self.h.halo_bytes()
+        self.buf = [torch.empty(nb, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        self.ipe = max(1, HALO // 6)
+        self.exchanged = False
+
+    def step(self, n):
+        done = 0
+        while done < n:
+            k = min(self.ipe, n - done)
+            flags = ((2 if self.exchanged else 0) | 1) if self.overlap else 0
+            self.h.step(k, flags)
+            done += k
+            self.h.halo_pack_both(self.buf[0].data_ptr(), self.buf[1].data_ptr())
+            self.h.halo_unpack_both(self.buf[1].data_ptr(), self.buf[0].data_ptr())  # my right edge is my left neighbour's right edge: my own left ghosts
+            self.exchanged = True
+
+    def sync(self):
+        self.h.sync()
+        torch.cuda.synchronize()
+
+
+outs = {1: SelfExchange(1), 0: SelfExchange(0)}
+
+
+def timed(obj, iters=210, frame=7):
+    obj.sync()
+    t0 = time.perf_counter()
+    for _ in range(iters // frame):
+        obj.step(frame)
+    obj.sync()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+for o in (plain, outs[1], outs[0]):
+    timed(o)
+if int(os.environ.get("TUNE", "8")):
+    plain.tune_placement(int(os.environ.get("TUNE", "8")))
+res = {"plain": [], "protocol, overlapped": [], "protocol, in order": []}
+for _ in range(REPS):
+    res["plain"].append(timed(plain))
+    res["protocol, overlapped"].append(timed(outs[1]))
+    res["protocol, in order"].append(timed(outs[0]))
+per = HALO // 6
+print(f"{WORK} {XG}x{Y} as one of 8 slabs ({XO} + 2 x {HALO} columns, {per} iterations per exchange): ms / iteration, {REPS} interleaved repetitions")
+for k, v in res.items():
+    print(f"  {k:22s} " + " ".join(f"{x:.4f}" for x in v) + f"   median {np.median(v):.4f}")
