@@ -1398,12 +1398,12 @@ inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *c
 
 // the fix pass of a launch group: every list entry recomputed exactly, spread over the chip (exits at once while the list is empty)
 inline void launch_wet_fix(float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, const WetFixList &fix, int *overflow, bool opt_out,
-                           hipStream_t stream)
+                           hipStream_t stream, int wgs = 0)
 {
   // the whole chip (512 workgroups = one wavefront per list entry up to 2048 entries) while the last list the host has heard of held
   // entries, a corner of it while the lists are empty; any grid is correct (grid-stride loop)
   const int last = fix.hint ? *(volatile const int *)fix.hint_host : 1;
-  const dim3 grid(last > 0 ? 512 : 32), block(256);
+  const dim3 grid(wgs > 0 ? wgs : (last > 0 ? 512 : 32)), block(256); // (wgs: the edge group of a slab -- a few strips -- asks for 64)
   if (opt_out)
     hipLaunchKernelGGL((k_wet_fix<true>), grid, block, 0, stream, ctx, iterNum, in, out, fix.count, fix.cells, fix.cap, overflow, fix.hint);
   else

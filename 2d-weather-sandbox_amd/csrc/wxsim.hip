@@ -680,7 +680,7 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
     const bool quiet = !(s->uni.userInputType >= 1) && !(s->uni.airplaneValues[3] < 0.0f || s->uni.airplaneValues[3] > 0.9f);
     auto group_on = [&](hipStream_t st, const WetFixList &fl, int lo0, int cnt0, int lo1 = 0, int cnt1 = 0, bool halved = false) {
       launch_march_wet(halved ? wet_shape_halved(shape) : shape, (float)s->iter, s->full_ctx, in, out, fl, opt_out, quiet, st, lo0, cnt0, lo1, cnt1); // (both ranges in ONE launch)
-      launch_wet_fix((float)s->iter, s->full_ctx, in, out, fl, &s->state->fix_overflow, opt_out, st);
+      launch_wet_fix((float)s->iter, s->full_ctx, in, out, fl, &s->state->fix_overflow, opt_out, st, halved ? 64 : 0);
     };
     auto group = [&](int lo0, int cnt0, int lo1 = 0, int cnt1 = 0) { group_on(s->stream, fix, lo0, cnt0, lo1, cnt1); };
     // edge strips: every output column wx_halo_pack reads ([halo, 2*halo) and its mirror) and every strip that reads ghost columns
