@@ -35,6 +35,7 @@ def uniforms():
 def fill(h, Xg, cols):
     if WORK == "dry":
         h.upload(*pkg.synth.dry_grid(Xg, Y, cols=cols))
+        h.slab_assert_water_free(True)  # (what the ranks agree on after an upload: the water-free marching kernel)
     else:
         h.setup_columns(pkg.synth.terrain_columns(Xg, Y, cols=cols))
 
@@ -65,14 +66,20 @@ class SelfExchange:
         self.buf = [torch.empty(nb, dtype=torch.uint8, device="cuda") for _ in range(2)]
         self.ipe = max(1, HALO // 6)
         self.exchanged = False
+        self.since = 0
 
     def step(self, n):
         done = 0
         while done < n:
-            k = min(self.ipe, n - done)
-            flags = ((2 if self.exchanged else 0) | 1) if self.overlap else 0
+            k = min(self.ipe - self.since, n - done)
+            last = self.since + k >= self.ipe
+            flags = ((2 if (self.exchanged and self.since == 0) else 0) | (1 if last else 0)) if self.overlap else 0
             self.h.step(k, flags)
             done += k
+            self.since += k
+            if not last:
+                continue
+            self.since = 0
             self.h.halo_pack_both(self.buf[0].data_ptr(), self.buf[1].data_ptr())
             self.h.halo_unpack_both(self.buf[1].data_ptr(), self.buf[0].data_ptr())  # my right edge is my left neighbour's right edge: my own left ghosts
             self.exchanged = True
