@@ -452,16 +452,30 @@ __device__ __forceinline__ void atomic_add_f(float *p, float v)
   if (v != 0.0f) unsafeAtomicAdd(p, v);
 }
 
+// Post-advection temperature of texel t on the marching wet kernel's path (t_in != nullptr): the pressure pass changes T in one kind of
+// cell only -- directly above a land surface cell (pressure_cell: wd_dist == 0 && wd_type == 1, the snow-melt hand-off) -- so the
+// marching kernel stores the post-advection temperature (t_in) only for rows that hold such a cell, and everywhere else the
+// post-pressure texture's T (base_in) IS the post-advection value. The test here is the one pressure_cell makes, on the same
+// post-advection wall texel of the cell below (rows wrap): wherever it holds, the row's t_in was stored.
+__device__ __forceinline__ float precip_T(const Geo &g, size_t t, const float4 *__restrict__ base_in, const float *__restrict__ t_in,
+                                          const char4 *__restrict__ wall_in)
+{
+  if (!t_in) return base_in[t].w;
+  const size_t row = (size_t)g.X, tb = t >= row ? t - row : t + (size_t)(g.Y - 1) * row;
+  const char4 wb = wall_in[tb];
+  return (wb.y == 0 && wb.x == 1) ? t_in[t] : base_in[t].w;
+}
+
 // one droplet of the pool: transform-feedback update + its deposit. Returns true for a droplet that stays inactive (the reference
 // blends +1 per such droplet into texel (0,0), precipitationShader.vert:158-159: counted by the caller).
 __device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const Uni &u, int n_drops, const float *__restrict__ drops_in,
                                                const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
                                                DevState *__restrict__ st, float *__restrict__ drops_out, const SplatGrid &sg, const SlabP &sp,
-                                               const float *__restrict__ t_in, const DetSplat &det)
+                                               const float *__restrict__ t_in, const DetSplat &det, const char4 *__restrict__ wall_in)
 {
-  // t_in != nullptr (two-kernel path): base_in is the POST-pressure base texture, whose velocity components equal the
-  // post-advection ones the reference samples (pressure_cell only touches P and T), and t_in holds the post-advection
-  // temperature -- kernel B then stores 4 instead of 16 extra bytes per cell for the droplets.
+  // t_in != nullptr (marching wet kernel): base_in is the POST-pressure base texture, whose velocity components equal the
+  // post-advection ones the reference samples (pressure_cell only touches P and T); the post-advection temperature comes from
+  // precip_T: t_in where the pressure pass changed it, base_in everywhere else.
   bool live = i < n_drops;
   if (live && det.key) det.key[i] = DET_KEY_NONE; // (overwritten below if this droplet deposits something)
   const int Y = g.Y;
@@ -506,7 +520,7 @@ __device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const 
       const bool cloudy = water.y > fminf(u.aboveZeroThreshold, u.subZeroThreshold);
       if (cloudy) {
         if (t_in)
-          base.w = t_in[t];
+          base.w = precip_T(g, t, base_in, t_in, wall_in);
         else
           base = base_in[t];
       }
@@ -572,7 +586,7 @@ __device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const 
         const size_t t = texel(g, tcx, tcy);
         water = water_in[t];
         base = base_in[t];
-        if (t_in) base.w = t_in[t];
+        if (t_in) base.w = precip_T(g, t, base_in, t_in, wall_in);
         realTemp = base.w - tcy * u.dryLapse;
       }
       const float totalMass = newM0 + newM1;
@@ -583,7 +597,7 @@ __device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const 
         newM1 = dpy;
       } else if (newPosy < -1.0f || water.x > 1000.0f) {
         const size_t tu = texel(g, tcx, tcy + g.texY);
-        if ((t_in ? t_in[tu] : base_in[tu].w) > 500.0f) newPosy += g.texY * 1.0f;
+        if (precip_T(g, tu, base_in, t_in, wall_in) > 500.0f) newPosy += g.texY * 1.0f;
         deposition[0] = newM0;
         deposition[1] = newM1;
         newM0 = -2.0f - dpx;
@@ -723,14 +737,14 @@ __device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const 
 __global__ __launch_bounds__(256) void k_precipitation(Geo g, Uni u, int n_drops, const float *__restrict__ drops_in,
                                                         const float4 *__restrict__ base_in, const float4 *__restrict__ water_in,
                                                         DevState *__restrict__ st, float *__restrict__ drops_out, SplatGrid sg, SlabP sp,
-                                                        const float *__restrict__ t_in, DetSplat det)
+                                                        const float *__restrict__ t_in, DetSplat det, const char4 *__restrict__ wall_in)
 {
   // t_in != nullptr (two-kernel path): base_in is the POST-pressure base texture, whose velocity components equal the
   // post-advection ones the reference samples (pressure_cell only touches P and T), and t_in holds the post-advection
   // temperature -- kernel B then stores 4 instead of 16 extra bytes per cell for the droplets.
   int count = 0; // still-inactive droplets seen by this wave (wave-uniform)
   for (int base_i = blockIdx.x * 256; base_i < n_drops; base_i += gridDim.x * 256) {
-    const bool c = precip_droplet(base_i + (int)threadIdx.x, g, u, n_drops, drops_in, base_in, water_in, st, drops_out, sg, sp, t_in, det);
+    const bool c = precip_droplet(base_i + (int)threadIdx.x, g, u, n_drops, drops_in, base_in, water_in, st, drops_out, sg, sp, t_in, det, wall_in);
     count += __popcll(__ballot(c));
   }
   // one atomic per workgroup (integers: exact in fp32 in any order)

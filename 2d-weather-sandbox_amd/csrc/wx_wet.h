@@ -580,6 +580,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   float4 st_p = make_float4(0.f, 0.f, 0.f, 0.f), st_q = st_p, st_l = st_p, st_ab = st_p;
   char4 st_w = make_char4(0, 0, 0, 0);
   bool st_valid = false;
+  bool st_td = false; // (wave-uniform) the stored row holds a cell directly above a land surface cell: its post-advection T differs from the post-pressure one
 
 #ifdef WX_WET_TIMING
   const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -716,7 +717,9 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       st_row(out.light.zw + e, so8, make_float2(st_l.z, st_l.w));
       if (OPT_OUT) st_row(out.base_disp + e, so16, st_ab);
 #ifndef WX_ABL_NO_TDISP
-      if (out.t_disp) st_row(out.t_disp + e, so4, st_ab.w);
+      // post-advection temperature for the droplets: only rows in which the pressure pass changed it (k_precipitation's precip_T makes
+      // the same test per texel and reads the post-pressure T everywhere else)
+      if (out.t_disp && st_td) st_row(out.t_disp + e, so4, st_ab.w);
 #endif
     }
     st_valid = false;
@@ -884,6 +887,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       const float vx_l = wave_from_left(ab.x);
       if (WX_T_GE(8)) {
         st_p = pressure_cell(ab, vx_l, adv_vy_prev, adv_T_prev, adv_w_prev.x, adv_w_prev.y);
+        if (out.t_disp) st_td = __any(adv_w_prev.y == 0 && adv_w_prev.x == 1); // (pressure_cell's condition, any lane of the row)
         MWLightAcc la{rg, li, ab.w, adv_T_prev, lz1, aw, awl};
 #ifdef WX_ABL_NOLIGHT
         st_l = make_float4(la.sun_at(0, r - 4), la.ir_up_at(r - 5), lz1, ab.w);
@@ -969,7 +973,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     st_row(out.light.y + e, so4, st_l.y);
     st_row(out.light.zw + e, so8, make_float2(st_l.z, st_l.w));
     if (OPT_OUT) st_row(out.base_disp + e, so16, st_ab);
-    if (out.t_disp) st_row(out.t_disp + e, so4, st_ab.w);
+    if (out.t_disp && st_td) st_row(out.t_disp + e, so4, st_ab.w);
   }
 #ifdef WX_WET_TIMING
   if (lane == 0) {

@@ -1323,7 +1323,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
         const int chunks = (s->n_drops + 255) / 256;
         hipLaunchKernelGGL(k_precipitation, dim3(chunks < precip_wgs ? chunks : precip_wgs), dim3(256), 0, s->stream, s->geo, u, s->n_drops, d_in,
                            two_kernel ? s->base[0] : ((fused || dry) ? s->base[2] : s->base[1]), s->water[1], s->state, d_out, s->sg, sp,
-                           two_kernel ? s->tdisp : nullptr, DetSplat{s->splat_order ? s->det_key[0] : nullptr, s->det_val});
+                           two_kernel ? s->tdisp : nullptr, DetSplat{s->splat_order ? s->det_key[0] : nullptr, s->det_val}, s->wall[0]);
         LAUNCH_CHECK(s, "precipitation");
       }
       if (s->splat_order) { // deterministic order: sort the deposit records by anchor (stable), add each run in droplet-index order
