@@ -1361,12 +1361,14 @@ inline WetLaunch wet_shape_halved(const WetLaunch &w)
 {
   WetLaunch h = w;
   int n = 0;
-  for (int sg = 0; sg < w.segs.n_seg && n < WMAXSEG - 1; sg++) {
+  for (int sg = 0; sg < w.segs.n_seg; sg++) n += w.segs.start[sg + 1] - w.segs.start[sg] >= 12 ? 2 : 1;
+  if (n > WMAXSEG) return w; // (the table is full: leave the shape as it is)
+  n = 0;
+  for (int sg = 0; sg < w.segs.n_seg; sg++) {
     const int a = w.segs.start[sg], b = w.segs.start[sg + 1];
     h.segs.start[n++] = a;
     if (b - a >= 12) h.segs.start[n++] = a + (b - a) / 2;
   }
-  if (n >= WMAXSEG) return w;
   h.segs.start[n] = w.segs.start[w.segs.n_seg];
   h.segs.n_seg = n;
   return h;

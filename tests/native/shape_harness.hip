@@ -16,6 +16,9 @@ int main(int argc, char **argv)
     printf("%s{\"X\": %d, \"Y\": %d, \"n_strips\": %d, \"bands\": %d, \"n_seg\": %d, \"start\": [", a > 1 ? ", " : "", g.X,
            g.Y, w.n_strips, w.segs.bands, w.segs.n_seg);
     for (int s = 0; s <= w.segs.n_seg; s++) printf("%s%d", s ? ", " : "", w.segs.start[s]);
+    const wx::WetLaunch hv = wx::wet_shape_halved(w); // (what the edge strips of a slab run with, next to the interior strips)
+    printf("], \"halved_n_seg\": %d, \"halved_start\": [", hv.segs.n_seg);
+    for (int s = 0; s <= hv.segs.n_seg; s++) printf("%s%d", s ? ", " : "", hv.segs.start[s]);
     printf("]}");
   }
   printf("]\n");

@@ -1402,3 +1402,46 @@ def test_brush_and_airplane_inputs_bit_exact(pkg, oracle, E, fused):
         for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "WATER_0", "LIGHT_1"):
             assert np.array_equal(h.read_rect(f), o.field(f)), (case, f)
         h.close()
+
+
+@pytest.mark.gpu
+def test_halo_pack_both_equals_two_single_side_calls(pkg, E):
+    """wx_halo_pack_both / wx_halo_unpack_both (both sides in one launch, ABI 8) == wx_halo_pack / wx_halo_unpack per side: the same
+    buffers byte for byte, the same ghost columns afterwards."""
+    import torch
+    X, Y, halo, xo = 512, 64, 12, 128
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    rng = np.random.default_rng(11)
+    air = wall[..., 1] != 0
+    base[..., 0] += np.where(air, rng.normal(0, 0.2, (Y, X)), 0).astype(np.float32)
+    gui = pkg.params.merge_settings(None)
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=1)
+    u["enablePrecipitation"] = 0
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    hs = []
+    for _ in range(2):
+        h = E.Handle(xo, Y, 0, X_global=X, x0=xo, halo=halo)
+        idx = (xo - halo + np.arange(xo + 2 * halo)) % X
+        h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]))
+        h.set_params(p, u["initial_T"])
+        h.step(2)
+        hs.append(h)
+    nb = hs[0].halo_bytes()
+    single = [torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    both = [torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    hs[0].halo_pack(0, single[0].data_ptr())
+    hs[0].halo_pack(1, single[1].data_ptr())
+    hs[1].halo_pack_both(both[0].data_ptr(), both[1].data_ptr())
+    hs[0].sync()
+    hs[1].sync()
+    assert torch.equal(single[0], both[0]) and torch.equal(single[1], both[1])
+    assert int(single[0].to(torch.int64).sum()) != 0
+    # unpack (crossed, as a slab whose neighbours are itself would): the ghost columns must agree
+    hs[0].halo_unpack(0, single[1].data_ptr())
+    hs[0].halo_unpack(1, single[0].data_ptr())
+    hs[1].halo_unpack_both(both[1].data_ptr(), both[0].data_ptr())
+    for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1"):
+        a, b = hs[0].read_rect(f), hs[1].read_rect(f)
+        assert np.array_equal(a, b), f
+    for h in hs:
+        h.close()

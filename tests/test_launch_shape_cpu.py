@@ -60,3 +60,18 @@ def test_default_shape_has_a_short_tail_on_the_metric_grid(harness):
     lens = [b - a for a, b in zip(s["start"], s["start"][1:])]
     assert lens[-1] < lens[-2] < lens[0] and lens[0] >= 48  # full segments first, the shortest last
     assert sh[(256, 96)]["bands"] == 0  # low grids keep the column blocks
+
+
+def test_halved_shape_covers_the_same_rows(harness):
+    """wet_shape_halved (the edge strips of a slab, launched next to its interior strips): every border of the shape it was made
+    from is still a border, every new border lies strictly inside a segment, nothing is empty."""
+    for env in (None, {"WX_WET_BANDS": "0"}, {"WX_WET_SPEC": "5x1,2x0.5,1x0.25"}):
+        for sh in _shapes(harness, env):
+            st, hv = sh["start"], sh["halved_start"]
+            assert len(hv) == sh["halved_n_seg"] + 1 and hv[0] == st[0] and hv[-1] == st[-1]
+            assert all(b > a for a, b in zip(hv, hv[1:])), (sh["X"], sh["Y"], hv)
+            assert set(st) <= set(hv)
+            assert len(hv) <= 129
+            for a, b in zip(st, st[1:]):
+                inner = [v for v in hv if a < v < b]
+                assert len(inner) == (1 if b - a >= 12 else 0) or len(hv) == len(st), (a, b, inner)
