@@ -1799,7 +1799,7 @@ static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int
   case WX_FIELD_CURL: *ptr = s->curl; *channels = 1; *elem = 4; return 0;
   case WX_FIELD_VORT: *ptr = s->vort; *channels = 2; *elem = 4; return 0;
   case WX_FIELD_PRECIP_FB: // stored with three channels; the RGBA texture (alpha: 0, the lightning request's fourth component at texel (1,0)) is made here
-    if (fb_to_rgba(s, y0, h)) return -1;
+    if (int rc = fb_to_rgba(s, y0, h)) return rc < -1 ? rc : WX_E_DEVICE; // (not -1: that means "unknown field" to the callers)
     *ptr = s->fb_rgba; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_PRECIP_DEP: *ptr = s->dep; *channels = 2; *elem = 4; return 0;
   default: return -1;
@@ -1864,7 +1864,10 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
   }
   const void *ptr;
   int ch, el;
-  if (field_info(s, field, &ptr, &ch, &el, y, h)) return fail(s, WX_E_INVALID, "wx_read_rect: unknown field %d", field);
+  if (int rc = field_info(s, field, &ptr, &ch, &el, y, h)) {
+    if (rc != -1) return rc; // (a field that is made on demand could not be made: the message is set)
+    return fail(s, WX_E_INVALID, "wx_read_rect: unknown field %d", field);
+  }
   if (w <= 0 || h <= 0 || x < 0 || y < 0 || x + w > s->X || y + h > s->Y)
     return fail(s, WX_E_RANGE, "wx_read_rect: rect (%d,%d %dx%d) outside %dx%d (no wrap)", x, y, w, h, s->X, s->Y);
   const bool is_wall = (el == 1);
@@ -1931,7 +1934,10 @@ int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst)
   size_t texel[6];
   for (int f = 0; f < 6; f++) { // (may enqueue a layout conversion of the light texture on the compute stream)
     int ch, el;
-    if (field_info(s, kStreamFields[f], &ptr[f], &ch, &el, y, h)) return fail(s, WX_E_INVALID, "wx_stream_frame: field %d", kStreamFields[f]);
+    if (int rc = field_info(s, kStreamFields[f], &ptr[f], &ch, &el, y, h)) {
+      if (rc != -1) return rc;
+      return fail(s, WX_E_INVALID, "wx_stream_frame: field %d", kStreamFields[f]);
+    }
     texel[f] = (size_t)ch * el;
   }
   { // the seventh block: emittedLight (RGBA16F) of the rectangle, computed now on the compute stream
