@@ -795,34 +795,44 @@ __global__ __launch_bounds__(256) void k_splat_runs(int n, const int *__restrict
 // deposits are box-summed, texture tiles that still hold the previous iteration's feedback are zeroed, accumulation tiles with
 // deposits are cleared afterwards. (One workgroup per tile with an early exit cost 0.2 ms at 16384 x 2048: 32768 workgroups, each
 // two dependent global round trips long, three per CU at a time because of the LDS the box sum needs.)
+// append t to a work list for the lanes that want it: one atomic per wavefront instead of one per lane (30 000 increments of one
+// address were most of this kernel's 8 us). All lanes of the wave must call it (converged).
+__device__ __forceinline__ void wave_append(int *counter, int *list, bool want, int t)
+{
+  const unsigned long long mask = __ballot(want);
+  if (!mask) return;
+  const int lane = threadIdx.x & 63, first = __ffsll((long long)mask) - 1;
+  int base = 0;
+  if (lane == first) base = atomicAdd(counter, __popcll(mask));
+  base = __shfl(base, first);
+  if (want) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+}
 __global__ __launch_bounds__(256) void k_splat_classify(int X, int Y, SplatGrid sg, int mailbox, int par)
 {
   const int T = sg.TXn * sg.TYn, t = blockIdx.x * blockDim.x + threadIdx.x;
   int *cnt = sg.work + 8 * par;
   if (t == 0)
     for (int k = 0; k < 5; k++) sg.work[8 * (par ^ 1) + k] = 0;
-  if (t >= T) return;
-  const int tby = t / sg.TXn, tbx = t - tby * sg.TXn;
-  if (sg.dirty[t]) sg.work[16 + 2 * T + atomicAdd(&cnt[2], 1)] = t;
-  if (tbx * STX >= X || tby * STY >= Y) return; // (the accumulation grid is one anchor wider / higher than the texture)
+  // (no early return: wave_append needs the whole wave)
+  const bool tile = t < T;
+  const int tc = tile ? t : 0, tby = tc / sg.TXn, tbx = tc - tby * sg.TXn;
+  wave_append(&cnt[2], sg.work + 16 + 2 * T, tile && sg.dirty[tc] != 0, tc);
+  const bool tex = tile && tbx * STX < X && tby * STY < Y; // (the accumulation grid is one anchor wider / higher than the texture)
   int a = 0, a2 = 0;
-  for (int dy = -1; dy <= 1; dy++)
-    for (int dx = -1; dx <= 1; dx++) {
-      const int ax = tbx + dx, ay = tby + dy;
-      if (ax >= 0 && ay >= 0 && ax < sg.TXn && ay < sg.TYn) {
-        a |= sg.dirty[ay * sg.TXn + ax];
-        a2 |= sg.dirty[T + ay * sg.TXn + ax];
+  if (tex)
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        const int ax = tbx + dx, ay = tby + dy;
+        if (ax >= 0 && ay >= 0 && ax < sg.TXn && ay < sg.TYn) {
+          a |= sg.dirty[ay * sg.TXn + ax];
+          a2 |= sg.dirty[T + ay * sg.TXn + ax];
+        }
       }
-    }
-  const bool corner = mailbox && t == 0;
-  if (a)
-    sg.work[16 + atomicAdd(&cnt[0], 1)] = t;
-  else if (!sg.fb_zero[2 * t] || corner)
-    sg.work[16 + T + atomicAdd(&cnt[1], 1)] = t;
-  if (a2)
-    sg.work[16 + 3 * T + atomicAdd(&cnt[3], 1)] = t;
-  else if (!sg.fb_zero[2 * t + 1])
-    sg.work[16 + 4 * T + atomicAdd(&cnt[4], 1)] = t;
+  const bool corner = mailbox && tc == 0;
+  wave_append(&cnt[0], sg.work + 16, tex && a != 0, tc);
+  wave_append(&cnt[1], sg.work + 16 + T, tex && a == 0 && (!sg.fb_zero[2 * tc] || corner), tc);
+  wave_append(&cnt[3], sg.work + 16 + 3 * T, tex && a2 != 0, tc);
+  wave_append(&cnt[4], sg.work + 16 + 4 * T, tex && a2 == 0 && !sg.fb_zero[2 * tc + 1], tc);
 }
 
 // One (tile, texture) work item: KIND 0 = the feedback texture from acc3, KIND 1 = the deposition texture
