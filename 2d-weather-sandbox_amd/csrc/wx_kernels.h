@@ -350,7 +350,7 @@ struct DevState {
   int fastest_bits;       // float bits of the largest |velocity component| that took a cell to the exact path (marching wet kernel)
   int pool_retired;       // exact mode: droplets that ended the iteration inactive among this iteration's status flips (k_pool_events_apply)
   float mailbox_w;        // fourth channel of the feedback texture's texel (1,0) -- the only texel whose alpha the reference ever writes (the
-                          // lightning request's fourth component): the texture itself is stored with three channels (k_lightning keeps it)
+                          // lightning request's fourth component): the texture itself is stored with three channels (lightning_update keeps it)
 };
 
 // Splat accumulation: a 12x12 point sprite anchored at pixel (i0,j0) adds the same value to pixels
@@ -930,7 +930,7 @@ __device__ __forceinline__ void splat_box_tile(float (*pl)[STY + 11][77], int X,
       if (KIND == 0) {
         float3 v = make_float3(pl[0][ry][cx], pl[1][ry][cx], pl[2][ry][cx]);
         if (corner && y == 0 && x == 0) v.x += st->px_count;
-        if (corner && y == 0 && x == 1) { // (the fourth component of the request: DevState::mailbox_w, k_lightning)
+        if (corner && y == 0 && x == 1) { // (the fourth component of the request: DevState::mailbox_w, lightning_update)
           v.x += st->px_light[0];
           v.y += st->px_light[1];
           v.z += st->px_light[2];
@@ -1016,8 +1016,16 @@ inline int splat_box_grid()
 }
 
 // zero the accumulation tiles that hold deposits (after k_splat_box consumed them)
-__global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg, int par)
+struct LightningArgs { // (the one-thread lightningLocation pass rides in the clear kernel: one launch less per iteration)
+  float iterNum;
+  int refresh_inactive, mailbox, defer;
+  const float3 *fb;
+  DevState *st;
+};
+__device__ __forceinline__ void lightning_update(float iterNum, int refresh_inactive, const float3 *__restrict__ fb, DevState *st, int mailbox, int defer);
+__global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg, int par, LightningArgs la)
 {
+  if (la.st && blockIdx.x == 0 && threadIdx.x == 0) lightning_update(la.iterNum, la.refresh_inactive, la.fb, la.st, la.mailbox, la.defer);
   const int T = sg.TXn * sg.TYn, n = sg.work[8 * par + 2];
   for (int wi = blockIdx.x; wi < n; wi += gridDim.x) {
     const int tile = sg.work[16 + 2 * T + wi];
@@ -1039,9 +1047,8 @@ __global__ __launch_bounds__(256) void k_splat_clear(int X, int Y, SplatGrid sg,
 // lightningLocationShader.frag:24-38 + the 600-iteration inactive count (app.js:5957-5966), one thread
 // (slab handles: the mailbox texels are not part of the local feedback texture -- the request is taken from the
 // accumulator directly, the inactive count is refreshed by wx_pool_edges_pack)
-__global__ void k_lightning(float iterNum, int refresh_inactive, const float3 *__restrict__ fb, DevState *st, int mailbox, int defer)
+__device__ __forceinline__ void lightning_update(float iterNum, int refresh_inactive, const float3 *__restrict__ fb, DevState *st, int mailbox, int defer)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (defer) { // exact slabs: the request stays in px_light until the ranks have summed theirs (k_pool_exact_resolve)
     st->px_count = 0.f;
     return;
@@ -1145,7 +1152,7 @@ __global__ void k_pool_events_apply(int n_ranks, size_t stride_bytes, int cap, c
   }
 }
 // exact mode, after k_pool_events_apply: the iteration records of all ranks -> the lightning request of the whole domain, accepted or
-// rejected exactly as k_lightning does (two requests of one iteration add up to a start time that is discarded), and -- in the
+// rejected exactly as lightning_update does (two requests of one iteration add up to a start time that is discarded), and -- in the
 // iterations in which the reference refreshes it -- the `inactiveDroplets` uniform: the droplets that were inactive before AND after
 // this iteration (every rank holds every inactive record: counted locally into px_count, minus this iteration's retirements) plus the
 // real deposit at texel (0,0), in the order the mailbox texel is built (box sum + count)

@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx
   const int total = *count, n = total < cap ? total : cap;
   if (total > cap && blockIdx.x == 0 && threadIdx.x == 0) *overflow = total;
   const int X = ctx->g.X, Y = ctx->g.Y;
-  const WetSlowArgs sa{ctx, in, iterNum};
+  // (entries whose footprints leave the patch fall back to wet_output_cell_exact, which builds its own argument block)
   for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
     const int2 c = cells[i];
     wet_fix_build_patch(ctx, &in, iterNum, &stages[wave], &pt, c.x, c.y, lane);

@@ -1343,15 +1343,12 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
         LAUNCH_CHECK(s, "splat_classify / splat_box");
       }
       {
-        ProfScope ps(s, K_LIGHTNING);
-        hipLaunchKernelGGL(k_lightning, dim3(1), dim3(64), 0, s->stream, u.iterNum, (int)(s->iter % 600 == 0), s->fb, s->state, s->pool_remote ? 0 : 1,
-                           s->pool_remote && s->pool_exact ? 1 : 0);
-        LAUNCH_CHECK(s, "lightning");
-      }
-      {
+        // lightningLocation pass (one thread: it reads texel (1,0) the box sum just wrote and the request in the state) + the clear of
+        // the accumulation tiles that held deposits, in one launch
         ProfScope ps(s, K_SPLAT);
         const int T = s->sg.TXn * s->sg.TYn;
-        hipLaunchKernelGGL(k_splat_clear, dim3(T < 2048 ? T : 2048), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->splat_par);
+        const LightningArgs la{u.iterNum, (int)(s->iter % 600 == 0), s->pool_remote ? 0 : 1, s->pool_remote && s->pool_exact ? 1 : 0, s->fb, s->state};
+        hipLaunchKernelGGL(k_splat_clear, dim3(T < 2048 ? T : 2048), dim3(256), 0, s->stream, s->X, s->Y, s->sg, s->splat_par, la);
         LAUNCH_CHECK(s, "splat_clear");
         s->splat_par ^= 1;
       }
