@@ -1409,9 +1409,10 @@ inline void launch_wet_fix(float iterNum, const FullCtx *ctx, const WetIn &in, c
   // the whole chip (512 workgroups = one wavefront per list entry up to 2048 entries) while the last list the host has heard of held
   // entries, a corner of it while the lists are empty; any grid is correct (grid-stride loop)
   const int last = fix.hint ? *(volatile const int *)fix.hint_host : -1; // (-1: no host word -- the whole chip every time)
-  // four entries per workgroup with room for twice the last list, 32 .. 512 workgroups (wgs: the edge group of a slab -- a few strips --
-  // asks for 64); the list is walked grid-stride, so any size is correct
-  const int want = last < 0 ? 512 : (last > 0 ? std::min(512, std::max(32, (last + 1) / 2)) : 32);
+  // four entries per workgroup with room for four times the last list (its length varies from iteration to iteration: room for twice
+  // cost the particle flow 6 us, 21 -> 27), 32 .. 512 workgroups (wgs: the edge group of a slab -- a few strips -- asks for 64); the
+  // list is walked grid-stride, so any size is correct
+  const int want = last < 0 ? 512 : (last > 0 ? std::min(512, std::max(32, last)) : 32);
   const dim3 grid(wgs > 0 ? wgs : want), block(256);
   if (opt_out)
     hipLaunchKernelGGL((k_wet_fix<true>), grid, block, 0, stream, ctx, iterNum, in, out, fix.count, fix.cells, fix.cap, overflow, fix.hint);
