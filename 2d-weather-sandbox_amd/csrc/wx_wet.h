@@ -91,12 +91,6 @@ namespace wx {
 #ifndef WX_WET_UNROLL2
 #define WX_WET_UNROLL2 1 // two row steps per loop iteration (measured -1.2 .. -1.6 % at 16384x2048: fewer register moves for the carried values)
 #endif
-#ifndef WX_WET_UNROLL2_FB
-#define WX_WET_UNROLL2_FB 0
-#endif
-#ifndef WX_WET_UNROLL2_OPT
-#define WX_WET_UNROLL2_OPT 0
-#endif
 #ifndef WX_WET_AIR
 #define WX_WET_AIR 1 // wave-uniform free-air instantiations of the boundary / advection / lighting stages
 #endif
@@ -942,7 +936,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   };
   // (a segment has at least one row: at least nine steps)
   for (; t < 8; r++, t++) step(std::true_type{});
-  if (WX_WET_UNROLL2 && (WX_WET_UNROLL2_FB || !HAS_FB) && (WX_WET_UNROLL2_OPT || !OPT_OUT)) {
+  if (WX_WET_UNROLL2 && !HAS_FB && !OPT_OUT) { // (doubling the other instantiations re-measured at four waves per SIMD: neutral, profiles/r04_unroll_variants_four_waves.txt)
     // two steps per loop iteration: the values carried from step to step (prefetched rows, the previous rows' registers, the deferred
     // stores) change registers between the two copies instead of being moved: -1.4 % without feedback loads; WITH them (particles on)
     // the doubled loop is 4-6 % slower, and the display-writing one (every tenth iteration) loses 2-8 %: only the plain instantiation
