@@ -60,6 +60,41 @@ __global__ __launch_bounds__(256) void k_read(Shape s, const float4 *__restrict_
   if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x; // (never true: keeps the loads alive)
 }
 
+// The same read stream through LDS-DMA (global_load_lds_dwordx4: the row lands in LDS without passing through registers), DEPTH rows in
+// flight per wave in a wave-private ring -- the "more bytes in flight without registers" lever of MI355X_MICROARCH.md for a kernel whose
+// occupancy is bound by registers. Reported next to the register-prefetch stream above (read_lds1 / read_lds2 / read_lds3).
+template <int DEPTH>
+__global__ __launch_bounds__(256) void k_read_lds(Shape s, const float4 *__restrict__ a, float *__restrict__ sink)
+{
+  __shared__ float4 ring[4][4][64]; // [wave][slot][lane]
+  int strip, y_lo, y_hi;
+  if (!my_rows(s, strip, y_lo, y_hi)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = strip * 64 + lane;
+  typedef const __attribute__((address_space(1))) void *GP;
+  typedef __attribute__((address_space(3))) void *LP;
+  auto issue = [&](int y) { __builtin_amdgcn_global_load_lds((GP)(a + (size_t)y * s.X + col), (LP)&ring[wave][(y - y_lo) & 3][0], 16, 0, 0); };
+  for (int k = 0; k < DEPTH; k++)
+    if (y_lo + k < y_hi) issue(y_lo + k);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int y = y_lo; y < y_hi; y++) {
+    if (y + DEPTH < y_hi) issue(y + DEPTH);
+    // rows still allowed in flight behind row y: those issued after it
+    const int behind = min(DEPTH, y_hi - 1 - y);
+    if (behind >= 3) __builtin_amdgcn_s_waitcnt(0x0F73);
+    else if (behind == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
+    else if (behind == 1) __builtin_amdgcn_s_waitcnt(0x0F71);
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f cur = *(volatile v4f *)&ring[wave][(y - y_lo) & 3][lane];
+    acc.x += cur.x;
+    acc.y += cur.y;
+    acc.z += cur.z;
+    acc.w += cur.w;
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
+}
+
 __global__ __launch_bounds__(256) void k_write(Shape s, float4 *__restrict__ b)
 {
   int strip, y_lo, y_hi;
@@ -187,13 +222,17 @@ int main(int argc, char **argv)
   const dim3 grid(8 * ((s.n_strips + 3) / 4) * s.segs_per_band), block(256);
   double r = 0, w = 0, cp = 0, mix = 0;
   if (timed("read", (double)n * 16, reps, [&] { hipLaunchKernelGGL(k_read, grid, block, 0, 0, s, a, sink); }, &r)) return 1;
+  double rl1 = 0, rl2 = 0, rl3 = 0;
+  if (timed("read_lds1", (double)n * 16, reps, [&] { hipLaunchKernelGGL(k_read_lds<1>, grid, block, 0, 0, s, a, sink); }, &rl1)) return 1;
+  if (timed("read_lds2", (double)n * 16, reps, [&] { hipLaunchKernelGGL(k_read_lds<2>, grid, block, 0, 0, s, a, sink); }, &rl2)) return 1;
+  if (timed("read_lds3", (double)n * 16, reps, [&] { hipLaunchKernelGGL(k_read_lds<3>, grid, block, 0, 0, s, a, sink); }, &rl3)) return 1;
   if (timed("write", (double)n * 16, reps, [&] { hipLaunchKernelGGL(k_write, grid, block, 0, 0, s, b); }, &w)) return 1;
   if (timed("copy", (double)n * 32, reps, [&] { hipLaunchKernelGGL(k_copy, grid, block, 0, 0, s, a, b); }, &cp)) return 1;
   MixIn in{a, c, (const int *)e, (const float *)(e + n * 4), (const float *)(e + n * 8), (const float *)(e + n * 12), (const float2 *)(e + n * 16)};
   MixOut out{b, d, (int *)f, (float *)(f + n * 4), (float *)(f + n * 8), (float2 *)(f + n * 12)};
   if (timed("mix", (double)n * (56 + 52), reps, [&] { hipLaunchKernelGGL(k_mix, grid, block, 0, 0, s, in, out); }, &mix)) return 1;
-  printf("{\"X\": %d, \"Y\": %d, \"seg_rows\": %d, \"waves\": %d, \"read_GBps\": %.1f, \"write_GBps\": %.1f, \"copy_GBps\": %.1f, "
+  printf("{\"X\": %d, \"Y\": %d, \"seg_rows\": %d, \"waves\": %d, \"read_GBps\": %.1f, \"read_lds_dma_GBps\": [%.1f, %.1f, %.1f], \"write_GBps\": %.1f, \"copy_GBps\": %.1f, "
          "\"wet_stream_mix_GBps\": %.1f, \"wet_stream_mix_ms\": %.4f, \"pattern\": \"64-lane x 16 B rows, row-marching waves with a one-row prefetch, 8 XCD row bands\"}\n",
-         s.X, s.Y, s.seg, s.n_strips * s.segs_per_band * 8, r, w, cp, mix, (double)n * 108 / mix / 1e6);
+         s.X, s.Y, s.seg, s.n_strips * s.segs_per_band * 8, r, rl1, rl2, rl3, w, cp, mix, (double)n * 108 / mix / 1e6);
   return 0;
 }
