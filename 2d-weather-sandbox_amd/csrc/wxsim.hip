@@ -55,6 +55,7 @@ const char *const kKernelNames[K_COUNT] = {"velocity", "curl", "vorticity", "bou
 struct ProfRec {
   hipEvent_t a, b;
   int kid;
+  bool shared_a; // `a` is the previous scope's `b` (one event per scope boundary: an event record costs the stream ~5 us)
 };
 
 } // namespace
@@ -193,6 +194,7 @@ struct wx_sim {
   std::vector<void **> slots;
   // profiling
   bool profiling = false;
+  hipEvent_t prof_tail = nullptr; // the event that closed the latest scope of the current wx_step call: the next scope starts from it
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
   double prof_ms[K_COUNT] = {0};
@@ -271,16 +273,21 @@ struct ProfScope {
   ProfScope(wx_sim *s_, int kid) : s(s_), on(s_->profiling)
   {
     if (on) {
+      // Scopes of one wx_step call follow each other on the stream with nothing but the odd memset or event wait in between: the event that
+      // closed one opens the next. Two records per boundary were a 10 us bubble between the kernels (rocprofv3 timeline of the bench:
+      // 1.5 % of a grid-only iteration, 4 % of one with particles); one is half of that.
       r.kid = kid;
-      r.a = get_event(s);
+      r.shared_a = s->prof_tail != nullptr;
+      r.a = r.shared_a ? s->prof_tail : get_event(s);
       r.b = get_event(s);
-      hipEventRecord(r.a, s->stream);
+      if (!r.shared_a) hipEventRecord(r.a, s->stream);
     }
   }
   ~ProfScope()
   {
     if (on) {
       hipEventRecord(r.b, s->stream);
+      s->prof_tail = r.b;
       s->prof.push_back(r);
     }
   }
@@ -296,10 +303,11 @@ void collect_profile(wx_sim *s)
       s->prof_ms[r.kid] += ms;
       s->prof_n[r.kid] += 1;
     }
-    s->ev_pool.push_back(r.a);
+    if (!r.shared_a) s->ev_pool.push_back(r.a); // (a shared one goes back with the record it closed)
     s->ev_pool.push_back(r.b);
   }
   s->prof.clear();
+  s->prof_tail = nullptr;
 }
 
 dim3 grid2d(const wx_sim *s) { return dim3((s->X + BX - 1) / BX, (s->Y + BY - 1) / BY); }
@@ -945,7 +953,7 @@ void wx_destroy(wx_sim *s)
   if (s->comm_stream) hipStreamSynchronize(s->comm_stream);
   transport_release(s);
   for (auto &r : s->prof) {
-    hipEventDestroy(r.a);
+    if (!r.shared_a) hipEventDestroy(r.a);
     hipEventDestroy(r.b);
   }
   for (auto e : s->ev_pool) hipEventDestroy(e);
@@ -1250,6 +1258,11 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   DeviceScope dev_scope(s);
   if (n_iter < 0) return fail(s, WX_E_INVALID, "wx_step: n_iter < 0");
   if (!s->uploaded || !s->have_params) return fail(s, WX_E_STATE, "wx_step before wx_upload / wx_set_params");
+  struct TailReset { // profile scopes share their boundary events only within one call (between calls the stream may idle)
+    wx_sim *s;
+    ~TailReset() { s->prof_tail = nullptr; }
+  } tail_reset{s};
+  s->prof_tail = nullptr;
   const unsigned mask = s->p.pass_mask;
   const bool precip = (mask & WX_PASS_PRECIPITATION) && s->p.enablePrecipitation && s->n_drops > 0;
   const size_t n = ncell(s);
