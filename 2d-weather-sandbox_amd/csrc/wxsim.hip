@@ -195,6 +195,7 @@ struct wx_sim {
   // profiling
   bool profiling = false;
   hipEvent_t prof_tail = nullptr; // the event that closed the latest scope of the current wx_step call: the next scope starts from it
+  bool prof_chain = false;        // inside wx_step: scopes follow each other on the stream (other entry points time their scope alone)
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
   double prof_ms[K_COUNT] = {0};
@@ -287,7 +288,7 @@ struct ProfScope {
   {
     if (on) {
       hipEventRecord(r.b, s->stream);
-      s->prof_tail = r.b;
+      s->prof_tail = s->prof_chain ? r.b : nullptr;
       s->prof.push_back(r);
     }
   }
@@ -1260,9 +1261,14 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   if (!s->uploaded || !s->have_params) return fail(s, WX_E_STATE, "wx_step before wx_upload / wx_set_params");
   struct TailReset { // profile scopes share their boundary events only within one call (between calls the stream may idle)
     wx_sim *s;
-    ~TailReset() { s->prof_tail = nullptr; }
+    ~TailReset()
+    {
+      s->prof_tail = nullptr;
+      s->prof_chain = false;
+    }
   } tail_reset{s};
   s->prof_tail = nullptr;
+  s->prof_chain = true;
   const unsigned mask = s->p.pass_mask;
   const bool precip = (mask & WX_PASS_PRECIPITATION) && s->p.enablePrecipitation && s->n_drops > 0;
   const size_t n = ncell(s);
