@@ -64,7 +64,7 @@ def parse():
                     help="eddies: smooth divergence-free eddies of 50..400 cells (a developed flow; default); noise: white noise per cell (worst case for the ring reads)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 32768 x 4096 dry north-star measurement (N=1)")
     ap.add_argument("--no-extras", action="store_true", help="skip at_rest / frame-1 / hbm_ceiling side measurements (N=1)")
-    ap.add_argument("--tune", type=int, default=12, help="wx_tune_placement: further device allocations to try for the handle's planes (0: keep the first)")
+    ap.add_argument("--tune", type=int, default=20, help="wx_tune_placement: further device allocations to try for the handle's planes (0: keep the first)")
     ap.add_argument("--verify", action="store_true", help="N > 1: checksum every rank's owned columns against an undecomposed run on rank 0")
     a = ap.parse_args()
     a.frame = max(1, a.frame)  # (0 or a negative value would never advance run_frames)
