@@ -77,7 +77,7 @@ namespace wx {
 #define WX_WET_SKIP_LOADS 1 // 1: no water / light loads in the first two warm-up steps; light_0.x only near walls. 2: only the latter. 0: neither
 #endif
 #ifndef WX_WET_NT_STORES
-#define WX_WET_NT_STORES 0
+#define WX_WET_NT_STORES 1 // nontemporal output stores: the rows a wave writes are read by nobody in this launch; kept out of the 4 MB L2 they stop evicting the input lines that neighbouring strips and segments share (FETCH_SIZE -8 %, +0.5..1.5 %: profiles/r04_ring_diet.txt section 7)
 #endif
 #ifndef WX_WET_ZW0
 #define WX_WET_ZW0 1 // wave-uniform skip of the precipitation-visual / smoke interpolations where those channels are zero (advection_cell NO_ZW)

@@ -16,7 +16,7 @@ print('   ', round(d['value']), 'Mcs/s', round(d['ms_per_step'],4), 'ms', {a:rou
   if [ -n "$TRAFFIC" ]; then
     for c in FETCH_SIZE WRITE_SIZE; do rm -rf /tmp/pv3
       WXSIM_LIB=$f rocprofv3 --pmc $c -d /tmp/pv3 -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-pmc --no-north-star --no-extras $BENCH_ARGS > /dev/null 2>&1
-      python $R/tools/rocpd_summary.py /tmp/pv3/*.db --skip 2 | grep -E "$PAT" | sed 's/_ZN2wx[0-9]*\(k_[a-z_]*\)[^|]*/\1 /' | tail -1 | sed "s/^/    $c KiB: /"
+      python $R/tools/rocpd_summary.py /tmp/pv3/*.db --skip 2 | grep -E "$PAT" | sed 's/_ZN2wx[0-9]*\(k_[a-z_]*\)[^|]*/\1 /' | tail -2 | sed "s/^/    $c KiB: /"
     done
   fi
   for d in /tmp/pv1 /tmp/pv2; do python $R/tools/rocpd_summary.py $d/*.db --skip 2 | grep -E "$PAT|kernel \| SQ" | sed 's/_ZN2wx[0-9]*\(k_[a-z_]*\)[^|]*/\1 /' | tail -2; done
