@@ -103,7 +103,7 @@ __device__ __forceinline__ void march_fence()
 // QUIET: no brush input, no airplane event in this iteration (see advection_cell)
 template <bool WRITE_DISP, bool WRITE_WALL, bool QUIET>
 __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u_arg, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows,
-                                                                     int n_full, int n_half, int band_h, int n_seg, int strip_lo, int split_at, int strip_lo2, int nt
+                                                                     int n_full, int n_half, int band_h, int n_seg, int strip_lo, int split_at, int strip_lo2
 #ifdef WX_MARCH_TIMING
                                                                      , unsigned long long *cycles
 #endif
@@ -200,9 +200,9 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     }
     if (st_valid && lane_out) { // row r-3
       const size_t e = (size_t)(r - 3) * X;
-      st_row_v(out.base + e, so16, st_p, nt != 0); // (nt: nontemporal stores on grids far larger than the memory-side cache, see st_row)
-      if (WRITE_WALL) st_row_v(out.wall + e, so4, st_w, nt != 0);
-      if (WRITE_DISP) st_row_v(out.base_disp + e, so16, st_ab, nt != 0);
+      st_row_v(out.base + e, so16, st_p);
+      if (WRITE_WALL) st_row_v(out.wall + e, so4, st_w);
+      if (WRITE_DISP) st_row_v(out.base_disp + e, so16, st_ab);
     }
     st_valid = false;
     // row r: P, T and wall enter the ring (velocity leaves them unchanged)
@@ -292,9 +292,9 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
 #endif
   if (st_valid && lane_out) { // the last row
     const size_t e = (size_t)(y_hi - 1) * X;
-    st_row_v(out.base + e, so16, st_p, nt != 0);
-    if (WRITE_WALL) st_row_v(out.wall + e, so4, st_w, nt != 0);
-    if (WRITE_DISP) st_row_v(out.base_disp + e, so16, st_ab, nt != 0);
+    st_row_v(out.base + e, so16, st_p);
+    if (WRITE_WALL) st_row_v(out.wall + e, so4, st_w);
+    if (WRITE_DISP) st_row_v(out.base_disp + e, so16, st_ab);
   }
 #ifdef WX_MARCH_TIMING
   if (lane == 0) {
@@ -361,8 +361,6 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
     }
   }
   const dim3 grid(WX_MARCH_XCD ? 8 * ((n_strips * n_seg + 7) / 8) : n_strips * n_seg);
-  int nt = (long long)g.X * g.Y >= WX_NT_MIN_CELLS ? 1 : 0;
-  if (const char *e = wx_tune_env("WX_NT")) nt = atoi(e) != 0;
   static bool dbg = wx_tune_env("WX_MARCH_DEBUG") != nullptr;
   if (dbg) {
     fprintf(stderr, "[wx_march] strips=%d seg_rows=%d segs=%d (bands of %d rows: %d full + 2 x %d short each) waves=%d\n", n_strips, seg_rows, n_seg, band_h, n_full, n_half, n_strips * n_seg);
@@ -372,9 +370,9 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
   static unsigned long long *cyc = nullptr;
   static int calls = 0;
   if (!cyc && hipMalloc((void **)&cyc, 16 * (size_t)n_strips_all * n_seg) != hipSuccess) return;
-#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, n_first, strip_lo2, nt, cyc)
+#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, n_first, strip_lo2, cyc)
 #else
-#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, n_first, strip_lo2, nt)
+#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, n_first, strip_lo2)
 #endif
   const bool quiet = !(u.userInputType >= 1) && !(u.airplaneValues[3] < 0.0f || u.airplaneValues[3] > 0.9f);
 #define WX_LAUNCH_MQ(D, W) \

@@ -76,6 +76,9 @@ namespace wx {
 #ifndef WX_WET_SKIP_LOADS
 #define WX_WET_SKIP_LOADS 1 // 1: no water / light loads in the first two warm-up steps; light_0.x only near walls. 2: only the latter. 0: neither
 #endif
+#ifndef WX_WET_NT_STORES
+#define WX_WET_NT_STORES 0
+#endif
 #ifndef WX_WET_ZW0
 #define WX_WET_ZW0 1 // wave-uniform skip of the precipitation-visual / smoke interpolations where those channels are zero (advection_cell NO_ZW)
 #endif
@@ -425,30 +428,28 @@ template <int N> struct NativeVec;
 template <> struct NativeVec<4> { typedef unsigned type; };
 template <> struct NativeVec<8> { typedef unsigned type __attribute__((ext_vector_type(2))); };
 template <> struct NativeVec<16> { typedef unsigned type __attribute__((ext_vector_type(4))); };
-template <class T> __device__ __forceinline__ void st_row(T *row, unsigned &byte_off, T v, bool nt = false)
+template <class T> __device__ __forceinline__ void st_row(T *row, unsigned &byte_off, T v)
 {
   typedef __attribute__((address_space(1))) char *GBytes;
   asm("" : "+v"(byte_off));
-  // nt (wave-uniform, chosen by the host for grids far larger than the 256 MB memory-side cache): nontemporal store -- the rows a wave
-  // writes are read by nobody in this launch; kept out of the 4 MB L2 they stop evicting the input lines that neighbouring strips and
-  // segments share (FETCH_SIZE -5..-8 % at 16384 x 2048, the dry stencil at 32768 x 4096 +2-3 %). A grid that fits the memory-side cache
-  // wants its outputs THERE for the next iteration: 4096 x 1024 dry loses 17 % with nontemporal stores (profiles/r04_ring_diet.txt, 7).
-  if (nt) {
-    typedef typename NativeVec<sizeof(T)>::type NV;
-    typedef __attribute__((address_space(1))) NV *GPtr;
-    __builtin_nontemporal_store(__builtin_bit_cast(NV, v), (GPtr)((GBytes)uniform_addr(row) + byte_off));
-  } else {
-    typedef __attribute__((address_space(1))) T *GPtr;
-    *(GPtr)((GBytes)uniform_addr(row) + byte_off) = v;
-  }
+#if WX_WET_NT_STORES
+  // streamed once, read again only by the next launch: keep the output rows from evicting the input lines that neighbouring
+  // strips still share (halo columns) out of the 4 MB L2
+  typedef typename NativeVec<sizeof(T)>::type NV;
+  typedef __attribute__((address_space(1))) NV *GPtr;
+  __builtin_nontemporal_store(__builtin_bit_cast(NV, v), (GPtr)((GBytes)uniform_addr(row) + byte_off));
+#else
+  typedef __attribute__((address_space(1))) T *GPtr;
+  *(GPtr)((GBytes)uniform_addr(row) + byte_off) = v;
+#endif
 }
 #else // host pass of the single-source compile: same meaning, never executed
 template <class T> __device__ __forceinline__ T ld_row(const T *row, unsigned &byte_off) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(row) + byte_off); }
-template <class T> __device__ __forceinline__ void st_row(T *row, unsigned &byte_off, T v, bool nt = false) { *reinterpret_cast<T *>(reinterpret_cast<char *>(row) + byte_off) = v; }
+template <class T> __device__ __forceinline__ void st_row(T *row, unsigned &byte_off, T v) { *reinterpret_cast<T *>(reinterpret_cast<char *>(row) + byte_off) = v; }
 #endif
 // by-value forms (a private copy of the offset per access): what the dry marching kernel uses -- there the in-place form is 2 % slower
 template <class T> __device__ __forceinline__ T ld_row_v(const T *row, unsigned byte_off) { return ld_row(row, byte_off); }
-template <class T> __device__ __forceinline__ void st_row_v(T *row, unsigned byte_off, T v, bool nt = false) { st_row(row, byte_off, v, nt); }
+template <class T> __device__ __forceinline__ void st_row_v(T *row, unsigned byte_off, T v) { st_row(row, byte_off, v); }
 __device__ __forceinline__ int ring_back(int s, int k, int n) // slot of the row k steps behind the one in slot s (ring of n)
 {
   const int v = s - k;
@@ -464,11 +465,9 @@ __device__ __forceinline__ int ring_back(int s, int k, int n) // slot of the row
 // branchy instantiations and cost about twice as much as free air, so the host makes the bottom segments shorter
 // (wet_launch_shape) and all waves of a launch finish together.
 constexpr int WMAXSEG = 128;
-constexpr long long WX_NT_MIN_CELLS = 8ll << 20; // nontemporal output stores from 8 Mi cells on (0.9 GB of inputs + outputs per iteration; the memory-side cache holds 256 MB)
 struct WetSegs {
   int n_seg;
-  int bands;              // XCD k takes the row band [k*Y/8, (k+1)*Y/8) of ALL strips; start[] is relative to it
-  int nt;                 // nontemporal output stores (grids far larger than the memory-side cache)
+  int bands;              // experimental (WX_WET_BANDS=1): XCD k takes the row band [k*Y/8, (k+1)*Y/8) of ALL strips; start[] is relative to it
   int start[WMAXSEG + 1];
 };
 // QUIET: no brush input and no airplane event in this iteration (the host looks at the uniforms): advection_cell without those sections.
@@ -495,8 +494,6 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   const WetIn &in = in_arg;
   const WetOut &out = out_arg;
 #endif
-#define WX_ST(p, o, v) st_row(p, o, v, nt_st)
-  const bool nt_st = segs.nt != 0; // (wave-uniform: nontemporal output stores, see st_row)
   __shared__ WetRing rings[WX_WET_WPB];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   WetRing &rg = rings[wave];
@@ -706,17 +703,17 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     // ---- the stores of the previous step's row (r-5), issued behind the prefetch ----
     if (st_valid && lane_out) {
       const size_t e = (size_t)(r - 5) * X;
-      WX_ST(out.base + e, so16, st_p);
-      WX_ST(out.water + e, so16, st_q);
-      WX_ST(out.wall + e, so4, st_w);
-      WX_ST(out.light.x + e, so4, st_l.x);
-      WX_ST(out.light.y + e, so4, st_l.y);
-      WX_ST(out.light.zw + e, so8, make_float2(st_l.z, st_l.w));
-      if (OPT_OUT) WX_ST(out.base_disp + e, so16, st_ab);
+      st_row(out.base + e, so16, st_p);
+      st_row(out.water + e, so16, st_q);
+      st_row(out.wall + e, so4, st_w);
+      st_row(out.light.x + e, so4, st_l.x);
+      st_row(out.light.y + e, so4, st_l.y);
+      st_row(out.light.zw + e, so8, make_float2(st_l.z, st_l.w));
+      if (OPT_OUT) st_row(out.base_disp + e, so16, st_ab);
 #ifndef WX_ABL_NO_TDISP
       // post-advection temperature for the droplets: only rows in which the pressure pass changed it (k_precipitation's precip_T makes
       // the same test per texel and reads the post-pressure T everywhere else)
-      if (out.t_disp && st_td) WX_ST(out.t_disp + e, so4, st_ab.w);
+      if (out.t_disp && st_td) st_row(out.t_disp + e, so4, st_ab.w);
 #endif
     }
     st_valid = false;
@@ -742,7 +739,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       c0 = curl_cell(v1x, v1y, wave_from_right(v1y), v0x);
       if (OPT_OUT) {
         const int yc = r - 2;
-        if (lane_out && yc >= y_lo && yc < y_hi) WX_ST(out.curl + (size_t)yc * X, so4, c0);
+        if (lane_out && yc >= y_lo && yc < y_hi) st_row(out.curl + (size_t)yc * X, so4, c0);
       }
     }
     float2 vf = make_float2(0.f, 0.f);
@@ -802,7 +799,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         WX_H_SET(h_zw0, __all(bq.z == 0.0f && bq.w == 0.0f));          // no rain / snow / smoke anywhere in it
         if (OPT_OUT) {
           const int yo = r - 3;
-          if (lane_out && yo >= y_lo && yo < y_hi) WX_ST(out.water0 + (size_t)yo * X, so16, bq);
+          if (lane_out && yo >= y_lo && yo < y_hi) st_row(out.water0 + (size_t)yo * X, so16, bq);
         }
       }
       // the pre-boundary values of this row are what the row above reads as its lower neighbour
@@ -963,14 +960,14 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   // ---- the last row ----
   if (st_valid && lane_out) {
     const size_t e = (size_t)(y_hi - 1) * X;
-    WX_ST(out.base + e, so16, st_p);
-    WX_ST(out.water + e, so16, st_q);
-    WX_ST(out.wall + e, so4, st_w);
-    WX_ST(out.light.x + e, so4, st_l.x);
-    WX_ST(out.light.y + e, so4, st_l.y);
-    WX_ST(out.light.zw + e, so8, make_float2(st_l.z, st_l.w));
-    if (OPT_OUT) WX_ST(out.base_disp + e, so16, st_ab);
-    if (out.t_disp && st_td) WX_ST(out.t_disp + e, so4, st_ab.w);
+    st_row(out.base + e, so16, st_p);
+    st_row(out.water + e, so16, st_q);
+    st_row(out.wall + e, so4, st_w);
+    st_row(out.light.x + e, so4, st_l.x);
+    st_row(out.light.y + e, so4, st_l.y);
+    st_row(out.light.zw + e, so8, make_float2(st_l.z, st_l.w));
+    if (OPT_OUT) st_row(out.base_disp + e, so16, st_ab);
+    if (out.t_disp && st_td) st_row(out.t_disp + e, so4, st_ab.w);
   }
 #ifdef WX_WET_TIMING
   if (lane == 0) {
@@ -980,7 +977,6 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
 #endif
 }
 
-#undef WX_ST
 #undef WX_WALL_RAW
 #undef WX_H_SET
 #undef WX_H_ROT
@@ -1259,8 +1255,6 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row, int bands_mode
   if (const char *e = wx_tune_env("WX_WET_BANDS")) bands = atoi(e) >= 2 ? g.Y >= 16 : (atoi(e) != 0 && g.Y >= 8 * 64); // (2: tests force it on small grids)
   const int Y = bands ? (g.Y + 7) / 8 : g.Y; // (bands: the shape of ONE band; the kernel clips it to the band's own height)
   w.segs.bands = bands ? 1 : 0;
-  w.segs.nt = (long long)g.X * g.Y >= WX_NT_MIN_CELLS ? 1 : 0;
-  if (const char *e = wx_tune_env("WX_NT")) w.segs.nt = atoi(e) != 0; // (debug build: force nontemporal stores on / off)
   w.n_strips = (g.X + WOUT - 1) / WOUT;
   int rounds = WX_WET_ROUNDS, minrows = 24; // (narrow slabs: 2144x2048 runs 17 % faster with 30-row unit segments + tail than with equal 32-row ones)
   const double alpha = wet_alpha();
