@@ -75,14 +75,17 @@ static const char *rccl_missing() { return "RCCL is not available in this proces
   } while (0)
 
 static int iters_per_exchange(const wx_sim *s) { return s->pool_remote ? std::max(1, WX_SLAB_PERIOD_PARTICLES(s->halo)) : std::max(1, s->halo / WX_SLAB_CONE); }
-// the stream the exchange of a slab runs on: its comm stream (grid-only slabs: overlapped with compute), else its compute stream
-// (slabs with particles: the pool exchange needs the finished iteration, so everything stays in order)
-static hipStream_t xstream(const wx_sim *s) { return s->comm_stream ? s->comm_stream : s->stream; }
+// the stream the exchange of a slab runs on (wxsim.hip: exchange_stream -- the comm stream unless the exchange must stay in order)
+static hipStream_t xstream(const wx_sim *s) { return exchange_stream(s); }
 // bytes per rank in the all-gather of status-flip events: a stride every rank knows without a host round trip inside the period
 // (pool_stride_update); a rank with more flips than fit is reported by the next blocking call (pool_overflow)
 static size_t pool_stride(const wx_sim *s)
 {
-  const size_t want = (POOL_HDR + sizeof(PoolEvent) * (size_t)(1 + s->pool_stride_events) + 4095) / 4096 * 4096;
+  // (exact mode sends a round after EVERY iteration: until the first counts are in, 262 144 events per rank and round -- eight times
+  // the start-up burst of configs[4] -- instead of the whole buffer; the per-period protocol's first exchange carries a whole period's
+  // burst and takes everything)
+  const long long ev = (s->pool_exact && s->pool_stride_events > (1 << 18)) ? (1 << 18) : s->pool_stride_events;
+  const size_t want = (POOL_HDR + sizeof(PoolEvent) * (size_t)(1 + ev) + 4095) / 4096 * 4096;
   return std::min(want, wx_pool_event_bytes(s));
 }
 

@@ -1082,23 +1082,23 @@ constexpr int POOL_HDR = 16;
 
 // exact mode: the first thread also files this rank's ITERATION RECORD -- an event with gid -1 carrying the lightning request it
 // collected (px_light, then cleared) and the real deposit at the domain's texel (0,0) (what the 600-iteration count reads on top of
-// the inactive count, app.js:5957-5966; NULL on ranks that do not own global column 0)
+// the inactive count, app.js:5957-5966; NULL on ranks that do not own global column 0). The record has a FIXED place, entry 0 -- the
+// host starts the entry counter at 1 in these modes (pool_events_pack_mode) --, so that its readers (k_pool_exact_resolve every
+// iteration, k_pool_lightning_latest every period: one thread each, on the critical path) look at one location instead of scanning up
+// to 64 K entries per rank for it, and so that an overflowing rank can never lose it
 __global__ void k_pool_events_pack(int n, int rank, int cap, unsigned short *__restrict__ flips, unsigned char *__restrict__ owned_once,
                                    const float *__restrict__ drops, int *__restrict__ hdr, PoolEvent *__restrict__ ev, DevState *st, int exact,
                                    const float3 *__restrict__ fb00)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (exact && i == 0) { // exact: 1 = the iteration record (lightning REQUEST), 2 = the period record (this rank's lightning STATE)
-    const int at = atomicAdd(hdr, 1);
-    if (at < cap) {
-      PoolEvent e;
-      e.gid = -1;
-      e.key = rank;
-      for (int c = 0; c < 4; c++) e.rec[c] = exact == 1 ? st->px_light[c] : st->lightning[c];
-      e.rec[4] = fb00 ? fb00->x : 0.f;
-      e.pad = 0;
-      ev[at] = e;
-    }
+    PoolEvent e;
+    e.gid = -1;
+    e.key = rank;
+    for (int c = 0; c < 4; c++) e.rec[c] = exact == 1 ? st->px_light[c] : st->lightning[c];
+    e.rec[4] = fb00 ? fb00->x : 0.f;
+    e.pad = 0;
+    ev[0] = e; // (entry 0 is reserved: the counter started at 1)
     if (exact == 1) st->px_light[0] = st->px_light[1] = st->px_light[2] = st->px_light[3] = 0.f;
   }
   if (i >= n) return;
@@ -1164,13 +1164,10 @@ __global__ void k_pool_exact_resolve(int n_ranks, size_t stride_bytes, int cap, 
   for (int r = 0; r < n_ranks; r++) { // (rank order: a fixed summation order)
     const int *hdr = reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
     const PoolEvent *ev = reinterpret_cast<const PoolEvent *>(bufs + (size_t)r * stride_bytes + POOL_HDR);
-    const int cnt = min(hdr[0], cap);
-    for (int k = 0; k < cnt; k++)
-      if (ev[k].gid < 0) {
-        for (int c = 0; c < 4; c++) n[c] += ev[k].rec[c];
-        fb00 += ev[k].rec[4];
-        break;
-      }
+    if (min(hdr[0], cap) >= 1 && ev[0].gid < 0) { // the iteration record: entry 0 (k_pool_events_pack)
+      for (int c = 0; c < 4; c++) n[c] += ev[0].rec[c];
+      fb00 += ev[0].rec[4];
+    }
   }
   if (refresh) st->inactiveDroplets = fb00 + (st->px_count - (float)retired[0]);
   st->px_count = 0.f;
@@ -1187,15 +1184,10 @@ __global__ void k_pool_lightning_latest(int n_ranks, size_t stride_bytes, int ca
   for (int r = 0; r < n_ranks; r++) {
     const int *hdr = reinterpret_cast<const int *>(bufs + (size_t)r * stride_bytes);
     const PoolEvent *ev = reinterpret_cast<const PoolEvent *>(bufs + (size_t)r * stride_bytes + POOL_HDR);
-    const int cnt = min(hdr[0], cap);
-    for (int k = 0; k < cnt; k++)
-      if (ev[k].gid < 0) {
-        if (ev[k].rec[2] > 0.f && (!have || ev[k].rec[2] > best[2])) {
-          for (int c = 0; c < 4; c++) best[c] = ev[k].rec[c];
-          have = true;
-        }
-        break;
-      }
+    if (min(hdr[0], cap) >= 1 && ev[0].gid < 0 && ev[0].rec[2] > 0.f && (!have || ev[0].rec[2] > best[2])) { // the period record: entry 0
+      for (int c = 0; c < 4; c++) best[c] = ev[0].rec[c];
+      have = true;
+    }
   }
   if (have)
     for (int c = 0; c < 4; c++) st->lightning[c] = best[c];

@@ -22,6 +22,12 @@
 #ifndef WX_MARCH_BANDS
 #define WX_MARCH_BANDS 1
 #endif
+#ifndef WX_MARCH_BAND_SEG_MIN
+#define WX_MARCH_BAND_SEG_MIN 8 // (3 warm-up rows per segment: 27 % redundant steps at 8 rows)
+#endif
+#ifndef WX_MARCH_FILL
+#define WX_MARCH_FILL 1.0 // waves the whole-width launch should hold, in units of the chip's wave slots (grids that fall short get shorter segments)
+#endif
 #ifndef WX_MARCH_BAND_SEG
 #define WX_MARCH_BAND_SEG 24 // (32768x4096, interleaved: 24-row band segments + tail 0.941-0.943 ms, 32-row 0.953, equal 32-row segments 0.954)
 #endif
@@ -350,8 +356,22 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
   int n_seg = (g.Y + seg_rows - 1) / seg_rows, n_full = n_seg, n_half = 0, band_h = 0;
   if (WX_MARCH_XCD && WX_MARCH_BANDS && !wx_tune_env("WX_MARCH_NOTAIL") && !wx_tune_env("WX_MARCH_SEG") && g.Y % 8 == 0) {
     int R = WX_MARCH_BAND_SEG;
-    if (const char *e = wx_tune_env("WX_MARCH_BAND_SEG")) R = atoi(e) >= 16 ? atoi(e) : R;
-    const int bh = g.Y / 8, tail = R / 2 + R / 4;
+    const int bh = g.Y / 8;
+    // Grids whose 24-row band segments do not fill the chip (4096 x 1024 -- BASELINE configs[1] -- is 69 strips x 56 segments = 3 864 waves
+    // for 5 120 slots): shorter unit segments, so that the whole-width launch holds at least one wave per slot -- a wave's row steps are
+    // serial, and a state that fits the 256 MB memory-side cache is latency-bound, not bandwidth-bound (round 5; the wet kernel has had
+    // the same rule since round 4, wet_launch_shape). Per band: bh / R full segments + the 1/2 + 1/4 tail ~ bh / R + 1.25 segments.
+    {
+      double fill = WX_MARCH_FILL;
+      if (const char *e = wx_tune_env("WX_MARCH_FILL")) fill = atof(e) > 0.0 ? atof(e) : fill;
+      const double per_band = (double)march_capacity() / (8.0 * n_strips_all) * fill;
+      if (per_band > 1.25 + 1.0) {
+        const int r_fill = (int)((double)bh / (per_band - 1.25));
+        if (r_fill < R) R = r_fill < WX_MARCH_BAND_SEG_MIN ? WX_MARCH_BAND_SEG_MIN : (r_fill & ~3);
+      }
+    }
+    if (const char *e = wx_tune_env("WX_MARCH_BAND_SEG")) R = atoi(e) >= 4 ? atoi(e) : R;
+    const int tail = R / 2 + R / 4;
     if (bh >= 3 * R) { // tall enough for at least two full segments and the tail per band
       band_h = bh;
       seg_rows = R;

@@ -593,6 +593,17 @@ static void light_to_rgba(wx_sim *s)
   s->light_planar = false;
 }
 
+// The stream EVERYTHING of a halo / droplet-pool exchange runs on (pack, transfers, unpack, the pool kernels): the handle's comm stream --
+// whoever created it, the library or the host (wx_set_comm_stream) -- unless the exchange has to stay in order with the iterations:
+// the exact particle mode (its per-iteration rounds need the finished iteration and are needed by the next one) and
+// WX_OPT_EXCHANGE_OVERLAP 0. One function, so that no two pieces of an exchange can ever disagree about their stream (with a
+// host-supplied comm stream and WX_OPT_POOL_EXACT the pool kernels ran on the compute stream and the transfers on the comm stream, unfenced).
+static hipStream_t exchange_stream(const wx_sim *s)
+{
+  const bool in_order = (s->pool_remote && s->pool_exact) || s->exchange_in_order;
+  return (s->comm_stream && !in_order) ? s->comm_stream : s->stream;
+}
+
 // the compute stream may not touch ghost columns before the comm stream has written them
 static void wait_unpacked(wx_sim *s)
 {
@@ -1853,6 +1864,7 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
   DeviceScope dev_scope(s);
   if (field == WX_FIELD_LIGHTNING) {
     if (dtype != WX_DTYPE_F32 || x != 0 || y != 0 || w != 1 || h != 1) return fail(s, WX_E_RANGE, "lightning data is a 1x1 f32 texture");
+    wait_unpacked(s); // (the per-period pool exchange writes the strike on the side stream: k_pool_lightning_latest)
     HIPCHK(s, hipMemcpyAsync(dst, s->state->lightning, 16, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return WX_OK;
@@ -2009,8 +2021,8 @@ int wx_set_comm_stream(wx_sim *s, void *hip_stream)
 void *wx_device_ptr(wx_sim *s, int field)
 {
   if (!s) return nullptr;
+  wait_unpacked(s); // whatever the caller enqueues on the compute stream next sees the unpacked ghost columns (and the exchanged lightning state)
   if (field == WX_FIELD_LIGHTNING) return s->state->lightning;
-  wait_unpacked(s); // whatever the caller enqueues on the compute stream next sees the unpacked ghost columns
   if (field == WX_FIELD_EMITTED) return emitted_rect(s, 0, 0, s->X, s->Y) == WX_OK ? s->emitted : nullptr; // (whole grid, computed now)
   const void *ptr;
   int ch, el;
@@ -2056,14 +2068,13 @@ static int halo_pack_impl(wx_sim *s, void *const dev_buf[2])
   const LightPlanes none{nullptr, nullptr, nullptr};
   HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
              s->pool_remote ? s->fb : nullptr, s->pool_remote ? s->dep : nullptr};
-  hipStream_t st = s->stream;
-  if (s->comm_stream) { // the packed columns are final behind ev_edges (or, without an edge-first step, behind everything enqueued so far)
+  hipStream_t st = exchange_stream(s);
+  if (st != s->stream) { // the packed columns are final behind ev_edges (or, without an edge-first step, behind everything enqueued so far)
     if (!s->edges_recorded) {
       HIPCHK(s, hipEventRecord(s->ev_edges, s->stream));
       s->edges_recorded = true;
     }
-    HIPCHK(s, hipStreamWaitEvent(s->comm_stream, s->ev_edges, 0));
-    st = s->comm_stream;
+    HIPCHK(s, hipStreamWaitEvent(st, s->ev_edges, 0));
   }
   ProfScope ps(s, K_HALO);
   int slots = 0;
@@ -2080,15 +2091,15 @@ static int halo_unpack_impl(wx_sim *s, void *const dev_buf[2])
   const LightPlanes none{nullptr, nullptr, nullptr};
   HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
              s->pool_remote ? s->fb : nullptr, s->pool_remote ? s->dep : nullptr};
-  hipStream_t st = s->comm_stream ? s->comm_stream : s->stream;
+  hipStream_t st = exchange_stream(s);
   ProfScope ps(s, K_HALO);
   int slots = 0;
   const HaloBufs hb = halo_bufs(s, dev_buf, false, &slots);
   hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256, slots), dim3(256), 0, st, f, s->X, s->Y, s->halo, hb,
                      s->water_trivial ? &s->state->ghost_nontrivial : nullptr);
   if (s->water_trivial) s->ghost_check = true;
-  if (s->comm_stream) { // whoever touches the ghost columns next on the compute stream waits for this
-    HIPCHK(s, hipEventRecord(s->ev_unpacked, s->comm_stream));
+  if (st != s->stream) { // whoever touches the ghost columns next on the compute stream waits for this
+    HIPCHK(s, hipEventRecord(s->ev_unpacked, st));
     s->unpack_pending = true;
   }
   if (s->pool_remote) { // the ghost tiles of the feedback texture now hold a neighbour's values: nothing is "known zero" any more
@@ -2144,7 +2155,7 @@ size_t wx_pool_edge_bytes(const wx_sim *s) { return s && s->pool_remote ? POOL_H
 // The stream the droplet-pool exchange kernels run on: the side stream when the handle has one (they then overlap with the interior
 // strips of the next iteration, like the grid halos), the compute stream otherwise and always in the exact mode (whose per-iteration
 // rounds need the finished iteration and are needed by the next one).
-static hipStream_t pool_stream(const wx_sim *s) { return s->comm_stream && !s->pool_exact ? s->comm_stream : s->stream; }
+static hipStream_t pool_stream(const wx_sim *s) { return exchange_stream(s); }
 // side stream: the pool kernels read what the iterations enqueued so far leave behind
 static int pool_fence(wx_sim *s, hipStream_t st)
 {
@@ -2183,7 +2194,9 @@ static int pool_events_pack_mode(wx_sim *s, void *dev_buf, int mode)
 {
   hipStream_t st = pool_stream(s);
   if (int rc = pool_fence(s, st)) return rc;
-  HIPCHK(s, hipMemsetAsync(dev_buf, 0, POOL_HDR, st));
+  // the header: entry counter (+ 3 spare words). With an iteration / period record (mode != 0) entry 0 is the record's and the counter
+  // starts at 1 (k_pool_events_pack)
+  HIPCHK(s, hipMemsetD32Async((hipDeviceptr_t)dev_buf, mode != 0 ? 1 : 0, POOL_HDR / 4, st));
   // (exact mode: + this rank's iteration record; the deposit at the domain's texel (0,0) comes from the rank that owns global column 0)
   hipLaunchKernelGGL(k_pool_events_pack, dim3((s->n_drops + 255) / 256), dim3(256), 0, st, s->n_drops, s->rank, s->pool_event_cap, s->pool_flips, s->pool_owned,
                      s->drops[0], (int *)dev_buf, (PoolEvent *)((char *)dev_buf + POOL_HDR), s->state, mode,

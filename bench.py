@@ -8,8 +8,10 @@ produced once per 10 iterations (`--frame 1` = every iteration, round 1's defini
 a seeded velocity field (sigma = 0.2 cells / iteration, `--flow`) is added on the device before the warm-up, so back-traces leave
 the lane's own cell; the figure for the still start state is reported next to it (`at_rest`).
 For N > 1 the same grid is cut into N column slabs (strong scaling) with a ring halo exchange over RCCL, overlapped with compute
-on a side stream; `--workload dry --X 32768 --Y 4096` runs BASELINE's north-star stencil the same way. `--verify` makes an N-rank run
-self-validating: every rank checksums its owned columns and rank 0 compares them with an undecomposed run of the same state.
+on a side stream; `--workload dry --X 32768 --Y 4096` runs BASELINE's north-star stencil the same way. Typed without a launcher
+(`python bench.py --gpus 8`: no WORLD_SIZE in the environment) the script re-executes itself under `torch.distributed.run`, one rank
+per GPU. An N-rank grid run is self-validating by default (`--no-verify` switches it off): every rank checksums its owned columns and
+rank 0 compares them with an undecomposed run of the same state (`"verify": "ok"`, `ranks_seen`, `transport` in the line).
 Prints one JSON line on rank 0 (contract in the task description): throughput with inputs resident in HBM, plus `roofline`
 (dominant kernel, HIP-event timed on the engine's stream), `cpu_baseline` (the CPU oracle timed on this box's host cores, N = 1 only),
 `hbm_ceiling` (tools/ubench_hbm: read / write / copy streams with the kernels' own access pattern) and `north_star_dry` (N = 1 only):
@@ -65,10 +67,28 @@ def parse():
     ap.add_argument("--no-north-star", action="store_true", help="skip the 32768 x 4096 dry north-star measurement (N=1)")
     ap.add_argument("--no-extras", action="store_true", help="skip at_rest / frame-1 / hbm_ceiling side measurements (N=1)")
     ap.add_argument("--tune", type=int, default=20, help="wx_tune_placement: further device allocations to try for the handle's planes (0: keep the first)")
-    ap.add_argument("--verify", action="store_true", help="N > 1: checksum every rank's owned columns against an undecomposed run on rank 0")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=True,
+                    help="N > 1, grid only (default ON): checksum every rank's owned columns against an undecomposed run of the same state on rank 0")
+    ap.add_argument("--no-verify", dest="verify", action="store_false", help="N > 1: skip the self-validation of the decomposed run")
     a = ap.parse_args()
     a.frame = max(1, a.frame)  # (0 or a negative value would never advance run_frames)
     return a
+
+
+def reference_cpu_path():
+    """the reference itself (its shaders under HeadlessChrome + SwiftShader, the `kaleido` pip package, driven by
+    oracle/golden/harness.js) is the preferred CPU baseline IF it can run on this box. It needs three things, none of which is part of
+    this repository's snapshot: the kaleido package, the reference checkout (its shader files are loaded at run time and may not
+    travel) and the harness next to it. Probe and say what is there; the timing itself is `oracle/golden/gen_golden.py save100raw`
+    (2.0-2.2 Mcell-steps/s at 100 x 100 on 8 vCPU in the build container)."""
+    import importlib.util
+    have_kaleido = importlib.util.find_spec("kaleido") is not None
+    have_ref = os.path.isdir("/root/reference/shaders")
+    have_harness = os.path.exists(os.path.join(ROOT, "oracle", "golden", "harness.js"))
+    if have_kaleido and have_ref and have_harness:
+        return "present (kaleido + /root/reference + harness): time it with oracle/golden/gen_golden.py; not run inside the bench"
+    missing = [n for n, ok in (("kaleido package", have_kaleido), ("/root/reference checkout", have_ref), ("oracle/golden/harness.js", have_harness)) if not ok]
+    return "absent on this box (missing: " + ", ".join(missing) + ")"
 
 
 def cpu_baseline(pkg, budget_s=12.0):
@@ -94,7 +114,7 @@ def cpu_baseline(pkg, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 2000:
             break
-    return {"value": X * Y * n / dt / 1e6, "unit": "Mcell-steps/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": X * Y * n / dt / 1e6, "unit": "Mcell-steps/s", "cores": os.cpu_count(), "kind": "port", "reference_cpu_path": reference_cpu_path(),
             "sample": f"CPU oracle (C/OpenMP restatement, not the reference itself), {X}x{Y} terrain grid, {n} iterations, {dt:.1f} s"}
 
 
@@ -297,6 +317,7 @@ def other_configs(a, pkg):
     dry, SURVEY 8d C2: 200 warm-up + 1000 timed) and configs[4] on one GPU (16384 x 2048 + 1 048 576 droplets over a cloud deck,
     200 iterations of spin-up, 200 timed; SURVEY's C5 protocol -- 2000 + 1000 -- is `bench.py --particles 1048576 --warmup 2000 --steps 1000`)."""
     import numpy as np
+    from weather_sandbox_amd import devtools
     out = {}
     # configs[0]
     g = np.load(os.path.join(ROOT, "tests", "golden", "save100raw.npz"))
@@ -312,6 +333,19 @@ def other_configs(a, pkg):
     out["c0_save100x100_1000_iterations"] = dict(measure_handle(h, X * Y, 1000, 100, a.frame), note="launch-bound (two launches per iteration); the reference "
                                                  "under SwiftShader on 8 vCPU: 2.0-2.2 Mcell-steps/s (BASELINE.md)")
     h.close()
+    # the reference's OWN grid sizes: a new simulation is 2500 x 300 by default and the resolution sliders end at 16000 x 500
+    # (/root/reference/index.html:325, 335); its frame is IterPerFrame = 10 iterations (app.js:398). Full wet iteration, setup-pass terrain.
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 50.0
+    for X, Y, name in ((2500, 300, "ref_default_2500x300"), (16000, 500, "ref_largest_16000x500")):
+        ur = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+        ur["enablePrecipitation"] = 0
+        h = pkg.engine.Handle(X, Y, 0)
+        h.setup_columns(pkg.synth.terrain_columns(X, Y))
+        h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), ur), ur["initial_T"])
+        devtools.seed_flow(h, a.flow if a.flow > 0 else 0.2, kind=a.flow_kind)
+        out[name] = dict(measure_handle(h, X * Y, 1000, 100, a.frame), note="the reference's own grid size, all six grid passes + lighting, particles off, moving fluid")
+        h.close()
     # configs[1]
     X, Y = 4096, 1024
     gui = pkg.params.merge_settings(None)
@@ -364,8 +398,33 @@ def p2p_selftest(dist, torch, rank, world, device):
         raise RuntimeError(f"rank {rank}: P2P self-test received {got} from ranks ({left}, {right})")
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): re-execute this script under
+    `torch.distributed.run`, one rank per GPU, rendezvous on 127.0.0.1 (the container's hostname may not resolve) -- the command the
+    driver types for N > 1, typed for it. Returns only if there is nothing to launch."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < a.gpus and not os.environ.get("WX_BENCH_SHARE_GPU"):
+        print(json.dumps({"error": f"--gpus {a.gpus} asked, {have} HIP device(s) visible on this box", "n_gpus": a.gpus, "devices_visible": have}), flush=True)
+        sys.exit(2)
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:  # a free port
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     a = parse()
+    self_launch(a)
     import numpy as np
     import torch
     import wxpkg
@@ -438,22 +497,24 @@ def main():
         x0_owned = slab.slab_columns(X, rank, world)[0]
         step, sync, barrier = drv.step, (lambda: (drv.sync(), torch.cuda.synchronize())), dist.barrier
 
+    # Where the planes lie in physical memory is worth several % (profiles/r03_alloc_probe.txt): the engine tries a few
+    # allocations with its own iteration and keeps the fastest -- set-up work, like the allocation itself; the state is unchanged. Done
+    # FIRST, so that every figure of this line (at_rest, the headline, frame_1) is measured on the SAME, kept placement.
+    placement = None
+    if a.tune > 0 and not (world > 1 and a.particles):
+        ms0, ms1 = stepper.tune_placement(a.tune, 30)
+        placement = {"tries": a.tune, "ms_per_iteration_first_allocation": ms0, "ms_per_iteration_kept": ms1,
+                     "applies_to": "value, at_rest and frame_1 (all measured after the search, on the kept placement)"}
     at_rest = None
     if world == 1 and a.flow > 0 and not a.no_extras and not a.particles:  # the still start state first (round 2's definition)
         run_frames(step, a.warmup, a.frame)
         condition_clocks(step, sync, a.frame)
         dt0, _ = timed_run(stepper, a.steps, a.frame, profile=False)
         at_rest = {"value": X * Y * a.steps / dt0 / 1e6, "ms_per_step": dt0 / a.steps * 1e3, "flow": devtools.flow_stats(stepper),
-                   "state": "still start state (what round 2 timed)"}
+                   "state": "still start state (what round 2 timed)", "placement": "the kept one (same as value)"}
     if a.flow > 0:  # a moving fluid: identical on slabs and on the undecomposed grid (function of the global cell index)
         devtools.seed_flow(stepper, a.flow, Xg=X, x0=x0_owned, kind=a.flow_kind)
     flow0 = devtools.flow_stats(stepper)
-    placement = None
-    if a.tune > 0 and not (world > 1 and a.particles):
-        # where the planes lie in physical memory is worth several % (profiles/r03_alloc_probe.txt): let the engine try a
-        # few allocations with its own iteration and keep the fastest -- set-up work, like the allocation itself; the state is unchanged
-        ms0, ms1 = stepper.tune_placement(a.tune, 30)
-        placement = {"tries": a.tune, "ms_per_iteration_first_allocation": ms0, "ms_per_iteration_kept": ms1}
 
     run_frames(step, a.warmup, a.frame)
     # the --warmup iterations above are the contract's; the clocks are conditioned by TIME on top of them (condition_clocks), so that a
@@ -488,7 +549,7 @@ def main():
     stepper.profile(False)
     prof_steps = a.steps if profile_inline else 16
     flow1 = devtools.flow_stats(stepper)
-    verify = "n/a (single rank)" if world == 1 else "not requested"
+    verify = "n/a (single rank)" if world == 1 else "off (--no-verify)"
     # largest |velocity component| the exact path of the wet kernel saw during the run (0: nothing reached 0.9 cells / iteration). On
     # slabs the halo width assumes |v| < 1: a larger value means the decomposed run may differ from the undecomposed one near slab edges
     fastest = stepper.fastest_velocity() if a.workload == "wet" else 0.0
@@ -594,7 +655,7 @@ def main():
         if world == 1 and not a.no_extras and a.frame != 1 and not a.particles:
             condition_clocks(lambda k: run_frames(stepper.step, k, 1), sync, a.frame)
             dt1, _ = timed_run(stepper, a.steps, 1, profile=False)  # round 1's definition: the display fields after EVERY iteration
-            out["frame_1"] = {"value": cells * a.steps / dt1 / 1e6, "ms_per_step": dt1 / a.steps * 1e3}
+            out["frame_1"] = {"value": cells * a.steps / dt1 / 1e6, "ms_per_step": dt1 / a.steps * 1e3, "placement": "the kept one (same as value)"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg)
         if world == 1 and not a.no_extras:

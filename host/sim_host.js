@@ -456,17 +456,33 @@ module.exports = {WeatherSim: WeatherSim, initialSimDateTime: initialSimDateTime
                   FIELD: FIELD};
 
 if (require.main === module) {
-  const args = process.argv.slice(2);
-  const flags = args.filter(function(a) { return a.startsWith('--'); });
-  const pos = args.filter(function(a) { return !a.startsWith('--'); });
+  // flags anywhere on the line; the value-taking ones as `--gpus 4` or `--gpus=4` (their values are NOT positional arguments)
+  const VALUED = {'--gpus': 1, '--halo': 1, '--transport': 1};
+  const flags = [], pos = [], opt = {};
+  for (let i = 2; i < process.argv.length; i++) {
+    const a = process.argv[i];
+    if (!a.startsWith('--')) { pos.push(a); continue; }
+    const eq = a.indexOf('=');
+    const name = eq >= 0 ? a.slice(0, eq) : a;
+    if (VALUED[name]) {
+      const v = eq >= 0 ? a.slice(eq + 1) : process.argv[++i];
+      if (v === undefined || v === '') { console.error(name + ' needs a value'); process.exit(2); }
+      opt[name] = v;
+    } else flags.push(name);
+  }
   if (pos.length < 2) {
     console.error('usage: node sim_host.js <in.weathersandbox> <iterations> [out.weathersandbox] [--sun-fixed] [--splat-order] [--gpus N [--halo H] [--transport rccl|local] [--exact]]');
     process.exit(2);
   }
   const sf = loadSave(pos[0]);
-  const num = function(flag, dflt) { const i = args.indexOf(flag); return i >= 0 ? parseInt(args[i + 1], 10) : dflt; };
-  const tr = args.indexOf('--transport') >= 0 ? args[args.indexOf('--transport') + 1] : 'auto';
-  const sim = new WeatherSim(sf, {sunFixed: flags.indexOf('--sun-fixed') >= 0, gpus: num('--gpus', 1), halo: args.indexOf('--halo') >= 0 ? num('--halo', 42) : null,
+  const num = function(flag, dflt) {
+    if (opt[flag] === undefined) return dflt;
+    const v = parseInt(opt[flag], 10);
+    if (!(v === v)) { console.error(flag + ': not a number: ' + opt[flag]); process.exit(2); }
+    return v;
+  };
+  const tr = opt['--transport'] !== undefined ? opt['--transport'] : 'auto';
+  const sim = new WeatherSim(sf, {sunFixed: flags.indexOf('--sun-fixed') >= 0, gpus: num('--gpus', 1), halo: opt['--halo'] !== undefined ? num('--halo', 42) : null,
                                   transport: tr == 'rccl' ? 1 : tr == 'local' ? 2 : 0});
   if (flags.indexOf('--splat-order') >= 0) sim.setOption(1, 1); // WX_OPT_SPLAT_ORDER: deterministic particle splats
   if (flags.indexOf('--exact') >= 0 && sim.slabs && sim.nDroplets) sim.setOption(7, 1); // WX_OPT_POOL_EXACT: slabs with particles == one handle, exactly

@@ -75,14 +75,23 @@ static napi_value throw_wx(napi_env env, wx_sim *s, int rc, const char *what)
 
 /* what the external wraps: the C handle plus the dimensions the array arguments are checked against. wx_sim * stays the
  * first member, so a slot pointer also reads as wx_sim ** */
-typedef struct {
+struct wx_gslot;
+typedef struct wx_slot {
   wx_sim *s;
   int32_t X, Y, N;
   int32_t borrowed; /* a slab of a group: the group destroys it */
+  /* borrowed slots: the group they belong to (NULL once it is gone), their link in its list, and a strong reference to the group's
+   * external -- a slab handle JS still holds keeps its group alive, and destroying the group turns every slab handle it lent out
+   * into a dead one ("expected a simulation handle") instead of a dangling pointer */
+  struct wx_gslot *group;
+  struct wx_slot *next_in_group;
+  napi_ref group_ref;
 } wx_slot;
-typedef struct {
+typedef struct wx_gslot {
   wx_group *g;
   int32_t N; /* droplets of the pool every slab holds */
+  int32_t Y; /* grid height, as given to groupCreate: what the slabs' array arguments are checked against */
+  wx_slot *slabs; /* the slab handles lent out (groupSlab) */
 } wx_gslot;
 
 static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv)
@@ -102,6 +111,7 @@ static wx_sim *get_handle(napi_env env, napi_value v)
     napi_throw_type_error(env, NULL, "expected a simulation handle");
     return NULL;
   }
+  if (!*(wx_sim **)p) napi_throw_type_error(env, NULL, "the simulation handle was destroyed (or the slab group it belonged to)");
   return *(wx_sim **)p;
 }
 static wx_slot *get_slot(napi_env env, napi_value v)
@@ -142,6 +152,14 @@ static void finalize_handle(napi_env env, void *data, void *hint)
 {
   wx_slot *slot = (wx_slot *)data;
   if (slot->s && !slot->borrowed) L.destroy(slot->s);
+  if (slot->borrowed) {
+    if (slot->group) { /* leave the group's list */
+      wx_slot **pp = &slot->group->slabs;
+      while (*pp && *pp != slot) pp = &(*pp)->next_in_group;
+      if (*pp) *pp = slot->next_in_group;
+    }
+    if (slot->group_ref) napi_delete_reference(env, slot->group_ref);
+  }
   free(slot);
 }
 
@@ -173,6 +191,9 @@ static napi_value Create(napi_env env, napi_callback_info info)
   slot->Y = Y;
   slot->N = N;
   slot->borrowed = 0;
+  slot->group = NULL;
+  slot->next_in_group = NULL;
+  slot->group_ref = NULL;
   napi_value ext;
   NAPI_CALL(env, napi_create_external(env, slot, finalize_handle, NULL, &ext));
   return ext;
@@ -549,9 +570,22 @@ static napi_value StreamWait(napi_env env, napi_callback_info info)
 }
 
 /* ---- the decomposed domain: N column slabs in this process (wx_group_*, include/wxsim.h) ---- */
+/* the group is going away: every slab handle it lent out becomes a dead handle */
+static void orphan_slabs(wx_gslot *gs)
+{
+  for (wx_slot *sl = gs->slabs; sl;) {
+    wx_slot *next = sl->next_in_group;
+    sl->s = NULL;
+    sl->group = NULL;
+    sl->next_in_group = NULL;
+    sl = next;
+  }
+  gs->slabs = NULL;
+}
 static void finalize_group(napi_env env, void *data, void *hint)
 {
   wx_gslot *gs = (wx_gslot *)data;
+  orphan_slabs(gs);
   if (gs->g) L.group_destroy(gs->g);
   free(gs);
 }
@@ -589,20 +623,23 @@ static napi_value GroupCreate(napi_env env, napi_callback_info info)
   wx_gslot *gs = (wx_gslot *)malloc(sizeof(*gs));
   gs->g = g;
   gs->N = v[5];
+  gs->Y = v[2];
+  gs->slabs = NULL;
   napi_value ext;
   NAPI_CALL(env, napi_create_external(env, gs, finalize_group, NULL, &ext));
   return ext;
 }
-/* groupSlab(group, i) -> handle of slab i, usable with upload / setParams / readRect ... (owned by the group) */
+/* groupSlab(group, i) -> handle of slab i, usable with upload / setParams / readRect ... (owned by the group; dead once the group is
+ * destroyed). The grid height its array arguments are checked against is the one groupCreate was given -- a third argument, which
+ * earlier versions took as Y, is ignored. */
 static napi_value GroupSlab(napi_env env, napi_callback_info info)
 {
   napi_value a[3];
-  if (get_args(env, info, 3, a)) return NULL;
+  if (get_args(env, info, 2, a)) return NULL;
   wx_gslot *gs = get_group(env, a[0]);
   if (!gs) return NULL;
-  int32_t i, Y;
+  int32_t i;
   NAPI_CALL(env, napi_get_value_int32(env, a[1], &i));
-  NAPI_CALL(env, napi_get_value_int32(env, a[2], &Y));
   wx_sim *s = L.group_slab(gs->g, i);
   if (!s) {
     napi_throw_range_error(env, NULL, "groupSlab: no such slab");
@@ -611,11 +648,23 @@ static napi_value GroupSlab(napi_env env, napi_callback_info info)
   wx_slot *slot = (wx_slot *)malloc(sizeof(*slot));
   slot->s = s;
   slot->X = L.local_width(s);
-  slot->Y = Y;
+  slot->Y = gs->Y;
   slot->N = gs->N;
   slot->borrowed = 1;
+  slot->group = NULL;
+  slot->next_in_group = NULL;
+  slot->group_ref = NULL;
   napi_value ext;
-  NAPI_CALL(env, napi_create_external(env, slot, finalize_handle, NULL, &ext));
+  if (napi_create_external(env, slot, finalize_handle, NULL, &ext) != napi_ok) {
+    free(slot);
+    napi_throw_error(env, NULL, "groupSlab: napi_create_external failed");
+    return NULL;
+  }
+  /* from here on the finalizer owns the slot */
+  if (napi_create_reference(env, a[0], 1, &slot->group_ref) != napi_ok) slot->group_ref = NULL;
+  slot->group = gs;
+  slot->next_in_group = gs->slabs;
+  gs->slabs = slot;
   return ext;
 }
 static napi_value GroupInfo(napi_env env, napi_callback_info info)
@@ -709,6 +758,7 @@ static napi_value GroupDestroy(napi_env env, napi_callback_info info)
   if (get_args(env, info, 1, a)) return NULL;
   void *p = NULL;
   if (napi_get_value_external(env, a[0], &p) == napi_ok && p && ((wx_gslot *)p)->g) {
+    orphan_slabs((wx_gslot *)p);
     L.group_destroy(((wx_gslot *)p)->g);
     ((wx_gslot *)p)->g = NULL;
   }
