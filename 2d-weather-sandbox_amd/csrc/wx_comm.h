@@ -74,7 +74,8 @@ static const char *rccl_missing() { return "RCCL is not available in this proces
     if (r_ != ncclSuccess) return fail((s), WX_E_DEVICE, "%s: %s", #expr, rccl_api()->GetErrorString(r_));          \
   } while (0)
 
-static int iters_per_exchange(const wx_sim *s) { return s->pool_remote ? std::max(1, WX_SLAB_PERIOD_PARTICLES(s->halo)) : std::max(1, s->halo / WX_SLAB_CONE); }
+// iterations per exchange under the |vx| bound the slabs currently agree on (wx_slab_period: halo / cone, cone = 6 + floor(bound))
+static int iters_per_exchange(const wx_sim *s) { return std::max(1, wx_slab_period(s)); }
 // the stream the exchange of a slab runs on (wxsim.hip: exchange_stream -- the comm stream unless the exchange must stay in order)
 static hipStream_t xstream(const wx_sim *s) { return exchange_stream(s); }
 // bytes per rank in the all-gather of status-flip events: a stride every rank knows without a host round trip inside the period
@@ -125,6 +126,20 @@ static int transport_prepare(wx_sim *s, int world)
     }
     s->ev_world = world;
   }
+  if (!s->vx_dev || s->vx_world != world) { // the slabs' measured |vx| maxima: one word each, all-gathered / copied with every exchange
+    hipFree(s->vx_dev);
+    if (s->vx_host) hipHostFree(s->vx_host);
+    s->vx_dev = nullptr;
+    s->vx_host = nullptr;
+    if (hipMalloc((void **)&s->vx_dev, sizeof(int) * (size_t)(1 + world)) != hipSuccess || hipHostMalloc((void **)&s->vx_host, sizeof(int) * 2 * (size_t)world, hipHostMallocDefault) != hipSuccess)
+      return fail(s, WX_E_NOMEM, "the |vx| words of the exchange");
+    memset(s->vx_host, 0, sizeof(int) * 2 * (size_t)world);
+    for (int i = 0; i < 2; i++)
+      if (!s->ev_vx[i]) HIPCHK(s, hipEventCreateWithFlags(&s->ev_vx[i], hipEventDisableTiming));
+    s->vx_have[0] = s->vx_have[1] = false;
+    s->vx_slot = 0;
+    s->vx_world = world;
+  }
   // the side stream of the exchange; the exact particle mode runs everything in order on the compute stream (wx_set_option may have
   // switched modes since the last call)
   const bool in_order = (s->pool_remote && s->pool_exact) || s->exchange_in_order;
@@ -157,6 +172,15 @@ void transport_release(wx_sim *s)
   hipFree(s->ev_mine);
   hipFree(s->ev_all);
   s->ev_mine = s->ev_all = nullptr;
+  hipFree(s->vx_dev);
+  s->vx_dev = nullptr;
+  if (s->vx_host) hipHostFree(s->vx_host);
+  s->vx_host = nullptr;
+  s->vx_world = 0;
+  for (int i = 0; i < 2; i++) {
+    if (s->ev_vx[i]) hipEventDestroy(s->ev_vx[i]);
+    s->ev_vx[i] = nullptr;
+  }
   if (s->ev_seen_host) hipHostFree(s->ev_seen_host);
   s->ev_seen_host = nullptr;
   if (s->ev_counted) hipEventDestroy(s->ev_counted);
@@ -292,6 +316,117 @@ static int pool_stride_update(Ring &R)
   return WX_OK;
 }
 
+// ---- slabs exact at any speed: the ring agrees on a |vx| bound per exchange period (include/wxsim.h, VxTrack in wx_tile.h) ----
+static float bits_to_float(int b)
+{
+  float v;
+  memcpy(&v, &b, 4);
+  return v;
+}
+// After an upload (or when a host wrote velocities through wx_device_ptr): every slab looks at its state, the ring takes the maximum.
+// The one place where the protocol waits for the device -- once per upload, before the first iteration.
+static int ring_vx_bootstrap(Ring &R)
+{
+  bool stale = false;
+  for (Party &q : R.p) stale = stale || q.s->vx_stale;
+  if (!stale) return WX_OK;
+  float v = 0.0f;
+  for (Party &q : R.p) {
+    DeviceScope ds(q.s);
+    float vi = 0.0f;
+    if (int rc = rpass(R, q.s, wx_slab_vx_take(q.s, &vi))) return rc;
+    v = std::max(v, vi);
+  }
+  if (R.transport == WX_TRANSPORT_RCCL && (int)R.p.size() < R.world) { // one rank per process: the other ranks' maxima
+    wx_sim *s = R.p[0].s;
+    DeviceScope ds(s);
+    RcclApi *a = rccl_api();
+    int bits;
+    memcpy(&bits, &v, 4);
+    std::vector<int> all((size_t)R.world, 0);
+    if (hipMemcpyAsync(s->vx_dev, &bits, 4, hipMemcpyHostToDevice, xstream(s)) != hipSuccess) return rfail(R, s, WX_E_DEVICE, "hipMemcpyAsync");
+    const ncclResult_t r = a->AllGather(s->vx_dev, s->vx_dev + 1, 1, ncclInt32, R.p[0].comm, xstream(s));
+    if (r != ncclSuccess) return rfail(R, s, WX_E_DEVICE, "ncclAllGather of the slabs' |vx|: %s", a->GetErrorString(r));
+    if (hipMemcpyAsync(all.data(), s->vx_dev + 1, 4 * (size_t)R.world, hipMemcpyDeviceToHost, xstream(s)) != hipSuccess || hipStreamSynchronize(xstream(s)) != hipSuccess)
+      return rfail(R, s, WX_E_DEVICE, "reading the slabs' |vx| back");
+    for (int b : all) v = std::max(v, bits_to_float(b));
+  }
+  for (Party &q : R.p) {
+    if (int rc = rpass(R, q.s, wx_slab_set_vx_bound(q.s, v))) return rc;
+    q.s->vx_have[0] = q.s->vx_have[1] = false;
+  }
+  return WX_OK;
+}
+// With every exchange: each slab's maximum of the period travels as one word (all-gathered over RCCL, or copied to the hosts' pinned
+// words where the slabs share a process), and the period that starts now is sized by the two LATEST COMPLETE measurements -- the rolls of
+// the previous exchanges, which finished a period ago: the host never waits for the device here.
+static int ring_vx_roll(Ring &R)
+{
+  wx_sim *s0 = R.p[0].s;
+  const bool rccl = R.transport == WX_TRANSPORT_RCCL;
+  const int slot = s0->vx_slot, prev = slot ^ 1, W = R.world;
+  // 1. the bound of the coming period, from what the earlier rolls left in the pinned words (read BEFORE the new roll overwrites `slot`)
+  float v = s0->vx_known;
+  if (s0->vx_have[prev]) {
+    v = 0.0f;
+    for (Party &q : R.p) {
+      wx_sim *s = q.s;
+      DeviceScope ds(s);
+      if (hipEventSynchronize(s->ev_vx[prev]) != hipSuccess) return rfail(R, s, WX_E_DEVICE, "waiting for the slabs' |vx| of the previous exchange");
+      for (int sl = 0; sl < 2; sl++) {
+        if (!s->vx_have[sl]) continue; // (the older roll too: a flow that slowed down for one period keeps its margin for one more)
+        if (rccl)
+          for (int r = 0; r < W; r++) v = std::max(v, bits_to_float(s->vx_host[sl * W + r]));
+        else
+          v = std::max(v, bits_to_float(s->vx_host[sl * W + q.rank]));
+      }
+    }
+  }
+  // 2. this exchange's roll
+  for (Party &q : R.p) {
+    wx_sim *s = q.s;
+    DeviceScope ds(s);
+    hipStream_t st = xstream(s);
+    if (s->vx_untracked) { // iterations of kernels that do not report their |vx|: look at the state they left
+      if (st != s->stream) { // (such kernels are never split: the exchange is behind the whole iteration)
+        if (!s->edges_recorded) {
+          if (hipEventRecord(s->ev_edges, s->stream) != hipSuccess) return rfail(R, s, WX_E_DEVICE, "hipEventRecord");
+          s->edges_recorded = true;
+        }
+        if (hipStreamWaitEvent(st, s->ev_edges, 0) != hipSuccess) return rfail(R, s, WX_E_DEVICE, "hipStreamWaitEvent");
+      }
+      vx_scan_enqueue(s, st);
+      s->vx_untracked = false;
+    }
+    hipLaunchKernelGGL(k_vx_roll, dim3(1), dim3(1), 0, st, s->state, s->vx_dev);
+  }
+  if (rccl) {
+    RcclApi *a = rccl_api();
+    if (a->GroupStart() != ncclSuccess) return rfail(R, nullptr, WX_E_DEVICE, "ncclGroupStart");
+    for (Party &q : R.p) {
+      DeviceScope ds(q.s);
+      const ncclResult_t r = a->AllGather(q.s->vx_dev, q.s->vx_dev + 1, 1, ncclInt32, q.comm, xstream(q.s));
+      if (r != ncclSuccess) {
+        a->GroupEnd();
+        return rfail(R, q.s, WX_E_DEVICE, "ncclAllGather of the slabs' |vx|: %s", a->GetErrorString(r));
+      }
+    }
+    if (a->GroupEnd() != ncclSuccess) return rfail(R, nullptr, WX_E_DEVICE, "ncclGroupEnd");
+  }
+  for (Party &q : R.p) {
+    wx_sim *s = q.s;
+    DeviceScope ds(s);
+    hipStream_t st = xstream(s);
+    const hipError_t e = rccl ? hipMemcpyAsync(s->vx_host + slot * W, s->vx_dev + 1, 4 * (size_t)W, hipMemcpyDeviceToHost, st)
+                              : hipMemcpyAsync(s->vx_host + slot * W + q.rank, s->vx_dev, 4, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess || hipEventRecord(s->ev_vx[slot], st) != hipSuccess) return rfail(R, s, WX_E_DEVICE, "copying the slabs' |vx| to the host");
+    s->vx_have[slot] = true;
+    s->vx_slot = prev;
+    if (int rc = rpass(R, s, wx_slab_set_vx_bound(s, v))) return rc;
+  }
+  return WX_OK;
+}
+
 // One exchange of every slab of the ring: my left edge -> the left neighbour's right ghosts, my right edge -> the right neighbour's left
 // ghosts; with particles also the droplet pool (status flips unless the exact mode already sent them, edge droplets in the same batch of
 // transfers as the grid halos).
@@ -309,6 +444,7 @@ static int ring_exchange(Ring &R)
     DeviceScope ds(q.s);
     if (int rc = rpass(R, q.s, wx_halo_pack_both(q.s, q.s->xsend[0], q.s->xsend[1]))) return rc; // (one launch: see HaloBufs)
   }
+  if (int rc = ring_vx_roll(R)) return rc; // the period that starts behind this exchange: how many ghost columns per iteration?
   if (particles && !R.p[0].s->pool_exact)
     if (int rc = pool_events_round(R, 2)) return rc;
   if (particles)
@@ -388,9 +524,15 @@ static int ring_step(Ring &R, int n_iter)
     }
     return WX_OK;
   }
-  const int ipe = iters_per_exchange(s0);
+  if (n_iter > 0)
+    if (int rc = ring_vx_bootstrap(R)) return rc;
   const bool particles = s0->pool_remote != nullptr, exact = particles && s0->pool_exact;
   for (int done = 0; done < n_iter;) {
+    const int ipe = iters_per_exchange(s0); // (the bound -- and with it the period -- is settled at every exchange)
+    if (s0->since_exchange >= ipe) { // (a bound that rose inside a period, through wx_slab_set_vx_bound: exchange first)
+      if (int rc = ring_exchange(R)) return rc;
+      continue;
+    }
     const int k = std::min(ipe - s0->since_exchange, n_iter - done);
     if (exact) { // one iteration at a time, each followed by the status flips / lightning requests of all slabs
       for (int it = 0; it < k; it++) {

@@ -351,7 +351,15 @@ struct DevState {
   int pool_retired;       // exact mode: droplets that ended the iteration inactive among this iteration's status flips (k_pool_events_apply)
   float mailbox_w;        // fourth channel of the feedback texture's texel (1,0) -- the only texel whose alpha the reference ever writes (the
                           // lightning request's fourth component): the texture itself is stored with three channels (lightning_update keeps it)
+  int vx_max_bits;        // float bits of the largest |vx| the marching kernels produced since the last roll (VxTrack, wx_tile.h; >= 0.5 only)
+  int cone_violation;     // float bits of a |vx| that reached the limit the current exchange period was sized for (slabs; 0: none)
 };
+// exchange time: this slab's measured maximum goes to `out` (one word; all-gathered / copied to the host by the transport), the
+// accumulator starts over. One thread.
+__global__ void k_vx_roll(DevState *st, int *__restrict__ out)
+{
+  out[0] = atomicExch(&st->vx_max_bits, 0);
+}
 
 // Splat accumulation: a 12x12 point sprite anchored at pixel (i0,j0) adds the same value to pixels
 // i0..i0+11 x j0..j0+11. Instead of 144 x 5 atomics per droplet the value is added ONCE at the anchor of a padded

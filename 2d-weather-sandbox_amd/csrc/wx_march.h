@@ -22,12 +22,6 @@
 #ifndef WX_MARCH_BANDS
 #define WX_MARCH_BANDS 1
 #endif
-#ifndef WX_MARCH_BAND_SEG_MIN
-#define WX_MARCH_BAND_SEG_MIN 8 // (3 warm-up rows per segment: 27 % redundant steps at 8 rows)
-#endif
-#ifndef WX_MARCH_FILL
-#define WX_MARCH_FILL 1.0 // waves the whole-width launch should hold, in units of the chip's wave slots (grids that fall short get shorter segments)
-#endif
 #ifndef WX_MARCH_BAND_SEG
 #define WX_MARCH_BAND_SEG 24 // (32768x4096, interleaved: 24-row band segments + tail 0.941-0.943 ms, 32-row 0.953, equal 32-row segments 0.954)
 #endif
@@ -109,7 +103,7 @@ __device__ __forceinline__ void march_fence()
 // QUIET: no brush input, no airplane event in this iteration (see advection_cell)
 template <bool WRITE_DISP, bool WRITE_WALL, bool QUIET>
 __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni u_arg, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows,
-                                                                     int n_full, int n_half, int band_h, int n_seg, int strip_lo, int split_at, int strip_lo2
+                                                                     int n_full, int n_half, int band_h, int n_seg, int strip_lo, int split_at, int strip_lo2, StripOrder order, VxTrack vx
 #ifdef WX_MARCH_TIMING
                                                                      , unsigned long long *cycles
 #endif
@@ -136,10 +130,26 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
   // 128-byte lines they share (2 halo columns each side; 60-column strips are not line aligned) are fetched into ONE L2
   // instead of two. Measured FETCH_SIZE: 1.22x -> 1.00x of the bytes the strips need; 32768x4096: 1.39 -> 1.11 ms.
   const int total = n_strips * n_seg, k = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int first = (int)(((long long)k * total) >> 3), count = (int)(((long long)(k + 1) * total) >> 3) - first;
-  if (j >= count) return;
-  const int item = first + j, seg = item / n_strips, sidx = item - seg * n_strips;
-  const int strip = sidx < split_at ? strip_lo + sidx : strip_lo2 + (sidx - split_at); // (two strip ranges in one launch: the edges of a slab)
+  int seg, strip;
+  bool is_edge = false; // (a split iteration's edge strip: waits for the ghost columns / reports when it is done)
+  if (order.mode == 0 || order.mode == 3) {
+    const int first = (int)(((long long)k * total) >> 3), count = (int)(((long long)(k + 1) * total) >> 3) - first;
+    if (j >= count) return;
+    const int item = first + j;
+    seg = item / n_strips;
+    const int sidx = item - seg * n_strips;
+    strip = sidx < split_at ? strip_lo + sidx : strip_lo2 + (sidx - split_at); // (two strip ranges in one launch: the edges of a slab)
+    if (order.mode == 3) is_edge = strip < order.nl || strip >= order.nr0; // (a shape without row bands: the hand-offs without the dispatch order)
+  } else {
+    // One launch over ALL strips of a slab (row bands: n_seg is a multiple of 8 and XCD k owns the segments [k * n_seg / 8, (k + 1) * n_seg / 8)),
+    // the edge strips of all its segments first (or last) in the XCD's dispatch order (StripOrder, wx_tile.h)
+    const int spx = n_seg >> 3;
+    StripPick pk;
+    if (!strip_order_pick(order, 0, n_strips, spx, 1, 0, j, seg, pk)) return;
+    seg += k * spx;
+    strip = pk.strip;
+    is_edge = pk.is_edge;
+  }
 #else
   const int sidx = blockIdx.x % n_strips, seg = blockIdx.x / n_strips;
   const int strip = sidx < split_at ? strip_lo + sidx : strip_lo2 + (sidx - split_at);
@@ -156,11 +166,16 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     const int t1 = sl - n_full, t2 = t1 - n_half, h2 = seg_rows >> 1, h4 = seg_rows >> 2, y0 = bnd * band_h;
     y_lo = y0 + (t1 < 0 ? sl * seg_rows : (t2 < 0 ? n_full * seg_rows + t1 * h2 : n_full * seg_rows + n_half * h2 + t2 * h4));
     y_hi = min(y_lo + (t1 < 0 ? seg_rows : (t2 < 0 ? h2 : h4)), y0 + band_h);
-    if (y_lo >= y_hi) return;
+    if (y_lo >= y_hi) {
+      if (is_edge && order.arrive != nullptr) strip_order_arrive(order, lane, false); // (an empty segment still counts as an edge item that is done)
+      return;
+    }
   } else {
     y_lo = seg * seg_rows;
     y_hi = min(y_lo + seg_rows, Y);
   }
+  if (is_edge && order.epoch != nullptr) strip_order_wait(order); // the ghost columns this strip reads are being written by the exchange
+  if (is_edge) strip_order_prio(order.prio);
   const unsigned lo4 = (unsigned)col * 4u, lo16 = (unsigned)col * 16u;                      // byte offsets of the loaded column
   const unsigned so4 = lane_out ? (unsigned)c_out * 4u : 0u, so16 = so4 * 4u;              // ... of the stored column
 
@@ -173,6 +188,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
   const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
   float adv_vy_prev = 0.f, adv_T_prev = 0.f;
   char4 adv_w_prev = make_char4(0, 0, 0, 0);
+  float vx_seen = 0.f;              // largest |vx| the velocity pass produced in this wave's rows (VxTrack)
   int big1 = 0, big2 = 0, big3 = 0; // "some |v| >= 0.9" of velocity rows r-1, r-2, r-3
   int nw1 = 0, nw2 = 0, nw3 = 0;    // "no wall cell in the row" of input rows r-1, r-2, r-3 (the wall texture does not change in this kernel)
   // the output row of the previous step, stored at the top of this one (right behind the prefetch): the single vmcnt wait of a
@@ -224,6 +240,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
       if (lane == 63) v.x = v.y = 0.0f; // has no right neighbour in the ring; no output lane ever reads this velocity
       MarchRing::put(rg.vx, s1, lane, v.x);
       MarchRing::put(rg.vy, s1, lane, v.y);
+      vx_seen = fmaxf(vx_seen, fabsf(v.x));
       big1 = __any(fmaxf(fabsf(v.x), fabsf(v.y)) >= 0.9f); // any back-trace of this row that may leave the 3x3 cells?
     }
     march_fence();
@@ -302,6 +319,8 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_march_dry(Geo g, Uni 
     if (WRITE_WALL) st_row_v(out.wall + e, so4, st_w);
     if (WRITE_DISP) st_row_v(out.base_disp + e, so16, st_ab);
   }
+  vx_track_commit(vx, vx_seen, lane, strip);
+  if (is_edge && order.arrive != nullptr) strip_order_arrive(order, lane, true); // the halo exchange may pack this strip's columns
 #ifdef WX_MARCH_TIMING
   if (lane == 0) {
     cycles[2 * ((size_t)seg * n_strips + strip)] = t_begin;
@@ -346,30 +365,25 @@ inline int march_dry_strips(const Geo &g) { return (g.X + MOUT - 1) / MOUT; }
 // A launch covers the strips [strip_lo, strip_lo + strip_count) (strip_count < 0: all of them): the whole width normally, the edge
 // strips and the interior separately where a slab overlaps its halo exchange with compute (cf. launch_march_wet). The row
 // segmentation is the one of the whole width, so that every strip is cut the same way whichever launch computes it.
-inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, const DryIn &in, const DryOut &out, bool write_disp, bool write_wall,
-                             hipStream_t stream, int strip_lo = 0, int strip_count = -1, int strip_lo2 = 0, int strip_count2 = 0)
+// order (split iterations of a slab, StripOrder): the launch covers all strips, the edge strips first / last in dispatch order where the
+// shape has row bands (else in the plain order: the device-side hand-offs work either way). Returns the number of edge items of the launch
+// (= the arrivals a gate kernel has to wait for), 0 without an order.
+inline int launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, const DryIn &in, const DryOut &out, bool write_disp, bool write_wall,
+                             hipStream_t stream, int strip_lo = 0, int strip_count = -1, int strip_lo2 = 0, int strip_count2 = 0, const StripOrder *order = nullptr,
+                             const VxTrack *vx = nullptr)
 {
   const int n_strips_all = march_dry_strips(g), n_first = strip_count < 0 ? n_strips_all : strip_count;
   const int n_strips = n_first + (strip_count2 > 0 ? strip_count2 : 0);
-  if (n_strips <= 0) return;
+  if (n_strips <= 0) return 0;
   int seg_rows = march_seg_rows(n_strips_all, g.Y);
   int n_seg = (g.Y + seg_rows - 1) / seg_rows, n_full = n_seg, n_half = 0, band_h = 0;
   if (WX_MARCH_XCD && WX_MARCH_BANDS && !wx_tune_env("WX_MARCH_NOTAIL") && !wx_tune_env("WX_MARCH_SEG") && g.Y % 8 == 0) {
     int R = WX_MARCH_BAND_SEG;
     const int bh = g.Y / 8;
-    // Grids whose 24-row band segments do not fill the chip (4096 x 1024 -- BASELINE configs[1] -- is 69 strips x 56 segments = 3 864 waves
-    // for 5 120 slots): shorter unit segments, so that the whole-width launch holds at least one wave per slot -- a wave's row steps are
-    // serial, and a state that fits the 256 MB memory-side cache is latency-bound, not bandwidth-bound (round 5; the wet kernel has had
-    // the same rule since round 4, wet_launch_shape). Per band: bh / R full segments + the 1/2 + 1/4 tail ~ bh / R + 1.25 segments.
-    {
-      double fill = WX_MARCH_FILL;
-      if (const char *e = wx_tune_env("WX_MARCH_FILL")) fill = atof(e) > 0.0 ? atof(e) : fill;
-      const double per_band = (double)march_capacity() / (8.0 * n_strips_all) * fill;
-      if (per_band > 1.25 + 1.0) {
-        const int r_fill = (int)((double)bh / (per_band - 1.25));
-        if (r_fill < R) R = r_fill < WX_MARCH_BAND_SEG_MIN ? WX_MARCH_BAND_SEG_MIN : (r_fill & ~3);
-      }
-    }
+    // (Round 5, measured: on grids whose 24-row band segments do not fill the chip -- 4096 x 1024, BASELINE configs[1], is 69 strips x 56
+    // segments = 3 864 waves for 5 120 slots -- shorter segments that would fill it are SLOWER: 24 rows 30.3 us per iteration, 20 / 16 / 12
+    // rows 30.7-31.0, 8 rows 31.6, 32 rows 36.9 (profiles/r05_c1_segment_sweep.txt; one handle, interleaved, at rest and moving). The
+    // 3 warm-up rows per segment cost more than the idle slots; 24 stays.)
     if (const char *e = wx_tune_env("WX_MARCH_BAND_SEG")) R = atoi(e) >= 4 ? atoi(e) : R;
     const int tail = R / 2 + R / 4;
     if (bh >= 3 * R) { // tall enough for at least two full segments and the tail per band
@@ -380,6 +394,18 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
       n_seg = 8 * (n_full + 2 * n_half);
     }
   }
+  StripOrder ord{};
+  if (order && order->mode != 0) {
+    ord = *order;
+    if (!(band_h > 0 && WX_MARCH_XCD)) ord.mode = 3;
+  }
+  const int edge_items = ord.mode != 0 ? (ord.nl + (n_strips_all - ord.nr0)) * n_seg : 0;
+  VxTrack vt = vx ? *vx : VxTrack{nullptr, nullptr, 0.0f, 0, 0};
+  if (vx && vx->zone_l < vx->zone_r) { // the watched zone arrives in COLUMNS: this kernel's strips are MOUT columns wide
+    vt.zone_l = (vx->zone_l + MOUT - 1) / MOUT;
+    vt.zone_r = vx->zone_r / MOUT;
+  }
+  // (an ordered launch groups edge and interior strips separately: with one wave per workgroup the count is the same)
   const dim3 grid(WX_MARCH_XCD ? 8 * ((n_strips * n_seg + 7) / 8) : n_strips * n_seg);
   static bool dbg = wx_tune_env("WX_MARCH_DEBUG") != nullptr;
   if (dbg) {
@@ -389,10 +415,10 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
 #ifdef WX_MARCH_TIMING
   static unsigned long long *cyc = nullptr;
   static int calls = 0;
-  if (!cyc && hipMalloc((void **)&cyc, 16 * (size_t)n_strips_all * n_seg) != hipSuccess) return;
-#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, n_first, strip_lo2, cyc)
+  if (!cyc && hipMalloc((void **)&cyc, 16 * (size_t)n_strips_all * n_seg) != hipSuccess) return 0;
+#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, n_first, strip_lo2, ord, vt, cyc)
 #else
-#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, n_first, strip_lo2)
+#define WX_LAUNCH_M(D, W, Q) hipLaunchKernelGGL((k_march_dry<D, W, Q>), grid, dim3(64), 0, stream, g, u, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, strip_lo, n_first, strip_lo2, ord, vt)
 #endif
   const bool quiet = !(u.userInputType >= 1) && !(u.airplaneValues[3] < 0.0f || u.airplaneValues[3] > 0.9f);
 #define WX_LAUNCH_MQ(D, W) \
@@ -425,6 +451,7 @@ inline void launch_march_dry(const Geo &g, const Uni &u, const FullCtx *ctx, con
     }
   }
 #endif
+  return edge_items;
 }
 
 } // namespace wx

@@ -6,6 +6,7 @@
 #include "wx_cells.h"
 
 #include <cstdlib>
+#include <algorithm>
 // Tuning switches are environment variables ONLY in builds with -DWX_DEBUG (make debug: variants/libwxsim_debug.so; the experiment
 // scripts under tools/ load that one through WXSIM_LIB). The shipped library reads no environment variable: it has one launch shape,
 // and what a host may choose goes through wx_set_option.
@@ -109,6 +110,164 @@ struct AdvOut {
   float4 b, w;
   char4 wl;
 };
+
+// ---- split iterations of a slab (wx_step_overlap) as ONE launch ----
+// The iteration before a halo exchange has to finish its EDGE strips first (the neighbours wait for their columns), the iteration after
+// it may read its ghost columns only once the exchange has written them. Rounds 2-4 cut such an iteration into two launch groups on two
+// streams joined by events (+8...15 % per iteration on the metric's slab: profiles/r04_slab_protocol_cost.txt). Round 5: one launch over
+// all strips; the DISPATCH ORDER puts the edge strips first (mode 1) or last (mode 2), and the hand-offs are device-side words:
+//   arrive:  every edge wave adds 1 once its outputs are visible device-wide (agent-scope release); a one-wave gate kernel on the comm
+//            stream polls the word and lets the pack kernel start while the interior strips still march;
+//   epoch:   the comm stream bumps it behind the unpack; edge waves (dispatched last) poll it before their first load, then one
+//            agent-scope acquire. A handful of polling waves cannot fill the chip, so the exchange they wait for always finds slots.
+#ifndef WX_SPIN_LIMIT
+#define WX_SPIN_LIMIT 2000000u // polls of ~2 us each
+#endif
+struct StripOrder {
+  int mode;              // 0: plain launch (strip ranges as given); 1: edge strips first in dispatch order; 2: edge strips last
+  int nl, nr0;           // the edge strips: [0, nl) and [nr0, n_strips_all)
+  unsigned *arrive;      // NULL: nobody waits for the edge strips (else: word [0] of the handle's sync words; [2] = "a poll gave up")
+  const unsigned *epoch; // NULL: the ghost columns are valid already (else: word [1])
+  unsigned epoch_want;
+  int edge_list;         // wet kernel: edge waves append their exact-path cells to the second list (consumed on the comm stream)
+  int prio;              // s_setprio level of the edge waves (0: none): all waves of a slab's launch are resident at once, so the DISPATCH order
+                         // alone does not make the edge strips finish first -- the SIMD's issue priority does
+  int nofence;           // (timing experiments only: no release fence in front of the arrival -- WRONG results)
+};
+// position `sloc`-th of the n_part strips of one part (edge / interior) of the strip range [a, b) -> strip; returns false past the end
+struct StripPick {
+  int strip;
+  bool is_edge;
+};
+// j: workgroup index within the XCD's share, wpb waves per workgroup; [a, b): the strips this XCD works on; n_seg segments each.
+// Order: all (segment, group) pairs of the first part, segment-major, then those of the second part.
+__device__ __forceinline__ bool strip_order_pick(const StripOrder &o, int a, int b, int n_seg, int wpb, int wave, int j, int &seg, StripPick &out)
+{
+  const int eL = max(0, min(b, o.nl) - a), r0 = max(a, o.nr0), eR = max(0, b - r0);
+  const int ne = eL + eR, ni = (b - a) - ne;
+  const int ge = (ne + wpb - 1) / wpb, gi = (ni + wpb - 1) / wpb;
+  const bool edges_first = o.mode == 1;
+  const int g1 = edges_first ? ge : gi;
+  const bool first = j < g1 * n_seg;
+  const int jj = first ? j : j - g1 * n_seg;
+  const bool is_edge = first == edges_first;
+  const int g = is_edge ? ge : gi, n = is_edge ? ne : ni;
+  if (jj >= g * n_seg) return false;
+  seg = jj / g;
+  const int sloc = (jj - seg * g) * wpb + wave;
+  if (sloc >= n) return false;
+  out.is_edge = is_edge;
+  out.strip = is_edge ? (sloc < eL ? a + sloc : r0 + (sloc - eL)) : a + eL + sloc;
+  return true;
+}
+// workgroups per segment-set an XCD needs for the strips [a, b) under an order (host side: grid size)
+inline int strip_order_groups(const StripOrder &o, int a, int b, int wpb)
+{
+  const int eL = std::max(0, std::min(b, o.nl) - a), r0 = std::max(a, o.nr0), eR = std::max(0, b - r0);
+  const int ne = eL + eR, ni = (b - a) - ne;
+  return (ne + wpb - 1) / wpb + (ni + wpb - 1) / wpb;
+}
+__device__ __forceinline__ void strip_order_prio(int prio)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+#endif
+}
+__device__ __forceinline__ void strip_order_wait(const StripOrder &o)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  // ONE relaxed poll loop -> ONE agent-scope acquire -> plain loads (MI355X_MICROARCH.md, inter-workgroup visibility). Every spin is
+  // bounded (~ seconds): a hand-off that never comes -- a protocol bug, a dead peer -- ends in an error flag the next blocking call
+  // reports, not in a hung GPU
+  unsigned spins = 0;
+  while ((int)(__hip_atomic_load(o.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - o.epoch_want) < 0) {
+    __builtin_amdgcn_s_sleep(64);
+    if (++spins > WX_SPIN_LIMIT) {
+      __hip_atomic_store(const_cast<unsigned *>(o.epoch) + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (2: an edge strip's epoch poll)
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+// every lane of the wave has issued its last store
+__device__ __forceinline__ void strip_order_arrive(const StripOrder &o, int lane, bool stored)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (stored && !o.nofence) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // writes the XCD's dirty lines back: the pack kernel may run on any XCD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the compiler may drop the wait behind buffer_wbl2: restated where it cannot)
+  }
+  if (lane == 0) __hip_atomic_fetch_add(o.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// ---- slabs exact at any speed: the fastest |vx| of an exchange period ----
+// One iteration's dependency cone is 5 + (1 + floor|vx|) columns per side: the advection pass back-traces `fragCoord - vel` for ANY vel
+// (advectionShader.frag:85-99, no clamp) and interpolates from the two columns around the foot point. The marching kernels therefore keep
+// the largest |vx| they produce (post-boundary velocities in the wet kernel, the velocity pass's output in the dry one: what the
+// back-trace uses) -- one v_max per row step and lane, one wave reduction + at most two atomics per wave -- so that the hosts can size
+// the next exchange period (cone = 6 + floor(bound), wx_comm.h) and so that a period whose assumed bound was exceeded is REPORTED.
+// Only the flow NEAR THE SLAB EDGES matters: the front of invalid ghost columns moves inwards from the edge of the local array, and a
+// jet further inside needs many iterations to get there (it enters the watched zone -- three halo widths from either edge -- at least
+// 2 * halo / |vx| iterations before it reaches the ghost columns: several exchange periods). A wave whose strip lies outside the zone
+// reports nothing (zone_l / zone_r in strips; whole-domain handles watch everything).
+struct VxTrack {
+  int *max_bits;   // float bits of the largest |vx| since the last roll (only values >= 0.5 are recorded: below that the cone is 6 anyway)
+  int *violation;  // float bits of a |vx| that reached `limit` (0: none)
+  float limit;     // |vx| the current period's ghost columns allow (cone - 5); <= 0: whole-domain handle, nothing to check
+  int zone_l, zone_r; // strips [0, zone_l) and [zone_r, n) are watched (zone_l >= zone_r: all of them)
+};
+__device__ __forceinline__ void vx_track_commit(const VxTrack &t, float lane_max, int lane, int strip = 0)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (t.zone_l < t.zone_r && strip >= t.zone_l && strip < t.zone_r) return; // (wave-uniform)
+  float m = lane_max;
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0 && t.max_bits != nullptr && m >= 0.5f) {
+    atomicMax(t.max_bits, __float_as_int(m)); // (bit patterns of positive floats order like ints)
+    if (t.limit > 0.0f && m >= t.limit) atomicMax(t.violation, __float_as_int(m));
+  }
+#endif
+}
+// the same for kernels that do not track while they run (tiled dry kernel, per-pass kernels) and after uploads: max |vx| of a base texture
+// (columns [0, col_l) and [col_r, X) of every row; col_l >= col_r: all columns)
+__global__ void k_vx_scan(int X, int Y, int col_l, int col_r, const float4 *__restrict__ base, VxTrack t)
+{
+  float m = 0.0f;
+  const size_t n = (size_t)X * Y;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % (size_t)X);
+    if (col_l >= col_r || x < col_l || x >= col_r) m = fmaxf(m, fabsf(base[i].x));
+  }
+  t.zone_l = t.zone_r = 0;
+  vx_track_commit(t, m, threadIdx.x & 63);
+}
+
+// comm stream: wait until the edge strips of the launch that carries `want` arrivals (cumulative) are done
+__global__ void k_strip_gate(unsigned *__restrict__ arrive, unsigned want)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned spins = 0;
+  while ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+    __builtin_amdgcn_s_sleep(64);
+    if (++spins > WX_SPIN_LIMIT) {
+      __hip_atomic_store(arrive + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (1: the gate's arrival poll)
+      __hip_atomic_store(arrive + 3, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+// comm stream, behind the unpack: the ghost columns are written
+__global__ void k_strip_epoch(unsigned *__restrict__ epoch, unsigned value)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_store(epoch, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 
 // light texture: interleaved RGBA32F (the reference's layout: per-pass / single-kernel paths, readback, halo buffers of
 // those paths) <-> the three planes of the marching kernel

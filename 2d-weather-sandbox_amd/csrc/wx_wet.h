@@ -473,14 +473,20 @@ struct WetSegs {
 // QUIET: no brush input and no airplane event in this iteration (the host looks at the uniforms): advection_cell without those sections.
 template <bool OPT_OUT, bool HAS_FB, bool QUIET>
 __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(const FullCtx *__restrict__ ctx, float iterNum, WetIn in_arg, WetOut out_arg,
-                                                                    WetFixList fix, int n_strips, int strip_lo,
-                                                                    int n_strips_all, WetSegs segs, int split_at, int strip_lo2)
+                                                                    WetFixList fix_arg, WetFixList fix_edge_arg, int n_strips, int strip_lo,
+                                                                    int n_strips_all, WetSegs segs, int split_at, int strip_lo2, StripOrder order_arg, VxTrack vx_arg)
 {
-  struct KArgs { // layout of the kernel-argument segment up to the pointer structs
+  struct KArgs { // layout of the kernel-argument segment (the parameter list as a struct)
     const FullCtx *ctx;
     float iterNum;
     WetIn in;
     WetOut out;
+    WetFixList fix[2]; // [1]: the edge strips' own list in a split iteration (StripOrder::edge_list)
+    int n_strips, strip_lo, n_strips_all;
+    WetSegs segs;
+    int split_at, strip_lo2;
+    StripOrder order;
+    VxTrack vx;
   };
 #if WX_WET_ARGS_MEM && defined(__HIP_DEVICE_COMPILE__)
   // The ~22 plane pointers are read from the kernel-argument segment (constant address space) where they are used: separate
@@ -490,9 +496,13 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   const KBytes ka_c = (KBytes)__builtin_amdgcn_kernarg_segment_ptr();
   const __attribute__((address_space(4))) WetIn &in = *(const __attribute__((address_space(4))) WetIn *)(ka_c + offsetof(KArgs, in));
   const __attribute__((address_space(4))) WetOut &out = *(const __attribute__((address_space(4))) WetOut *)(ka_c + offsetof(KArgs, out));
+  // (the split-iteration order likewise: read where it is used -- prologue and epilogue --, nothing of it lives in the row loop)
+  const __attribute__((address_space(4))) StripOrder &order_c = *(const __attribute__((address_space(4))) StripOrder *)(ka_c + offsetof(KArgs, order));
+#define WX_ORDER() (StripOrder{order_c.mode, order_c.nl, order_c.nr0, order_c.arrive, order_c.epoch, order_c.epoch_want, order_c.edge_list, order_c.prio, order_c.nofence})
 #else
   const WetIn &in = in_arg;
   const WetOut &out = out_arg;
+#define WX_ORDER() (order_arg)
 #endif
   __shared__ WetRing rings[WX_WET_WPB];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -519,13 +529,30 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   const int n_seg = segs.n_seg, k = blockIdx.x & 7, j = blockIdx.x >> 3;
   const bool bands = segs.bands != 0;
   const int sk0 = bands ? 0 : (k * n_strips) >> 3, nk = bands ? n_strips : (((k + 1) * n_strips) >> 3) - sk0, gk = (nk + WX_WET_WPB - 1) / WX_WET_WPB;
-  if (j >= gk * n_seg) return;
-  const int seg = j / gk, sloc = (j - seg * gk) * WX_WET_WPB + wave;
-  if (sloc >= nk) return;
-  // (a launch may cover two strip ranges -- the left and the right edge strips of a slab: the first split_at strips start at strip_lo,
-  // the others at strip_lo2)
-  const int sidx = sk0 + sloc;
-  const int strip = sidx < split_at ? strip_lo + sidx : strip_lo2 + (sidx - split_at), item = ((bands ? k * n_seg : 0) + seg) * n_strips_all + strip;
+  int seg, strip;
+  bool is_edge = false; // (wave-uniform) a split iteration's edge strip: waits for the ghost columns / reports when it is done
+  bool sig_edge = false, edge_list = false;
+  const int order_mode = WX_ORDER().mode;
+  if (order_mode == 0 || order_mode == 4) {
+    if (j >= gk * n_seg) return;
+    seg = j / gk;
+    const int sloc = (j - seg * gk) * WX_WET_WPB + wave;
+    if (sloc >= nk) return;
+    // (a launch may cover two strip ranges -- the left and the right edge strips of a slab: the first split_at strips start at strip_lo,
+    // the others at strip_lo2)
+    const int sidx = sk0 + sloc;
+    strip = sidx < split_at ? strip_lo + sidx : strip_lo2 + (sidx - split_at);
+    is_edge = order_mode == 4; // (the edge group of the two-launch protocol: every strip of the launch is an edge strip -- issue priority only)
+  } else { // one launch over ALL strips, the edge strips first (or last) in dispatch order (StripOrder, wx_tile.h)
+    const StripOrder order = WX_ORDER();
+    StripPick pk;
+    if (!strip_order_pick(order, sk0, sk0 + nk, n_seg, WX_WET_WPB, wave, j, seg, pk)) return;
+    strip = pk.strip;
+    is_edge = pk.is_edge;
+    sig_edge = is_edge && order.arrive != nullptr;
+    edge_list = is_edge && order.edge_list != 0;
+  }
+  const int item = ((bands ? k * n_seg : 0) + seg) * n_strips_all + strip;
   const int band_lo = bands ? (int)(((long long)k * g.Y) >> 3) : 0, band_hi = bands ? (int)(((long long)(k + 1) * g.Y) >> 3) : g.Y;
   const int c_out = strip * WOUT + lane - WLO; // output column of this lane (may be >= X in the last strip, < 0 in the first)
   const int col = wrapmod(c_out, X);           // column this lane loads / computes
@@ -534,7 +561,15 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   unsigned lo12 = (unsigned)col * 12u; // (feedback texels)
   unsigned so4 = lane_out ? (unsigned)c_out * 4u : 0u, so8 = so4 * 2u, so16 = so4 * 4u;    // ... of the stored column
   const int y_lo = band_lo + segs.start[seg], y_hi = min(band_lo + segs.start[seg + 1], band_hi);
-  if (y_lo >= y_hi) return;
+  if (y_lo >= y_hi) { // (an empty segment of a clipped band still counts as an edge item that is done)
+    if (sig_edge) strip_order_arrive(WX_ORDER(), lane, false);
+    return;
+  }
+  if (is_edge) { // the ghost columns this strip reads are being written by the exchange
+    const StripOrder order = WX_ORDER();
+    if (order.epoch != nullptr) strip_order_wait(order);
+    strip_order_prio(order.prio);
+  }
 #define WX_WALL_RAW (reinterpret_cast<const int *>(in.wall))
   (void)item;
 
@@ -568,6 +603,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   unsigned h_nowall = 0; // "no wall cell" of the same rows
   unsigned h_zw0 = 0;    // "precipitation-visual and smoke channels of the water are all zero" of the same rows
   unsigned h_near = 15;  // "some cell at or next to a wall" of input rows r .. r-3
+  float vx_seen = 0.f;   // largest |vx| among the post-boundary velocities of this wave's rows (VxTrack: slabs size their exchange period by it)
 #define WX_H_SET(h, v) h = ((h) & ~1u) | ((v) ? 1u : 0u)
 #define WX_H_ROT(h) h = ((h) << 1) | ((h) & 1u)
   // outputs of the previous step, stored at the top of this one
@@ -793,6 +829,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         (&rg.qy[0][0])[oq] = bq.y;
         (&rg.qz[0][0])[oq] = bq.z;
         (&rg.qw[0][0])[oq] = bq.w;
+        vx_seen = fmaxf(vx_seen, fabsf(bb.x));
         // back-traces of this row that may leave the 3x3 cells? (lanes 2 .. 60 feed an advection that is used)
         WX_H_SET(h_big, __any(lane >= 2 && lane <= 60 && !(fmaxf(fabsf(bb.x), fabsf(bb.y)) < 0.9f)));
         WX_H_SET(h_nowall, __all(lane < 2 || lane > 60 || bwl.y != 0)); // no wall cell in this post-boundary row (as far as advection reads it)
@@ -837,6 +874,14 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
           int n_add = (int)oA + (int)oB + (int)oC;
 #ifdef WX_ABL_NOFIX // (timing-only ablation builds produce garbage velocities: keep them from flooding the exact path)
           n_add = 0;
+#endif
+          // (the list: read from the kernel-argument segment HERE, in the rare branch -- nothing of it is live in the loop; the edge strips
+          // of a split iteration have a list of their own, consumed on the comm stream before the halo is packed)
+#if WX_WET_ARGS_MEM && defined(__HIP_DEVICE_COMPILE__)
+          const __attribute__((address_space(4))) WetFixList &fix =
+              *(const __attribute__((address_space(4))) WetFixList *)(ka_c + offsetof(KArgs, fix) + (edge_list ? sizeof(WetFixList) : 0));
+#else
+          const WetFixList &fix = edge_list ? fix_edge_arg : fix_arg;
 #endif
           if (fix.fastest) atomicMax(fix.fastest, __float_as_int(m)); // (m >= 0.9 or NaN: the bit patterns of positive floats order like ints)
           if (n_add) {
@@ -969,6 +1014,16 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     if (OPT_OUT) st_row(out.base_disp + e, so16, st_ab);
     if (out.t_disp && st_td) st_row(out.t_disp + e, so4, st_ab.w);
   }
+  {
+#if WX_WET_ARGS_MEM && defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) VxTrack &vc = *(const __attribute__((address_space(4))) VxTrack *)(ka_c + offsetof(KArgs, vx));
+    vx_track_commit(VxTrack{vc.max_bits, vc.violation, vc.limit, vc.zone_l, vc.zone_r}, vx_seen, lane, strip);
+#else
+    vx_track_commit(vx_arg, vx_seen, lane, strip);
+#endif
+  }
+  if (sig_edge) strip_order_arrive(WX_ORDER(), lane, true); // the halo exchange may pack this strip's columns
+#undef WX_ORDER
 #ifdef WX_WET_TIMING
   if (lane == 0) {
     out.cycles[2 * (size_t)item] = t_begin;
@@ -1368,14 +1423,26 @@ inline WetLaunch wet_shape_halved(const WetLaunch &w)
   return h;
 }
 
-inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, const WetFixList &fix,
-                             bool opt_out, bool quiet, hipStream_t stream, int strip_lo = 0, int strip_count = -1, int strip_lo2 = 0, int strip_count2 = 0)
+// order (split iterations of a slab, StripOrder): returns the number of edge items of the launch (= the arrivals a gate kernel waits for)
+inline int launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *ctx, const WetIn &in, const WetOut &out, const WetFixList &fix,
+                             bool opt_out, bool quiet, hipStream_t stream, int strip_lo = 0, int strip_count = -1, int strip_lo2 = 0, int strip_count2 = 0,
+                             const StripOrder *order = nullptr, const WetFixList *fix_edge = nullptr, const VxTrack *vx = nullptr)
 {
   // (strip_count2 > 0: a second strip range in the same launch -- the two edges of a slab)
   const int ns1 = strip_count < 0 ? w.n_strips : strip_count, ns = ns1 + (strip_count2 > 0 ? strip_count2 : 0);
-  if (ns <= 0) return;
+  if (ns <= 0) return 0;
+  StripOrder ord{};
+  if (order && order->mode != 0) ord = *order; // (an ordered launch covers the whole width: strip_lo 0, all strips)
   // 8 XCDs x (workgroups of the largest column block) x segments; surplus workgroups / waves exit at once
-  const dim3 grid(8 * (((w.segs.bands ? ns : (ns + 7) / 8) + WX_WET_WPB - 1) / WX_WET_WPB) * w.segs.n_seg);
+  int groups = ((w.segs.bands ? ns : (ns + 7) / 8) + WX_WET_WPB - 1) / WX_WET_WPB;
+  if (ord.mode != 0 && ord.mode != 4) { // edge and interior strips are grouped into workgroups separately: up to one more group per XCD
+    groups = 0;
+    for (int k = 0; k < 8; k++) {
+      const int a = w.segs.bands ? 0 : (k * ns) >> 3, b = w.segs.bands ? ns : ((k + 1) * ns) >> 3;
+      groups = std::max(groups, strip_order_groups(ord, a, b, WX_WET_WPB));
+    }
+  }
+  const dim3 grid(8 * groups * w.segs.n_seg);
   static bool dbg = wx_tune_env("WX_MARCH_DEBUG") != nullptr;
   if (dbg) {
     fprintf(stderr, "[wx_wet] strips=%d segs=%d waves=%d first/last segment rows=%d/%d\n", w.n_strips, w.segs.n_seg, w.n_strips * w.segs.n_seg,
@@ -1383,8 +1450,14 @@ inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *c
     dbg = false;
   }
   const bool has_fb = in.fb != nullptr;
+  const WetFixList fe = fix_edge ? *fix_edge : fix;
+  VxTrack vt = vx ? *vx : VxTrack{nullptr, nullptr, 0.0f, 0, 0};
+  if (vx && vx->zone_l < vx->zone_r) { // the watched zone arrives in COLUMNS: this kernel's strips are WOUT columns wide
+    vt.zone_l = (vx->zone_l + WOUT - 1) / WOUT;
+    vt.zone_r = vx->zone_r / WOUT;
+  }
 #define WX_LAUNCH_W(O, F, Q) \
-  hipLaunchKernelGGL((k_march_wet<O, F, Q>), grid, dim3(64 * WX_WET_WPB), 0, stream, ctx, iterNum, in, out, fix, ns, strip_lo, w.n_strips, w.segs, ns1, strip_lo2)
+  hipLaunchKernelGGL((k_march_wet<O, F, Q>), grid, dim3(64 * WX_WET_WPB), 0, stream, ctx, iterNum, in, out, fix, fe, ns, strip_lo, w.n_strips, w.segs, ns1, strip_lo2, ord, vt)
 #define WX_LAUNCH_WQ(O, F) \
   do { if (quiet) WX_LAUNCH_W(O, F, true); else WX_LAUNCH_W(O, F, false); } while (0)
   if (opt_out) {
@@ -1394,6 +1467,7 @@ inline void launch_march_wet(const WetLaunch &w, float iterNum, const FullCtx *c
   }
 #undef WX_LAUNCH_WQ
 #undef WX_LAUNCH_W
+  return (ord.mode != 0 && ord.mode != 4) ? (ord.nl + (w.n_strips - ord.nr0)) * w.segs.n_seg * (w.segs.bands ? 8 : 1) : 0;
 }
 
 // the fix pass of a launch group: every list entry recomputed exactly, spread over the chip (exits at once while the list is empty)

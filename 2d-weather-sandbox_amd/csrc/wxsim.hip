@@ -26,6 +26,10 @@
 
 using namespace wx;
 
+#ifndef WX_SPLIT_PRIO
+#define WX_SPLIT_PRIO 0 // s_setprio level of the edge waves of a split iteration (StripOrder::prio)
+#endif
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -140,6 +144,21 @@ struct wx_sim {
   // instead of in front of it (in order it cost a 2132-column slab +0.045 ms per iteration, profiles/r04_slab_protocol_cost.txt)
   hipStream_t edge_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // Round 5: a split iteration as ONE ordered launch with device-side hand-offs (StripOrder, wx_tile.h) instead of two launch groups on two
+  // streams: sync_words[0] = arrivals of edge items (cumulative; a gate kernel on the comm stream waits for arrive_target),
+  // sync_words[1] = the ghost epoch (bumped on the comm stream behind every unpack; edge strips dispatched last poll for epoch_host)
+  int split_launch = 0;          // WX_OPT_SPLIT_LAUNCH: 0 (default) = the two launch groups of rounds 2-4; 1 = one ordered launch (round 5: measured, not faster)
+  unsigned *sync_words = nullptr;
+  unsigned arrive_target = 0, epoch_host = 0;
+  bool gate_pending = false;     // the latest iteration's edge strips report through sync_words[0]; their exact-path list (fix_count2) is still
+                                 // to be consumed -- by the halo pack on the comm stream, else by settle_edges on the compute stream
+  bool gate_wet = false;         // ... and it was the wet kernel (there is a list to consume)
+  bool split_check = false;      // a split iteration ran since the give-up flag (sync_words[2]) was last looked at
+  bool gate_passed = false;      // the comm stream already holds the gate of the latest iteration: a further pack of the same exchange is ordered behind it
+  WetIn gate_in{};
+  WetOut gate_out{};
+  float gate_iter = 0.f;
+  bool gate_opt_out = false;
   int *fix_count2 = nullptr;     // the edge group's own list of exact-path cells (the groups run concurrently)
   int2 *fix_cells2 = nullptr;
   int fix_cap2 = 0;
@@ -163,6 +182,20 @@ struct wx_sim {
   int *ev_seen_host = nullptr; // pinned: pool_seen_max as of the last round
   hipEvent_t ev_counted = nullptr;
   bool count_pending = false;
+  // Slabs exact at any speed (VxTrack, wx_tile.h): one iteration invalidates 6 + floor|vx| ghost columns per side. The hosts of all slabs
+  // agree on a bound for |vx| per exchange period (measured by the kernels a period or two earlier, with a margin: wx_slab_set_vx_bound);
+  // the period is sized by it and the kernels report a |vx| that reaches it (cone_violation: never a silent divergence).
+  int cone = WX_SLAB_CONE;
+  float vx_bound = 0.f;
+  bool vx_stale = true;           // the state was replaced from outside since |vx| was last looked at: scan it before the next period is sized
+  bool vx_untracked = false;      // an iteration since the last roll ran a kernel that does not track |vx| (tiled dry kernel, per-pass kernels)
+  bool vx_check = false;          // a limit was in force since the violation word was last looked at
+  float vx_known = 0.f;           // the latest measurement the bound was derived from
+  int *vx_dev = nullptr;          // device: [0] my rolled maximum, [1 .. world] everybody's (all-gathered)
+  int *vx_host = nullptr;         // pinned: [2][world] the maxima of the two latest rolls
+  hipEvent_t ev_vx[2] = {nullptr, nullptr};
+  bool vx_have[2] = {false, false};
+  int vx_slot = 0, vx_world = 0;
   int since_exchange = 0;         // iterations since the ghost columns were last fresh (upload or exchange)
   bool exchanged = false;         // ... and they came from an exchange (the next step may run its interior strips first)
   int air_from_row = -1;       // lowest row above which every cell is free air (cost model of the row segmentation); -1: to be measured
@@ -505,6 +538,7 @@ int copy_wall(wx_sim *s, const char4 *src, char4 *dst)
 // One iteration with the reference's pass structure (one kernel per draw call).
 int iterate_per_pass(wx_sim *s, unsigned mask)
 {
+  s->vx_untracked = true; // (these kernels do not report their |vx|: the exchange scans the state instead)
   const dim3 grid = grid2d(s), block(BX, BY);
   const Geo g = s->geo;
   Uni u = s->uni;
@@ -612,6 +646,67 @@ static void wait_unpacked(wx_sim *s)
   s->unpack_pending = false;
 }
 
+// device words of the ordered split launch + the edge strips' own exact-path list (created by the first split iteration)
+static int split_launch_ready(wx_sim *s, bool need_fix_list)
+{
+  if (!s->sync_words) {
+    if (hipMalloc((void **)&s->sync_words, 4 * sizeof(unsigned)) != hipSuccess || hipMemsetAsync(s->sync_words, 0, 4 * sizeof(unsigned), s->stream) != hipSuccess)
+      return fail(s, WX_E_NOMEM, "wx_step: the split launch's device words");
+    s->arrive_target = s->epoch_host = 0;
+  }
+  if (need_fix_list && !s->fix_count2) {
+    const size_t cap = std::min<size_t>(std::max<size_t>((size_t)s->Y * 8 * 64, 1u << 14), 1u << 20); // (a few strips' worth of cells)
+    if (hipMalloc((void **)&s->fix_count2, 8) != hipSuccess || hipMalloc((void **)&s->fix_cells2, cap * sizeof(int2)) != hipSuccess ||
+        hipMemsetAsync(s->fix_count2, 0, 8, s->stream) != hipSuccess)
+      return fail(s, WX_E_NOMEM, "wx_step: the edge strips' exact-path cell list");
+    s->fix_cap2 = (int)cap;
+    if (wx_tune_env("WX_SPLIT_PREWARM") && s->comm_stream && s->full_ctx) {
+      // (experiment) the fix kernel needs 652 bytes of scratch per lane: let the comm stream's hardware queue get its scratch ring now,
+      // while nothing on the chip is polling for the exchange this kernel is part of
+      hipStreamSynchronize(s->stream);
+      const WetFixList fix2{s->fix_count2, s->fix_cells2, s->fix_cap2, nullptr, &s->state->fastest_bits, nullptr};
+      WetIn in{};
+      WetOut out{};
+      launch_wet_fix(0.f, s->full_ctx, in, out, fix2, &s->state->fix_overflow, false, s->comm_stream, 64);
+      hipStreamSynchronize(s->comm_stream);
+    }
+  }
+  return WX_OK;
+}
+// The edge strips of the latest split iteration left exact-path cells on their own list and nobody has packed the halo since (a host
+// that asked for WX_OVERLAP_EDGES_FIRST and then did something else): consume the list on the compute stream -- it is ordered behind
+// the whole launch, so no gate is needed -- before anything looks at those cells.
+static void settle_edges(wx_sim *s)
+{
+  if (!s->gate_pending) return;
+  if (s->gate_wet) {
+    const WetFixList fix2{s->fix_count2, s->fix_cells2, s->fix_cap2, nullptr, &s->state->fastest_bits, nullptr};
+    launch_wet_fix(s->gate_iter, s->full_ctx, s->gate_in, s->gate_out, fix2, &s->state->fix_overflow, s->gate_opt_out, s->stream, 64);
+  }
+  s->gate_pending = false;
+}
+// comm stream: the ghost columns (and whatever else an exchange writes) are in place -- the event for the compute stream's stream-ordered
+// consumers, the epoch word for edge strips that are already resident and polling
+static int mark_unpacked(wx_sim *s, hipStream_t st)
+{
+  HIPCHK(s, hipEventRecord(s->ev_unpacked, st));
+  s->unpack_pending = true;
+  if (s->sync_words) {
+    s->epoch_host += 1;
+    hipLaunchKernelGGL(k_strip_epoch, dim3(1), dim3(1), 0, st, s->sync_words + 1, s->epoch_host);
+  }
+  return WX_OK;
+}
+
+// what the marching kernels report their |vx| to: the accumulator always, the limit of the current exchange period on slabs
+static VxTrack vx_track(wx_sim *s)
+{
+  if (s->halo > 0) s->vx_check = true;
+  // slabs watch three halo widths from either edge of the local array (in columns here; the launch functions turn them into strips)
+  const int zl = s->halo > 0 ? 3 * s->halo : 0, zr = s->halo > 0 ? s->X - 3 * s->halo : 0;
+  return VxTrack{&s->state->vx_max_bits, &s->state->cone_violation, s->halo > 0 ? (float)(s->cone - 5) : 0.0f, zl, zr};
+}
+
 // stream / events / second exact-path list of the concurrent edge group (created by the first split iteration)
 static int edge_stream_ready(wx_sim *s, bool need_fix_list)
 {
@@ -698,8 +793,17 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
     // one launch group: marching kernel over a strip range (or two) -> the fix pass over what it recorded (leaves the list empty)
     // no brush input, no airplane event (the common case: a running simulation): the instantiation without those sections
     const bool quiet = !(s->uni.userInputType >= 1) && !(s->uni.airplaneValues[3] < 0.0f || s->uni.airplaneValues[3] > 0.9f);
+    const VxTrack vt = vx_track(s);
     auto group_on = [&](hipStream_t st, const WetFixList &fl, int lo0, int cnt0, int lo1 = 0, int cnt1 = 0, bool halved = false) {
-      launch_march_wet(halved ? wet_shape_halved(shape) : shape, (float)s->iter, s->full_ctx, in, out, fl, opt_out, quiet, st, lo0, cnt0, lo1, cnt1); // (both ranges in ONE launch)
+      StripOrder eo{}; // the edge group of the two-launch protocol: its waves may get a higher issue priority (StripOrder::prio; mode 4)
+      if (halved) {
+        eo.mode = 4;
+        eo.prio = WX_SPLIT_PRIO;
+        if (const char *e = wx_tune_env("WX_SPLIT_PRIO")) eo.prio = atoi(e);
+        if (const char *e = wx_tune_env("WX_SPLIT_HALVE")) halved = atoi(e) != 0;
+        if (eo.prio == 0) eo.mode = 0;
+      }
+      launch_march_wet(halved ? wet_shape_halved(shape) : shape, (float)s->iter, s->full_ctx, in, out, fl, opt_out, quiet, st, lo0, cnt0, lo1, cnt1, eo.mode ? &eo : nullptr, nullptr, &vt); // (both ranges in ONE launch)
       launch_wet_fix((float)s->iter, s->full_ctx, in, out, fl, &s->state->fix_overflow, opt_out, st, halved ? 64 : 0);
     };
     auto group = [&](int lo0, int cnt0, int lo1 = 0, int cnt1 = 0) { group_on(s->stream, fix, lo0, cnt0, lo1, cnt1); };
@@ -709,8 +813,50 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
     if (edge_mode == 0 || s->halo == 0 || nl >= nr0) {
       if (edge_mode & 2) wait_unpacked(s);
       group(0, -1);
+    } else if (s->split_launch) {
+      // ONE launch over all strips (round 5): the edge strips first in dispatch order when an exchange follows (they report on a device
+      // word the comm stream's gate kernel polls), last when one precedes (they poll the epoch word the comm stream bumps behind the
+      // unpack). No second stream, no join events, one fix pass on this stream; the edge strips' own exact-path list is consumed on the
+      // comm stream in front of the pack (halo_pack_impl) -- B's strips next to them are ordered behind that through the epoch too.
+      if (int rc = split_launch_ready(s, true)) return rc;
+      StripOrder ord{};
+      ord.mode = (edge_mode & 1) ? 1 : 2;
+      ord.nl = nl;
+      ord.nr0 = nr0;
+      if (edge_mode == 3) wait_unpacked(s); // (a one-iteration period: the whole launch behind the unpack, the edge strips first all the same)
+      if ((edge_mode & 2) && s->unpack_pending) {
+        ord.epoch = s->sync_words + 1;
+        ord.epoch_want = s->epoch_host;
+        // (the interior strips bordering the edge strips read four of their columns -- cells the comm stream's fix pass may still be
+        // rewriting: they wait with the edges)
+        if (ord.nl + 1 < ord.nr0 - 1) {
+          ord.nl += 1;
+          ord.nr0 -= 1;
+        }
+        s->unpack_pending = false; // (this launch waits on the device; everything behind it on the stream is ordered behind it)
+      }
+      if (edge_mode & 1) {
+        ord.arrive = s->sync_words;
+        ord.edge_list = 1;
+      }
+      ord.prio = WX_SPLIT_PRIO;
+      if (const char *e = wx_tune_env("WX_SPLIT_PRIO")) ord.prio = atoi(e);
+      if (const char *e = wx_tune_env("WX_SPLIT_NOFENCE")) ord.nofence = atoi(e);
+      const WetFixList fix2{s->fix_count2, s->fix_cells2, s->fix_cap2, nullptr, &s->state->fastest_bits, nullptr};
+      s->split_check = true;
+      const int items = launch_march_wet(shape, (float)s->iter, s->full_ctx, in, out, fix, opt_out, quiet, s->stream, 0, -1, 0, 0, &ord, &fix2, &vt);
+      launch_wet_fix((float)s->iter, s->full_ctx, in, out, fix, &s->state->fix_overflow, opt_out, s->stream, 0);
+      if (edge_mode & 1) {
+        s->arrive_target += (unsigned)items;
+        s->gate_pending = true;
+        s->gate_wet = true;
+        s->gate_in = in;
+        s->gate_out = out;
+        s->gate_iter = (float)s->iter;
+        s->gate_opt_out = opt_out;
+      }
     } else {
-      // The edge group on its own stream, the interior group on the compute stream, side by side: the edge stream starts behind
+      // (rounds 2-4, WX_OPT_SPLIT_LAUNCH 0) The edge group on its own stream, the interior group on the compute stream, side by side: the edge stream starts behind
       // everything the compute stream holds so far (and behind the unpack where the ghosts are still in flight), the compute stream
       // goes on behind both groups. What the comm stream waits for before it packs (ev_edges) is the edge group alone.
       if (int rc = edge_stream_ready(s, true)) return rc;
@@ -788,14 +934,38 @@ int iterate_dry(wx_sim *s, bool write_disp, int edge_mode = 0)
     const int n_strips = march_dry_strips(s->geo);
     // edge strips: every output column wx_halo_pack reads ([halo, 2*halo) and its mirror) and every strip that reads ghost columns
     const int nl = s->halo > 0 ? (2 * s->halo - 1) / MOUT + 1 : 0, nr0 = s->halo > 0 ? (s->X - 2 * s->halo) / MOUT : n_strips;
+    const VxTrack vt = vx_track(s);
     auto launch_on = [&](hipStream_t st, int lo, int cnt, int lo2 = 0, int cnt2 = 0) {
-      launch_march_dry(s->geo, s->uni, s->full_ctx, in, out, write_disp, !wall_const, st, lo, cnt, lo2, cnt2);
+      launch_march_dry(s->geo, s->uni, s->full_ctx, in, out, write_disp, !wall_const, st, lo, cnt, lo2, cnt2, nullptr, &vt);
     };
     auto launch = [&](int lo, int cnt) { launch_on(s->stream, lo, cnt); };
     if (edge_mode == 0 || s->halo == 0 || nl >= nr0) {
       if (edge_mode & 2) wait_unpacked(s);
       launch(0, -1);
-    } else { // edge strips and interior side by side (see iterate_march_wet)
+    } else if (s->split_launch) { // one ordered launch with device-side hand-offs (see iterate_march_wet)
+      if (int rc = split_launch_ready(s, false)) return rc;
+      StripOrder ord{};
+      ord.mode = (edge_mode & 1) ? 1 : 2;
+      ord.nl = nl;
+      ord.nr0 = nr0;
+      if (edge_mode == 3) wait_unpacked(s);
+      if ((edge_mode & 2) && s->unpack_pending) {
+        ord.epoch = s->sync_words + 1;
+        ord.epoch_want = s->epoch_host;
+        s->unpack_pending = false;
+      }
+      if (edge_mode & 1) ord.arrive = s->sync_words;
+      ord.prio = WX_SPLIT_PRIO;
+      if (const char *e = wx_tune_env("WX_SPLIT_PRIO")) ord.prio = atoi(e);
+      if (const char *e = wx_tune_env("WX_SPLIT_NOFENCE")) ord.nofence = atoi(e);
+      s->split_check = true;
+      const int items = launch_march_dry(s->geo, s->uni, s->full_ctx, in, out, write_disp, !wall_const, s->stream, 0, -1, 0, 0, &ord, &vt);
+      if (edge_mode & 1) {
+        s->arrive_target += (unsigned)items;
+        s->gate_pending = true;
+        s->gate_wet = false;
+      }
+    } else { // (rounds 2-4) edge strips and interior side by side (see iterate_march_wet)
       if (int rc = edge_stream_ready(s, false)) return rc;
       hipEventRecord(s->ev_fork, s->stream);
       hipStreamWaitEvent(s->edge_stream, s->ev_fork, 0);
@@ -816,6 +986,7 @@ int iterate_dry(wx_sim *s, bool write_disp, int edge_mode = 0)
     wall_written = !wall_const;
   } else {
     ProfScope ps(s, K_FUSED_DRY);
+    s->vx_untracked = true; // (the tiled kernel does not report its |vx|: the exchange scans the state instead)
     launch_fused_dry(s->geo, s->uni, s->full_ctx, in, out, water, write_disp, s->stream);
     LAUNCH_CHECK(s, "fused_dry");
   }
@@ -1006,6 +1177,7 @@ void wx_destroy(wx_sim *s)
   }
   hipFree(s->fix_count2);
   hipFree(s->fix_cells2);
+  hipFree(s->sync_words);
   dfree(s, s->state);
   dfree(s, s->pool_remote);
   dfree(s, s->pool_owned);
@@ -1124,7 +1296,7 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   HIPCHK(s, hipMemsetAsync(s->fb, 0, n * 12, s->stream));
   HIPCHK(s, hipMemsetAsync(s->dep, 0, n * 8, s->stream));
   HIPCHK(s, hipMemsetAsync(s->state->lightning, 0, 16, s->stream));
-  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 52, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow, pool_overflow, pool_seen_max, fastest_bits, pool_retired, mailbox_w
+  HIPCHK(s, hipMemsetAsync(&s->state->px_count, 0, 60, s->stream)); // px_count, px_light[4], scratch_int, ghost_nontrivial, fix_overflow, pool_overflow, pool_seen_max, fastest_bits, pool_retired, mailbox_w, vx_max_bits, cone_violation
   if (int rc = pool_reset(s)) return rc;
   if (s->sg.acc3) {
     HIPCHK(s, hipMemsetAsync(s->sg.acc3, 0, (size_t)s->sg.AP * s->sg.AH * 12, s->stream));
@@ -1143,6 +1315,9 @@ static int reset_after_upload(wx_sim *s, const float *drops)
   s->exact_pending = 0;
   s->since_exchange = 0; // (wx_slab_step / wx_group_step: the ghost columns are fresh, and not from an exchange)
   s->exchanged = false;
+  s->vx_stale = true;    // (whatever velocities the new state holds: looked at before the next exchange period is sized)
+  s->vx_untracked = false;
+  s->vx_have[0] = s->vx_have[1] = false;
   s->ran_fused = false;
   s->even = 1;
   s->emit_lit = false; // (the reference re-creates the emittedLight texture with the others)
@@ -1280,6 +1455,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   } tail_reset{s};
   s->prof_tail = nullptr;
   s->prof_chain = true;
+  settle_edges(s); // (the previous call ended with an edges-first iteration that no halo pack followed)
   const unsigned mask = s->p.pass_mask;
   const bool precip = (mask & WX_PASS_PRECIPITATION) && s->p.enablePrecipitation && s->n_drops > 0;
   const size_t n = ncell(s);
@@ -1300,10 +1476,10 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   if (precip && s->pool_remote && s->pool_exact && n_iter > 0 && (n_iter > 1 || s->exact_pending > 0))
     return fail(s, WX_E_STATE, "wx_step: WX_OPT_POOL_EXACT takes one iteration per call, each followed by wx_pool_events_pack / all-gather / wx_pool_events_apply");
   if (precip && s->pool_remote && n_iter > 0) { // slab with particles: refuse an over-long call BEFORE any iteration runs
-    const int allowed = WX_SLAB_PERIOD_PARTICLES(s->halo) - s->period_j; // (include/wxsim.h: 6 columns for the first iteration, 9 for every further one)
+    const int allowed = wx_slab_period(s) - s->period_j; // (include/wxsim.h: `cone` columns for the first iteration, cone + 3 for every further one)
     if (n_iter > allowed)
       return fail(s, WX_E_STATE, "wx_step: %d iterations asked, %d done since the last halo exchange; %d ghost columns allow %d per period with particles",
-                  n_iter, s->period_j, s->halo, WX_SLAB_PERIOD_PARTICLES(s->halo));
+                  n_iter, s->period_j, s->halo, wx_slab_period(s));
   }
   // overlap needs the kernel that can be launched per strip range; everything else orders the exchange on the compute stream
   // (with particles only the iteration AFTER an exchange splits: precipitation needs the whole grid of its iteration, and the
@@ -1315,6 +1491,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
     light_to_rgba(s);
   }
   s->edges_recorded = false;
+  if (n_iter > 0) s->gate_passed = false;
   for (int it = 0; it < n_iter; it++) {
     int edge_mode = 0;
     if (can_split) edge_mode = ((flags & WX_OVERLAP_EDGES_LAST) && it == 0 ? 2 : 0) | ((flags & WX_OVERLAP_EDGES_FIRST) && it == n_iter - 1 && !precip ? 1 : 0);
@@ -1345,7 +1522,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
         if (s->pool_remote) { // slab: the grid of this iteration is valid on the owned columns + (halo - 6*(j+1)) ghost columns; the
           // feedback texture is exact where every droplet within a sprite radius (6 px) was processed, so the owned columns
           // need 6 valid ghost columns even in the last iteration of a period
-          const int margin = s->halo - WX_SLAB_CONE - WX_SLAB_CONE_PARTICLES * s->period_j; // >= 6: checked before the loop
+          const int margin = s->halo - s->cone - (s->cone + 3) * s->period_j; // >= 6: checked before the loop
           sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, s->period_j + 1, s->pool_remote, s->pool_flips, s->pool_owned, s->pool_exact};
           d_in = d_out = s->drops[0]; // the partitioned pool is updated in place
         }
@@ -1433,6 +1610,10 @@ int wx_set_option(wx_sim *s, int option, int value)
     s->pool_exact = value != 0;
     s->exact_pending = 0;
     return WX_OK;
+  case WX_OPT_SPLIT_LAUNCH: // split iterations (wx_step_overlap): 1 = one ordered launch + device-side hand-offs, 0 = two launch groups on two streams
+    if (int rc = wx_sync(s)) return rc;
+    s->split_launch = value != 0;
+    return WX_OK;
   case WX_OPT_EXCHANGE_OVERLAP: // (takes effect at the next wx_slab_step / wx_exchange / wx_group_step: transport_prepare)
     s->exchange_in_order = value == 0;
     return WX_OK;
@@ -1472,6 +1653,32 @@ int wx_set_option(wx_sim *s, int option, int value)
 // checked every ghost texel on the device; a blocking call is where the verdict is collected (never a silent divergence).
 static int validate_ghost_flag(wx_sim *s)
 {
+  if (s->vx_check) { // did a velocity reach the bound the exchange period was sized for?
+    int bits = 0;
+    HIPCHK(s, hipMemcpyAsync(&bits, &s->state->cone_violation, 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    s->vx_check = false;
+    if (bits) {
+      float v;
+      memcpy(&v, &bits, 4);
+      HIPCHK(s, hipMemsetAsync(&s->state->cone_violation, 0, 4, s->stream));
+      return fail(s, WX_E_STATE, "|vx| reached %.3f cells / iteration in an exchange period sized for |vx| < %d (%d ghost columns per iteration): the flow accelerated "
+                                 "faster than the margin of wx_slab_set_vx_bound allows, ghost columns were consumed faster than assumed and the slab may differ "
+                                 "from the undecomposed run since", v, s->cone - 5, s->cone);
+    }
+  }
+  if (s->sync_words && s->split_check) { // did a device-side hand-off of a split iteration give up polling?
+    unsigned w[4] = {0, 0, 0, 0};
+    HIPCHK(s, hipMemcpyAsync(w, s->sync_words, 16, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    s->split_check = false;
+    if (w[2]) {
+      HIPCHK(s, hipMemsetAsync(s->sync_words + 2, 0, 8, s->stream));
+      return fail(s, WX_E_STATE, "a device-side hand-off of a split iteration (edge strips <-> halo exchange) was not answered within its poll limit (%s; arrivals %u of %u "
+                                 "(gate wanted %u), epoch %u of %u): the exchange did not run or a peer is gone; the results since are invalid",
+                  w[2] == 1 ? "the gate kernel waiting for the edge strips" : "an edge strip waiting for the ghost columns", w[0], s->arrive_target, w[3], w[1], s->epoch_host);
+    }
+  }
   if (s->fix_check) { // did a marching iteration find more cells with |v| >= 0.9 than the exact-path list holds?
     int over = 0;
     HIPCHK(s, hipMemcpyAsync(&over, &s->state->fix_overflow, 4, hipMemcpyDeviceToHost, s->stream));
@@ -1766,10 +1973,65 @@ int wx_slab_assert_water_free(wx_sim *s, int agreed)
   return WX_OK;
 }
 
+// ---- slabs exact at any speed ----
+int wx_slab_cone(const wx_sim *s) { return s ? s->cone : 0; }
+
+int wx_slab_period(const wx_sim *s)
+{
+  if (!s || s->halo <= 0) return 0;
+  if (s->pool_remote) { // with particles: the sprite radius (6) stays valid in the last iteration; `cone` for the first, cone + 3 for every further one
+    if (s->halo < 6 + s->cone) return 0;
+    return std::min(15, 1 + (s->halo - 6 - s->cone) / (s->cone + 3)); // (at most 15: the flip history is a 16-bit mask)
+  }
+  return s->halo / s->cone;
+}
+
+int wx_slab_set_vx_bound(wx_sim *s, float v_measured)
+{
+  if (!s) return WX_E_INVALID;
+  if (!(v_measured >= 0.0f)) return fail(s, WX_E_INVALID, "wx_slab_set_vx_bound: %g", v_measured);
+  // the margin: a flow measured at v may be at 1.25 v + 0.25 by the time the period it sizes is over (one to two periods later); below
+  // 0.6 cells / iteration that still is less than one cell
+  const float bound = v_measured * 1.25f + 0.25f;
+  const int cone = WX_SLAB_CONE + (bound >= 1.0f ? (int)floorf(bound) : 0);
+  if (s->halo > 0 && (cone > s->halo || (s->pool_remote && 6 + cone > s->halo)))
+    return fail(s, WX_E_STATE, "|vx| up to %.2f cells / iteration needs %d ghost columns per iteration; the handle has %d: a wider halo (wx_create_slab) is needed for this flow",
+                v_measured, cone, s->halo);
+  s->vx_known = v_measured;
+  s->vx_bound = bound;
+  s->cone = cone;
+  return WX_OK;
+}
+
+// the state as it lies in base_0, for kernels that do not track while they run and for states that came from outside
+static void vx_scan_enqueue(wx_sim *s, hipStream_t st)
+{
+  const VxTrack t = vx_track(s);
+  hipLaunchKernelGGL(k_vx_scan, dim3(1024), dim3(256), 0, st, s->X, s->Y, t.zone_l, t.zone_r, s->base[0], VxTrack{t.max_bits, t.violation, 0.0f, 0, 0});
+}
+
+int wx_slab_vx_take(wx_sim *s, float *vmax)
+{
+  if (!s || !vmax) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
+  if (!s->uploaded) return fail(s, WX_E_STATE, "wx_slab_vx_take before wx_upload");
+  settle_edges(s);
+  wait_unpacked(s);
+  if (s->vx_stale || s->vx_untracked) vx_scan_enqueue(s, s->stream);
+  int bits = 0;
+  HIPCHK(s, hipMemcpyAsync(&bits, &s->state->vx_max_bits, 4, hipMemcpyDeviceToHost, s->stream));
+  HIPCHK(s, hipMemsetAsync(&s->state->vx_max_bits, 0, 4, s->stream));
+  HIPCHK(s, hipStreamSynchronize(s->stream));
+  s->vx_stale = s->vx_untracked = false;
+  memcpy(vmax, &bits, 4);
+  return WX_OK;
+}
+
 int wx_sync(wx_sim *s)
 {
   if (!s) return WX_E_INVALID;
   DeviceScope dev_scope(s);
+  settle_edges(s);
   if (s->comm_stream) HIPCHK(s, hipStreamSynchronize(s->comm_stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
   return validate_ghost_flag(s);
@@ -1869,6 +2131,7 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return WX_OK;
   }
+  settle_edges(s);
   wait_unpacked(s); // ghost columns written on the comm stream are part of what a readback sees
   if (int rc = validate_ghost_flag(s)) return rc;
   if (field == WX_FIELD_EMITTED) {
@@ -1957,6 +2220,7 @@ int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst)
     HIPCHK(s, hipEventCreateWithFlags(&s->ev_fields_ready, hipEventDisableTiming));
     HIPCHK(s, hipEventCreateWithFlags(&s->ev_copy_done, hipEventDisableTiming));
   }
+  settle_edges(s);
   wait_unpacked(s); // ghost columns written on the comm stream are part of what a frame shows
   const void *ptr[6];
   size_t texel[6];
@@ -2008,6 +2272,8 @@ int wx_set_comm_stream(wx_sim *s, void *hip_stream)
   if (!s) return WX_E_INVALID;
   DeviceScope dev_scope(s);
   HIPCHK(s, hipStreamSynchronize(s->stream));
+  settle_edges(s);
+  HIPCHK(s, hipStreamSynchronize(s->stream));
   if (s->comm_stream) HIPCHK(s, hipStreamSynchronize(s->comm_stream));
   s->comm_stream = (hipStream_t)hip_stream;
   s->edges_recorded = s->unpack_pending = false;
@@ -2015,18 +2281,23 @@ int wx_set_comm_stream(wx_sim *s, void *hip_stream)
     HIPCHK(s, hipEventCreateWithFlags(&s->ev_edges, hipEventDisableTiming));
     HIPCHK(s, hipEventCreateWithFlags(&s->ev_unpacked, hipEventDisableTiming));
   }
+  // (the epoch word has to exist before the first unpack on a side stream: an edge strip polls it for exactly that unpack)
+  if (hip_stream)
+    if (int rc = split_launch_ready(s, false)) return rc;
   return WX_OK;
 }
 
 void *wx_device_ptr(wx_sim *s, int field)
 {
   if (!s) return nullptr;
+  settle_edges(s);
   wait_unpacked(s); // whatever the caller enqueues on the compute stream next sees the unpacked ghost columns (and the exchanged lightning state)
   if (field == WX_FIELD_LIGHTNING) return s->state->lightning;
   if (field == WX_FIELD_EMITTED) return emitted_rect(s, 0, 0, s->X, s->Y) == WX_OK ? s->emitted : nullptr; // (whole grid, computed now)
   const void *ptr;
   int ch, el;
   if (field_info(s, field, &ptr, &ch, &el)) return nullptr;
+  if (field == WX_FIELD_BASE_CUR) s->vx_stale = true; // (the caller may write velocities through the pointer: devtools.seed_flow does)
   return const_cast<void *>(ptr);
 }
 
@@ -2069,13 +2340,38 @@ static int halo_pack_impl(wx_sim *s, void *const dev_buf[2])
   HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
              s->pool_remote ? s->fb : nullptr, s->pool_remote ? s->dep : nullptr};
   hipStream_t st = exchange_stream(s);
-  if (st != s->stream) { // the packed columns are final behind ev_edges (or, without an edge-first step, behind everything enqueued so far)
+  if (st != s->stream && s->gate_pending && s->gate_wet && !wx_tune_env("WX_SPLIT_FIX_ON_COMM")) {
+    // ONE ordered launch of the WET kernel: its edge strips left exact-path cells on their own list. Consuming it HERE, on the comm
+    // stream, behind a gate kernel would let the pack start while the interior still marches -- built and measured in round 5, and
+    // withdrawn: k_wet_fix needs 652 bytes of scratch per lane, which the runtime hands out per dispatch ("use once") only when the
+    // queue can be given it -- seen to stall for SECONDS while the next iteration's edge strips were resident and polling for this very
+    // exchange (the poll limit turned the deadlock into an error; profiles/r05_slab_protocol_cost.txt). So the list is consumed on the
+    // compute stream behind the whole launch, and the pack waits for that: no overlap inside this iteration, none lost in the next.
+    settle_edges(s);
+    HIPCHK(s, hipEventRecord(s->ev_edges, s->stream));
+    s->edges_recorded = true;
+    HIPCHK(s, hipStreamWaitEvent(st, s->ev_edges, 0));
+    s->gate_passed = true;
+  } else if (st != s->stream && s->gate_pending) {
+    // the latest iteration was ONE ordered launch whose edge strips report on a device word: a one-wave gate kernel waits for them (the
+    // interior strips are still marching), then the pack may read (dry stencil: no exact-path list, every kernel here is scratch-free)
+    hipLaunchKernelGGL(k_strip_gate, dim3(1), dim3(64), 0, st, s->sync_words, s->arrive_target);
+    if (s->gate_wet && !wx_tune_env("WX_SPLIT_NOFIX2")) {
+      const WetFixList fix2{s->fix_count2, s->fix_cells2, s->fix_cap2, nullptr, &s->state->fastest_bits, nullptr};
+      launch_wet_fix(s->gate_iter, s->full_ctx, s->gate_in, s->gate_out, fix2, &s->state->fix_overflow, s->gate_opt_out, st, 64);
+    }
+    s->gate_pending = false;
+    s->gate_passed = true;
+  } else if (st != s->stream && s->gate_passed) {
+    // (the other side of the same exchange, packed by a call of its own: the gate is earlier in this stream)
+  } else if (st != s->stream) { // the packed columns are final behind ev_edges (or, without an edge-first step, behind everything enqueued so far)
     if (!s->edges_recorded) {
       HIPCHK(s, hipEventRecord(s->ev_edges, s->stream));
       s->edges_recorded = true;
     }
     HIPCHK(s, hipStreamWaitEvent(st, s->ev_edges, 0));
   }
+  settle_edges(s); // (an in-order pack: the edge strips' exact-path cells on the compute stream)
   ProfScope ps(s, K_HALO);
   int slots = 0;
   const HaloBufs hb = halo_bufs(s, dev_buf, true, &slots);
@@ -2098,10 +2394,8 @@ static int halo_unpack_impl(wx_sim *s, void *const dev_buf[2])
   hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256, slots), dim3(256), 0, st, f, s->X, s->Y, s->halo, hb,
                      s->water_trivial ? &s->state->ghost_nontrivial : nullptr);
   if (s->water_trivial) s->ghost_check = true;
-  if (st != s->stream) { // whoever touches the ghost columns next on the compute stream waits for this
-    HIPCHK(s, hipEventRecord(s->ev_unpacked, st));
-    s->unpack_pending = true;
-  }
+  if (st != s->stream) // whoever touches the ghost columns next on the compute stream waits for this
+    if (int rc = mark_unpacked(s, st)) return rc;
   if (s->pool_remote) { // the ghost tiles of the feedback texture now hold a neighbour's values: nothing is "known zero" any more
     hipMemsetAsync(s->sg.fb_zero, 0, 2 * (size_t)s->sg.TXn * s->sg.TYn, s->stream);
     s->fb_dirty = true;
@@ -2171,9 +2465,7 @@ static int pool_fence(wx_sim *s, hipStream_t st)
 static int pool_applied(wx_sim *s, hipStream_t st)
 {
   if (st == s->stream) return WX_OK;
-  HIPCHK(s, hipEventRecord(s->ev_unpacked, st));
-  s->unpack_pending = true;
-  return WX_OK;
+  return mark_unpacked(s, st);
 }
 
 #define POOL_ONLY(s, what) \

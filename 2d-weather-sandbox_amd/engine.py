@@ -36,7 +36,7 @@ EXPORTS = [
     "wx_set_option", "wx_water_free", "wx_slab_assert_water_free", "wx_tune_placement",
     "wx_comm_unique_id", "wx_comm_init", "wx_exchange", "wx_slab_step", "wx_group_create", "wx_group_destroy", "wx_group_last_error",
     "wx_group_count", "wx_group_transport", "wx_group_slab", "wx_group_agree", "wx_group_step", "wx_group_sync", "wx_group_set_option",
-    "wx_group_exchange",
+    "wx_group_exchange", "wx_slab_vx_take", "wx_slab_set_vx_bound", "wx_slab_cone", "wx_slab_period",
 ]
 
 
@@ -123,6 +123,10 @@ def lib() -> C.CDLL:
     L.wx_setup_columns.argtypes = [vp] + [vp] * 8
     L.wx_init_droplets.argtypes = [vp, C.c_uint32]
     L.wx_fastest_velocity.argtypes = [vp, C.POINTER(C.c_float)]
+    L.wx_slab_vx_take.argtypes = [vp, C.POINTER(C.c_float)]
+    L.wx_slab_set_vx_bound.argtypes = [vp, C.c_float]
+    L.wx_slab_cone.argtypes = [vp]
+    L.wx_slab_period.argtypes = [vp]
     L.wx_setup_terrain.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_double] + [vp] * 4
     L.wx_stream_bytes.argtypes = [i32, i32]
     L.wx_stream_bytes.restype = C.c_size_t
@@ -287,7 +291,7 @@ class Handle:
         """The host's assertion that EVERY slab of the domain was uploaded water-free (wx_slab_assert_water_free)."""
         self._chk(lib().wx_slab_assert_water_free(self._h, 1 if agreed else 0))
 
-    OPT_SPLAT_ORDER, OPT_CHECK_LAUNCHES, OPT_KERNEL_SET, OPT_DRY_KERNEL, OPT_ROW_BANDS, OPT_FIX_CAP, OPT_POOL_EXACT, OPT_EXCHANGE_OVERLAP = 1, 2, 3, 4, 5, 6, 7, 8
+    OPT_SPLAT_ORDER, OPT_CHECK_LAUNCHES, OPT_KERNEL_SET, OPT_DRY_KERNEL, OPT_ROW_BANDS, OPT_FIX_CAP, OPT_POOL_EXACT, OPT_EXCHANGE_OVERLAP, OPT_SPLIT_LAUNCH = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
     def set_option(self, option: int, value: int):
         """wx_set_option: OPT_SPLAT_ORDER 1 = deterministic particle splats (sorted, droplet-index order); OPT_CHECK_LAUNCHES 1 =
@@ -428,6 +432,25 @@ class Handle:
         v = C.c_float(0)
         self._chk(lib().wx_fastest_velocity(self._h, C.byref(v)))
         return float(v.value)
+
+    # ---- slabs exact at any speed (include/wxsim.h): the hosts of all slabs agree on a |vx| bound per exchange period ----
+    def slab_vx_take(self) -> float:
+        """Largest |vx| this slab has seen since the last take (0 below 0.5 cells / iteration); synchronises."""
+        v = C.c_float(0)
+        self._chk(lib().wx_slab_vx_take(self._h, C.byref(v)))
+        return float(v.value)
+
+    def slab_set_vx_bound(self, v_measured: float):
+        """v_measured = the maximum over ALL slabs: sizes the coming exchange period (cone = 6 + floor(1.25 v + 0.25) once that reaches 1)."""
+        self._chk(lib().wx_slab_set_vx_bound(self._h, C.c_float(float(v_measured))))
+
+    @property
+    def slab_cone(self) -> int:
+        return int(lib().wx_slab_cone(self._h))
+
+    @property
+    def slab_period(self) -> int:
+        return int(lib().wx_slab_period(self._h))
 
     def init_droplets(self, seed: int = 1):
         """initRainDrops() on the device (wx_init_droplets): a fresh all-inactive pool, a pure function of the seed."""

@@ -175,6 +175,15 @@ class HipSlabEngine:
     def sync(self):
         self.h.sync()
 
+    # slabs exact at any speed (include/wxsim.h): the |vx| this slab measured / the bound all slabs agreed on
+    def vx_take(self) -> float:
+        return self.h.slab_vx_take()
+
+    def set_vx_bound(self, v: float) -> int:
+        """Sizes the coming exchange period by the maximum over all slabs; returns the iterations per exchange."""
+        self.h.slab_set_vx_bound(v)
+        return self.h.slab_period
+
 
 EXACT_EVENTS_PER_ITERATION = 16384  # status flips a rank can report per iteration in exact mode (the all-gather has a fixed stride: no
                                      # host round trip for the counts); more is an error reported by the next blocking call
@@ -264,6 +273,19 @@ class SlabSim:
         t = torch.tensor([1 if e.water_free() else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         e.assert_water_free(bool(int(t.item())))
+
+    def agree_vx_bound(self):
+        """Slabs exact at any speed: one iteration invalidates 6 + floor|vx| ghost columns, so at the start of every exchange period the
+        ranks all-reduce (MAX) the largest |vx| each of them measured and size the period by it (wx_slab_vx_take / wx_slab_set_vx_bound;
+        a velocity that outruns the bound inside the period is reported by the next blocking call). The host-driven exchange pays a
+        synchronisation per period for it; the in-library transport (wx_slab_step) carries the maxima with the exchange instead."""
+        e = self.engine
+        if self.world == 1 or not hasattr(e, "vx_take"):
+            return
+        dev = self.send[0].device if (self.send[0].is_cuda and not self._stage) else torch.device("cpu")
+        t = torch.tensor([e.vx_take()], dtype=torch.float32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self.iters_per_exchange = max(1, e.set_vx_bound(float(t.item())))
 
     @property
     def handle(self):
@@ -393,12 +415,14 @@ class SlabSim:
             e.set_lightning(new_light.cpu().numpy())
 
     def step(self, n: int):
-        if self._native:  # periods, launch order around the exchange and the exchange itself: wx_slab_step
+        if self._native:  # periods, launch order around the exchange, the |vx| bound and the exchange itself: wx_slab_step
             self.engine.h.slab_step(n)
             self._iters += n
             return
         done = 0
         while done < n:
+            if self._since_exchange == 0:
+                self.agree_vx_bound()
             k = min(self.iters_per_exchange - self._since_exchange, n - done)
             if self.exact:  # one iteration per call, each followed by the events of all ranks
                 for _ in range(k):

@@ -293,11 +293,21 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
     return res
 
 
-def measure_handle(h, cells, steps, warmup, frame, algo_bytes=None):
-    """warm-up, clock conditioning, `steps` timed iterations on one handle with the per-kernel profile: the entry of one configuration."""
+def measure_handle(h, cells, steps, warmup, frame, algo_bytes=None, events_in_timed_region=True):
+    """warm-up, clock conditioning, `steps` timed iterations on one handle with the per-kernel profile: the entry of one configuration.
+
+    events_in_timed_region=False (configurations whose iteration is tens of microseconds): the timed region runs WITHOUT the per-kernel
+    HIP events -- two event records per launch group are a ~3 us bubble each, 10 % of a 31 us iteration (profiles/r04_bench_timeline_event_gaps.txt,
+    profiles/r05_c1_segment_sweep.txt: 30.8 us per iteration without them, 34.5 with) -- and a second, profiled run of the same length follows for
+    the kernel breakdown; `roofline_frac` is then taken from the un-profiled whole step (launch gaps included: conservative), the event-timed
+    figure is reported next to it."""
     run_frames(h.step, warmup, frame)
     condition_clocks(h.step, h.sync, frame)
-    dt, prof = timed_run(h, steps, frame)
+    if events_in_timed_region:
+        dt, prof = timed_run(h, steps, frame)
+    else:
+        dt, _ = timed_run(h, steps, frame, profile=False)
+        _, prof = timed_run(h, steps, frame)
     out = {"value": cells * steps / dt / 1e6, "unit": "Mcell-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
            "kernels_ms_per_step": {k: v[0] / steps for k, v in prof.items()}}
     if prof:
@@ -307,7 +317,13 @@ def measure_handle(h, cells, steps, warmup, frame, algo_bytes=None):
         out["avg_launch_ms"] = ms / cnt
         if ab:
             out["algo_bytes_per_cell"] = ab
-            out["roofline_frac"] = ab * cells / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS
+            ev = ab * cells / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if events_in_timed_region:
+                out["roofline_frac"] = ev
+            else:
+                out["roofline_frac"] = ab * cells / (dt / steps) / 1e9 / HBM_PEAK_GBS
+                out["roofline_frac_event_timed"] = ev
+                out["timed_region"] = "no per-kernel events (a second, profiled run gives kernels_ms_per_step / avg_launch_ms); roofline_frac from the whole un-profiled step"
     return out
 
 
@@ -330,7 +346,7 @@ def other_configs(a, pkg):
     h = pkg.engine.Handle(X, Y, 0)
     h.upload(g["in_base"], g["in_water"], g["in_wall"])
     h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
-    out["c0_save100x100_1000_iterations"] = dict(measure_handle(h, X * Y, 1000, 100, a.frame), note="launch-bound (two launches per iteration); the reference "
+    out["c0_save100x100_1000_iterations"] = dict(measure_handle(h, X * Y, 1000, 100, a.frame, events_in_timed_region=False), note="launch-bound (two launches per iteration); the reference "
                                                  "under SwiftShader on 8 vCPU: 2.0-2.2 Mcell-steps/s (BASELINE.md)")
     h.close()
     # the reference's OWN grid sizes: a new simulation is 2500 x 300 by default and the resolution sliders end at 16000 x 500
@@ -344,7 +360,7 @@ def other_configs(a, pkg):
         h.setup_columns(pkg.synth.terrain_columns(X, Y))
         h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), ur), ur["initial_T"])
         devtools.seed_flow(h, a.flow if a.flow > 0 else 0.2, kind=a.flow_kind)
-        out[name] = dict(measure_handle(h, X * Y, 1000, 100, a.frame), note="the reference's own grid size, all six grid passes + lighting, particles off, moving fluid")
+        out[name] = dict(measure_handle(h, X * Y, 1000, 100, a.frame, events_in_timed_region=False), note="the reference's own grid size, all six grid passes + lighting, particles off, moving fluid")
         h.close()
     # configs[1]
     X, Y = 4096, 1024
@@ -354,7 +370,7 @@ def other_configs(a, pkg):
     h = pkg.engine.Handle(X, Y, 0)
     h.upload(*pkg.synth.dry_grid(X, Y))
     h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), ud), ud["initial_T"])
-    out["c1_dry_4096x1024"] = measure_handle(h, X * Y, 1000, 200, a.frame)
+    out["c1_dry_4096x1024"] = measure_handle(h, X * Y, 1000, 200, a.frame, events_in_timed_region=False)
     h.close()
     # configs[4] on one GPU
     X, Y, N = 16384, 2048, 1048576

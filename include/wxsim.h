@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WX_ABI_VERSION 8
+#define WX_ABI_VERSION 9
 
 /* error codes */
 #define WX_OK 0
@@ -122,6 +122,25 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
 #define WX_SLAB_CONE 6
 #define WX_SLAB_CONE_PARTICLES 9
 #define WX_SLAB_PERIOD_PARTICLES(halo) ((halo) < 12 ? 0 : ((1 + ((halo) - 12) / WX_SLAB_CONE_PARTICLES) < 15 ? (1 + ((halo) - 12) / WX_SLAB_CONE_PARTICLES) : 15))
+/* Slabs exact at ANY speed (round 5). The figures above hold for |vx| < 1 cell / iteration -- the shaders' documented range
+ * (common.glsl:40-41), which the reference never enforces: advectionShader.frag:85-99 back-traces `fragCoord - vel` for any vel, so one
+ * iteration's cone really is 6 + floor|vx| columns. The marching kernels therefore keep the largest |vx| they produce, and the HOSTS OF ALL
+ * SLABS agree on a bound per exchange period:
+ *   wx_slab_vx_take(s, &v)       the largest |vx| this slab has seen since the last take (0 below 0.5; synchronises; after an upload /
+ *                                wx_device_ptr(BASE_CUR) the state itself is scanned first)
+ *   wx_slab_set_vx_bound(s, v)   v = the maximum over ALL slabs: the coming period assumes |vx| < 1.25 v + 0.25 (a flow measured at v may
+ *                                have accelerated by the time the period is over), i.e. cone = 6 + floor(1.25 v + 0.25) once that
+ *                                reaches 1 -- WX_E_STATE if the halo is too thin for it
+ *   wx_slab_cone(s), wx_slab_period(s)   ghost columns per iteration / iterations per exchange under the current bound (with particles:
+ *                                cone for the first iteration, cone + 3 for every further one, a sprite radius left in the last)
+ * A |vx| that reaches the bound inside a period is REPORTED by the next blocking call (WX_E_STATE), never silent. wx_slab_step /
+ * wx_group_step do all of this themselves without a host round trip inside a period: the maxima travel with the exchange (one word per
+ * slab, all-gathered) and size the period after the next; slab.py's host-driven exchange all-reduces them. Hosts that drive
+ * wx_step_overlap / wx_halo_* themselves call the three functions once per period. */
+int wx_slab_vx_take(wx_sim *s, float *vmax);
+int wx_slab_set_vx_bound(wx_sim *s, float v_measured);
+int wx_slab_cone(const wx_sim *s);
+int wx_slab_period(const wx_sim *s);
 
 void wx_destroy(wx_sim *s);
 const char *wx_last_error(const wx_sim *s); /* also valid with s == NULL for create failures */
@@ -209,6 +228,12 @@ int wx_sync(wx_sim *s);
  *   needs precipitation's feedback texture); 0 = everything in order on the compute stream -- same results bit for bit (tests), and
  *   what the exact particle mode always does. */
 #define WX_OPT_EXCHANGE_OVERLAP 8
+/* WX_OPT_SPLIT_LAUNCH (slab handles with a comm stream): how wx_step_overlap runs a split iteration. 1 (default, round 5) = ONE launch over
+ *   all strips whose dispatch order puts the edge strips first / last, with device-side hand-offs: the edge strips report on a device
+ *   word that a one-wave gate kernel on the comm stream polls before the halo is packed, and poll an epoch word the comm stream bumps
+ *   behind the unpack -- no second stream, no join events on the compute stream. 0 = the edge strips and the interior as two launch
+ *   groups on two streams joined by events (rounds 2-4; kept for A/B measurements: tools/slab_protocol_cost.py). Same results. */
+#define WX_OPT_SPLIT_LAUNCH 9
 int wx_set_option(wx_sim *s, int option, int value);
 
 /* iterNum global (app.js:440) */
@@ -338,7 +363,7 @@ int wx_lightning_set(wx_sim *s, const float in[4]);
  *   wx_exchange(s)                         pack both edges -> ncclGroupStart; ncclSend x 2; ncclRecv x 2; ncclGroupEnd -> unpack both
  *                                          ghost strips, all enqueued on the handle's comm stream (one of the library's own unless
  *                                          wx_set_comm_stream named one); never blocks the host
- *   wx_slab_step(s, n)                     n iterations with one wx_exchange per halo / WX_SLAB_CONE iterations; the iteration before
+ *   wx_slab_step(s, n)                     n iterations with one wx_exchange per wx_slab_period(s) iterations; the iteration before
  *                                          an exchange launches its edge strips first, the one after it its interior strips first
  *                                          (wx_step_overlap), so the transfer runs behind the interior of both. Replaces the loop
  *                                          body app.js:5830-6005 for one slab of a decomposed domain.
@@ -378,10 +403,8 @@ int wx_group_sync(wx_group *g);
 
 /* The largest |velocity component| [cells / iteration] among the cells the marching wet kernel handed to its exact path (back-traces
  * of 0.9 cells and more) since the last call; 0 if there was none; NaN if a velocity was NaN. Resets the value; synchronises the
- * handle's stream. Whole-domain handles are exact at any speed. On SLAB handles the halo width assumes |v| < 1 (the advection reaches
- * 1 + ceil|v| columns: 6 columns per iteration in all, WX_SLAB_CONE): a value >= 1 says that cells near a slab edge may have used ghost
- * columns that were no longer valid in the last iterations of a period, i.e. the slabs may differ from the undecomposed run there
- * (the simulation itself is as valid as the reference's at such speeds; bench.py --verify measures the difference). */
+ * handle's stream. Whole-domain handles and slabs are exact at any speed (slabs size their exchange period by the |vx| they measure:
+ * wx_slab_set_vx_bound above); the value is a diagnostic of the flow, nothing more. */
 int wx_fastest_velocity(wx_sim *s, float *cells_per_iteration);
 
 /* Per-kernel device time from HIP events recorded on the handle's stream around every launch.

@@ -745,13 +745,17 @@ def _run_overlapped(E, slabs, comm, bufs, per, n_iter):
         exchanged = True
 
 
-@pytest.mark.parametrize("nslab,halo,X,bands", [(2, 12, 1024, None), (4, 24, 4096, None), (2, 6, 128, None), (2, 12, 1024, "2")])
-def test_slab_overlapped_exchange_equals_whole_domain(pkg, E, monkeypatch, nslab, halo, X, bands):
+@pytest.mark.parametrize("nslab,halo,X,bands,split", [(2, 12, 1024, None, 1), (4, 24, 4096, None, 1), (2, 6, 128, None, 1), (2, 12, 1024, "2", 1),
+                                                      (4, 24, 4096, "2", 1), (2, 12, 1024, None, 0), (4, 24, 4096, "2", 0)])
+def test_slab_overlapped_exchange_equals_whole_domain(pkg, E, monkeypatch, nslab, halo, X, bands, split):
     """The exchange / compute overlap (wx_set_comm_stream + wx_step_overlap): N slab handles on one GPU, each with its own compute
     stream and its own comm stream, nothing synchronised on the host between the steps -- the edge strips of the last iteration
     run first, pack + copy + unpack proceed on the comm streams while the interior strips compute, the edge strips of the next
-    iteration wait for the unpack event. Ten exchange periods, bit for bit the undecomposed handle. (A slab too narrow to have
-    interior strips, the third case, degrades to the in-order exchange through the same calls.)"""
+    iteration wait for the unpack. Ten exchange periods, bit for bit the undecomposed handle. (A slab too narrow to have
+    interior strips, the third case, degrades to the in-order exchange through the same calls.) `split` = WX_OPT_SPLIT_LAUNCH: 1 (the
+    default since round 5) runs a split iteration as ONE launch whose dispatch order puts the edge strips first / last, with device-side
+    hand-offs (arrival word + gate kernel, epoch word); 0 = the two launch groups on two streams of rounds 2-4. The velocities
+    (sigma 0.2) put a few dozen cells per iteration on the exact path, also in edge strips: their own list, consumed on the comm stream."""
     import torch
     monkeypatch.setenv("WX_FUSED", "2")
     if bands:  # the row-band launch shape of wide slabs (e.g. two ranks on 32768 columns), forced onto this small grid
@@ -779,6 +783,7 @@ def test_slab_overlapped_exchange_equals_whole_domain(pkg, E, monkeypatch, nslab
         comm.append(torch.cuda.Stream())
         h.set_stream(main[r].cuda_stream)
         h.set_comm_stream(comm[r].cuda_stream)
+        h.set_option(E.Handle.OPT_SPLIT_LAUNCH, split)
         slabs.append(h)
         bufs.append([torch.empty(h.halo_bytes(), dtype=torch.uint8, device="cuda") for _ in range(2)])
     _run_overlapped(E, slabs, comm, bufs, per, n_iter)
@@ -823,16 +828,17 @@ def _dry_slabs(pkg, E, X, Y, nslab, halo, base, water, wall, u, assert_free):
     return slabs, comm, bufs, free
 
 
-@pytest.mark.parametrize("nslab,halo,X,wet_rank", [(2, 12, 1024, None), (4, 24, 4096, None), (2, 12, 1024, 1), (4, 12, 2048, 2)])
-def test_dry_slab_overlapped_exchange_equals_whole_domain(pkg, E, nslab, halo, X, wet_rank):
+@pytest.mark.parametrize("nslab,halo,X,wet_rank,Y,split", [(2, 12, 1024, None, 96, 1), (4, 24, 4096, None, 96, 1), (2, 12, 1024, 1, 96, 1), (4, 12, 2048, 2, 96, 1),
+                                                           (4, 24, 4096, None, 576, 1), (2, 12, 1024, None, 96, 0), (4, 24, 4096, None, 576, 0)])
+def test_dry_slab_overlapped_exchange_equals_whole_domain(pkg, E, nslab, halo, X, wet_rank, Y, split):
     """BASELINE's north-star stencil (pass_mask DRY) on slabs with the exchange overlapped: the water-free row-marching kernel takes
     strip ranges like the wet one (edge strips / interior). It may only run when NO slab carries water -- the hosts agree on that
     once per upload (wx_water_free -> all-reduce MIN -> wx_slab_assert_water_free), so no step ever reads a flag back. With water in
     ONE rank's slab (wet_rank) every handle falls back to the water-carrying kernel; both ways the owned columns equal the
-    undecomposed handle bit for bit over ten exchange periods."""
-    Y = 96
+    undecomposed handle bit for bit over ten exchange periods. Y = 576 gives the row-band launch shape (72-row bands), whose split
+    iterations are ONE launch with the edge strips first / last in every XCD's dispatch order (`split` = WX_OPT_SPLIT_LAUNCH, see the wet test)."""
     per, n_iter = halo // 6, 10 * (halo // 6) + 1
-    base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=0.2)
+    base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=0.2 if Y < 200 else 0.12)  # (the taller grid's eddies are faster: |v| < 1 is the precondition of the fixed period)
     rng = np.random.Generator(np.random.Philox(77))
     base[1:, :, 2] += rng.normal(0, 1e-3, (Y - 1, X)).astype(np.float32)
     xo = X // nslab
@@ -844,6 +850,7 @@ def test_dry_slab_overlapped_exchange_equals_whole_domain(pkg, E, nslab, halo, X
     slabs, comm, bufs, free = _dry_slabs(pkg, E, X, Y, nslab, halo, base, water, wall, u, None)
     assert free == [r != wet_rank for r in range(nslab)]
     for h in slabs:
+        h.set_option(E.Handle.OPT_SPLIT_LAUNCH, split)
         h.profile(True)
     _run_overlapped(E, slabs, comm, bufs, per, n_iter)
     for h in slabs:
@@ -938,7 +945,9 @@ def test_slab_particles_equal_whole_domain(pkg, E, nslab, order):
     pkg.synth.add_cloud_deck(water, wall)
     rng = np.random.default_rng(4)
     air = wall[..., 1] != 0
-    base[..., 0] += np.where(air, rng.normal(0, 0.3, (Y, X)), 0).astype(np.float32)  # droplets drift across slab edges
+    # droplets drift across slab edges (|vx| clipped below one cell / iteration: these tests drive wx_step / wx_halo_* with the FIXED periods of
+    # the 6-column cone, which the handles now hold their hosts to -- tests/test_group_transport.py::test_group_is_exact_at_any_speed covers faster flow)
+    base[..., 0] += np.where(air, np.clip(rng.normal(0, 0.3, (Y, X)), -0.8, 0.8), 0).astype(np.float32)
     drops = pkg.synth.init_rain_drops(N)
     na = 2500  # active droplets: everywhere, plus clusters on the slab edges and on the domain edge
     px = rng.uniform(-1, 1, na)
@@ -1075,7 +1084,7 @@ def test_slab_particles_exact_mode_is_bit_identical(pkg, E, nslab):
     pkg.synth.add_cloud_deck(water, wall)
     rng = np.random.default_rng(11)
     air = wall[..., 1] != 0
-    base[..., 0] += np.where(air, rng.normal(0, 0.3, (Y, X)), 0).astype(np.float32)
+    base[..., 0] += np.where(air, np.clip(rng.normal(0, 0.3, (Y, X)), -0.8, 0.8), 0).astype(np.float32)  # (fixed 6-column periods: |vx| < 1)
     deck = air & (water[..., 1] > 0)
     water[..., 1] += np.where(deck, 2.5, 0).astype(np.float32)  # dense: lightning requests
     water[..., 0] += np.where(deck, 2.5, 0).astype(np.float32)

@@ -81,6 +81,89 @@ def test_group_local_transport_equals_whole_domain(pkg, nslab, halo, X, wet, mon
     whole.close()
 
 
+def _jet_scene(pkg, X, Y, nslab, wet):
+    """Jets of 1.5 .. 2.5 cells / iteration straddling EVERY slab edge (and the periodic seam), in both directions: faster than the
+    shaders' documented range (common.glsl:40-41) but nothing the reference clamps (advectionShader.frag:85-99)."""
+    if wet:
+        base, water, wall, u = _scene(pkg, X, Y)
+    else:
+        u = pkg.params.uniforms_from_gui(pkg.params.merge_settings(None), Y, quad_scale=0, pass_mask=pkg.params.PASS_DRY)
+        u["enablePrecipitation"] = 0
+        base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=0.1)
+    xo = X // nslab
+    for b in range(nslab):  # slab edge at column b * xo (b = 0: the periodic seam)
+        cols = (b * xo + np.arange(-70, 70)) % X
+        ramp = np.interp(np.arange(-70, 70), [-70, -40, 40, 70], [0.0, 1.0, 1.0, 0.0]).astype(np.float32)
+        for rows, v in ((slice(34, 40), 1.8), (slice(44, 50), -1.6)):
+            base[rows, cols, 0] = np.where(wall[rows, cols, 1] != 0, v * ramp, base[rows, cols, 0])
+        core = (b * xo + np.arange(-3, 3)) % X  # a core beyond two cells / iteration: the exact path's general fallback
+        base[36:38, core, 0] = np.where(wall[36:38, core, 1] != 0, 2.4, base[36:38, core, 0])
+    return base, water, wall, u
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nslab,wet", [(2, True), (4, True), (2, False), (4, False)])
+def test_group_is_exact_at_any_speed(pkg, nslab, wet):
+    """SURVEY 8e's determinism check without the |v| < 1 caveat of rounds 1-4: one iteration's dependency cone is 6 + floor|vx| columns,
+    the marching kernels measure |vx|, and the slabs size every exchange period by the bound they agree on (wx_slab_set_vx_bound; here
+    through wx_group_step: bootstrap scan after the upload, then the maxima travel with every exchange). Jets of 1.5 .. 2.5 cells /
+    iteration across every slab edge, wet iteration and the dry north-star stencil, in-library transport: bit for bit one handle."""
+    E = pkg.engine
+    X, Y, halo = 2048, 64, 42
+    base, water, wall, u = _jet_scene(pkg, X, Y, nslab, wet)
+    assert np.abs(base[..., 0]).max() > 2.0
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    g = E.Group(nslab, X, Y, halo=halo, devices=[0] * nslab, transport=E.TRANSPORT_LOCAL)
+    g.upload(base, water, wall)
+    g.set_params(p, u["initial_T"])
+    whole = E.Handle(X, Y, 0)
+    whole.upload(base, water, wall)
+    whole.set_params(p, u["initial_T"])
+    cones = []
+    for k in (1, 5, 8, 3):  # call boundaries anywhere relative to the (now variable) exchange periods
+        g.step(k)
+        whole.step(k)
+        cones.append(g.slabs[0].slab_cone)
+    g.sync()
+    assert cones[0] >= 6 + 3, cones  # the bootstrap scan saw the 2.4 core: 6 + floor(1.25 * 2.4 + 0.25) = 9 columns per iteration
+    assert all(h.slab_cone == cones[-1] and h.slab_period == halo // cones[-1] for h in g.slabs)
+    vmax = float(np.abs(whole.read_rect("BASE_CUR")[..., 0]).max())
+    assert vmax > 1.0, vmax  # still faster than one cell per iteration at the end: the cone of rounds 1-4 would not have held
+    for f in FIELDS[:3] if not wet else FIELDS:
+        assert np.array_equal(g.read(f), whole.read_rect(f)), f
+    g.close()
+    whole.close()
+
+
+@pytest.mark.gpu
+def test_slab_outrunning_its_vx_bound_is_reported(pkg):
+    """A host that drives wx_step_overlap / wx_halo_* itself and never tells the handle about fast flow (wx_slab_set_vx_bound) keeps the
+    6-column cone -- and gets WX_E_STATE from the next blocking call once a |vx| reaches one cell per iteration: never a silent divergence."""
+    E = pkg.engine
+    X, Y, halo = 1024, 64, 12
+    base, water, wall, u = _jet_scene(pkg, X, Y, 2, True)
+    h = E.Handle(X // 2, Y, 0, X_global=X, x0=0, halo=halo)
+    idx = (-halo + np.arange(X // 2 + 2 * halo)) % X
+    h.upload(np.ascontiguousarray(base[:, idx]), np.ascontiguousarray(water[:, idx]), np.ascontiguousarray(wall[:, idx]))
+    h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    assert h.slab_cone == 6 and h.slab_period == 2
+    h.step(1)
+    with pytest.raises(E.WxError) as ei:
+        h.sync()
+    assert ei.value.code == -5 and "|vx| reached" in str(ei.value)
+    # told about the flow, the same handle sizes its period accordingly; 12 ghost columns are too few for 6 cells / iteration
+    v = h.slab_vx_take()
+    assert v > 1.5
+    h.slab_set_vx_bound(v)
+    assert h.slab_cone == 6 + int(1.25 * v + 0.25) >= 8 and h.slab_period == 1
+    with pytest.raises(E.WxError) as ei:
+        h.slab_set_vx_bound(6.0)
+    assert "wider halo" in str(ei.value)
+    h.slab_set_vx_bound(0.7)
+    assert h.slab_cone == 7 and h.slab_period == 1
+    h.close()
+
+
 def _particle_scene(pkg, X, Y, N, seed=4):
     """A cloud deck over terrain, droplets everywhere incl. on the slab edges and at the domain edge, a drift that carries them across."""
     base, water, wall = pkg.synth.terrain_grid(X, Y)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """What the exchange PROTOCOL costs one rank of an 8-GPU run, measured on one GPU that the slab has to itself: ONE slab of X/8 owned
 columns whose neighbours are itself (a periodic domain X/8 wide + ghost columns; wx_step_overlap with the edge-first / interior-first
-flags, wx_halo_pack / wx_halo_unpack on a comm stream as slab.py issues them -- every launch an N-GPU rank makes, minus the link), against the same slab shape
-stepped as a plain handle (what tools/slab_shapes.py times). Usage: python tools/slab_protocol_cost.py [X_global Y halo reps]"""
+flags, wx_halo_pack / wx_halo_unpack on a comm stream as slab.py issues them -- every launch an N-GPU rank makes, minus the link), against the same handle
+stepped without any exchange (what tools/slab_shapes.py times) -- ONE handle for all modes, so that the placement lottery drops out. Usage: python tools/slab_protocol_cost.py [X_global Y halo reps]"""
 import os
 import sys
 import time
@@ -42,38 +42,46 @@ def fill(h, Xg, cols):
 
 u = uniforms()
 p = pkg.params.fill_struct(pkg.params.WxParams(), u)
-# (a) the slab as a plain handle: no exchange, one launch group per iteration
-plain = E.Handle(XO, Y, 0, X_global=XG, x0=3 * XO, halo=HALO)
-fill(plain, XG, (3 * XO - HALO, XO + 2 * HALO))
-plain.set_params(p, u["initial_T"])
-devtools.seed_flow(plain, 0.2, Xg=XG, x0=3 * XO)
-# (b) the same shape as a periodic domain of its own: the slab's neighbours are itself -- the whole host-driven protocol of slab.py
-#     (wx_step_overlap flags, pack / unpack on a comm stream), minus the link
 import ctypes  # noqa: E402
 
 
 class SelfExchange:
-    def __init__(self, overlap):
+    """ONE handle (one placement of the planes: handles of one process differ by +-8 % from the placement alone, section 4 of LABNOTES) run in
+    four modes: no exchange at all (`plain`: what a slab's kernels cost), the overlapped protocol as one ordered launch per split iteration
+    (round 5) or as two launch groups on two streams (rounds 2-4), and the protocol in order on the compute stream."""
+
+    def __init__(self):
         self.h = E.Handle(XO, Y, 0, X_global=XO, x0=0, halo=HALO)
         fill(self.h, XO, (XO - HALO, XO + 2 * HALO))
         self.h.set_params(p, u["initial_T"])
         devtools.seed_flow(self.h, 0.2, Xg=XO, x0=0)
-        self.overlap = overlap
-        self.comm = torch.cuda.Stream(priority=-1) if overlap else None
-        if overlap:
-            self.h.set_comm_stream(self.comm.cuda_stream)
+        self.comm = torch.cuda.Stream(priority=-1)
         nb = self.h.halo_bytes()
         self.buf = [torch.empty(nb, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        self.ipe = max(1, HALO // 6)
-        self.exchanged = False
-        self.since = 0
+        # (this tool drives wx_step_overlap / wx_halo_* itself: it tells the handle once that the seeded flow stays below 1.5 cells / iteration
+        # -- 7 ghost columns per iteration -- and sizes its periods by that)
+        self.h.slab_set_vx_bound(1.0)
+        self.ipe = max(1, self.h.slab_period)
+        self.mode = None
+
+    def set_mode(self, mode):  # "plain" | "one" | "two" | "inorder"
+        self.h.sync()
+        torch.cuda.synchronize()
+        self.h.set_comm_stream(self.comm.cuda_stream if mode in ("one", "two") else 0)
+        if mode in ("one", "two"):
+            self.h.set_option(E.Handle.OPT_SPLIT_LAUNCH, 1 if mode == "one" else 0)
+        self.mode, self.exchanged, self.since = mode, False, 0
 
     def step(self, n):
+        if self.mode == "plain":
+            self.h.step(n)
+            return
+        overlap = self.mode in ("one", "two")
         done = 0
         while done < n:
             k = min(self.ipe - self.since, n - done)
             last = self.since + k >= self.ipe
-            flags = ((2 if (self.exchanged and self.since == 0) else 0) | (1 if last else 0)) if self.overlap else 0
+            flags = ((2 if (self.exchanged and self.since == 0) else 0) | (1 if last else 0)) if overlap else 0
             self.h.step(k, flags)
             done += k
             self.since += k
@@ -89,28 +97,32 @@ class SelfExchange:
         torch.cuda.synchronize()
 
 
-outs = {1: SelfExchange(1), 0: SelfExchange(0)}
+sx = SelfExchange()
 
 
-def timed(obj, iters=210, frame=7):
-    obj.sync()
+def timed(mode, iters=210, frame=7):
+    sx.set_mode(mode)
+    sx.step(2 * frame)
+    sx.sync()
     t0 = time.perf_counter()
     for _ in range(iters // frame):
-        obj.step(frame)
-    obj.sync()
+        sx.step(frame)
+    sx.sync()
     return (time.perf_counter() - t0) / iters * 1e3
 
 
-for o in (plain, outs[1], outs[0]):
-    timed(o)
+MODES = {"plain": "plain (no exchange)", "one": "protocol, overlapped: ONE ordered launch (r5)", "two": "protocol, overlapped: two launch groups (r4)",
+         "inorder": "protocol, in order"}
+for m in MODES:
+    timed(m)
 if int(os.environ.get("TUNE", "8")):
-    plain.tune_placement(int(os.environ.get("TUNE", "8")))
-res = {"plain": [], "protocol, overlapped": [], "protocol, in order": []}
+    sx.set_mode("plain")
+    sx.h.tune_placement(int(os.environ.get("TUNE", "8")))
+res = {v: [] for v in MODES.values()}
 for _ in range(REPS):
-    res["plain"].append(timed(plain))
-    res["protocol, overlapped"].append(timed(outs[1]))
-    res["protocol, in order"].append(timed(outs[0]))
-per = HALO // 6
+    for m, label in MODES.items():
+        res[label].append(timed(m))
+per = sx.ipe
 print(f"{WORK} {XG}x{Y} as one of 8 slabs ({XO} + 2 x {HALO} columns, {per} iterations per exchange): ms / iteration, {REPS} interleaved repetitions")
 for k, v in res.items():
-    print(f"  {k:22s} " + " ".join(f"{x:.4f}" for x in v) + f"   median {np.median(v):.4f}")
+    print(f"  {k:48s} " + " ".join(f"{x:.4f}" for x in v) + f"   median {np.median(v):.4f}")
