@@ -9,6 +9,7 @@
 #include "wx_wet.h"
 #include "wx_dry.h"
 #include "wx_march.h"
+#include "wx_march2.h"
 #include "wx_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -50,11 +51,12 @@ enum KernelId {
   K_FUSED_DRY,  // velocity + advection + pressure (pass_mask WX_PASS_DRY)
   K_MARCH_DRY,  // the same as a row-marching wavefront kernel (wx_march.h)
   K_MARCH_WET,  // the whole iteration as one row-marching wavefront kernel (wx_wet.h)
+  K_MARCH_DRY2, // TWO dry iterations per launch (wx_march2.h)
   K_COUNT
 };
 const char *const kKernelNames[K_COUNT] = {"velocity", "curl", "vorticity", "boundary", "advection", "pressure", "lighting",
                                            "precipitation", "lightning", "splat_box", "copy", "halo", "fused_dry_vel_advect_pressure", "march_dry_vel_advect_pressure",
-                                           "march_wet_full_iteration"};
+                                           "march_wet_full_iteration", "march_dry2_two_iterations_per_launch"};
 
 struct ProfRec {
   hipEvent_t a, b;
@@ -96,6 +98,9 @@ struct wx_sim {
   int64_t iter = 0;
   int dry_march = 1;     // water-free dry iteration: 1 = row-marching wavefront kernel (wx_march.h, default: 0.32 vs 0.38 ms at
                          // 16384x2048), 0 = LDS-tiled kernel (wx_dry.h); env WX_DRY_MARCH
+  int dry_pairs = 1;     // WX_OPT_DRY_PAIRS: the water-free dry stencil two iterations per launch where it can (wx_march2.h; round 5)
+  int *pair_redo = nullptr;  // device word: a pair met a back-trace its second iteration has no exact path for
+  bool pair_check = false;
   int bands_mode = 1;    // WX_OPT_ROW_BANDS
   int fix_cap_request = 0; // WX_OPT_FIX_CAP (0: a quarter of the grid)
   int fused = 2;         // non-zero (default): the whole iteration as one row-marching kernel (wx_wet.h); 0: one kernel per reference
@@ -1000,6 +1005,27 @@ int iterate_dry(wx_sim *s, bool write_disp, int edge_mode = 0)
   return WX_OK;
 }
 
+// Two iterations of the water-free dry stencil in one launch (wx_march2.h): base[0] -> base[1], one swap; the wall texture is constant
+// (the caller checked). write_disp: the post-advection base of the SECOND iteration goes to base[2].
+int iterate_dry_pair(wx_sim *s, bool write_disp)
+{
+  if (!s->pair_redo) {
+    if (hipMalloc((void **)&s->pair_redo, 8) != hipSuccess || hipMemsetAsync(s->pair_redo, 0, 8, s->stream) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_step: the pair kernel's redo word");
+  }
+  DryIn in{s->base[0], s->wall[0], s->water[1]};
+  DryOut out{s->base[1], s->wall[1], s->water[2], s->base[2]};
+  {
+    ProfScope ps(s, K_MARCH_DRY2);
+    const VxTrack vt = vx_track(s);
+    // (water[2] -- the spare of the wet ping-pong, dead in the water-free dry state -- holds the intermediate state of a repeated pair)
+    launch_march_dry2(s->geo, s->uni, s->full_ctx, in, out, write_disp, s->stream, &vt, s->pair_redo, s->water[2]);
+    LAUNCH_CHECK(s, "march_dry2");
+  }
+  s->pair_check = true;
+  std::swap(s->base[0], s->base[1]);
+  return WX_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -1178,6 +1204,7 @@ void wx_destroy(wx_sim *s)
   hipFree(s->fix_count2);
   hipFree(s->fix_cells2);
   hipFree(s->sync_words);
+  hipFree(s->pair_redo);
   dfree(s, s->state);
   dfree(s, s->pool_remote);
   dfree(s, s->pool_owned);
@@ -1497,6 +1524,18 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
     if (can_split) edge_mode = ((flags & WX_OVERLAP_EDGES_LAST) && it == 0 ? 2 : 0) | ((flags & WX_OVERLAP_EDGES_FIRST) && it == n_iter - 1 && !precip ? 1 : 0);
     if (can_split && it == 0 && !(edge_mode & 2)) wait_unpacked(s);
     int rc;
+    // the water-free dry stencil in PAIRS (WX_OPT_DRY_PAIRS): two iterations per launch while two are left, none of them split
+    const bool pair = dry && s->dry_pairs && !precip && edge_mode == 0 && it + 1 < n_iter && dry_marches(s) && s->wall_veg_ok && s->p.userInputType < 0 &&
+                      !(s->p.airplaneValues[3] > 0.9f) && s->Y >= 16 &&
+                      !(can_split && (flags & WX_OVERLAP_EDGES_FIRST) && it + 1 == n_iter - 1);
+    if (pair) {
+      rc = iterate_dry_pair(s, it + 2 == n_iter);
+      if (rc != WX_OK) return rc;
+      s->ran_fused = true;
+      s->iter += 2; // (`even` toggles twice)
+      it += 1;
+      continue;
+    }
     if (dry)
       rc = iterate_dry(s, precip || it == n_iter - 1, edge_mode);
     else if (fused)
@@ -1609,6 +1648,10 @@ int wx_set_option(wx_sim *s, int option, int value)
     if (int rc = wx_sync(s)) return rc;
     s->pool_exact = value != 0;
     s->exact_pending = 0;
+    return WX_OK;
+  case WX_OPT_DRY_PAIRS:
+    if (int rc = wx_sync(s)) return rc;
+    s->dry_pairs = value != 0;
     return WX_OK;
   case WX_OPT_SPLIT_LAUNCH: // split iterations (wx_step_overlap): 1 = one ordered launch + device-side hand-offs, 0 = two launch groups on two streams
     if (int rc = wx_sync(s)) return rc;

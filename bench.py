@@ -43,6 +43,9 @@ ALGO_BYTES = {
     # marching kernel only when the brush / an airplane crash could change it
     "fused_dry_vel_advect_pressure": 36,
     "march_dry_vel_advect_pressure": 36,
+    # WX_OPT_DRY_PAIRS: one launch = TWO iterations = two cell-steps per cell: 2 x A_dry algorithmic bytes per launch (A_dry is per
+    # cell-STEP); what the launch really moves is 36 B/cell (the second iteration's input never leaves the wavefront) -- see roofline.traffic
+    "march_dry2_two_iterations_per_launch": 72,
 }
 VERIFY_FIELDS = ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1")
 
@@ -67,6 +70,7 @@ def parse():
     ap.add_argument("--no-north-star", action="store_true", help="skip the 32768 x 4096 dry north-star measurement (N=1)")
     ap.add_argument("--no-extras", action="store_true", help="skip at_rest / frame-1 / hbm_ceiling side measurements (N=1)")
     ap.add_argument("--tune", type=int, default=20, help="wx_tune_placement: further device allocations to try for the handle's planes (0: keep the first)")
+    ap.add_argument("--dry-pairs", type=int, default=1, choices=[0, 1], help="dry stencil: WX_OPT_DRY_PAIRS (two iterations per launch; round 5 prototype)")
     ap.add_argument("--verify", dest="verify", action="store_true", default=True,
                     help="N > 1, grid only (default ON): checksum every rank's owned columns against an undecomposed run of the same state on rank 0")
     ap.add_argument("--no-verify", dest="verify", action="store_false", help="N > 1: skip the self-validation of the decomposed run")
@@ -133,7 +137,7 @@ def hbm_ceiling(X, Y):
 
 KERNEL_SYMBOL = {  # profile name -> substring of the kernel symbol rocprofv3 reports
     "march_wet_full_iteration": "k_march_wet",
-    "fused_dry_vel_advect_pressure": "k_fused_dry", "march_dry_vel_advect_pressure": "k_march_dry", "advection": "k_advection", "boundary": "k_boundary", "lighting": "k_lighting",
+    "fused_dry_vel_advect_pressure": "k_fused_dry", "march_dry_vel_advect_pressure": "k_march_dry", "march_dry2_two_iterations_per_launch": "k_march_dry2", "advection": "k_advection", "boundary": "k_boundary", "lighting": "k_lighting",
     "velocity": "k_velocity", "pressure": "k_pressure", "curl": "k_curl", "vorticity": "k_vorticity", "precipitation": "k_precipitation",
 }
 
@@ -158,14 +162,14 @@ def pmc_traffic(a, kernel, X=None, Y=None, workload=None):
             nfr = max(1, int(a.frame))
             cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", str(nfr), "--warmup", str(nfr),
                    "--X", str(X or a.X), "--Y", str(Y or a.Y), "--workload", workload or a.workload, "--no-cpu-baseline", "--no-pmc",
-                   "--no-north-star", "--no-extras", "--frame", str(a.frame), "--flow", str(a.flow), "--flow-kind", a.flow_kind, "--tune", "0"]
+                   "--no-north-star", "--no-extras", "--frame", str(a.frame), "--flow", str(a.flow), "--flow-kind", a.flow_kind, "--tune", "0", "--dry-pairs", str(a.dry_pairs)]
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
             c = sqlite3.connect(dbs[0])
             rows = c.execute("select k.kernel_name, d.event_id, d.start from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol k "
                              "on d.kernel_id = k.id order by d.start").fetchall()
-            ev = [e for n, e, _ in rows if sym in n][nfr:]  # skip the warm-up launches
+            ev = [e for n, e, _ in rows if sym in n and (sym != "k_march_dry" or "k_march_dry2" not in n)][nfr:]  # skip the warm-up launches
             per = []
             for e in ev:
                 v = c.execute("select sum(value) from rocpd_pmc_event where event_id = ?", (e,)).fetchone()[0]
@@ -243,6 +247,7 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
     h.upload(base, water, wall)
     del base, water, wall
     h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    h.set_option(h.OPT_DRY_PAIRS, a.dry_pairs)
     n = (steps // a.frame) * a.frame
     placement = None
     if a.tune > 0:
@@ -487,6 +492,7 @@ def main():
         h = pkg.engine.Handle(X, Y, a.particles)
         if a.workload == "dry":
             h.upload(*pkg.synth.dry_grid(X, Y))
+            h.set_option(h.OPT_DRY_PAIRS, a.dry_pairs)
         else:  # device-side initialiser: 1-D terrain / sounding descriptors instead of 1.2 GB of host arrays
             h.setup_columns(pkg.synth.terrain_columns(X, Y, cloud_deck=bool(a.particles)),
                             pkg.synth.init_rain_drops(a.particles) if a.particles else None)

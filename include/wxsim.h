@@ -234,6 +234,13 @@ int wx_sync(wx_sim *s);
  *   behind the unpack -- no second stream, no join events on the compute stream. 0 = the edge strips and the interior as two launch
  *   groups on two streams joined by events (rounds 2-4; kept for A/B measurements: tools/slab_protocol_cost.py). Same results. */
 #define WX_OPT_SPLIT_LAUNCH 9
+/* WX_OPT_DRY_PAIRS (round 5; default 1): the water-free dry stencil (pass_mask WX_PASS_DRY, no water anywhere, no brush, wall texture
+ *   constant) runs TWO iterations per launch wherever two are left in a wx_step call and neither is a split iteration -- the second
+ *   iteration's input never leaves the wavefront (csrc/wx_march2.h): 18 instead of 36 bytes per cell-step, 0.71 instead of 0.86 ms per
+ *   iteration at 32768 x 4096. Same results bit for bit: a pair whose second iteration meets a back-trace of 0.9 cells or more (it has no
+ *   exact path: its inputs exist in no texture) raises a device flag, and two predicated one-iteration launches that follow every pair
+ *   (a few microseconds while the flag is down) then repeat it from the untouched inputs. 0 = one iteration per launch. */
+#define WX_OPT_DRY_PAIRS 10
 int wx_set_option(wx_sim *s, int option, int value);
 
 /* iterNum global (app.js:440) */

@@ -230,9 +230,13 @@ def test_dry_config_pass_mask(pkg, oracle, E, fused, X, Y, moist):
 
 
 @pytest.mark.parametrize("X,Y", [(256, 128), (130, 50), (64, 8), (1000, 70), (4100, 20)])
-def test_dry_marching_kernel(pkg, oracle, E, X, Y, monkeypatch):
+@pytest.mark.parametrize("pairs", [0, 1])
+def test_dry_marching_kernel(pkg, oracle, E, X, Y, monkeypatch, pairs):
     """The row-marching wavefront kernel (wx_march.h, WX_DRY_MARCH=1) on the water-free dry state: bit-exact vs the
-    oracle, strips and row segments that do not divide the grid, |v| > 0.9 through the out-of-line path."""
+    oracle, strips and row segments that do not divide the grid, |v| > 0.9 through the out-of-line path. pairs = WX_OPT_DRY_PAIRS: 1
+    (the default since round 5) runs two iterations per launch (wx_march2.h) -- with these velocities nearly every pair's second
+    iteration meets a back-trace it has no exact path for and is repeated by the predicated one-iteration launches: still the oracle,
+    bit for bit."""
     monkeypatch.setenv("WX_DRY_MARCH", "1")
     monkeypatch.setenv("WX_FUSED", "1")
     base, water, wall = pkg.synth.dry_grid(X, Y)
@@ -242,17 +246,22 @@ def test_dry_marching_kernel(pkg, oracle, E, X, Y, monkeypatch):
     base[1:, :, 0] += rng.normal(0, 0.35, (Y - 1, X)).astype(np.float32)
     u = pkg.params.uniforms_from_gui(pkg.params.merge_settings(None), Y, pass_mask=pkg.params.PASS_DRY)
     h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
+    h.set_option(E.Handle.OPT_DRY_PAIRS, pairs)
     h.profile(True)
     for _ in range(3):
         h.step(7)
         o.step(7)
         _assert_grid_equal(h, o, ["BASE_CUR", "BASE_DISP", "WATER_CUR", "WATER_0", "WALL_CUR"])
     prof = h.profile_read()
-    assert prof["march_dry_vel_advect_pressure"][1] == 21, prof  # the marching kernel is what ran
+    if pairs and Y >= 16:  # three pairs and the odd one out per call
+        assert prof["march_dry2_two_iterations_per_launch"][1] == 9 and prof["march_dry_vel_advect_pressure"][1] == 3, prof
+    else:
+        assert prof["march_dry_vel_advect_pressure"][1] == 21, prof  # the marching kernel is what ran
 
 
+@pytest.mark.parametrize("pairs", [0, 1])
 @pytest.mark.parametrize("X,Y", [(700, 160), (130, 96)])
-def test_dry_marching_kernel_with_obstacles(pkg, oracle, E, X, Y, monkeypatch):
+def test_dry_marching_kernel_with_obstacles(pkg, oracle, E, X, Y, monkeypatch, pairs):
     """Wall blocks inside the dry domain: the marching dry kernel switches between its free-air instantiation of the advection stage
     (rows whose footprints reach no wall cell: one vote per input row, three rows of history) and the wall-aware one, several times
     per segment, next to strip borders and the periodic seam. Bit-exact vs the oracle."""
@@ -271,12 +280,17 @@ def test_dry_marching_kernel_with_obstacles(pkg, oracle, E, X, Y, monkeypatch):
     water[wall[..., 1] == 0, 0] = 1001.0  # the marker the advection pass gives wall cells (advectionShader.frag:403-409): "water-free" state
     u = pkg.params.uniforms_from_gui(pkg.params.merge_settings(None), Y, pass_mask=pkg.params.PASS_DRY)
     h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
+    h.set_option(E.Handle.OPT_DRY_PAIRS, pairs)
     h.profile(True)
     for _ in range(3):
         h.step(5)
         o.step(5)
         _assert_grid_equal(h, o, ["BASE_CUR", "BASE_DISP", "WATER_CUR", "WALL_CUR"])
-    assert h.profile_read()["march_dry_vel_advect_pressure"][1] == 15  # the marching kernel is what ran
+    prof = h.profile_read()
+    if pairs:  # two pairs and the odd one out per call
+        assert prof["march_dry2_two_iterations_per_launch"][1] == 6 and prof["march_dry_vel_advect_pressure"][1] == 3, prof
+    else:
+        assert prof["march_dry_vel_advect_pressure"][1] == 15, prof  # the marching kernel is what ran
     h.close()
 
 
@@ -296,7 +310,7 @@ def test_dry_water_free_flag_is_dropped_when_water_appears(pkg, oracle, E, monke
         h.profile(True)
         h.step(2)
         o.step(2)
-        assert h.profile_read()["march_dry_vel_advect_pressure"][1] == 2  # water-free so far: the marching kernel ran
+        assert h.profile_read()["march_dry2_two_iterations_per_launch"][1] == 1  # water-free so far: the marching kernel ran (one pair)
         if scenario == "brush":
             u2 = dict(u_dry, userInputType=2, userInputValues=(0.5, 0.5, 0.8, 20.0))  # TOOL_WATER: adds vapour (and cloud)
         else:
@@ -310,7 +324,8 @@ def test_dry_water_free_flag_is_dropped_when_water_appears(pkg, oracle, E, monke
             _assert_grid_equal(h, o, ["BASE_CUR", "WATER_CUR", "WALL_CUR"])
         if scenario == "brush":
             assert h.read_rect("WATER_CUR")[Y // 2, X // 2, 0] > 0.1
-        assert "march_dry_vel_advect_pressure" not in h.profile_read()  # the water-carrying kernels took over
+        names = set(h.profile_read())
+        assert "march_dry_vel_advect_pressure" not in names and "march_dry2_two_iterations_per_launch" not in names  # the water-carrying kernels took over
         h.close()
 
 
@@ -1452,5 +1467,47 @@ def test_halo_pack_both_equals_two_single_side_calls(pkg, E):
     for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1"):
         a, b = hs[0].read_rect(f), hs[1].read_rect(f)
         assert np.array_equal(a, b), f
+    for h in hs:
+        h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("X,Y,sigma", [(4096, 1024, 0.1), (1000, 96, 0.1), (130, 50, 0.1), (8192, 512, 0.1), (4096, 1024, 0.3), (1000, 96, 0.35)])
+def test_dry_pairs_equal_single_iterations(pkg, E, oracle, X, Y, sigma):
+    """WX_OPT_DRY_PAIRS (round 5 prototype, csrc/wx_march2.h): two iterations of the water-free dry stencil per launch -- the second
+    iteration's input row never leaves the wavefront. Bit for bit the one-iteration kernel at odd and even counts, with frames that end
+    inside a pair (the display fields of the last iteration), on banded and unbanded launch shapes and a ragged grid, over terrain-free
+    and wall-bottomed states -- and, on the small grid, the oracle. sigma 0.3 / 0.35: hundreds of cells beyond 0.9 cells / iteration, also
+    in second iterations, which have no exact path: those pairs are repeated by the predicated one-iteration launches (k_march_dry_redo)."""
+    base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=sigma)
+    rng = np.random.Generator(np.random.Philox(9))
+    base[1:, :, 2] += rng.normal(0, 1e-3, (Y - 1, X)).astype(np.float32)
+    u = _dry_uniforms(pkg, Y)
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    hs = []
+    for pairs in (0, 1):
+        h = E.Handle(X, Y, 0)
+        h.upload(base, water, wall)
+        h.set_params(p, u["initial_T"])
+        h.set_option(E.Handle.OPT_DRY_PAIRS, pairs)
+        hs.append(h)
+    ref = None
+    if X * Y <= 200000:
+        ref = oracle.OracleSim(X, Y, 0)
+        ref.upload(base, water, wall)
+        ref.set_params(u)
+    for k in (1, 4, 7, 10, 2):
+        for h in hs:
+            h.profile(True)
+            h.step(k)
+        names = [set(h.profile_read()) for h in hs]
+        assert "march_dry2_two_iterations_per_launch" not in names[0]
+        assert ("march_dry2_two_iterations_per_launch" in names[1]) == (k >= 2), names
+        for f in ("BASE_CUR", "BASE_DISP", "WALL_CUR", "WATER_CUR"):
+            assert np.array_equal(hs[0].read_rect(f), hs[1].read_rect(f)), (k, f)
+        if ref is not None:
+            ref.step(k)
+            assert np.array_equal(hs[1].read_rect("BASE_CUR"), ref.field("BASE_CUR")), k
+        assert hs[0].iter == hs[1].iter
     for h in hs:
         h.close()
