@@ -47,6 +47,12 @@ ALGO_BYTES = {
     # cell-STEP); what the launch really moves is 36 B/cell (the second iteration's input never leaves the wavefront) -- see roofline.traffic
     "march_dry2_two_iterations_per_launch": 72,
 }
+# iterations one launch of a kernel advances (the pair kernel: two): ALGO_BYTES is per LAUNCH, SURVEY's figures are per cell-STEP
+ITERS_PER_LAUNCH = {"march_dry2_two_iterations_per_launch": 2}
+PAIR_NOTE = ("one launch = TWO iterations (WX_OPT_DRY_PAIRS, csrc/wx_march2.h): `achieved` / `frac` count SURVEY 8d's A_dry = 36 B per cell-STEP, i.e. 72 B/cell per "
+             "launch, as the contract defines them -- temporal blocking moves only 36 B/cell per launch (the second iteration's input never leaves the wavefront), "
+             "so `frac` is no longer bounded by 1 (at rest it exceeds it); `frac_moved` = the bytes a launch MUST move (36 B/cell) / time / peak, `traffic` = what it "
+             "did move: the kernel is now bound by the vector ALU (`valu.busy_frac` with 4 cycles per wave64 instruction reads > 1: the real issue rate is ~3.6)")
 VERIFY_FIELDS = ("BASE_CUR", "WATER_CUR", "WALL_CUR", "LIGHT_0", "LIGHT_1")
 
 
@@ -262,10 +268,14 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
         name, (ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / cnt
         achieved = ALGO_BYTES[name] * X * Y / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "algo_bytes_per_cell": ALGO_BYTES[name], "avg_launch_ms": avg_ms, "launches": cnt, "traffic": None}
+        if ITERS_PER_LAUNCH.get(name, 1) > 1:
+            roof["iterations_per_launch"] = ITERS_PER_LAUNCH[name]
+            roof["frac_moved"] = ALGO_BYTES[name] / ITERS_PER_LAUNCH[name] * X * Y / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["note"] = PAIR_NOTE
         return {"state": label, "value": X * Y * n / dt / 1e6, "ms_per_step": dt / n * 1e3, "runs_Mcell_steps_per_s": [X * Y * n / r[0] / 1e6 for r in runs],
-                "flow": devtools.flow_stats(h),
-                "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                             "algo_bytes_per_cell": ALGO_BYTES[name], "avg_launch_ms": avg_ms, "launches": cnt, "traffic": None}}
+                "flow": devtools.flow_stats(h), "roofline": roof}
 
     rest = measure("at rest (SURVEY 8d C2: v = 0, P = 0)")
     moving = noise = None
@@ -323,10 +333,12 @@ def measure_handle(h, cells, steps, warmup, frame, algo_bytes=None, events_in_ti
         if ab:
             out["algo_bytes_per_cell"] = ab
             ev = ab * cells / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if ITERS_PER_LAUNCH.get(name, 1) > 1:
+                out["iterations_per_launch"] = ITERS_PER_LAUNCH[name]
             if events_in_timed_region:
                 out["roofline_frac"] = ev
             else:
-                out["roofline_frac"] = ab * cells / (dt / steps) / 1e9 / HBM_PEAK_GBS
+                out["roofline_frac"] = ab / ITERS_PER_LAUNCH.get(name, 1) * cells / (dt / steps) / 1e9 / HBM_PEAK_GBS  # (per cell-STEP against the time of a step)
                 out["roofline_frac_event_timed"] = ev
                 out["timed_region"] = "no per-kernel events (a second, profiled run gives kernels_ms_per_step / avg_launch_ms); roofline_frac from the whole un-profiled step"
     return out
@@ -621,6 +633,10 @@ def main():
                     "algorithmic_bytes_per_launch": ALGO_BYTES.get(name, 0) * local_cells, "avg_launch_ms": avg_ms, "launches": cnt,
                     "algo_bytes_per_cell": ALGO_BYTES.get(name, 0),
                     "kernels_ms_per_step": {k: v[0] / prof_steps for k, v in prof.items()}}
+            if ITERS_PER_LAUNCH.get(name, 1) > 1:
+                roof["iterations_per_launch"] = ITERS_PER_LAUNCH[name]
+                roof["frac_moved"] = roof["frac"] / ITERS_PER_LAUNCH[name]
+                roof["note"] = PAIR_NOTE
             if world == 1 and not a.no_extras:
                 # the runtime's own device-to-device copy of 1 GiB, read + write bytes counted (kept for comparison with round 2; the
                 # ceiling that matters is hbm_ceiling below: the kernels' own access pattern)
