@@ -1306,7 +1306,11 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row, int bands_mode
   // Grids at least 512 rows high: XCD k takes the row band [k*Y/8, (k+1)*Y/8) of ALL strips instead of a column block of every
   // segment -- each XCD then streams one contiguous eighth of every plane: -3..-8 % kernel time at 16384x2048 and 32768x4096,
   // -5 % on a 4192x4096 slab, -9 % on a 2144x2048 one (profiles/r02_wet_tail_shape.txt).
-  bool bands = bands_mode >= 2 ? g.Y >= 16 : (bands_mode != 0 && WX_WET_BANDS && g.Y >= 8 * 64);
+  // Round 5, the reference's own sizes (tools/ref_sizes_bands.py, profiles/r05_ref_sizes.txt): NARROW grids below 512 rows gain from the
+  // bands too -- 2500 x 300 (the reference's default: 45 strips) 45.3 -> 36.9 us per iteration, 5000 x 400 65.4 -> 60.0 -- while wide low
+  // ones lose (16000 x 300: 120.5 -> 142.6): bands also for grids of fewer than 128 strips that are at least 128 rows high.
+  const int strips_all = (g.X + WOUT - 1) / WOUT;
+  bool bands = bands_mode >= 2 ? g.Y >= 16 : (bands_mode != 0 && WX_WET_BANDS && (g.Y >= 8 * 64 || (strips_all < 128 && g.Y >= 128)));
   if (const char *e = wx_tune_env("WX_WET_BANDS")) bands = atoi(e) >= 2 ? g.Y >= 16 : (atoi(e) != 0 && g.Y >= 8 * 64); // (2: tests force it on small grids)
   const int Y = bands ? (g.Y + 7) / 8 : g.Y; // (bands: the shape of ONE band; the kernel clips it to the band's own height)
   w.segs.bands = bands ? 1 : 0;
