@@ -436,6 +436,7 @@ static int ring_exchange(Ring &R)
   if (R.world < 2) return WX_OK;
   const bool local = R.transport == WX_TRANSPORT_LOCAL;
   const bool particles = R.p[0].s->pool_remote != nullptr;
+  for (Party &q : R.p) q.s->xchg_inline = dry_runs_in_order(q.s); // (decided once per exchange: xstream() below is one stream throughout)
   if (particles)
     if (int rc = pool_stride_update(R)) return rc;
   if (local) // my send buffers are free once both neighbours have copied the previous exchange out of them
@@ -460,8 +461,9 @@ static int ring_exchange(Ring &R)
     for (int i = 0; i < n; i++) {
       wx_sim *s = R.p[i].s, *L = R.p[(i + n - 1) % n].s, *Rt = R.p[(i + 1) % n].s;
       DeviceScope ds(s);
-      bool ok = hipMemcpyAsync(s->xrecv[0], L->xsend[1], s->xbytes, hipMemcpyDefault, xstream(s)) == hipSuccess && // left ghosts <- left neighbour's right edge
-                hipMemcpyAsync(s->xrecv[1], Rt->xsend[0], s->xbytes, hipMemcpyDefault, xstream(s)) == hipSuccess; // right ghosts <- right neighbour's left edge
+      const size_t mb = wx_halo_message_bytes(s); // (the base texture alone between slabs of the agreed water-free dry stencil)
+      bool ok = hipMemcpyAsync(s->xrecv[0], L->xsend[1], mb, hipMemcpyDefault, xstream(s)) == hipSuccess && // left ghosts <- left neighbour's right edge
+                hipMemcpyAsync(s->xrecv[1], Rt->xsend[0], mb, hipMemcpyDefault, xstream(s)) == hipSuccess; // right ghosts <- right neighbour's left edge
       if (ok && particles) {
         const size_t gb = wx_pool_edge_bytes(s);
         ok = hipMemcpyAsync(s->precv[0], L->psend[1], gb, hipMemcpyDefault, xstream(s)) == hipSuccess &&
@@ -480,10 +482,11 @@ static int ring_exchange(Ring &R)
       DeviceScope ds(s);
       const int left = (q.rank + R.world - 1) % R.world, right = (q.rank + 1) % R.world;
       hipStream_t st = xstream(s);
-      ncclResult_t r = a->Send(s->xsend[0], s->xbytes, ncclUint8, left, q.comm, st);
-      if (r == ncclSuccess) r = a->Send(s->xsend[1], s->xbytes, ncclUint8, right, q.comm, st);
-      if (r == ncclSuccess) r = a->Recv(s->xrecv[1], s->xbytes, ncclUint8, right, q.comm, st);
-      if (r == ncclSuccess) r = a->Recv(s->xrecv[0], s->xbytes, ncclUint8, left, q.comm, st);
+      const size_t mb = wx_halo_message_bytes(s); // (equal on every rank: the format changes only through collective calls)
+      ncclResult_t r = a->Send(s->xsend[0], mb, ncclUint8, left, q.comm, st);
+      if (r == ncclSuccess) r = a->Send(s->xsend[1], mb, ncclUint8, right, q.comm, st);
+      if (r == ncclSuccess) r = a->Recv(s->xrecv[1], mb, ncclUint8, right, q.comm, st);
+      if (r == ncclSuccess) r = a->Recv(s->xrecv[0], mb, ncclUint8, left, q.comm, st);
       if (particles) {
         const size_t gb = wx_pool_edge_bytes(s);
         if (r == ncclSuccess) r = a->Send(s->psend[0], gb, ncclUint8, left, q.comm, st);

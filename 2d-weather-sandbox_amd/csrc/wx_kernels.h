@@ -1301,6 +1301,8 @@ __global__ void k_inactive_from_count(DevState *st)
 // ------------------------------------------------------------------------------------------------
 // halo pack / unpack of the state carried across iterations (base_0, wall_0, water_1, light_0, light_1)
 // buffer layout: [base h*Y float4][water h*Y float4][light0 h*Y float4][light1 h*Y float4][wall h*Y char4]
+// base_only (round 5): a slab of the agreed water-free dry stencil -- its iterations write nothing but the base texture, so the ghost
+// columns of every other texture stay what the upload made them -- sends [base h*Y float4] alone: 16 of 68 bytes per cell
 // ------------------------------------------------------------------------------------------------
 struct HaloPtrs {
   float4 *base, *water, *light0, *light1;
@@ -1318,7 +1320,7 @@ struct HaloBufs {
   float2 *buf8[2];
   char4 *buf4[2];
 };
-__global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, HaloBufs hb)
+__global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, HaloBufs hb, int base_only)
 {
   const int n = h * Y, x_start = hb.x_start[blockIdx.y];
   float4 *buf16 = hb.buf16[blockIdx.y];
@@ -1328,6 +1330,7 @@ __global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, HaloBufs hb)
     const int y = i / h, c = i - y * h;
     const size_t s = cidx(x_start + c, y, X);
     buf16[i] = f.base[s];
+    if (base_only) continue;
     buf16[n + i] = f.water[s];
     if (f.lp0.x) {
       const float2 a = f.lp0.zw[s], b = f.lp1.zw[s];
@@ -1345,7 +1348,7 @@ __global__ void k_halo_pack(HaloPtrs f, int X, int Y, int h, HaloBufs hb)
     }
   }
 }
-__global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, HaloBufs hb, int *ghost_nontrivial)
+__global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, HaloBufs hb, int *ghost_nontrivial, int base_only)
 {
   const int n = h * Y, x_start = hb.x_start[blockIdx.y];
   const float4 *buf16 = hb.buf16[blockIdx.y];
@@ -1355,6 +1358,7 @@ __global__ void k_halo_unpack(HaloPtrs f, int X, int Y, int h, HaloBufs hb, int 
     const int y = i / h, c = i - y * h;
     const size_t s = cidx(x_start + c, y, X);
     f.base[s] = buf16[i];
+    if (base_only) continue;
     const float4 q = buf16[n + i];
     f.water[s] = q;
     if (ghost_nontrivial) { // same test as wx_upload's: 0 in air, only the wall marker in wall cells, vegetation >= 0

@@ -221,6 +221,14 @@ struct wx_sim {
   bool ghost_check = false;   // ghost columns were unpacked while water_trivial: DevState::ghost_nontrivial is validated by the next blocking call
   bool local_water_free = false; // what the last upload established for THIS handle's cells (wx_water_free)
   bool slab_dry_agreed = false;  // the host asserted that every slab of the domain was uploaded water-free (wx_slab_assert_water_free)
+  // ... and from then on this slab's halo messages carry the base texture alone (wx_halo_message_bytes): the water-free dry iteration
+  // writes nothing else, so the ghost columns of water, wall and light stay what the upload made them. Latched by the (collective)
+  // assertion and dropped by it or by a step that runs anything else -- the same call with the same parameters on every rank --, never
+  // by a rank-local event: two neighbours must not disagree about the size of a message
+  bool halo_base_only = false;
+  // (set per exchange by the library's transport, wx_comm.h: a period that runs in order anyway keeps its exchange on the compute stream --
+  // two cross-stream event hops per period cost the north star's slab 0.005 ms per iteration, profiles/r05_dry_slab_inorder.txt)
+  bool xchg_inline = false;
   // device storage of the handle (see storage_begin): blocks[0] = the arena of the small objects (or of everything: WX_ARENA=1), then one
   // allocation per large plane; every pointer member that lives in a block is registered, so that wx_tune_placement can move the
   // whole state to another set of allocations
@@ -639,7 +647,7 @@ static void light_to_rgba(wx_sim *s)
 // host-supplied comm stream and WX_OPT_POOL_EXACT the pool kernels ran on the compute stream and the transfers on the comm stream, unfenced).
 static hipStream_t exchange_stream(const wx_sim *s)
 {
-  const bool in_order = (s->pool_remote && s->pool_exact) || s->exchange_in_order;
+  const bool in_order = (s->pool_remote && s->pool_exact) || s->exchange_in_order || s->xchg_inline;
   return (s->comm_stream && !in_order) ? s->comm_stream : s->stream;
 }
 
@@ -924,6 +932,16 @@ static bool dry_has_water(const wx_sim *s)
 // ... and does it run the row-marching kernel (wx_march.h: the water-free state, strips of 60 columns), which can be launched
 // per strip range, or the tiled one (wx_dry.h)?
 static bool dry_marches(const wx_sim *s) { return !dry_has_water(s) && s->dry_march && s->X >= 64; }
+
+// Does a slab run its exchange periods IN ORDER (no split iterations, wx_step_overlap's flags ignored)? The agreed water-free dry stencil
+// with base-only halo messages does: its iterations then go in pairs (two per launch), which split iterations cannot.
+static bool dry_runs_in_order(const wx_sim *s)
+{
+  const bool dry = s->fused && (s->p.pass_mask & 0x3Fu) == WX_PASS_DRY;
+  const bool precip = (s->p.pass_mask & WX_PASS_PRECIPITATION) && s->p.enablePrecipitation && s->n_drops > 0;
+  return dry && s->halo_base_only && s->dry_pairs && !precip && dry_marches(s) && s->wall_veg_ok && s->p.userInputType < 0 && !(s->p.airplaneValues[3] > 0.9f) &&
+         s->Y >= 16;
+}
 
 // edge_mode: as iterate_march_wet (marching kernel only)
 int iterate_dry(wx_sim *s, bool write_disp, int edge_mode = 0)
@@ -1498,7 +1516,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   // ... and the water texture stays known trivial only through water-free dry iterations (iterate_dry's `water == false` case)
   // (local_water_free goes with it: it is what wx_slab_assert_water_free re-arms water_trivial from, and after a step that can create
   // water only a new upload may establish it again -- ADVICE round 3)
-  if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] != 0.0f || s->p.soundingForcing != 0.0f) s->water_trivial = s->local_water_free = false;
+  if (!dry || s->p.userInputType >= 0 || s->p.airplaneValues[3] != 0.0f || s->p.soundingForcing != 0.0f) s->water_trivial = s->local_water_free = s->halo_base_only = false;
   if (s->p.userInputType >= 10) s->air_from_row = -1; // wall tools: the terrain may grow (re-measured after the call)
   if (precip && s->pool_remote && s->pool_exact && n_iter > 0 && (n_iter > 1 || s->exact_pending > 0))
     return fail(s, WX_E_STATE, "wx_step: WX_OPT_POOL_EXACT takes one iteration per call, each followed by wx_pool_events_pack / all-gather / wx_pool_events_apply");
@@ -1511,7 +1529,12 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   // overlap needs the kernel that can be launched per strip range; everything else orders the exchange on the compute stream
   // (with particles only the iteration AFTER an exchange splits: precipitation needs the whole grid of its iteration, and the
   // exchange needs the feedback texture precipitation leaves behind -- so the exchange hides behind the next interior strips)
-  const bool can_split = (fused || (dry && dry_marches(s))) && s->comm_stream != nullptr && s->halo > 0 && !(precip && s->pool_exact);
+  // The agreed water-free dry stencil runs its periods IN ORDER: iterations in pairs (two per launch), none of them split, and a
+  // base-only halo message a quarter the size -- measured on the north star's slab (4096 + 2 x 42 columns x 4096 rows, tools/
+  // slab_protocol_cost.py, profiles/r05_dry_slab_inorder.txt): 0.115 ms per iteration + the link time of 2.75 MB per side and period
+  // against 0.133 with split edge / interior iterations that must run one iteration per launch
+  const bool dry_in_order = dry_runs_in_order(s);
+  const bool can_split = (fused || (dry && dry_marches(s))) && s->comm_stream != nullptr && s->halo > 0 && !(precip && s->pool_exact) && !dry_in_order;
   if (!can_split) wait_unpacked(s);
   if (!fused && s->light_planar) { // the per-pass / dry kernels take the light textures interleaved (the conversion reads ghost columns)
     wait_unpacked(s);
@@ -1768,7 +1791,7 @@ struct TuneSnap { // host-side state that iterations change; the rotating plane 
   Ref base[3], water[3], light[2], wall[2], drops[2], lpx[3], lpy[3], lpzw[3];
   int even, drop_cur, splat_par, period_j, air_from_row;
   int64_t iter;
-  bool ran_fused, light_planar, fb_dirty, water_trivial, local_water_free, wall_veg_ok, ghost_check, emit_lit, fix_check, wet_shape_valid;
+  bool ran_fused, light_planar, fb_dirty, water_trivial, local_water_free, wall_veg_ok, ghost_check, emit_lit, fix_check, wet_shape_valid, halo_base_only;
   Uni emit_uni;
 };
 bool snap_take(const wx_sim *s, TuneSnap &t)
@@ -1782,7 +1805,7 @@ bool snap_take(const wx_sim *s, TuneSnap &t)
   for (int i = 0; i < 3; i++) { t.base[i] = ref(s->base[i]); t.water[i] = ref(s->water[i]); t.lpx[i] = ref(s->lp[i].x); t.lpy[i] = ref(s->lp[i].y); t.lpzw[i] = ref(s->lp[i].zw); }
   for (int i = 0; i < 2; i++) { t.light[i] = ref(s->light[i]); t.wall[i] = ref(s->wall[i]); t.drops[i] = ref(s->drops[i]); }
   t.even = s->even; t.drop_cur = s->drop_cur; t.splat_par = s->splat_par; t.period_j = s->period_j; t.air_from_row = s->air_from_row; t.iter = s->iter;
-  t.ran_fused = s->ran_fused; t.light_planar = s->light_planar; t.fb_dirty = s->fb_dirty; t.water_trivial = s->water_trivial; t.local_water_free = s->local_water_free; t.wall_veg_ok = s->wall_veg_ok;
+  t.ran_fused = s->ran_fused; t.light_planar = s->light_planar; t.fb_dirty = s->fb_dirty; t.water_trivial = s->water_trivial; t.local_water_free = s->local_water_free; t.wall_veg_ok = s->wall_veg_ok; t.halo_base_only = s->halo_base_only;
   t.ghost_check = s->ghost_check; t.emit_lit = s->emit_lit; t.fix_check = s->fix_check; t.wet_shape_valid = s->wet_shape_valid; t.emit_uni = s->emit_uni;
   return ok;
 }
@@ -1795,7 +1818,7 @@ void snap_put(wx_sim *s, const TuneSnap &t) // (into the block set the handle po
   }
   for (int i = 0; i < 2; i++) { s->light[i] = (float4 *)at(t.light[i]); s->wall[i] = (char4 *)at(t.wall[i]); s->drops[i] = (float *)at(t.drops[i]); }
   s->even = t.even; s->drop_cur = t.drop_cur; s->splat_par = t.splat_par; s->period_j = t.period_j; s->air_from_row = t.air_from_row; s->iter = t.iter;
-  s->ran_fused = t.ran_fused; s->light_planar = t.light_planar; s->fb_dirty = t.fb_dirty; s->water_trivial = t.water_trivial; s->local_water_free = t.local_water_free; s->wall_veg_ok = t.wall_veg_ok;
+  s->ran_fused = t.ran_fused; s->light_planar = t.light_planar; s->fb_dirty = t.fb_dirty; s->water_trivial = t.water_trivial; s->local_water_free = t.local_water_free; s->wall_veg_ok = t.wall_veg_ok; s->halo_base_only = t.halo_base_only;
   s->ghost_check = t.ghost_check; s->emit_lit = t.emit_lit; s->fix_check = t.fix_check; s->wet_shape_valid = t.wet_shape_valid; s->emit_uni = t.emit_uni;
 }
 // every registered pointer of the handle moves from the current block set to `to` (same block, same offset)
@@ -2013,6 +2036,7 @@ int wx_slab_assert_water_free(wx_sim *s, int agreed)
   if (!s) return WX_E_INVALID;
   s->slab_dry_agreed = agreed != 0;
   s->water_trivial = s->local_water_free && (s->halo == 0 || s->slab_dry_agreed);
+  s->halo_base_only = s->slab_dry_agreed && s->halo > 0 && !s->pool_remote; // (by the host's word alone: equal on every slab even if the word was wrong)
   return WX_OK;
 }
 
@@ -2349,6 +2373,9 @@ int wx_local_width(const wx_sim *s) { return s ? s->X : 0; }
 // base_0, water_1, light_0, light_1 (float4), wall_0 (char4); handles that carry particles also exchange the feedback
 // (float4) and deposition (float2) textures, which the boundary pass of the next iteration reads
 size_t wx_halo_bytes(const wx_sim *s) { return s ? (size_t)s->halo * s->Y * (4 * 16 + 4 + (s->pool_remote ? 16 + 8 : 0)) : 0; }
+// what a halo message of the CURRENT period occupies at the front of such a buffer: the base texture alone between slabs that agreed on
+// the water-free dry stencil (wx_slab_assert_water_free), else all of it. Equal on every rank at every exchange (see halo_base_only).
+size_t wx_halo_message_bytes(const wx_sim *s) { return s ? (s->halo_base_only ? (size_t)s->halo * s->Y * 16 : wx_halo_bytes(s)) : 0; }
 
 static int halo_xstart(const wx_sim *s, int side, bool pack)
 {
@@ -2378,6 +2405,10 @@ static int halo_pack_impl(wx_sim *s, void *const dev_buf[2])
 {
   DeviceScope dev_scope(s);
   if (s->halo == 0) return fail(s, WX_E_STATE, "handle has no halo");
+  if (s->halo_base_only && !(s->water_trivial && s->wall_veg_ok))
+    return fail(s, WX_E_STATE, "the slabs agreed on the water-free dry stencil (wx_slab_assert_water_free(s, 1)) but THIS slab is not water-free -- its upload "
+                               "carried water, or it was given new contents since: its neighbours expect base-only halo messages. Combine wx_water_free "
+                               "of every slab and call wx_slab_assert_water_free on all of them again");
   const int n = s->halo * s->Y;
   const LightPlanes none{nullptr, nullptr, nullptr};
   HaloPtrs f{s->base[0], s->water[1], s->light[0], s->light[1], s->light_planar ? s->lp[0] : none, s->light_planar ? s->lp[1] : none, s->wall[0],
@@ -2418,7 +2449,7 @@ static int halo_pack_impl(wx_sim *s, void *const dev_buf[2])
   ProfScope ps(s, K_HALO);
   int slots = 0;
   const HaloBufs hb = halo_bufs(s, dev_buf, true, &slots);
-  hipLaunchKernelGGL(k_halo_pack, dim3((n + 255) / 256, slots), dim3(256), 0, st, f, s->X, s->Y, s->halo, hb);
+  hipLaunchKernelGGL(k_halo_pack, dim3((n + 255) / 256, slots), dim3(256), 0, st, f, s->X, s->Y, s->halo, hb, s->halo_base_only ? 1 : 0);
   HIPCHK(s, hipGetLastError());
   return WX_OK;
 }
@@ -2434,9 +2465,11 @@ static int halo_unpack_impl(wx_sim *s, void *const dev_buf[2])
   ProfScope ps(s, K_HALO);
   int slots = 0;
   const HaloBufs hb = halo_bufs(s, dev_buf, false, &slots);
+  // (a base-only message carries no water to validate: what the neighbour holds was checked by its own upload)
+  const bool check = s->water_trivial && !s->halo_base_only;
   hipLaunchKernelGGL(k_halo_unpack, dim3((n + 255) / 256, slots), dim3(256), 0, st, f, s->X, s->Y, s->halo, hb,
-                     s->water_trivial ? &s->state->ghost_nontrivial : nullptr);
-  if (s->water_trivial) s->ghost_check = true;
+                     check ? &s->state->ghost_nontrivial : nullptr, s->halo_base_only ? 1 : 0);
+  if (check) s->ghost_check = true;
   if (st != s->stream) // whoever touches the ghost columns next on the compute stream waits for this
     if (int rc = mark_unpacked(s, st)) return rc;
   if (s->pool_remote) { // the ghost tiles of the feedback texture now hold a neighbour's values: nothing is "known zero" any more

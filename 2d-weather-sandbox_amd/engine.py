@@ -29,7 +29,7 @@ DTYPE_F32, DTYPE_I8, DTYPE_I32, DTYPE_F16 = 0, 1, 2, 3
 EXPORTS = [
     "wx_create", "wx_create_slab", "wx_destroy", "wx_last_error", "wx_abi_version", "wx_upload", "wx_set_params",
     "wx_step", "wx_sync", "wx_get_iter", "wx_set_iter", "wx_read_rect", "wx_read_particles", "wx_set_stream",
-    "wx_device_ptr", "wx_local_width", "wx_halo_bytes", "wx_halo_pack", "wx_halo_unpack", "wx_halo_pack_both", "wx_halo_unpack_both", "wx_profile",
+    "wx_device_ptr", "wx_local_width", "wx_halo_bytes", "wx_halo_message_bytes", "wx_halo_pack", "wx_halo_unpack", "wx_halo_pack_both", "wx_halo_unpack_both", "wx_profile",
     "wx_profile_read", "wx_kernel_count", "wx_kernel_name", "wx_slab_set_rank", "wx_slab_period_begin", "wx_pool_event_bytes",
     "wx_pool_edge_bytes", "wx_pool_events_pack", "wx_pool_events_apply", "wx_pool_edges_pack", "wx_pool_edges_apply", "wx_pool_flags", "wx_lightning_get", "wx_lightning_set", "wx_setup_columns", "wx_setup_terrain", "wx_init_droplets", "wx_fastest_velocity",
     "wx_stream_bytes", "wx_host_alloc", "wx_host_free", "wx_stream_frame", "wx_stream_wait", "wx_set_comm_stream", "wx_step_overlap",
@@ -98,6 +98,8 @@ def lib() -> C.CDLL:
     L.wx_local_width.argtypes = [vp]
     L.wx_halo_bytes.argtypes = [vp]
     L.wx_halo_bytes.restype = C.c_size_t
+    L.wx_halo_message_bytes.argtypes = [vp]
+    L.wx_halo_message_bytes.restype = C.c_size_t
     L.wx_halo_pack.argtypes = [vp, i32, vp]
     L.wx_halo_unpack.argtypes = [vp, i32, vp]
     L.wx_halo_pack_both.argtypes = [vp, vp, vp]
@@ -346,6 +348,11 @@ class Handle:
 
     def halo_bytes(self) -> int:
         return lib().wx_halo_bytes(self._h)
+
+    def halo_message_bytes(self) -> int:
+        """What a halo message of the current period occupies at the front of a wx_halo_bytes buffer (the base texture alone between slabs
+        of the agreed water-free dry stencil)."""
+        return lib().wx_halo_message_bytes(self._h)
 
     def halo_pack(self, side: int, dev_ptr: int):
         self._chk(lib().wx_halo_pack(self._h, side, C.c_void_p(dev_ptr)))

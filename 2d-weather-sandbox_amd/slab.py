@@ -156,6 +156,11 @@ class HipSlabEngine:
     def new_buffer(self) -> torch.Tensor:
         return torch.empty(self.nbytes, dtype=torch.uint8, device=self.device)
 
+    def message_bytes(self) -> int:
+        """Bytes of a halo buffer that a message of the current period occupies (wx_halo_message_bytes: the base texture alone between
+        slabs of the agreed water-free dry stencil); equal on every rank."""
+        return self.h.halo_message_bytes()
+
     def pack(self, side: int, buf: torch.Tensor):
         self.h.halo_pack(side, buf.data_ptr())
 
@@ -337,8 +342,9 @@ class SlabSim:
                 # 2. ownership by position; the droplets near my edges become the neighbours' ghost copies
                 refresh = (self._iters // 600) != ((self._iters - self._since_exchange) // 600)  # app.js:5957-5966: every 600 iterations
                 e.pool_edges_pack(self.psend[0], self.psend[1], refresh)
-            out = [self.send[0], self.send[1]] + (self.psend if self.particles else [])
-            inn = [self.recv[0], self.recv[1]] + (self.precv if self.particles else [])
+            mb = e.message_bytes() if hasattr(e, "message_bytes") else len(self.send[0])  # (what the packed message occupies of its buffer)
+            out = [self.send[0][:mb], self.send[1][:mb]] + (self.psend if self.particles else [])
+            inn = [self.recv[0][:mb], self.recv[1][:mb]] + (self.precv if self.particles else [])
             if self._stage:
                 e.sync()
                 out = [t.cpu() for t in out]

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WX_ABI_VERSION 9
+#define WX_ABI_VERSION 10
 
 /* error codes */
 #define WX_OK 0
@@ -292,6 +292,15 @@ int wx_local_width(const wx_sim *s);                /* X_owned + 2*halo */
  * pack the `halo` outermost OWNED columns of one side into a contiguous device buffer / unpack a
  * neighbour's buffer into this handle's ghost columns. side: 0 = left (low x), 1 = right. */
 size_t wx_halo_bytes(const wx_sim *s);
+/* (ABI 10) How much of such a buffer a message of the CURRENT period occupies, from its first byte: wx_halo_bytes normally; between slabs
+ * that agreed on the water-free dry stencil (wx_slab_assert_water_free(s, 1) below) the base texture alone -- 16 of the 68 bytes per cell:
+ * that iteration writes nothing else, so the ghost columns of water, wall and light stay what the upload made them. A host transport
+ * sends / receives this many bytes of the buffers it packs / unpacks (buffers are still sized by wx_halo_bytes). The value changes only
+ * through calls every rank makes alike -- wx_slab_assert_water_free, or a wx_step whose parameters leave the water-free dry stencil --, so
+ * neighbours never disagree about a message's size; a slab that was given new contents in between is refused by wx_halo_pack
+ * (WX_E_STATE) until the slabs have agreed again. Such slabs also run their periods in order (iterations in pairs, none split:
+ * wx_step_overlap's flags are ignored), which is faster there than the overlap (profiles/r05_dry_slab_inorder.txt). */
+size_t wx_halo_message_bytes(const wx_sim *s);
 int wx_halo_pack(wx_sim *s, int side, void *dev_buf);
 int wx_halo_unpack(wx_sim *s, int side, const void *dev_buf);
 /* both sides in ONE launch each (ABI 8): next to a marching kernel that holds every wave slot of the chip a second small launch queues
@@ -314,9 +323,11 @@ int wx_halo_unpack_both(wx_sim *s, const void *dev_left, const void *dev_right);
  * (36 B/cell) while the handle KNOWS it is trivial (0 in air, only the wall marker in walls: established by wx_upload, dropped by
  * anything that can create water). A slab also receives its neighbours' ghost columns, so it relies on that only after the host
  * has established it for every slab: wx_water_free(s) reports what the last wx_upload found for THIS handle, the host combines
- * the answers of all ranks (slab.py: all-reduce MIN) and passes the result to wx_slab_assert_water_free on every handle. The
- * assertion is validated on the device at every wx_halo_unpack; a violation is reported by the next blocking call (wx_sync,
- * wx_read_rect) as WX_E_STATE. Without the assertion a slab handle runs the water-carrying dry kernel. */
+ * the answers of all ranks (slab.py: all-reduce MIN) and passes the result to wx_slab_assert_water_free on every handle. A
+ * wrong assertion is never silent: the slab whose own contents contradict it refuses its next wx_halo_pack (WX_E_STATE; ABI 10 --
+ * agreed slabs exchange the base texture alone, wx_halo_message_bytes), and handles that carry particles, which keep the full
+ * message, validate the arriving water on the device at every wx_halo_unpack (reported by the next blocking call). Without the
+ * assertion a slab handle runs the water-carrying dry kernel. */
 int wx_water_free(const wx_sim *s);
 int wx_slab_assert_water_free(wx_sim *s, int agreed);
 

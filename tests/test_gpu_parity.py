@@ -886,8 +886,8 @@ def test_dry_slab_overlapped_exchange_equals_whole_domain(pkg, E, nslab, halo, X
 
 
 def test_dry_slab_wrong_water_free_assertion_is_reported(pkg, E):
-    """A host that asserts "every slab is water-free" although a neighbour's slab carries water gets WX_E_STATE from the next
-    blocking call after the ghost columns arrived (validated on the device by wx_halo_unpack) -- never a silent divergence."""
+    """A host that asserts "every slab is water-free" although one slab carries water gets WX_E_STATE from that slab's next wx_halo_pack
+    (ABI 10: agreed slabs exchange the base texture alone, and the slab that knows better refuses to) -- never a silent divergence."""
     X, Y, nslab, halo = 1024, 64, 2, 12
     base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=0.05)
     x0 = X // 2 + halo + 1  # inside rank 1's slab, just outside rank 0's ghost columns, drifting left at 0.8 cells / iteration
@@ -896,11 +896,10 @@ def test_dry_slab_wrong_water_free_assertion_is_reported(pkg, E):
     u = _dry_uniforms(pkg, Y)
     slabs, comm, bufs, free = _dry_slabs(pkg, E, X, Y, nslab, halo, base, water, wall, u, True)  # wrong on purpose
     assert free == [True, False]
-    _run_overlapped(E, slabs, comm, bufs, halo // 6, 3 * (halo // 6))
+    assert [h.halo_message_bytes() for h in slabs] == [halo * Y * 16] * 2  # (by the host's word: the two agree about the message size)
     with pytest.raises(E.WxError) as ei:
-        slabs[0].sync()
-    assert ei.value.code == -5 and "ghost columns carry water" in str(ei.value)
-    slabs[1].sync()  # (its own slab is not water-free: it never relied on the assertion)
+        _run_overlapped(E, slabs, comm, bufs, halo // 6, 3 * (halo // 6))
+    assert ei.value.code == -5 and "THIS slab is not water-free" in str(ei.value)
     for h in slabs:
         h.close()
 

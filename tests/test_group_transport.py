@@ -81,6 +81,63 @@ def test_group_local_transport_equals_whole_domain(pkg, nslab, halo, X, wet, mon
     whole.close()
 
 
+@pytest.mark.gpu
+def test_dry_slabs_exchange_the_base_texture_alone(pkg):
+    """(ABI 10) Slabs that agreed on the water-free dry stencil send 16 of the 68 bytes per halo cell -- that iteration writes nothing but
+    the base texture -- and run their periods in order, iterations in pairs. The ghost columns of water, wall and light must still be what
+    the upload made them when the parameters leave the dry stencil: the WET iterations that follow (full-size messages again) equal the
+    undecomposed handle bit for bit, which they cannot unless every ghost texture was valid when they started."""
+    E = pkg.engine
+    X, Y, halo, nslab = 2048, 64, 12, 4
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 35.0
+    ud = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0, pass_mask=pkg.params.PASS_DRY)
+    uw = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    ud["enablePrecipitation"] = uw["enablePrecipitation"] = 0
+    base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=0.1)
+    pd, pw = (pkg.params.fill_struct(pkg.params.WxParams(), u) for u in (ud, uw))
+    g = E.Group(nslab, X, Y, halo=halo, devices=[0] * nslab, transport=E.TRANSPORT_LOCAL)
+    whole = E.Handle(X, Y, 0)
+    for h in (g, whole):
+        h.upload(base, water, wall)
+        h.set_params(pd, ud["initial_T"])
+    assert all(h.halo_bytes() == halo * Y * 68 and h.halo_message_bytes() == halo * Y * 16 for h in g.slabs)
+    g.slabs[0].profile(True)
+    for k in (1, 4, 8):  # 13 iterations: six exchanges of the period 2, call boundaries anywhere
+        g.step(k)
+        whole.step(k)
+    g.sync()
+    # (a period of two iterations as ONE pair launch: with split edge / interior iterations -- B, then A -- there would be no pair at all)
+    assert g.slabs[0].profile_read()["march_dry2_two_iterations_per_launch"][1] >= 4
+    g.slabs[0].profile(False)
+    for f in FIELDS:
+        assert np.array_equal(g.read(f), whole.read_rect(f)), f
+    assert all(h.halo_message_bytes() == halo * Y * 16 for h in g.slabs)
+    for h in (g, whole):
+        h.set_params(pw, uw["initial_T"])
+    g.step(9)
+    whole.step(9)
+    g.sync()
+    assert all(h.halo_message_bytes() == h.halo_bytes() for h in g.slabs)  # (dropped by the first wet step, on every slab alike)
+    for f in FIELDS:
+        assert np.array_equal(g.read(f), whole.read_rect(f)), f
+    # ... and a slab that is given new contents on its own is refused until the slabs have agreed again
+    for h in (g, whole):
+        h.upload(base, water, wall)
+        h.set_params(pd, ud["initial_T"])
+    assert all(h.halo_message_bytes() == halo * Y * 16 for h in g.slabs)
+    xo = X // nslab
+    cols = (1 * xo - halo + np.arange(xo + 2 * halo)) % X
+    wet_water = water[:, cols].copy()
+    wet_water[40, 100, 0] = 0.01
+    g.slabs[1].upload(base[:, cols].copy(), wet_water, wall[:, cols].copy())
+    with pytest.raises(E.WxError, match="THIS slab is not water-free"):
+        g.step(halo // 6)
+        g.sync()
+    g.close()
+    whole.close()
+
+
 def _jet_scene(pkg, X, Y, nslab, wet):
     """Jets of 1.5 .. 2.5 cells / iteration straddling EVERY slab edge (and the periodic seam), in both directions: faster than the
     shaders' documented range (common.glsl:40-41) but nothing the reference clamps (advectionShader.frag:85-99)."""

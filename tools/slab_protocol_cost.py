@@ -123,6 +123,9 @@ for _ in range(REPS):
     for m, label in MODES.items():
         res[label].append(timed(m))
 per = sx.ipe
+if sx.h.halo_message_bytes() != sx.h.halo_bytes():
+    print(f"# agreed water-free dry slab: halo message {sx.h.halo_message_bytes()} of {sx.h.halo_bytes()} bytes (base texture alone); the library runs its periods IN ORDER, "
+          "iterations in pairs -- wx_step_overlap's flags are ignored: the two 'overlapped' rows are the in-order protocol on the comm stream")
 print(f"{WORK} {XG}x{Y} as one of 8 slabs ({XO} + 2 x {HALO} columns, {per} iterations per exchange): ms / iteration, {REPS} interleaved repetitions")
 for k, v in res.items():
     print(f"  {k:48s} " + " ".join(f"{x:.4f}" for x in v) + f"   median {np.median(v):.4f}")
