@@ -552,7 +552,8 @@ static int ring_step(Ring &R, int n_iter)
         DeviceScope ds(s);
         // the iteration before an exchange launches its edge strips first, the one after it its interior strips first (wx_step_overlap;
         // with particles only the latter: the exchange -- grid, feedback texture and droplet pool -- hides behind the next interior)
-        const unsigned flags = ((s->since_exchange == 0 && s->exchanged) ? WX_OVERLAP_EDGES_LAST : 0u) | (s->since_exchange + k >= ipe ? WX_OVERLAP_EDGES_FIRST : 0u);
+        const unsigned flags = ((s->since_exchange == 0 && s->exchanged) ? WX_OVERLAP_EDGES_LAST : 0u) | (s->since_exchange + k >= ipe ? WX_OVERLAP_EDGES_FIRST : 0u) |
+                               (done + k < n_iter ? WX_OVERLAP_MORE_TO_COME : 0u); // (only the call's last piece stores the display-side fields)
         if (int rc = rpass(R, s, wx_step_overlap(s, k, flags))) return rc;
         s->since_exchange += k;
       }

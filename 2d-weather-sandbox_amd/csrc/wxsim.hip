@@ -1542,6 +1542,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   }
   s->edges_recorded = false;
   if (n_iter > 0) s->gate_passed = false;
+  const int show_at = (flags & WX_OVERLAP_MORE_TO_COME) ? -1 : n_iter - 1; // the iteration that also stores the display-side fields
   for (int it = 0; it < n_iter; it++) {
     int edge_mode = 0;
     if (can_split) edge_mode = ((flags & WX_OVERLAP_EDGES_LAST) && it == 0 ? 2 : 0) | ((flags & WX_OVERLAP_EDGES_FIRST) && it == n_iter - 1 && !precip ? 1 : 0);
@@ -1552,7 +1553,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
                       !(s->p.airplaneValues[3] > 0.9f) && s->Y >= 16 &&
                       !(can_split && (flags & WX_OVERLAP_EDGES_FIRST) && it + 1 == n_iter - 1);
     if (pair) {
-      rc = iterate_dry_pair(s, it + 2 == n_iter);
+      rc = iterate_dry_pair(s, it + 1 == show_at);
       if (rc != WX_OK) return rc;
       s->ran_fused = true;
       s->iter += 2; // (`even` toggles twice)
@@ -1560,9 +1561,9 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       continue;
     }
     if (dry)
-      rc = iterate_dry(s, precip || it == n_iter - 1, edge_mode);
+      rc = iterate_dry(s, precip || it == show_at, edge_mode);
     else if (fused)
-      rc = iterate_march_wet(s, it == n_iter - 1, precip, edge_mode);
+      rc = iterate_march_wet(s, it == show_at, precip, edge_mode);
     else
       rc = iterate_per_pass(s, mask);
     if (rc != WX_OK) return rc;

@@ -430,6 +430,7 @@ class SlabSim:
             if self._since_exchange == 0:
                 self.agree_vx_bound()
             k = min(self.iters_per_exchange - self._since_exchange, n - done)
+            more = done + k < n and hasattr(self.engine, "h")  # WX_OVERLAP_MORE_TO_COME: only the last piece of this step stores the display-side fields
             if self.exact:  # one iteration per call, each followed by the events of all ranks
                 for _ in range(k):
                     self.engine.step(1)
@@ -438,7 +439,9 @@ class SlabSim:
                 # first iteration after an exchange: interior strips first, edge strips once the ghosts have arrived;
                 # last iteration before one: edge strips first, so that the exchange starts while the interior computes
                 flags = (2 if (self._since_exchange == 0 and self._exchanged) else 0) | (1 if self._since_exchange + k >= self.iters_per_exchange else 0)
-                self.engine.step(k, flags)
+                self.engine.step(k, flags | (4 if more else 0))
+            elif more:
+                self.engine.step(k, 4)
             else:
                 self.engine.step(k)
             done += k

@@ -333,6 +333,12 @@ int wx_slab_assert_water_free(wx_sim *s, int agreed);
 
 #define WX_OVERLAP_EDGES_FIRST 1u
 #define WX_OVERLAP_EDGES_LAST 2u
+/* (ABI 10) This call is one piece of a longer step -- another wx_step / wx_step_overlap follows before anything reads a display-side
+ * field (WX_FIELD_BASE_DISP, _WATER_0, _CURL, the emitted-light image): its last iteration does not store them. A slab host cuts
+ * a frame of 10 iterations into exchange periods of 6 or 7; without the flag every piece ends with an iteration that stores 36 B per
+ * cell nobody looks at -- 4 of 30 iterations, +4 % on the metric's slab (profiles/r05_slab_protocol_cost.txt). wx_slab_step /
+ * wx_group_step set it themselves for every piece but the last. */
+#define WX_OVERLAP_MORE_TO_COME 4u
 int wx_set_comm_stream(wx_sim *s, void *hip_stream); /* NULL: pack / unpack on the compute stream again */
 int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags);
 

@@ -67,8 +67,8 @@ class SelfExchange:
     def set_mode(self, mode):  # "plain" | "one" | "two" | "inorder"
         self.h.sync()
         torch.cuda.synchronize()
-        self.h.set_comm_stream(self.comm.cuda_stream if mode in ("one", "two") else 0)
-        if mode in ("one", "two"):
+        self.h.set_comm_stream(self.comm.cuda_stream if mode in ("one", "two", "two_a") else 0)
+        if mode in ("one", "two", "two_a"):
             self.h.set_option(E.Handle.OPT_SPLIT_LAUNCH, 1 if mode == "one" else 0)
         self.mode, self.exchanged, self.since = mode, False, 0
 
@@ -76,13 +76,14 @@ class SelfExchange:
         if self.mode == "plain":
             self.h.step(n)
             return
-        overlap = self.mode in ("one", "two")
+        overlap = self.mode in ("one", "two", "two_a")
+        b_split = 0 if self.mode == "two_a" else 2  # (two_a: only the iteration BEFORE an exchange is split; the one after it waits for the unpack)
         done = 0
         while done < n:
             k = min(self.ipe - self.since, n - done)
             last = self.since + k >= self.ipe
-            flags = ((2 if (self.exchanged and self.since == 0) else 0) | (1 if last else 0)) if overlap else 0
-            self.h.step(k, flags)
+            flags = ((b_split if (self.exchanged and self.since == 0) else 0) | (1 if last else 0)) if overlap else 0
+            self.h.step(k, flags | (4 if done + k < n else 0))  # (WX_OVERLAP_MORE_TO_COME: only the frame's last piece stores the display-side fields)
             done += k
             self.since += k
             if not last:
@@ -112,6 +113,7 @@ def timed(mode, iters=210, frame=7):
 
 
 MODES = {"plain": "plain (no exchange)", "one": "protocol, overlapped: ONE ordered launch (r5)", "two": "protocol, overlapped: two launch groups (r4)",
+         "two_a": "  the same, only the iteration BEFORE split",
          "inorder": "protocol, in order"}
 for m in MODES:
     timed(m)
