@@ -69,6 +69,10 @@ def test_group_local_transport_equals_whole_domain(pkg, nslab, halo, X, wet, mon
     whole.step(n_iter)
     for f in FIELDS:
         assert np.array_equal(g.read(f), whole.read_rect(f)), f
+    # the display-side fields are stored by the LAST piece of a step only (WX_OVERLAP_MORE_TO_COME on every other piece of wx_group_step's
+    # period pieces): what the group shows after the call is what one handle shows
+    for f in (("BASE_DISP", "WATER_0", "CURL") if wet else ("BASE_DISP",)):
+        assert np.array_equal(g.read(f), whole.read_rect(f)), f
     assert g.slabs[0].iter == whole.iter
     # a re-upload restarts the exchange period (fresh ghost columns): same result again
     g.upload(base, water, wall)
