@@ -541,7 +541,7 @@ static int ring_step(Ring &R, int n_iter)
       for (int it = 0; it < k; it++) {
         for (Party &q : R.p) {
           DeviceScope ds(q.s);
-          if (int rc = rpass(R, q.s, wx_step(q.s, 1))) return rc;
+          if (int rc = rpass(R, q.s, wx_step_overlap(q.s, 1, done + it + 1 < n_iter ? WX_OVERLAP_MORE_TO_COME : 0u))) return rc;
           q.s->since_exchange += 1;
         }
         if (int rc = pool_events_round(R, 1)) return rc;

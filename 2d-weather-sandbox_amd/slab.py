@@ -432,8 +432,11 @@ class SlabSim:
             k = min(self.iters_per_exchange - self._since_exchange, n - done)
             more = done + k < n and hasattr(self.engine, "h")  # WX_OVERLAP_MORE_TO_COME: only the last piece of this step stores the display-side fields
             if self.exact:  # one iteration per call, each followed by the events of all ranks
-                for _ in range(k):
-                    self.engine.step(1)
+                for j in range(k):
+                    if hasattr(self.engine, "h") and done + j + 1 < n:
+                        self.engine.step(1, 4)  # (WX_OVERLAP_MORE_TO_COME)
+                    else:
+                        self.engine.step(1)
                     self.exact_events()
             elif self._overlap:
                 # first iteration after an exchange: interior strips first, edge strips once the ghosts have arrived;
