@@ -119,7 +119,7 @@ struct WetOut {
   float4 *water;     // post-advection
   LightPlanes light;
   float4 *base_disp; // optional (OPT_OUT): post-advection base (baseTexture_1)
-  float4 *water0;    // optional (OPT_OUT): post-boundary water (waterTexture_0)
+  float4 *water0;    // optional (OPT_OUT): post-boundary water (waterTexture_0); NULL = not stored (made on demand)
   float *curl;       // optional (OPT_OUT)
   float *t_disp;     // optional (runtime): post-advection temperature for the droplets
 #ifdef WX_WET_TIMING
@@ -836,7 +836,8 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
         WX_H_SET(h_zw0, __all(bq.z == 0.0f && bq.w == 0.0f));          // no rain / snow / smoke anywhere in it
         if (OPT_OUT) {
           const int yo = r - 3;
-          if (lane_out && yo >= y_lo && yo < y_hi) st_row(out.water0 + (size_t)yo * X, so16, bq);
+          // (NULL: the host makes waterTexture_0 on demand -- only saves read it, wxsim.hip materialize_water0)
+          if (out.water0 && lane_out && yo >= y_lo && yo < y_hi) st_row(out.water0 + (size_t)yo * X, so16, bq);
         }
       }
       // the pre-boundary values of this row are what the row above reads as its lower neighbour

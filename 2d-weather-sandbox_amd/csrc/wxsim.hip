@@ -80,6 +80,16 @@ struct wx_sim {
   // emittedLight on demand (k_emitted): did the most recent iteration run the lighting pass, and with which uniforms
   bool emit_lit = false;
   Uni emit_uni;
+  // waterTexture_0 (post-boundary water: what a save stores, app.js:6587-6589 -- no display pass samples it) is made ON DEMAND after a
+  // step of the marching wet kernel without particles: the display iteration of a frame then stores 20 instead of 36 extra bytes per
+  // cell (958 -> ~830 us at 16384 x 2048). The inputs of the last iteration stay where the ping-pong left them until the next step
+  // (base[1], wall[1], water[2], light_0's planes); materialize_water0 runs velocity -> curl -> vorticity -> boundary of the per-pass
+  // kernel set on them, with the parameters of THAT iteration (w0_uni; the initial_T row is copied aside if wx_set_params replaces it).
+  bool water0_pending = false, w0_even = false, w0_initT_saved = false, lazy_water0 = true;
+  Uni w0_uni;
+  float4 *w0_b1 = nullptr, *w0_b2 = nullptr, *w0_light = nullptr;
+  char4 *w0_w1 = nullptr, *w0_w2 = nullptr;
+  float *w0_initT = nullptr, *w0_curl = nullptr;
   half4 *emitted = nullptr; // RGBA16F, allocated by the first read
   int drop_cur = 0;      // particle buffer holding the latest state
   // slab handles with particles (see SlabP in wx_kernels.h)
@@ -758,7 +768,17 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
   WetIn in{s->base[0], s->wall[0], s->water[1], LightPlanesC{s->lp[0].x, s->lp[0].y, s->lp[0].zw},
            LightPlanesC{s->lp[src].x, s->lp[src].y, s->lp[src].zw}, fb ? s->fb : nullptr, fb ? s->dep : nullptr, fb ? s->sg.fb_zero : nullptr,
            s->zero_row, s->sg.TXn};
-  WetOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], s->water[0], s->curl, precip ? s->tdisp : nullptr};
+  // (waterTexture_0 on demand: see water0_pending; with particles the feedback textures the boundary stage read are gone after the iteration)
+  const bool lazy_w0 = opt_out && !precip && !fb && s->lazy_water0;
+  WetOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], lazy_w0 ? nullptr : s->water[0], s->curl, precip ? s->tdisp : nullptr};
+  if (opt_out) {
+    s->water0_pending = lazy_w0;
+    s->w0_even = s->even;
+    s->w0_initT_saved = false;
+    s->w0_uni = s->uni;
+    s->w0_uni.iterNum = (float)s->iter;
+    s->w0_uni.iterI = (int)s->w0_uni.iterNum;
+  }
 #ifdef WX_WET_TIMING
   static unsigned long long *dbg_cycles = nullptr;
   if (!dbg_cycles && hipMalloc((void **)&dbg_cycles, 16 * 8192 * WMAXSEG) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_step: timing buffer");
@@ -1171,6 +1191,9 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
 
 int wx_create(int X, int Y, int n_droplets, wx_sim **out) { return wx_create_slab(X, Y, 0, X, 0, n_droplets, out); }
 
+static void water0_scratch_free(wx_sim *s);
+static int materialize_water0(wx_sim *s);
+
 void wx_destroy(wx_sim *s)
 {
   if (!s) return;
@@ -1191,6 +1214,9 @@ void wx_destroy(wx_sim *s)
     dfree(s, s->wall[i]);
     dfree(s, s->drops[i]);
   }
+  water0_scratch_free(s);
+  hipFree(s->w0_initT);
+  s->w0_initT = nullptr;
   dfree(s, s->base[2]);
   dfree(s, s->curl);
   hipFree(s->emitted);
@@ -1331,6 +1357,7 @@ int wx_init_droplets(wx_sim *s, uint32_t seed)
 static int reset_after_upload(wx_sim *s, const float *drops)
 {
   const size_t n = ncell(s);
+  s->water0_pending = false; // (waterTexture_0 is what was uploaded)
   for (int i = 0; i < 2; i++) {
     HIPCHK(s, hipMemsetAsync(s->light[i], 0, n * 16, s->stream));
     if (drops && s->n_drops > 0)
@@ -1467,6 +1494,11 @@ int wx_set_params(wx_sim *s, const wx_params *p, const float *initial_T, const f
   build_geo(s);
   build_uni(s);
   const size_t nb = ((size_t)s->Y + 1) * 4;
+  if (initial_T && s->water0_pending && !s->w0_initT_saved) { // waterTexture_0 of the last iteration is still to be made: with ITS initial_T
+    if (!s->w0_initT) HIPCHK(s, hipMalloc((void **)&s->w0_initT, nb));
+    HIPCHK(s, hipMemcpyAsync(s->w0_initT, s->initial_T, nb, hipMemcpyDeviceToDevice, s->stream));
+    s->w0_initT_saved = true;
+  }
   if (initial_T) HIPCHK(s, hipMemcpyAsync(s->initial_T, initial_T, nb, hipMemcpyHostToDevice, s->stream));
   if (sounding_T) HIPCHK(s, hipMemcpyAsync(s->snd_T, sounding_T, nb, hipMemcpyHostToDevice, s->stream));
   if (sounding_W) HIPCHK(s, hipMemcpyAsync(s->snd_W, sounding_W, nb, hipMemcpyHostToDevice, s->stream));
@@ -1542,6 +1574,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   }
   s->edges_recorded = false;
   if (n_iter > 0) s->gate_passed = false;
+  if (n_iter > 0) s->water0_pending = false; // (the inputs of the previous step's last iteration are about to be overwritten)
   const int show_at = (flags & WX_OVERLAP_MORE_TO_COME) ? -1 : n_iter - 1; // the iteration that also stores the display-side fields
   for (int it = 0; it < n_iter; it++) {
     int edge_mode = 0;
@@ -1677,6 +1710,10 @@ int wx_set_option(wx_sim *s, int option, int value)
     if (int rc = wx_sync(s)) return rc;
     s->dry_pairs = value != 0;
     return WX_OK;
+  case WX_OPT_WATER0_ON_DEMAND:
+    if (int rc = materialize_water0(s)) return rc;
+    s->lazy_water0 = value != 0;
+    return WX_OK;
   case WX_OPT_SPLIT_LAUNCH: // split iterations (wx_step_overlap): 1 = one ordered launch + device-side hand-offs, 0 = two launch groups on two streams
     if (int rc = wx_sync(s)) return rc;
     s->split_launch = value != 0;
@@ -1792,7 +1829,7 @@ struct TuneSnap { // host-side state that iterations change; the rotating plane 
   Ref base[3], water[3], light[2], wall[2], drops[2], lpx[3], lpy[3], lpzw[3];
   int even, drop_cur, splat_par, period_j, air_from_row;
   int64_t iter;
-  bool ran_fused, light_planar, fb_dirty, water_trivial, local_water_free, wall_veg_ok, ghost_check, emit_lit, fix_check, wet_shape_valid, halo_base_only;
+  bool ran_fused, light_planar, fb_dirty, water_trivial, local_water_free, wall_veg_ok, ghost_check, emit_lit, fix_check, wet_shape_valid, halo_base_only, water0_pending;
   Uni emit_uni;
 };
 bool snap_take(const wx_sim *s, TuneSnap &t)
@@ -1806,7 +1843,7 @@ bool snap_take(const wx_sim *s, TuneSnap &t)
   for (int i = 0; i < 3; i++) { t.base[i] = ref(s->base[i]); t.water[i] = ref(s->water[i]); t.lpx[i] = ref(s->lp[i].x); t.lpy[i] = ref(s->lp[i].y); t.lpzw[i] = ref(s->lp[i].zw); }
   for (int i = 0; i < 2; i++) { t.light[i] = ref(s->light[i]); t.wall[i] = ref(s->wall[i]); t.drops[i] = ref(s->drops[i]); }
   t.even = s->even; t.drop_cur = s->drop_cur; t.splat_par = s->splat_par; t.period_j = s->period_j; t.air_from_row = s->air_from_row; t.iter = s->iter;
-  t.ran_fused = s->ran_fused; t.light_planar = s->light_planar; t.fb_dirty = s->fb_dirty; t.water_trivial = s->water_trivial; t.local_water_free = s->local_water_free; t.wall_veg_ok = s->wall_veg_ok; t.halo_base_only = s->halo_base_only;
+  t.ran_fused = s->ran_fused; t.light_planar = s->light_planar; t.fb_dirty = s->fb_dirty; t.water_trivial = s->water_trivial; t.local_water_free = s->local_water_free; t.wall_veg_ok = s->wall_veg_ok; t.halo_base_only = s->halo_base_only; t.water0_pending = s->water0_pending;
   t.ghost_check = s->ghost_check; t.emit_lit = s->emit_lit; t.fix_check = s->fix_check; t.wet_shape_valid = s->wet_shape_valid; t.emit_uni = s->emit_uni;
   return ok;
 }
@@ -1819,7 +1856,7 @@ void snap_put(wx_sim *s, const TuneSnap &t) // (into the block set the handle po
   }
   for (int i = 0; i < 2; i++) { s->light[i] = (float4 *)at(t.light[i]); s->wall[i] = (char4 *)at(t.wall[i]); s->drops[i] = (float *)at(t.drops[i]); }
   s->even = t.even; s->drop_cur = t.drop_cur; s->splat_par = t.splat_par; s->period_j = t.period_j; s->air_from_row = t.air_from_row; s->iter = t.iter;
-  s->ran_fused = t.ran_fused; s->light_planar = t.light_planar; s->fb_dirty = t.fb_dirty; s->water_trivial = t.water_trivial; s->local_water_free = t.local_water_free; s->wall_veg_ok = t.wall_veg_ok; s->halo_base_only = t.halo_base_only;
+  s->ran_fused = t.ran_fused; s->light_planar = t.light_planar; s->fb_dirty = t.fb_dirty; s->water_trivial = t.water_trivial; s->local_water_free = t.local_water_free; s->wall_veg_ok = t.wall_veg_ok; s->halo_base_only = t.halo_base_only; s->water0_pending = t.water0_pending;
   s->ghost_check = t.ghost_check; s->emit_lit = t.emit_lit; s->fix_check = t.fix_check; s->wet_shape_valid = t.wet_shape_valid; s->emit_uni = t.emit_uni;
 }
 // every registered pointer of the handle moves from the current block set to `to` (same block, same offset)
@@ -1887,6 +1924,7 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
   if (tries < 1 || iters_per_try < 1) return fail(s, WX_E_INVALID, "wx_tune_placement: tries >= 1, iters_per_try >= 1");
   if (!s->uploaded || !s->have_params) return fail(s, WX_E_STATE, "wx_tune_placement before wx_upload / wx_set_params");
   if (s->pool_remote) return fail(s, WX_E_STATE, "wx_tune_placement: not on slab handles with particles (the exchange period would advance)");
+  if (int rc = materialize_water0(s)) return rc; // (the probes' iterations overwrite the inputs it is made from)
   if (int rc = wx_sync(s)) return rc;
   TuneSnap snap;
   if (s->blocks.empty() || !snap_take(s, snap)) return fail(s, WX_E_STATE, "wx_tune_placement: the handle's planes are not in registered blocks");
@@ -2140,13 +2178,61 @@ static int fb_to_rgba(wx_sim *s, int y0, int h) // rows [y0, y0 + h) (h <= 0: th
   return hipGetLastError() == hipSuccess ? WX_OK : WX_E_DEVICE;
 }
 
+static void water0_scratch_free(wx_sim *s)
+{
+  for (void *q : {(void *)s->w0_b1, (void *)s->w0_b2, (void *)s->w0_light, (void *)s->w0_w1, (void *)s->w0_w2, (void *)s->w0_curl}) hipFree(q);
+  s->w0_b1 = s->w0_b2 = s->w0_light = nullptr;
+  s->w0_w1 = s->w0_w2 = nullptr;
+  s->w0_curl = nullptr;
+}
+// waterTexture_0 of the last iteration, made now (see wx_sim::water0_pending): the per-pass kernels velocity -> curl -> vorticity -> boundary
+// on the inputs that iteration read -- the same cell functions on the same operands as the marching kernel's stages, so the same values
+// (tests/test_gpu_parity.py compares the two kernel sets field by field, WATER_0 included). On the compute stream, behind the step.
+static int materialize_water0(wx_sim *s)
+{
+  if (!s->water0_pending) return WX_OK;
+  DeviceScope dev_scope(s);
+  const size_t n = ncell(s);
+  if (!s->w0_b1) { // (first use on this handle: 60 B per cell of scratch)
+    bool ok = hipMalloc((void **)&s->w0_b1, n * 16) == hipSuccess && hipMalloc((void **)&s->w0_b2, n * 16) == hipSuccess && hipMalloc((void **)&s->w0_light, n * 16) == hipSuccess &&
+              hipMalloc((void **)&s->w0_w1, n * 4) == hipSuccess && hipMalloc((void **)&s->w0_w2, n * 4) == hipSuccess && hipMalloc((void **)&s->w0_curl, n * 4) == hipSuccess;
+    if (!ok) {
+      water0_scratch_free(s);
+      (void)hipGetLastError();
+      return fail(s, WX_E_NOMEM, "waterTexture_0 on demand: %zu bytes of scratch", n * 60);
+    }
+  }
+  const dim3 grid = grid2d(s), block(BX, BY);
+  // where the ping-pong left that iteration's inputs (iterate_march_wet's swaps): base_0 / wall_0 -> [1], water_1 -> [2]; light_0: the
+  // planes the odd iterations retire into [2], untouched by the even ones
+  const float4 *base_in = s->base[1], *water_in = s->water[2];
+  const char4 *wall_in = s->wall[1];
+  const LightPlanes &l0 = s->w0_even ? s->lp[0] : s->lp[2];
+  const float4 *light0 = s->w0_light;
+  if (s->w0_even && !s->light_planar)
+    light0 = s->light[0]; // (a reader switched the light textures to RGBA since: light_0 was not written by that iteration)
+  else
+    hipLaunchKernelGGL(k_light_from_planes, dim3(2048), dim3(256), 0, s->stream, n, LightPlanesC{l0.x, l0.y, l0.zw}, s->w0_light);
+  ProfScope ps(s, K_BOUNDARY);
+  hipLaunchKernelGGL(k_velocity, grid, block, 0, s->stream, s->geo, s->w0_uni, base_in, wall_in, s->w0_b1, s->w0_w1);
+  hipLaunchKernelGGL(k_curl, grid, block, 0, s->stream, s->geo, s->w0_b1, s->w0_curl); // (not s->curl: a streamed frame may be reading it)
+  hipLaunchKernelGGL(k_vorticity, grid, block, 0, s->stream, s->geo, s->w0_curl, s->vort);
+  GridPtrs in{s->w0_b1, water_in, s->w0_w1, s->vort, light0, nullptr, nullptr};
+  hipLaunchKernelGGL(k_boundary, grid, block, 0, s->stream, s->geo, s->w0_uni, s->w0_initT_saved ? s->w0_initT : s->initial_T, in, s->w0_b2, s->water[0], s->w0_w2);
+  LAUNCH_CHECK(s, "waterTexture_0 on demand");
+  s->water0_pending = false;
+  return WX_OK;
+}
+
 // (y0, h: the rows a reader is going to look at -- fields that are made on demand are only made there)
 static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int *elem, int y0 = 0, int h = 0)
 {
   switch (field) {
   case WX_FIELD_BASE_CUR: *ptr = s->base[0]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_BASE_DISP: *ptr = s->ran_fused ? s->base[2] : s->base[1]; *channels = 4; *elem = 4; return 0;
-  case WX_FIELD_WATER_0: *ptr = s->water[0]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_WATER_0:
+    if (int rc = materialize_water0(s)) return rc < -1 ? rc : WX_E_DEVICE; // (not -1: that means "unknown field" to the callers)
+    *ptr = s->water[0]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_WATER_CUR: *ptr = s->water[1]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_WALL_CUR: *ptr = s->wall[0]; *channels = 4; *elem = 1; return 0;
   // wallTexture_1 (post-advection) == wallTexture_0 after the pressure pass-through; the single-kernel paths keep one copy

@@ -294,6 +294,7 @@ class Handle:
         self._chk(lib().wx_slab_assert_water_free(self._h, 1 if agreed else 0))
 
     OPT_SPLAT_ORDER, OPT_CHECK_LAUNCHES, OPT_KERNEL_SET, OPT_DRY_KERNEL, OPT_ROW_BANDS, OPT_FIX_CAP, OPT_POOL_EXACT, OPT_EXCHANGE_OVERLAP, OPT_SPLIT_LAUNCH, OPT_DRY_PAIRS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+    OPT_WATER0_ON_DEMAND = 11  # waterTexture_0 made when asked for (default 1) instead of stored by every frame's last iteration
 
     def set_option(self, option: int, value: int):
         """wx_set_option: OPT_SPLAT_ORDER 1 = deterministic particle splats (sorted, droplet-index order); OPT_CHECK_LAUNCHES 1 =

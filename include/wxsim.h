@@ -241,6 +241,11 @@ int wx_sync(wx_sim *s);
  *   exact path: its inputs exist in no texture) raises a device flag, and two predicated one-iteration launches that follow every pair
  *   (a few microseconds while the flag is down) then repeat it from the untouched inputs. 0 = one iteration per launch. */
 #define WX_OPT_DRY_PAIRS 10
+/* (ABI 10) 1 (default): waterTexture_0 -- the post-boundary water of a step's last iteration, which only saves read (app.js:6587-6589) --
+ * is made when somebody asks for WX_FIELD_WATER_0 (per-pass kernels on the retained inputs of that iteration, with its parameters)
+ * instead of being stored by every frame's last iteration: 16 of the 36 display-side bytes per cell. Applies to the marching wet kernel
+ * without particles; 0 = always stored by the iteration itself. Bit-identical either way (tests/test_gpu_parity.py). */
+#define WX_OPT_WATER0_ON_DEMAND 11
 int wx_set_option(wx_sim *s, int option, int value);
 
 /* iterNum global (app.js:440) */

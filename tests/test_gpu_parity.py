@@ -329,6 +329,58 @@ def test_dry_water_free_flag_is_dropped_when_water_appears(pkg, oracle, E, monke
         h.close()
 
 
+def test_water0_on_demand_equals_stored(pkg, oracle, E):
+    """(ABI 10, WX_OPT_WATER0_ON_DEMAND) waterTexture_0 -- what a save stores, no display pass samples it -- is made when asked for: the
+    per-pass kernels on the inputs the step's last iteration left behind, with THAT iteration's parameters. Against a handle whose
+    iterations store it themselves (option 0) and against the oracle: after odd and even iteration counts, with the light textures
+    switched to RGBA by a reader in between, after wx_set_params replaced the parameters AND the initial_T row, across a placement
+    search, and twice in a row."""
+    X, Y = 700, 160
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    rng = np.random.Generator(np.random.Philox(5))
+    air = wall[..., 1] != 0
+    base[..., 0] += np.where(air, rng.normal(0, 0.2, (Y, X)), 0).astype(np.float32)
+    base[..., 1] += np.where(air, rng.normal(0, 0.1, (Y, X)), 0).astype(np.float32)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 30.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+    gui2 = dict(gui, sunAngle=70.0, dryLapseRate=9.0)
+    u2 = pkg.params.uniforms_from_gui(gui2, Y, quad_scale=0)
+    u2["enablePrecipitation"] = 0
+    assert not np.array_equal(np.asarray(u["initial_T"]), np.asarray(u2["initial_T"]))
+    lazy, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
+    stored = E.Handle(X, Y, 0)
+    stored.set_option(stored.OPT_WATER0_ON_DEMAND, 0)
+    stored.upload(base, water, wall)
+    stored.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    lazy.profile(True)
+    cur = u
+    for k, how in ((3, "plain"), (2, "light first"), (5, "params"), (4, "tune"), (1, "twice")):
+        for h in (lazy, stored):
+            h.step(k)
+        o.step(k)
+        if how == "light first":  # a reader switches the light textures to RGBA before anybody asks for waterTexture_0
+            assert np.array_equal(lazy.read_rect("LIGHT_0"), o.field("LIGHT_0"))
+        if how == "params":  # the NEXT frame's parameters arrive before the save asks: waterTexture_0 belongs to the iteration that ran
+            cur = u2 if cur is u else u
+            for h in (lazy, stored):
+                h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), cur), cur["initial_T"])
+            o.set_params(cur)
+        if how == "tune":
+            lazy.tune_placement(2, 3)
+        w0 = lazy.read_rect("WATER_0")
+        assert np.array_equal(w0, stored.read_rect("WATER_0")), how
+        assert np.array_equal(w0, o.field("WATER_0")), how
+        if how == "twice":
+            assert np.array_equal(lazy.read_rect("WATER_0"), w0)
+        _assert_grid_equal(lazy, o)
+    names = lazy.profile_read()
+    assert names["boundary"][1] >= 4, names  # the on-demand passes ran (once per question, not per frame)
+    lazy.close()
+    stored.close()
+
+
 @pytest.mark.parametrize("X,Y,bands", [(700, 200, None), (1100, 260, "2"), (130, 50, None)])
 def test_fast_cells_exact_path_vs_oracle(pkg, oracle, E, monkeypatch, X, Y, bands):
     """Cells whose back-trace leaves the 3 x 3 neighbourhood (|v| >= 0.9 cells / iteration) go through the fix pass of the marching
