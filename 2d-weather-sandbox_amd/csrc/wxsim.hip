@@ -2237,8 +2237,20 @@ static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int
   case WX_FIELD_WALL_CUR: *ptr = s->wall[0]; *channels = 4; *elem = 1; return 0;
   // wallTexture_1 (post-advection) == wallTexture_0 after the pressure pass-through; the single-kernel paths keep one copy
   case WX_FIELD_WALL_DISP: *ptr = s->ran_fused ? s->wall[0] : s->wall[1]; *channels = 4; *elem = 1; return 0;
-  case WX_FIELD_LIGHT_0: light_to_rgba(s); *ptr = s->light[0]; *channels = 4; *elem = 4; return 0;
-  case WX_FIELD_LIGHT_1: light_to_rgba(s); *ptr = s->light[1]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_LIGHT_0:
+  case WX_FIELD_LIGHT_1: {
+    // the marching wet kernel keeps the light textures as planes: a reader gets the RGBA texels of the rows it looks at, made now in the
+    // interleaved buffer -- the planes stay the live copy (switching both textures to RGBA and back cost a display host that samples
+    // lightTexture_0 every frame 128 B per cell and frame)
+    const int i = field == WX_FIELD_LIGHT_1 ? 1 : 0;
+    if (s->light_planar) {
+      const int r0 = h > 0 ? y0 : 0, rows = h > 0 ? h : s->Y;
+      const size_t off = (size_t)r0 * s->X, cnt = (size_t)rows * s->X;
+      const int wgs = (int)std::min<size_t>(2048, (cnt + 255) / 256);
+      hipLaunchKernelGGL(k_light_from_planes, dim3(wgs), dim3(256), 0, s->stream, cnt, LightPlanesC{s->lp[i].x + off, s->lp[i].y + off, s->lp[i].zw + off}, s->light[i] + off);
+    }
+    *ptr = s->light[i]; *channels = 4; *elem = 4; return 0;
+  }
   case WX_FIELD_CURL: *ptr = s->curl; *channels = 1; *elem = 4; return 0;
   case WX_FIELD_VORT: *ptr = s->vort; *channels = 2; *elem = 4; return 0;
   case WX_FIELD_PRECIP_FB: // stored with three channels; the RGBA texture (alpha: 0, the lightning request's fourth component at texel (1,0)) is made here
