@@ -1196,6 +1196,15 @@ __global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   WetPatch &pt = patches[wave];
   const int total = *count, n = total < cap ? total : cap;
+  if (total == 0) {
+    // The usual case, and a launch that is pure latency on a small grid (5 us of a 20 us iteration at 100 x 100): nothing to recompute and
+    // nothing to reset -- one load, and out. count[2] remembers what the host's hint word was last told: it is set back once.
+    if (blockIdx.x == 0 && threadIdx.x == 0 && hint && count[2] != 0) {
+      count[2] = 0;
+      __hip_atomic_store(hint, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
   if (total > cap && blockIdx.x == 0 && threadIdx.x == 0) *overflow = total;
   const int X = ctx->g.X, Y = ctx->g.Y;
   // (entries whose footprints leave the patch fall back to wet_output_cell_exact, which builds its own argument block)
@@ -1239,6 +1248,7 @@ __global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx
   __syncthreads();
   if (threadIdx.x == 0 && atomicAdd(count + 1, 1) == (int)gridDim.x - 1) {
     count[1] = 0;
+    count[2] = total;
     __hip_atomic_store(count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (hint) __hip_atomic_store(hint, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }

@@ -679,8 +679,8 @@ static int split_launch_ready(wx_sim *s, bool need_fix_list)
   }
   if (need_fix_list && !s->fix_count2) {
     const size_t cap = std::min<size_t>(std::max<size_t>((size_t)s->Y * 8 * 64, 1u << 14), 1u << 20); // (a few strips' worth of cells)
-    if (hipMalloc((void **)&s->fix_count2, 8) != hipSuccess || hipMalloc((void **)&s->fix_cells2, cap * sizeof(int2)) != hipSuccess ||
-        hipMemsetAsync(s->fix_count2, 0, 8, s->stream) != hipSuccess)
+    if (hipMalloc((void **)&s->fix_count2, 16) != hipSuccess || hipMalloc((void **)&s->fix_cells2, cap * sizeof(int2)) != hipSuccess ||
+        hipMemsetAsync(s->fix_count2, 0, 16, s->stream) != hipSuccess)
       return fail(s, WX_E_NOMEM, "wx_step: the edge strips' exact-path cell list");
     s->fix_cap2 = (int)cap;
     if (wx_tune_env("WX_SPLIT_PREWARM") && s->comm_stream && s->full_ctx) {
@@ -744,8 +744,8 @@ static int edge_stream_ready(wx_sim *s, bool need_fix_list)
   }
   if (need_fix_list && !s->fix_count2) {
     const size_t cap = std::min<size_t>(std::max<size_t>((size_t)s->Y * 8 * 64, 1u << 14), 1u << 20); // (a few strips' worth of cells)
-    if (hipMalloc((void **)&s->fix_count2, 8) != hipSuccess || hipMalloc((void **)&s->fix_cells2, cap * sizeof(int2)) != hipSuccess ||
-        hipMemsetAsync(s->fix_count2, 0, 8, s->stream) != hipSuccess)
+    if (hipMalloc((void **)&s->fix_count2, 16) != hipSuccess || hipMalloc((void **)&s->fix_cells2, cap * sizeof(int2)) != hipSuccess ||
+        hipMemsetAsync(s->fix_count2, 0, 16, s->stream) != hipSuccess)
       return fail(s, WX_E_NOMEM, "wx_step: the edge group's exact-path cell list");
     s->fix_cap2 = (int)cap;
   }
@@ -806,8 +806,8 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
   if (!s->fix_cells) { // (once per handle) room for a quarter of the grid's cells, at most 8 M entries
     size_t cap = std::min<size_t>(std::max<size_t>(ncell(s) / 4, 1u << 16), 1u << 23);
     if (s->fix_cap_request > 0) cap = (size_t)s->fix_cap_request; // (WX_OPT_FIX_CAP; tests: provoke the overflow report)
-    if (hipMalloc((void **)&s->fix_count, 8) != hipSuccess || hipMalloc((void **)&s->fix_cells, cap * sizeof(int2)) != hipSuccess ||
-        hipMemsetAsync(s->fix_count, 0, 8, s->stream) != hipSuccess) // {entries, arrival ticket of the fix pass}: the fix pass leaves both at 0
+    if (hipMalloc((void **)&s->fix_count, 16) != hipSuccess || hipMalloc((void **)&s->fix_cells, cap * sizeof(int2)) != hipSuccess ||
+        hipMemsetAsync(s->fix_count, 0, 16, s->stream) != hipSuccess) // {entries, arrival ticket of the fix pass, what the hint word was last told, -}: the fix pass leaves the first two at 0
       return fail(s, WX_E_NOMEM, "wx_step: %zu bytes for the exact-path cell list", cap * sizeof(int2));
     s->fix_cap = (int)cap;
     // (optional: without the mapped word every fix launch covers the whole chip)
@@ -815,6 +815,8 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
         hipHostMalloc((void **)&s->fix_hint_host, sizeof(int), hipHostMallocMapped) == hipSuccess && s->fix_hint_host) {
       *s->fix_hint_host = 1;
       if (hipHostGetDevicePointer((void **)&s->fix_hint_dev, s->fix_hint_host, 0) != hipSuccess) s->fix_hint_dev = nullptr;
+      static const int one = 1; // (count[2]: what the hint word was last told -- the first empty launch sets it back to 0)
+      if (s->fix_hint_dev) hipMemcpyAsync(s->fix_count + 2, &one, 4, hipMemcpyHostToDevice, s->stream);
     } else {
       s->fix_hint_host = nullptr;
       (void)hipGetLastError();
