@@ -329,6 +329,28 @@ def test_dry_water_free_flag_is_dropped_when_water_appears(pkg, oracle, E, monke
         h.close()
 
 
+def test_more_to_come_pieces_equal_one_step(pkg, oracle, E):
+    """(ABI 10, WX_OVERLAP_MORE_TO_COME) A step cut into pieces -- what a slab host does at every exchange period -- whose pieces but the
+    last skip the display-side stores: state AND display-side fields after the last piece equal one undivided step and the oracle."""
+    X, Y = 700, 160
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    rng = np.random.Generator(np.random.Philox(8))
+    air = wall[..., 1] != 0
+    base[..., 0] += np.where(air, rng.normal(0, 0.2, (Y, X)), 0).astype(np.float32)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = 40.0
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+    h, o = _make_pair(pkg, oracle, E, X, Y, base, water, wall, u)
+    for pieces in ((3, 2), (1, 1, 4), (6,)):
+        for i, k in enumerate(pieces):
+            h.step(k, 4 if i + 1 < len(pieces) else 0)
+        o.step(sum(pieces))
+        _assert_grid_equal(h, o)
+        assert np.array_equal(h.read_rect("CURL"), o.field("CURL"))
+    h.close()
+
+
 def test_water0_on_demand_equals_stored(pkg, oracle, E):
     """(ABI 10, WX_OPT_WATER0_ON_DEMAND) waterTexture_0 -- what a save stores, no display pass samples it -- is made when asked for: the
     per-pass kernels on the inputs the step's last iteration left behind, with THAT iteration's parameters. Against a handle whose
