@@ -1376,7 +1376,9 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row, int bands_mode
         // alone asks for 5 x 44 rows + tail at 16384 x 2048; 4 x 52 + 1/2 + 1/4 + 1/8 is 1.3 % faster on one placement
         // (profiles/r04_ring_diet.txt). Narrow slabs stay with the short segments that fill the chip.
         const int by_unit = (int)(Y / 52.0 - 0.875 + 0.5);
-        if (n_full > by_unit && by_unit >= 1 && (long long)w.n_strips * 8 * (by_unit + 3) >= 2LL * wet_capacity()) n_full = by_unit;
+        // (... "well over": three and a half rounds. The 8192-column slab of a 2-GPU run -- 148 strips, two rounds of 52-row units -- runs
+        // 6.6 % faster with the ten 25-row units + tail the rounds rule gives it: profiles/r05_slab_segment_specs.txt)
+        if (n_full > by_unit && by_unit >= 1 && (long long)w.n_strips * 8 * (by_unit + 3) >= 7LL * wet_capacity() / 2) n_full = by_unit;
       }
       const int n8 = bands ? (n_full >= 4 ? 1 : 0) : c - 1; // segments of weight 1/8
       const int n = n_full + 2 * c + n8;

@@ -37,6 +37,8 @@ def timed(spec, n=300):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+if int(os.environ.get("TUNE", "0")):  # (the optimum may depend on the placement level: search first, like bench.py does)
+    print("placement:", h.tune_placement(int(os.environ["TUNE"])))
 res = {s: [] for s in SPECS}
 for s in SPECS:
     timed(s, 40)
