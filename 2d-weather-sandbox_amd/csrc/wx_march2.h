@@ -358,7 +358,14 @@ inline void launch_march_dry2(const Geo &g, const Uni &u, const FullCtx *ctx, co
 {
   const int n_strips = march2_strips(g);
   int R = WX_MARCH2_BAND_SEG;
-  if (R <= 0) R = std::max(8, std::min(128, ((3 * (g.Y / 8)) / 16) & ~3));
+  if (R <= 0) {
+    R = std::max(8, std::min(128, ((3 * (g.Y / 8)) / 16) & ~3));
+    // narrow slabs: where segments of that height leave more than half of the chip's wave slots (16 per CU) empty, the height that fills
+    // them once -- 2048 + 2 x 42 columns x 2048 rows (39 strips): 48 rows 0.0438, 24 rows 0.0351 ms per iteration; the north star's slab
+    // (75 strips x 4096 rows) and 4096 x 1024 keep their 96 / 24 rows (profiles/r05_slab_segment_specs.txt)
+    const long long fill = (long long)n_strips * g.Y / (16LL * 256LL);
+    if (g.Y % 8 == 0 && 2 * fill <= R) R = std::max(8, (int)((fill + 7) / 8) * 8);
+  }
   if (const char *e = wx_tune_env("WX_MARCH2_BAND_SEG")) R = atoi(e) >= 8 ? atoi(e) : R;
   int seg_rows = std::min(R, g.Y), n_seg = (g.Y + seg_rows - 1) / seg_rows, n_full = n_seg, n_half = 0, band_h = 0;
   if (g.Y % 8 == 0 && g.Y / 8 >= 3 * R) {
