@@ -20,7 +20,8 @@ XG = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 Y = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 HALO = int(sys.argv[3]) if len(sys.argv) > 3 else 42
 REPS = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-XO = XG // 8
+NSLAB = int(os.environ.get("NSLAB", "8"))  # (the slab of one rank of an NSLAB-GPU run)
+XO = XG // NSLAB
 WORK = os.environ.get("WORKLOAD", "wet")
 
 
@@ -128,6 +129,6 @@ per = sx.ipe
 if sx.h.halo_message_bytes() != sx.h.halo_bytes():
     print(f"# agreed water-free dry slab: halo message {sx.h.halo_message_bytes()} of {sx.h.halo_bytes()} bytes (base texture alone); the library runs its periods IN ORDER, "
           "iterations in pairs -- wx_step_overlap's flags are ignored: the two 'overlapped' rows are the in-order protocol on the comm stream")
-print(f"{WORK} {XG}x{Y} as one of 8 slabs ({XO} + 2 x {HALO} columns, {per} iterations per exchange): ms / iteration, {REPS} interleaved repetitions")
+print(f"{WORK} {XG}x{Y} as one of {NSLAB} slabs ({XO} + 2 x {HALO} columns, {per} iterations per exchange): ms / iteration, {REPS} interleaved repetitions")
 for k, v in res.items():
     print(f"  {k:48s} " + " ".join(f"{x:.4f}" for x in v) + f"   median {np.median(v):.4f}")
