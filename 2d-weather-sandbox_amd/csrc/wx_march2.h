@@ -8,9 +8,13 @@
 // HBM sees base 16 R + 16 W and wall 4 R per cell and PAIR of iterations: 18 B per cell-step instead of 36. The price: the cone of the
 // chained stencils doubles (56 of 64 lanes produce output instead of 60; 7 warm-up steps per segment instead of 3), a second ring, and
 // one wave now does twice the arithmetic per row step. Same cell functions on the same operands as k_march_dry (wx_cells.h): the result
-// is bit-identical to two launches of it -- EXCEPT that a back-trace of 0.9 cells or more has no exact path in the second iteration
-// (its inputs exist in no texture): such a launch raises `*redo` and the host repeats the pair with the one-iteration kernel (the
-// inputs are intact: the pair writes the other buffer). Only the water-free, wall-constant, brush-free state marches in pairs.
+// is bit-identical to two launches of it. A back-trace of 0.9 cells or more in the SECOND iteration has no exact path inside the march
+// (its inputs exist in no texture): like the wet kernel, the wave leaves a placeholder and RECORDS the cell (Dry2Fix); k_dry2_fix behind
+// the pair rebuilds the neighbourhood of every recorded cell from the pair's untouched inputs -- iteration 1 on an 11 x 11 patch, stage
+// by stage through LDS, then iteration 2 for the three output cells the recorded one feeds -- one wavefront per entry (round 6; round 5
+// repeated the WHOLE GRID twice for a single such cell: 2.4 x per iteration). Only a back-trace of three cells and more in the second
+// iteration (or a list overflow) still repeats the pair with the one-iteration kernel. Only the water-free, wall-constant, brush-free
+// state marches in pairs.
 #pragma once
 #include "wx_march.h"
 
@@ -61,10 +65,21 @@ template <int K> __device__ __forceinline__ M2Fp<K> make_fp(const M2Acc<K> &a, i
 #ifndef WX_MARCH2_MINWAVES
 #define WX_MARCH2_MINWAVES 4
 #endif
+// The second iteration's exact path. ctl: {entries, arrival ticket of the fix pass, what the host's hint word was last told, epoch of the
+// pair that has to be repeated whole, pairs repeated whole, -, cells recomputed (64 bits)}; the fix pass leaves the first two at 0.
+struct Dry2Fix {
+  int *ctl;
+  int2 *cells;         // second-iteration advection cells (column, row) with a back-trace of 0.9 cells or more, recorded by the wave that owns them
+  int cap;
+  int epoch;           // of this pair (counts from 1)
+  int *hint;           // host-visible word (pinned, mapped; may be NULL): the length of the last list, read (stale) by the host to size the next fix launch
+  const int *hint_host;
+};
+enum { D2_COUNT = 0, D2_TICKET = 1, D2_TOLD = 2, D2_REDO_EPOCH = 3, D2_N_REDO = 4, D2_FIXED = 6 };
 // WRITE_DISP: also store the post-advection base of the SECOND iteration (baseTexture_1 of the last iteration of a frame: display side)
 template <bool QUIET, bool WRITE_DISP>
 __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows, int n_full, int n_half,
-                                                                        int band_h, int n_seg, VxTrack vx, int *__restrict__ redo)
+                                                                        int band_h, int n_seg, VxTrack vx, Dry2Fix fix)
 {
   __shared__ March2Ring rg;
   CUni &u = as_constant(ctx->u);
@@ -109,7 +124,6 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
   float vx_seen = 0.f;
   unsigned h_big1 = 0, h_big2 = 0; // bit k: "some |v| >= 0.9" in the velocity row k steps back (bit 0 = the row this step produced)
   unsigned h_nw = 0;               // bit k: input row r-k holds no wall cell
-  bool bad = false;                // a second-iteration back-trace that needs the exact path
 
   const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
   int r = y_lo - 4;
@@ -200,16 +214,29 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
       const int y = yw_m4, yc = rc - 4;
       float4 ab, aw;
       char4 awl;
+      bool fast2 = true;
       if (h_big2 & 7u) {
         const float m = fmaxf(fmaxf(fmaxf(fabsf(rg.vx[1][yc & 3][lr]), fabsf(rg.vx[1][yc & 3][lr - 1])), fmaxf(fabsf(rg.vx[1][(yc + 1) & 3][lr]), fabsf(rg.vx[1][(yc + 1) & 3][lr - 1]))),
                               fmaxf(fmaxf(fabsf(rg.vy[1][yc & 3][lr]), fabsf(rg.vy[1][(yc - 1) & 3][lr])), fmaxf(fabsf(rg.vy[1][yc & 3][lr + 1]), fabsf(rg.vy[1][(yc - 1) & 3][lr + 1]))));
-        bad = bad || (!(m < 0.9f) && lane >= 3 && lane <= 60); // no exact path here: the host repeats the pair one iteration at a time
+        fast2 = m < 0.9f;
+        // No exact path here (the inputs of this iteration exist in no texture): the cell keeps a placeholder, and the wave that OWNS it as an
+        // output cell records it -- k_dry2_fix recomputes the three output cells it feeds (its own, the right neighbour's pressure: vx of the
+        // left cell, the upper neighbour's: vy, T, wall of the lower cell), whichever wave owns those. Rare path: one returning atomic per lane.
+        if (!fast2 && lane_out && r - 4 >= y_lo) {
+          const int at = atomicAdd(fix.ctl + D2_COUNT, 1);
+          if (at < fix.cap) fix.cells[at] = make_int2(c_out, r - 4);
+        }
       }
       const M2Acc<1> a{rg, lr, yc};
-      if ((h_nw & 56u) == 56u) // no wall cell in rows r-3 .. r-5
-        advection_cell<true, true, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
-      else
-        advection_cell<true, false, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
+      if (fast2) {
+        if ((h_nw & 56u) == 56u) // no wall cell in rows r-3 .. r-5
+          advection_cell<true, true, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
+        else
+          advection_cell<true, false, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
+      } else { // placeholder (the post-velocity texel)
+        ab = a.base(0, 0);
+        awl = a.wall(0, 0);
+      }
       if (r >= y_lo + 4) {
         st_p = pressure_cell(ab, wave_from_left(ab.x), a2_vy, a2_T, a2_w.x, a2_w.y);
         st_ab = ab;
@@ -230,20 +257,184 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
     st_row_v(out.base + (size_t)(y_hi - 1) * X, so16, st_p);
     if (WRITE_DISP) st_row_v(out.base_disp + (size_t)(y_hi - 1) * X, so16, st_ab);
   }
-  if (__any(bad) && lane == 0) atomicOr(redo, 1);
   vx_track_commit(vx, vx_seen, lane, strip);
 }
 
-// ---- the repeat of a pair whose second iteration met a back-trace of 0.9 cells or more: ONE iteration per launch, persistent, predicated ----
-// Launched twice behind every pair (inputs -> scratch -> the pair's output buffer) with a small grid; while *pred is 0 -- almost always --
-// every workgroup leaves after one scalar load. When it runs it walks the pair's own (segment, strip) items with the same cell functions
-// as k_march_dry (its exact out-of-line path included: THIS iteration's inputs are in global memory), so the repeated pair equals two
-// launches of k_march_dry bit for bit. Not tuned: it runs when a storm core sits in a water-free dry run, i.e. hardly ever.
+// ---- k_dry2_fix: the second iteration's exact path -- one wavefront per recorded cell ----
+// Entry (X0, Y0): advection_2 of that cell had a back-trace of 0.9 cells or more. It feeds the OUTPUT cells (X0, Y0), (X0 + 1, Y0) [pressure:
+// vx of the left cell] and (X0, Y0 + 1) [pressure: vy, T, wall of the lower cell]; those three need advection_2 of seven cells
+// ([-1, 1] x [-1, 1] without two corners). The wave rebuilds what they read from the pair's untouched INPUTS, stage by stage through
+// LDS, the way the passes follow each other (offsets relative to the entry, one 18 x 18 frame [-8, 9] for every stage):
+//   base_0 / wall      [-8, 9]   loaded once
+//   velocity_1         [-8, 8]   velocity_cell
+//   advection_1        [-5, 5]   advection_cell on the stage (back-traces shorter than three cells stay inside; the others take the
+//                                one-iteration kernels' exact path from global memory, advection_cell_dry_global: any length)
+//   pressure_1         [-4, 5]   = the second iteration's input
+//   velocity_2         [-4, 4]
+//   advection_2        7 cells   advection_cell on the stage: covers back-traces shorter than three cells
+//   pressure_2         3 cells   stored (+ the display field)
+// Same cell functions on the same operands as the marching loop: the same values. A second-iteration footprint that leaves the stage
+// (|v| >= 3: the state is blowing up) raises the epoch word, and the predicated one-iteration launches behind the fix pass repeat the
+// whole pair, as does a list that overflowed. Recomputing an output is idempotent, so the order of the entries does not matter.
+constexpr int F2W = 18, F2N = F2W * F2W, F2C = 8; // stage width, cells, stage coordinate of the entry
+struct Dry2FixStage {
+  float b0x[F2N], b0y[F2N], b0P[F2N], b0T[F2N];
+  char4 w[F2N];
+  float v1x[F2N], v1y[F2N];
+  float a1x[F2N], a1y[F2N], a1P[F2N], a1T[F2N];
+  char4 a1w[F2N];
+  float b1P[F2N], b1T[F2N];
+  float v2x[F2N], v2y[F2N];
+};
+// post-velocity base of one iteration on the stage: (vx, vy) valid on [lo, hi]^2, P / T / wall wherever those are
+struct Dry2StageAcc {
+  const float *vx, *vy, *P, *T;
+  const char4 *w;
+  int cx, cy, lo, hi;
+  bool *bad; // set when a texel outside [lo, hi]^2 is asked for
+  __device__ __forceinline__ int at(int dx, int dy) const
+  {
+    const int x = cx + dx, y = cy + dy;
+    if (x < lo || x > hi || y < lo || y > hi) {
+      *bad = true;
+      return cy * F2W + cx;
+    }
+    return y * F2W + x;
+  }
+  __device__ __forceinline__ float4 base(int dx, int dy) const
+  {
+    const int i = at(dx, dy);
+    return make_float4(vx[i], vy[i], P[i], T[i]);
+  }
+  __device__ __forceinline__ char4 wall(int dx, int dy) const { return w[at(dx, dy)]; }
+  __device__ __forceinline__ float4 base_off(int dx, int dy) const { return base(dx, dy); }
+  __device__ __forceinline__ char4 wall_off(int dx, int dy) const { return wall(dx, dy); }
+  __device__ __forceinline__ float4 water_off(int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+
+template <bool QUIET, bool WRITE_DISP>
+__global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_fix(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, Dry2Fix fix)
+{
+  __shared__ Dry2FixStage st;
+  __shared__ float o_x[8], o_y[8], o_P[8], o_T[8];
+  __shared__ char4 o_w[8];
+  int *ctl = fix.ctl;
+  const int total = ctl[D2_COUNT], lane = threadIdx.x;
+  if (total == 0) { // the usual case: one load, and out (the host's hint word is set back once)
+    if (blockIdx.x == 0 && lane == 0 && fix.hint && ctl[D2_TOLD] != 0) {
+      ctl[D2_TOLD] = 0;
+      __hip_atomic_store(fix.hint, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  const int X = g.X, Y = g.Y;
+  const int n = total <= fix.cap ? total : 0; // (an overflowed list: the whole pair is repeated, nothing to do here)
+  bool whole = total > fix.cap;
+  for (int e = blockIdx.x; e < n; e += gridDim.x) {
+    const int2 c = fix.cells[e];
+    for (int i = lane; i < F2N; i += 64) { // the pair's inputs
+      const int sy = i / F2W, sx = i - sy * F2W;
+      const size_t gi = fidx(wrapmod(c.x - F2C + sx, X), wrapmod(c.y - F2C + sy, Y), X);
+      const float4 b = in.base[gi];
+      st.b0x[i] = b.x;
+      st.b0y[i] = b.y;
+      st.b0P[i] = b.z;
+      st.b0T[i] = b.w;
+      st.w[i] = in.wall[gi];
+    }
+    wave_fence();
+    for (int k = lane; k < 17 * 17; k += 64) { // velocity_1 on [0, 16]^2
+      const int sy = k / 17, sx = k - sy * 17, i = sy * F2W + sx;
+      const float4 v = velocity_cell(ctx->u, make_float4(st.b0x[i], st.b0y[i], st.b0P[i], st.b0T[i]), st.b0P[i + 1], st.b0P[i + F2W], st.w[i].y);
+      st.v1x[i] = v.x;
+      st.v1y[i] = v.y;
+    }
+    wave_fence();
+    for (int k = lane; k < 11 * 11; k += 64) { // advection_1 on [3, 13]^2
+      const int sy = 3 + k / 11, sx = 3 + k % 11, i = sy * F2W + sx;
+      const int gx = wrapmod(c.x - F2C + sx, X), gy = wrapmod(c.y - F2C + sy, Y);
+      bool left = false;
+      const Dry2StageAcc a{st.v1x, st.v1y, st.b0P, st.b0T, st.w, sx, sy, 0, 16, &left};
+      float4 ab, aw;
+      char4 awl;
+      advection_cell<true, false, false, QUIET>(ctx->u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, gx, gy, a, ab, aw, awl);
+      if (left) { // a footprint outside the stage: the exact path of the one-iteration kernels
+        const AdvOut o = advection_cell_dry_global(ctx, in, false, gx, gy);
+        ab = o.b;
+        awl = o.wl;
+      }
+      st.a1x[i] = ab.x;
+      st.a1y[i] = ab.y;
+      st.a1P[i] = ab.z;
+      st.a1T[i] = ab.w;
+      st.a1w[i] = awl;
+    }
+    wave_fence();
+    for (int k = lane; k < 10 * 10; k += 64) { // pressure_1 on [4, 13]^2: the second iteration's input
+      const int sy = 4 + k / 10, sx = 4 + k % 10, i = sy * F2W + sx;
+      const float4 p = pressure_cell(make_float4(st.a1x[i], st.a1y[i], st.a1P[i], st.a1T[i]), st.a1x[i - 1], st.a1y[i - F2W], st.a1T[i - F2W], st.a1w[i - F2W].x,
+                                     st.a1w[i - F2W].y);
+      st.b1P[i] = p.z;
+      st.b1T[i] = p.w;
+    }
+    wave_fence();
+    for (int k = lane; k < 9 * 9; k += 64) { // velocity_2 on [4, 12]^2
+      const int sy = 4 + k / 9, sx = 4 + k % 9, i = sy * F2W + sx;
+      const float4 v = velocity_cell(ctx->u, make_float4(st.a1x[i], st.a1y[i], st.b1P[i], st.b1T[i]), st.b1P[i + 1], st.b1P[i + F2W], st.w[i].y);
+      st.v2x[i] = v.x;
+      st.v2y[i] = v.y;
+    }
+    wave_fence();
+    bool left2 = false;
+    if (lane < 7) { // advection_2: lanes 0..2 the output cells themselves, 3..6 the neighbours below / left of them
+      const int ox = lane == 1 || lane == 5 ? 1 : (lane == 3 || lane == 6 ? -1 : 0), oy = lane == 2 || lane == 6 ? 1 : (lane == 4 || lane == 5 ? -1 : 0);
+      const Dry2StageAcc a{st.v2x, st.v2y, st.b1P, st.b1T, st.w, F2C + ox, F2C + oy, 4, 12, &left2};
+      float4 ab, aw;
+      char4 awl;
+      advection_cell<true, false, false, QUIET>(ctx->u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, wrapmod(c.x + ox, X), wrapmod(c.y + oy, Y), a, ab, aw, awl);
+      o_x[lane] = ab.x;
+      o_y[lane] = ab.y;
+      o_P[lane] = ab.z;
+      o_T[lane] = ab.w;
+      o_w[lane] = awl;
+    }
+    wave_fence();
+    if (__any(left2)) {
+      whole = true;
+    } else if (lane < 3) {
+      // lane 0: (0, 0) <- left (-1, 0) = 3, below (0, -1) = 4;  lane 1: (1, 0) <- left (0, 0) = 0, below (1, -1) = 5;
+      // lane 2: (0, 1) <- left (-1, 1) = 6, below (0, 0) = 0
+      const int il = lane == 0 ? 3 : (lane == 1 ? 0 : 6), id = lane == 0 ? 4 : (lane == 1 ? 5 : 0);
+      const float4 ab = make_float4(o_x[lane], o_y[lane], o_P[lane], o_T[lane]);
+      const float4 p = pressure_cell(ab, o_x[il], o_y[id], o_T[id], o_w[id].x, o_w[id].y);
+      const size_t gi = fidx(wrapmod(c.x + (lane == 1 ? 1 : 0), X), wrapmod(c.y + (lane == 2 ? 1 : 0), Y), X);
+      out.base[gi] = p;
+      if (WRITE_DISP) out.base_disp[gi] = ab;
+    }
+    wave_fence(); // the stage is rewritten by the next entry
+  }
+  if (whole && lane == 0 && atomicMax(ctl + D2_REDO_EPOCH, fix.epoch) < fix.epoch) atomicAdd(ctl + D2_N_REDO, 1);
+  // the list is empty again for the next pair: reset by the LAST workgroup to get here (every workgroup has read the count by then)
+  if (lane == 0 && atomicAdd(ctl + D2_TICKET, 1) == (int)gridDim.x - 1) {
+    ctl[D2_TICKET] = 0;
+    ctl[D2_TOLD] = total;
+    atomicAdd(reinterpret_cast<unsigned long long *>(ctl + D2_FIXED), (unsigned long long)n);
+    __hip_atomic_store(ctl + D2_COUNT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fix.hint) __hip_atomic_store(fix.hint, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ---- the repeat of a WHOLE pair (a second-iteration back-trace of three cells or more, or an overflowed list): ONE iteration per launch, ----
+// ---- persistent, predicated ----
+// Launched twice behind every pair's fix pass (inputs -> scratch -> the pair's output buffer) with a small grid; while the epoch word is not
+// this pair's -- almost always -- every workgroup leaves after one scalar load. When it runs it walks the pair's own (segment, strip) items
+// with the same cell functions as k_march_dry (its exact out-of-line path included: THIS iteration's inputs are in global memory), so the
+// repeated pair equals two launches of k_march_dry bit for bit. Not tuned: it runs when the state is blowing up.
 template <bool QUIET, bool WRITE_DISP>
 __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry_redo(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows, int n_full,
-                                                                            int n_half, int band_h, int n_seg, VxTrack vx, const int *__restrict__ pred)
+                                                                            int n_half, int band_h, int n_seg, VxTrack vx, const int *__restrict__ ctl, int epoch)
 {
-  if (*pred == 0) return;
+  if (ctl[D2_REDO_EPOCH] != epoch) return;
   __shared__ March2Ring rg;
   CUni &u = as_constant(ctx->u);
   const CFloatP initial_T = as_constant(ctx->initial_T), snd_T = as_constant(ctx->snd_T), snd_W = as_constant(ctx->snd_W), snd_Vel = as_constant(ctx->snd_Vel);
@@ -251,8 +442,8 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry_redo(Geo g
   const int total = n_strips * n_seg;
   const int lr = lane < 1 ? 1 : (lane > 62 ? 62 : lane), lright = lane < 63 ? lane + 1 : 63;
   const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
-  float vx_seen = 0.f;
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
+    float vx_seen = 0.f;
     const int seg = item / n_strips, strip = item - seg * n_strips;
     const int c_out = strip * M2OUT + lane - M2LO, col = wrapmod(c_out, X);
     const bool lane_out = lane >= M2LO && lane < M2LO + M2OUT && c_out < X;
@@ -331,15 +522,7 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry_redo(Geo g
       b_prev = b_cur;
       w_prev_y = w_cur.y;
     }
-  }
-  vx_track_commit(VxTrack{vx.max_bits, vx.violation, vx.limit, 0, 0}, vx_seen, lane);
-}
-// behind the two repeat launches: the flag starts over (and the repeats are counted)
-__global__ void k_march_dry_redo_done(int *__restrict__ flag)
-{
-  if (flag[0]) {
-    flag[0] = 0;
-    flag[1] += 1;
+    vx_track_commit(vx, vx_seen, lane, strip); // (per item: the watched zone of a slab is in strips, as in k_march_dry2)
   }
 }
 
@@ -352,9 +535,9 @@ __global__ void k_march_dry_redo_done(int *__restrict__ flag)
 #endif
 inline int march2_strips(const Geo &g) { return (g.X + M2OUT - 1) / M2OUT; }
 // (whole width only: pairs do not take part in split iterations)
-// redo: {flag, number of repeated pairs}; scratch: a base-sized buffer for the intermediate state of a repeated pair
-inline void launch_march_dry2(const Geo &g, const Uni &u, const FullCtx *ctx, const DryIn &in, const DryOut &out, bool write_disp, hipStream_t stream, const VxTrack *vx, int *redo,
-                              float4 *scratch)
+// fix: the second iteration's exact-path list + control words; scratch: a base-sized buffer for the intermediate state of a pair repeated whole
+inline void launch_march_dry2(const Geo &g, const Uni &u, const FullCtx *ctx, const DryIn &in, const DryOut &out, bool write_disp, hipStream_t stream, const VxTrack *vx,
+                              const Dry2Fix &fix, float4 *scratch)
 {
   const int n_strips = march2_strips(g);
   int R = WX_MARCH2_BAND_SEG;
@@ -382,7 +565,7 @@ inline void launch_march_dry2(const Geo &g, const Uni &u, const FullCtx *ctx, co
   }
   const dim3 grid(8 * ((n_strips * n_seg + 7) / 8));
   const bool quiet = !(u.userInputType >= 1) && !(u.airplaneValues[3] < 0.0f || u.airplaneValues[3] > 0.9f);
-#define WX_LAUNCH_M2(Q, D) hipLaunchKernelGGL((k_march_dry2<Q, D>), grid, dim3(64), 0, stream, g, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vt, redo)
+#define WX_LAUNCH_M2(Q, D) hipLaunchKernelGGL((k_march_dry2<Q, D>), grid, dim3(64), 0, stream, g, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vt, fix)
   if (quiet) {
     if (write_disp) WX_LAUNCH_M2(true, true); else WX_LAUNCH_M2(true, false);
   } else {
@@ -390,13 +573,26 @@ inline void launch_march_dry2(const Geo &g, const Uni &u, const FullCtx *ctx, co
   }
 #undef WX_LAUNCH_M2
   if (wx_tune_env("WX_MARCH2_NOREDO")) return; // (timing experiments)
-  // the predicated repeat: inputs -> scratch -> the pair's output buffer (+ the display field of the second iteration)
+  // the fix pass: one wavefront per recorded cell; a corner of the chip while the lists are empty (the host's stale hint word), room for four
+  // times the last list otherwise, at most 4096 workgroups of one wave (the list is walked grid-stride: any size is correct)
+  {
+    const int last = fix.hint_host ? *(volatile const int *)fix.hint_host : -1;
+    const dim3 fgrid(last < 0 ? 1024 : (last > 0 ? std::min(4096, std::max(64, 4 * last)) : 32));
+#define WX_LAUNCH_F(Q, D) hipLaunchKernelGGL((k_dry2_fix<Q, D>), fgrid, dim3(64), 0, stream, g, ctx, in, out, fix)
+    if (quiet) {
+      if (write_disp) WX_LAUNCH_F(true, true); else WX_LAUNCH_F(true, false);
+    } else {
+      if (write_disp) WX_LAUNCH_F(false, true); else WX_LAUNCH_F(false, false);
+    }
+#undef WX_LAUNCH_F
+  }
+  // the predicated repeat of the whole pair: inputs -> scratch -> the pair's output buffer (+ the display field of the second iteration)
   const dim3 rgrid(std::min<unsigned>(grid.x, 2048u));
   DryIn in2 = in;
   in2.base = scratch;
   DryOut out1 = out;
   out1.base = scratch;
-#define WX_LAUNCH_R(Q, D, I, O) hipLaunchKernelGGL((k_march_dry_redo<Q, D>), rgrid, dim3(64), 0, stream, g, ctx, I, O, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vt, redo)
+#define WX_LAUNCH_R(Q, D, I, O) hipLaunchKernelGGL((k_march_dry_redo<Q, D>), rgrid, dim3(64), 0, stream, g, ctx, I, O, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vt, fix.ctl, fix.epoch)
   if (quiet) {
     WX_LAUNCH_R(true, false, in, out1);
     if (write_disp) WX_LAUNCH_R(true, true, in2, out); else WX_LAUNCH_R(true, false, in2, out);
@@ -405,7 +601,6 @@ inline void launch_march_dry2(const Geo &g, const Uni &u, const FullCtx *ctx, co
     if (write_disp) WX_LAUNCH_R(false, true, in2, out); else WX_LAUNCH_R(false, false, in2, out);
   }
 #undef WX_LAUNCH_R
-  hipLaunchKernelGGL(k_march_dry_redo_done, dim3(1), dim3(1), 0, stream, redo);
 }
 
 } // namespace wx

@@ -109,8 +109,11 @@ struct wx_sim {
   int dry_march = 1;     // water-free dry iteration: 1 = row-marching wavefront kernel (wx_march.h, default: 0.32 vs 0.38 ms at
                          // 16384x2048), 0 = LDS-tiled kernel (wx_dry.h); env WX_DRY_MARCH
   int dry_pairs = 1;     // WX_OPT_DRY_PAIRS: the water-free dry stencil two iterations per launch where it can (wx_march2.h; round 5)
-  int *pair_redo = nullptr;  // device word: a pair met a back-trace its second iteration has no exact path for
-  bool pair_check = false;
+  // the pair kernel's exact path (wx_march2.h, Dry2Fix): control words, the list of recorded cells, the host-visible length of the last list
+  int *pair_ctl = nullptr;
+  int2 *pair_cells = nullptr;
+  int pair_cap = 0, pair_epoch = 0;
+  int *pair_hint_host = nullptr, *pair_hint_dev = nullptr;
   int bands_mode = 1;    // WX_OPT_ROW_BANDS
   int fix_cap_request = 0; // WX_OPT_FIX_CAP (0: a quarter of the grid)
   int fused = 2;         // non-zero (default): the whole iteration as one row-marching kernel (wx_wet.h); 0: one kernel per reference
@@ -1045,23 +1048,55 @@ int iterate_dry(wx_sim *s, bool write_disp, int edge_mode = 0)
   return WX_OK;
 }
 
+// The reference clears the feedback / deposition textures every iteration (app.js:5933-5937); here they are rewritten by the box sum while
+// particles run, and cleared ONCE by the first iteration after they were switched off (whichever kernel runs it).
+static void clear_particle_textures(wx_sim *s)
+{
+  if (!s->fb_dirty) return;
+  const size_t n = ncell(s);
+  hipMemsetAsync(s->fb, 0, n * 12, s->stream);
+  hipMemsetAsync(s->dep, 0, n * 8, s->stream);
+  if (s->sg.fb_zero) hipMemsetAsync(s->sg.fb_zero, 1, 2 * (size_t)s->sg.TXn * s->sg.TYn, s->stream);
+  s->fb_dirty = false;
+}
+
 // Two iterations of the water-free dry stencil in one launch (wx_march2.h): base[0] -> base[1], one swap; the wall texture is constant
 // (the caller checked). write_disp: the post-advection base of the SECOND iteration goes to base[2].
 int iterate_dry_pair(wx_sim *s, bool write_disp)
 {
-  if (!s->pair_redo) {
-    if (hipMalloc((void **)&s->pair_redo, 8) != hipSuccess || hipMemsetAsync(s->pair_redo, 0, 8, s->stream) != hipSuccess) return fail(s, WX_E_NOMEM, "wx_step: the pair kernel's redo word");
+  if (!s->pair_ctl) { // (once per handle) the second iteration's exact-path list: room for 1/64 of the grid's cells, 64 Ki .. 1 Mi entries
+    size_t cap = std::min<size_t>(std::max<size_t>(ncell(s) / 64, 1u << 16), 1u << 20);
+    if (s->fix_cap_request > 0) cap = (size_t)s->fix_cap_request; // (WX_OPT_FIX_CAP; tests: provoke the overflow -> the whole pair is repeated)
+    if (const char *e = wx_tune_env("WX_MARCH2_FIX_CAP")) cap = (size_t)atoi(e); // (0: every recorded cell repeats the whole pair -- round 5's behaviour, for A/B timing)
+    if (hipMalloc((void **)&s->pair_ctl, 32) != hipSuccess || hipMalloc((void **)&s->pair_cells, std::max<size_t>(cap, 1) * sizeof(int2)) != hipSuccess ||
+        hipMemsetAsync(s->pair_ctl, 0, 32, s->stream) != hipSuccess)
+      return fail(s, WX_E_NOMEM, "wx_step: %zu bytes for the pair kernel's exact-path list", cap * sizeof(int2));
+    s->pair_cap = (int)cap;
+    s->pair_epoch = 0;
+    if (hipHostMalloc((void **)&s->pair_hint_host, sizeof(int), hipHostMallocMapped) == hipSuccess && s->pair_hint_host) {
+      *s->pair_hint_host = 1;
+      if (hipHostGetDevicePointer((void **)&s->pair_hint_dev, s->pair_hint_host, 0) != hipSuccess) s->pair_hint_dev = nullptr;
+      static const int one = 1; // (ctl[D2_TOLD]: what the hint word was last told -- the first empty fix launch sets it back to 0)
+      if (s->pair_hint_dev) hipMemcpyAsync(s->pair_ctl + D2_TOLD, &one, 4, hipMemcpyHostToDevice, s->stream);
+    } else {
+      s->pair_hint_host = nullptr;
+      (void)hipGetLastError();
+    }
   }
   DryIn in{s->base[0], s->wall[0], s->water[1]};
   DryOut out{s->base[1], s->wall[1], s->water[2], s->base[2]};
   {
     ProfScope ps(s, K_MARCH_DRY2);
     const VxTrack vt = vx_track(s);
-    // (water[2] -- the spare of the wet ping-pong, dead in the water-free dry state -- holds the intermediate state of a repeated pair)
-    launch_march_dry2(s->geo, s->uni, s->full_ctx, in, out, write_disp, s->stream, &vt, s->pair_redo, s->water[2]);
+    if (++s->pair_epoch == 0x7fffffff) { // (the device keeps the LARGEST epoch that asked for a repeat: start over, a few times per century)
+      hipMemsetAsync(s->pair_ctl + D2_REDO_EPOCH, 0, 4, s->stream);
+      s->pair_epoch = 1;
+    }
+    const Dry2Fix fix{s->pair_ctl, s->pair_cells, s->pair_cap, s->pair_epoch, s->pair_hint_dev, s->pair_hint_dev ? s->pair_hint_host : nullptr};
+    // (water[2] -- the spare of the wet ping-pong, dead in the water-free dry state -- holds the intermediate state of a pair repeated whole)
+    launch_march_dry2(s->geo, s->uni, s->full_ctx, in, out, write_disp, s->stream, &vt, fix, s->water[2]);
     LAUNCH_CHECK(s, "march_dry2");
   }
-  s->pair_check = true;
   std::swap(s->base[0], s->base[1]);
   return WX_OK;
 }
@@ -1250,7 +1285,9 @@ void wx_destroy(wx_sim *s)
   hipFree(s->fix_count2);
   hipFree(s->fix_cells2);
   hipFree(s->sync_words);
-  hipFree(s->pair_redo);
+  hipFree(s->pair_ctl);
+  hipFree(s->pair_cells);
+  if (s->pair_hint_host) hipHostFree(s->pair_hint_host);
   dfree(s, s->state);
   dfree(s, s->pool_remote);
   dfree(s, s->pool_owned);
@@ -1593,6 +1630,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       s->ran_fused = true;
       s->iter += 2; // (`even` toggles twice)
       it += 1;
+      clear_particle_textures(s); // (particles were switched off: the reference's clear, app.js:5933-5937, as below)
       continue;
     }
     if (dry)
@@ -1661,11 +1699,8 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
       s->fb_dirty = true;
       if (s->pool_remote) s->period_j++;
       if (s->pool_remote && s->pool_exact) s->exact_pending++;
-    } else if (s->fb_dirty) { // particles were switched off: the reference's clear leaves both textures zero
-      hipMemsetAsync(s->fb, 0, n * 12, s->stream);
-      hipMemsetAsync(s->dep, 0, n * 8, s->stream);
-      if (s->sg.fb_zero) hipMemsetAsync(s->sg.fb_zero, 1, 2 * (size_t)s->sg.TXn * s->sg.TYn, s->stream);
-      s->fb_dirty = false;
+    } else {
+      clear_particle_textures(s); // particles were switched off: the reference's clear leaves both textures zero
     }
     s->iter++;
   }
@@ -2067,6 +2102,24 @@ int wx_fastest_velocity(wx_sim *s, float *cells_per_iteration)
   HIPCHK(s, hipMemsetAsync(&s->state->fastest_bits, 0, 4, s->stream));
   HIPCHK(s, hipStreamSynchronize(s->stream));
   memcpy(cells_per_iteration, &bits, 4);
+  return WX_OK;
+}
+
+// the pair kernel's exact path since the last call: second-iteration cells recomputed by k_dry2_fix, pairs repeated whole; resets both
+int wx_pair_stats(wx_sim *s, int64_t *cells_recomputed, int64_t *pairs_repeated)
+{
+  if (!s) return WX_E_INVALID;
+  DeviceScope dev_scope(s);
+  int ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (s->pair_ctl) {
+    HIPCHK(s, hipMemcpyAsync(ctl, s->pair_ctl, 32, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->pair_ctl + D2_N_REDO, 0, 16, s->stream)); // {pairs repeated, -, cells recomputed (64 bits)}
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+  }
+  int64_t fixed;
+  memcpy(&fixed, ctl + D2_FIXED, 8);
+  if (cells_recomputed) *cells_recomputed = fixed;
+  if (pairs_repeated) *pairs_repeated = ctl[D2_N_REDO];
   return WX_OK;
 }
 

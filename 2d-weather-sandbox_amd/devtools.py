@@ -106,6 +106,40 @@ def seed_flow(h: Handle, sigma: float, seed: int = 1, Xg: Optional[int] = None, 
     torch.cuda.synchronize()
 
 
+def seed_vortices(h: Handle, n: int, peak: float = 1.3, radius: float = 6.0, seed: int = 5) -> None:
+    """Adds ``n`` compact vortices (synth.add_vortices: curls of Gaussian stream-function blobs, divergence-free on the staggered grid,
+    tangential speed ``peak`` cells / iteration at r = ``radius``) at seeded places of a WHOLE-DOMAIN handle, on the device, unclamped --
+    the reference has no velocity clamp (advectionShader.frag:85-99): cells with |v| >= 0.9 are what the kernels' exact paths are for."""
+    if h.halo:
+        raise ValueError("seed_vortices: whole-domain handles only")
+    h.sync()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    base = field_tensor(h, "BASE_CUR")
+    wall = field_tensor(h, "WALL_CUR")
+    rng = np.random.Generator(np.random.Philox(seed))
+    A = float(peak) * float(radius) * float(np.exp(0.5))
+    R = int(np.ceil(6 * radius)) + 2
+    for k in range(n):
+        cx = float(rng.uniform(R + 1, h.X - R - 2))
+        cy = float(rng.uniform(R + 2, h.Y - R - 2))
+        sg = 1.0 if k % 2 == 0 else -1.0
+        y0, x0 = int(cy) - R, int(cx) - R
+        ys = torch.arange(y0, y0 + 2 * R + 1, device=dev, dtype=torch.float64)
+        xs = torch.arange(x0, x0 + 2 * R + 1, device=dev, dtype=torch.float64)
+
+        def psi(xx, yy):
+            r2 = (xx[None, :] + 0.5 - cx) ** 2 + (yy[:, None] + 0.5 - cy) ** 2
+            return sg * A * torch.exp(-r2 / (2.0 * radius * radius))
+
+        p11, p10, p01 = psi(xs, ys), psi(xs, ys - 1.0), psi(xs - 1.0, ys)
+        win = (slice(y0, y0 + 2 * R + 1), slice(x0, x0 + 2 * R + 1))
+        air = wall[win][..., 1] != 0
+        for c, v in ((0, p11 - p10), (1, -(p11 - p01))):
+            v = v.to(torch.float32)
+            base[win][..., c] += torch.where(air, v, torch.zeros_like(v))
+    torch.cuda.synchronize()
+
+
 def flow_stats(h: Handle) -> Dict[str, float]:
     """|v| statistics of the owned columns' air cells (post-pressure state)."""
     h.sync()

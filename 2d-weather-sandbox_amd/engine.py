@@ -36,7 +36,7 @@ EXPORTS = [
     "wx_set_option", "wx_water_free", "wx_slab_assert_water_free", "wx_tune_placement",
     "wx_comm_unique_id", "wx_comm_init", "wx_exchange", "wx_slab_step", "wx_group_create", "wx_group_destroy", "wx_group_last_error",
     "wx_group_count", "wx_group_transport", "wx_group_slab", "wx_group_agree", "wx_group_step", "wx_group_sync", "wx_group_set_option",
-    "wx_group_exchange", "wx_slab_vx_take", "wx_slab_set_vx_bound", "wx_slab_cone", "wx_slab_period",
+    "wx_group_exchange", "wx_slab_vx_take", "wx_slab_set_vx_bound", "wx_slab_cone", "wx_slab_period", "wx_pair_stats",
 ]
 
 
@@ -125,6 +125,7 @@ def lib() -> C.CDLL:
     L.wx_setup_columns.argtypes = [vp] + [vp] * 8
     L.wx_init_droplets.argtypes = [vp, C.c_uint32]
     L.wx_fastest_velocity.argtypes = [vp, C.POINTER(C.c_float)]
+    L.wx_pair_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.wx_slab_vx_take.argtypes = [vp, C.POINTER(C.c_float)]
     L.wx_slab_set_vx_bound.argtypes = [vp, C.c_float]
     L.wx_slab_cone.argtypes = [vp]
@@ -440,6 +441,12 @@ class Handle:
         v = C.c_float(0)
         self._chk(lib().wx_fastest_velocity(self._h, C.byref(v)))
         return float(v.value)
+
+    def pair_stats(self):
+        """(cells recomputed by the pair kernel's exact path, pairs repeated whole) since the last call; resets both; synchronises."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(lib().wx_pair_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     # ---- slabs exact at any speed (include/wxsim.h): the hosts of all slabs agree on a |vx| bound per exchange period ----
     def slab_vx_take(self) -> float:

@@ -179,6 +179,35 @@ def dry_grid(X: int, Y: int, gui=None, seed: int = 1234, noise_K: float = 0.05, 
     return base, water, wall
 
 
+def add_vortices(base: np.ndarray, wall: np.ndarray, centers, radius: float, peak: float) -> int:
+    """Adds compact vortices to base[..., 0:2] in place: the discrete curl of Gaussian stream-function blobs psi = A exp(-r^2 / 2 s^2) on
+    the staggered grid (vx = psi(x, y) - psi(x, y-1), vy = -(psi(x, y) - psi(x-1, y)): divergence-free for pressureShader.frag:16-43, so the
+    pressure pass does not radiate them away), periodic in x, tangential speed `peak` cells / iteration at r = s = `radius`. Nothing clamps
+    the velocity: the reference has no clamp either (advectionShader.frag:85-99), and |v| >= 0.9 is what the kernels' exact paths are for.
+    ``centers``: (x, y) pairs, or (x, y, sign). Returns the number of air cells with a velocity component of 0.9 or more."""
+    Y, X = base.shape[:2]
+    A = float(peak) * float(radius) * float(np.exp(0.5))
+    R = int(np.ceil(6 * radius)) + 2
+    air = wall[..., 1] != 0
+    for c in centers:
+        cx, cy, sg = float(c[0]), float(c[1]), (float(c[2]) if len(c) > 2 else 1.0)
+        ys = np.arange(max(1, int(cy) - R), min(Y, int(cy) + R + 1))
+        xs = np.arange(int(cx) - R, int(cx) + R + 1)
+
+        def psi(xx, yy):
+            r2 = (xx[None, :] + 0.5 - cx) ** 2 + (yy[:, None] + 0.5 - cy) ** 2
+            return sg * A * np.exp(-r2 / (2.0 * radius * radius))
+
+        xf, yf = xs.astype(np.float64), ys.astype(np.float64)
+        p11, p10, p01 = psi(xf, yf), psi(xf, yf - 1.0), psi(xf - 1.0, yf)
+        vx, vy = (p11 - p10).astype(np.float32), (-(p11 - p01)).astype(np.float32)
+        xw = xs % X
+        m = air[np.ix_(ys, xw)]
+        base[np.ix_(ys, xw, [0])] += np.where(m, vx, 0)[..., None]
+        base[np.ix_(ys, xw, [1])] += np.where(m, vy, 0)[..., None]
+    return int(((np.maximum(np.abs(base[..., 0]), np.abs(base[..., 1])) >= 0.9) & air).sum())
+
+
 def init_rain_drops(n: int, seed: int = 7) -> np.ndarray:
     """initRainDrops() (app.js:4901-4913): inactive droplets whose fields are random seeds."""
     rng = np.random.Generator(np.random.Philox(seed))

@@ -285,6 +285,9 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
         if a.flow_kind != "noise" and not a.no_extras:  # the worst case for the ring reads: every lane's footprint differs from its neighbour's
             devtools.seed_flow(h, a.flow, kind="noise", seed=2)
             noise = measure(f"white-noise velocities on top, std {a.flow} cells/iteration (worst case)")
+    fast = None
+    if a.flow > 0 and a.dry_pairs and not a.no_extras:
+        fast = fast_cells_entry(a, h, X, Y, n, moving)
     h.close()
     main_ = moving or rest
     res = {"workload": f"{X}x{Y} dry-air grid, pressure+velocity+advection only (BASELINE north_star / configs[1] passes), frames of {a.frame}",
@@ -294,6 +297,8 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
     if moving:
         res["at_rest"] = {k: rest[k] for k in ("value", "ms_per_step", "runs_Mcell_steps_per_s", "flow")}
         res["at_rest"]["roofline_frac"] = rest["roofline"]["frac"]
+    if fast:
+        res["with_fast_cells"] = fast
     if noise:
         res["white_noise_worst_case"] = {k: noise[k] for k in ("value", "ms_per_step", "runs_Mcell_steps_per_s", "flow")}
         res["white_noise_worst_case"]["roofline_frac"] = noise["roofline"]["frac"]
@@ -306,6 +311,30 @@ def north_star_dry(a, pkg, X=32768, Y=4096, steps=200, warmup=20):
         if conflicts is not None:
             res["roofline"]["lds_bank_conflict_cycles_per_launch"] = conflicts
     return res
+
+
+def fast_cells_entry(a, h, X, Y, n, clean):
+    """Round-5 verdict, item 1: the reference has no velocity clamp (advectionShader.frag:85-99), and the pair kernel's SECOND iteration has
+    no exact path inside the march for back-traces of 0.9 cells and more. The same flow plus a handful of seeded vortices of 1.3 cells /
+    iteration (fresh ones before every timed run: they decay), timed like the claim; `cells_recomputed` / `pairs_repeated_whole` are the
+    device's own counters (wx_pair_stats). Round 5 repeated the whole grid twice per such pair (2.4 x per iteration)."""
+    from weather_sandbox_amd import devtools
+    runs = []
+    for k in range(3):
+        devtools.seed_vortices(h, 8, peak=1.3, radius=20.0, seed=11 + k)
+        before = devtools.flow_stats(h)
+        condition_clocks(h.step, h.sync, a.frame, seconds=0.05)
+        h.pair_stats()
+        dt, _ = timed_run(h, n, a.frame, profile=False)
+        fixed, repeated = h.pair_stats()
+        after = devtools.flow_stats(h)
+        runs.append({"ms_per_step": dt / n * 1e3, "cells_recomputed": fixed, "pairs_repeated_whole": repeated,
+                     "cells_ge_0.9_before": before["cells_component_ge_0.9"], "cells_ge_0.9_after": after["cells_component_ge_0.9"], "max_v_before": before["max_v"]})
+    worst = max(runs, key=lambda r: r["ms_per_step"])
+    return {"flow": "the moving fluid + 8 fresh vortices of 1.3 cells / iteration (radius 20) before each of three timed runs", "steps_per_run": n,
+            "value": X * Y / worst["ms_per_step"] / 1e3, "unit": "Mcell-steps/s", "ms_per_step": worst["ms_per_step"],
+            "vs_clean_flow": worst["ms_per_step"] / clean["ms_per_step"], "runs": runs,
+            "exact_path": "k_dry2_fix: one wavefront per recorded second-iteration cell (csrc/wx_march2.h); bit-identical to one iteration per launch"}
 
 
 def measure_handle(h, cells, steps, warmup, frame, algo_bytes=None, events_in_timed_region=True):

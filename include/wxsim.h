@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WX_ABI_VERSION 10
+#define WX_ABI_VERSION 11
 
 /* error codes */
 #define WX_OK 0
@@ -228,18 +228,19 @@ int wx_sync(wx_sim *s);
  *   needs precipitation's feedback texture); 0 = everything in order on the compute stream -- same results bit for bit (tests), and
  *   what the exact particle mode always does. */
 #define WX_OPT_EXCHANGE_OVERLAP 8
-/* WX_OPT_SPLIT_LAUNCH (slab handles with a comm stream): how wx_step_overlap runs a split iteration. 1 (default, round 5) = ONE launch over
- *   all strips whose dispatch order puts the edge strips first / last, with device-side hand-offs: the edge strips report on a device
- *   word that a one-wave gate kernel on the comm stream polls before the halo is packed, and poll an epoch word the comm stream bumps
- *   behind the unpack -- no second stream, no join events on the compute stream. 0 = the edge strips and the interior as two launch
- *   groups on two streams joined by events (rounds 2-4; kept for A/B measurements: tools/slab_protocol_cost.py). Same results. */
+/* WX_OPT_SPLIT_LAUNCH (slab handles with a comm stream): how wx_step_overlap runs a split iteration. 0 (DEFAULT) = the edge strips and the
+ *   interior as two launch groups on two streams joined by events (rounds 2-4: measured faster, profiles/r05_slab_protocol_cost.txt).
+ *   1 (experimental, round 5) = ONE launch over all strips whose dispatch order puts the edge strips first / last, with device-side
+ *   hand-offs: the edge strips report on a device word that a one-wave gate kernel on the comm stream polls before the halo is packed, and
+ *   poll an epoch word the comm stream bumps behind the unpack -- no second stream, no join events on the compute stream. Same results. */
 #define WX_OPT_SPLIT_LAUNCH 9
 /* WX_OPT_DRY_PAIRS (round 5; default 1): the water-free dry stencil (pass_mask WX_PASS_DRY, no water anywhere, no brush, wall texture
  *   constant) runs TWO iterations per launch wherever two are left in a wx_step call and neither is a split iteration -- the second
  *   iteration's input never leaves the wavefront (csrc/wx_march2.h): 18 instead of 36 bytes per cell-step, 0.71 instead of 0.86 ms per
- *   iteration at 32768 x 4096. Same results bit for bit: a pair whose second iteration meets a back-trace of 0.9 cells or more (it has no
- *   exact path: its inputs exist in no texture) raises a device flag, and two predicated one-iteration launches that follow every pair
- *   (a few microseconds while the flag is down) then repeat it from the untouched inputs. 0 = one iteration per launch. */
+ *   iteration at 32768 x 4096. Same results bit for bit: a second-iteration cell whose back-trace is 0.9 cells or more (no exact path
+ *   inside the march: its inputs exist in no texture) is recorded and recomputed from the pair's untouched inputs by a small fix kernel
+ *   behind the pair (round 6: one wavefront per cell; wx_pair_stats); only a back-trace of three cells or more -- or an overflowing list --
+ *   makes two predicated one-iteration launches repeat the whole pair. 0 = one iteration per launch. */
 #define WX_OPT_DRY_PAIRS 10
 /* (ABI 10) 1 (default): waterTexture_0 -- the post-boundary water of a step's last iteration, which only saves read (app.js:6587-6589) --
  * is made when somebody asks for WX_FIELD_WATER_0 (per-pass kernels on the retained inputs of that iteration, with its parameters)
@@ -435,6 +436,13 @@ int wx_group_sync(wx_group *g);
  * handle's stream. Whole-domain handles and slabs are exact at any speed (slabs size their exchange period by the |vx| they measure:
  * wx_slab_set_vx_bound above); the value is a diagnostic of the flow, nothing more. */
 int wx_fastest_velocity(wx_sim *s, float *cells_per_iteration);
+
+/* (ABI 11) The pair kernel's exact path (WX_OPT_DRY_PAIRS) since the last call: how many second-iteration cells k_dry2_fix recomputed
+ * (back-traces of 0.9 .. 3 cells: one wavefront per cell, a few microseconds each) and how many pairs were repeated WHOLE with the
+ * one-iteration kernel (a second-iteration back-trace of three cells or more, or more recorded cells than the list holds: 1/64 of the
+ * grid's cells, 64 Ki .. 1 Mi entries, WX_OPT_FIX_CAP). Either pointer may be NULL. Resets both; synchronises the handle's stream. The
+ * reference has no velocity clamp (advectionShader.frag:85-99); results are bit-identical to one iteration per launch whatever these say. */
+int wx_pair_stats(wx_sim *s, int64_t *cells_recomputed, int64_t *pairs_repeated);
 
 /* Per-kernel device time from HIP events recorded on the handle's stream around every launch.
  * wx_profile(s, 1) starts collecting, wx_profile_read returns accumulated milliseconds and launch counts

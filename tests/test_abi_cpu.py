@@ -23,7 +23,7 @@ def test_header_symbols_all_exported(engine):
     L = C.CDLL(engine.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), f"{name} not exported by libwxsim.so"
-    assert engine.lib().wx_abi_version() == 10
+    assert engine.lib().wx_abi_version() == 11
 
 
 def test_params_struct_matches_header(engine, pkg):

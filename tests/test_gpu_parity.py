@@ -1551,7 +1551,7 @@ def test_dry_pairs_equal_single_iterations(pkg, E, oracle, X, Y, sigma):
     iteration's input row never leaves the wavefront. Bit for bit the one-iteration kernel at odd and even counts, with frames that end
     inside a pair (the display fields of the last iteration), on banded and unbanded launch shapes and a ragged grid, over terrain-free
     and wall-bottomed states -- and, on the small grid, the oracle. sigma 0.3 / 0.35: hundreds of cells beyond 0.9 cells / iteration, also
-    in second iterations, which have no exact path: those pairs are repeated by the predicated one-iteration launches (k_march_dry_redo)."""
+    in second iterations, which have no exact path inside the march: recorded and recomputed by k_dry2_fix (round 6; wx_pair_stats)."""
     base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=sigma)
     rng = np.random.Generator(np.random.Philox(9))
     base[1:, :, 2] += rng.normal(0, 1e-3, (Y - 1, X)).astype(np.float32)
@@ -1582,5 +1582,78 @@ def test_dry_pairs_equal_single_iterations(pkg, E, oracle, X, Y, sigma):
             ref.step(k)
             assert np.array_equal(hs[1].read_rect("BASE_CUR"), ref.field("BASE_CUR")), k
         assert hs[0].iter == hs[1].iter
+    fixed, repeated = hs[1].pair_stats()
+    if sigma >= 0.3:
+        assert fixed > 0, "white noise of sigma 0.3 puts second-iteration cells beyond 0.9: the exact path must have run"
+    assert hs[0].pair_stats() == (0, 0)
+    for h in hs:
+        h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("X,Y", [(1000, 96), (4096, 1024), (2132, 2048)])
+def test_dry_pairs_fast_cells_take_the_cell_granular_exact_path(pkg, E, oracle, X, Y):
+    """(round 6) The reference has no velocity clamp (advectionShader.frag:85-99). A second-iteration cell of the pair kernel whose
+    back-trace is 0.9 cells or more is recorded and recomputed by k_dry2_fix (one wavefront per cell: iteration 1 on a patch from the
+    pair's inputs, then the three outputs the cell feeds) -- round 5 repeated the whole grid twice for one such cell. Compact vortices of
+    1.4 cells / iteration on strip borders (multiples of 56 columns), segment / band borders, the periodic seam, the floor and the top
+    row: bit for bit the one-iteration kernel (and the oracle on the small grid), cells recomputed > 0, NO pair repeated whole. Then
+    5 cells / iteration (second-iteration footprints leave the fix kernel's stage) and a list of 4 entries (overflow): the pair is
+    repeated whole, still bit for bit."""
+    base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=0.1)
+    seg = max(8, min(128, ((3 * (Y // 8)) // 16) & ~3))  # (launch_march_dry2's unit segment height on banded shapes)
+    centers = [(0.5, Y * 0.4), (56 * 5 + 0.5, Y - 3.0, -1), (56 * 9, 4.0), (X - 56 * 3 - 1, Y // 8 + 0.5, -1), (X // 2 + 28, float(seg)), (X // 3, Y // 2 - 0.5, -1)]
+    n_fast = pkg.synth.add_vortices(base, wall, centers, 5.0, 1.4)
+    assert n_fast > 100
+    u = _dry_uniforms(pkg, Y)
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+
+    def handles(b, cap=None):
+        hs = []
+        for pairs in (0, 1):
+            h = E.Handle(X, Y, 0)
+            if cap is not None:
+                h.set_option(E.Handle.OPT_FIX_CAP, cap)
+            h.upload(b, water, wall)
+            h.set_params(p, u["initial_T"])
+            h.set_option(E.Handle.OPT_DRY_PAIRS, pairs)
+            hs.append(h)
+        return hs
+
+    def compare(hs, ref, steps):
+        for k in steps:
+            for h in hs:
+                h.step(k)
+            for f in ("BASE_CUR", "BASE_DISP"):
+                assert np.array_equal(hs[0].read_rect(f), hs[1].read_rect(f)), (k, f)
+            if ref is not None:
+                ref.step(k)
+                assert np.array_equal(hs[1].read_rect("BASE_CUR"), ref.field("BASE_CUR")), k
+
+    ref = None
+    if X * Y <= 200000:
+        ref = oracle.OracleSim(X, Y, 0)
+        ref.upload(base, water, wall)
+        ref.set_params(u)
+    hs = handles(base)
+    compare(hs, ref, (2, 4, 3, 10))
+    fixed, repeated = hs[1].pair_stats()
+    assert fixed > 0 and repeated == 0, (fixed, repeated)
+    for h in hs:
+        h.close()
+    # second-iteration back-traces of three cells and more: the stage of the fix kernel is left -> the whole pair is repeated
+    b3 = base.copy()
+    pkg.synth.add_vortices(b3, wall, [(X // 2 + 100.5, Y // 2 + 0.5)], 10.0, 5.0)
+    hs = handles(b3)
+    compare(hs, None, (2, 4))
+    fixed, repeated = hs[1].pair_stats()
+    assert repeated > 0, (fixed, repeated)
+    for h in hs:
+        h.close()
+    # a list too short for the recorded cells: the whole pair is repeated
+    hs = handles(base, cap=4)
+    compare(hs, None, (2, 2))
+    fixed, repeated = hs[1].pair_stats()
+    assert repeated > 0, (fixed, repeated)
     for h in hs:
         h.close()

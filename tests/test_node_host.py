@@ -38,7 +38,7 @@ def test_addon_builds_loads_and_fails_loudly_without_gpu(pkg):
     js = ("const m=require('%s'); console.log(m.abiVersion());"
           "try{m.create(64,32,0); console.log('created')}catch(e){console.log('ERR '+e.message)}" % os.path.join(ROOT, "host", "wxsim_napi.node"))
     out = subprocess.check_output([NODE, "-e", js]).decode().split("\n")
-    assert out[0] == "10"
+    assert out[0] == "11"
     import torch
     if not torch.cuda.is_available():
         assert out[1].startswith("ERR") and "no CPU fallback" in out[1]
