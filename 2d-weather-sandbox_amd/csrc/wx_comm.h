@@ -323,8 +323,10 @@ static float bits_to_float(int b)
   memcpy(&v, &b, 4);
   return v;
 }
-// After an upload (or when a host wrote velocities through wx_device_ptr): every slab looks at its state, the ring takes the maximum.
-// The one place where the protocol waits for the device -- once per upload, before the first iteration.
+// After an upload: every slab looks at its state, the ring takes the maximum. The one place where the protocol waits for the device -- once
+// per upload, before the first iteration. With one rank per process the decision below is rank-local and the all-gather is a collective:
+// wx_upload / wx_setup_* on the slabs of an initialised ring are therefore COLLECTIVE calls (every rank, before the next exchange:
+// include/wxsim.h); nothing else sets vx_stale (velocities written through wx_device_ptr only mark the state for the next roll's scan).
 static int ring_vx_bootstrap(Ring &R)
 {
   bool stale = false;
@@ -395,7 +397,7 @@ static int ring_vx_roll(Ring &R)
         }
         if (hipStreamWaitEvent(st, s->ev_edges, 0) != hipSuccess) return rfail(R, s, WX_E_DEVICE, "hipStreamWaitEvent");
       }
-      vx_scan_enqueue(s, st);
+      vx_scan_enqueue(s, st, true);
       s->vx_untracked = false;
     }
     hipLaunchKernelGGL(k_vx_roll, dim3(1), dim3(1), 0, st, s->state, s->vx_dev);

@@ -109,6 +109,11 @@ struct wx_sim {
   int dry_march = 1;     // water-free dry iteration: 1 = row-marching wavefront kernel (wx_march.h, default: 0.32 vs 0.38 ms at
                          // 16384x2048), 0 = LDS-tiled kernel (wx_dry.h); env WX_DRY_MARCH
   int dry_pairs = 1;     // WX_OPT_DRY_PAIRS: the water-free dry stencil two iterations per launch where it can (wx_march2.h; round 5)
+  // placement (wx_tune_placement): the search runs ONCE per handle -- by the host's call, or inside the first wx_step of a whole-domain
+  // handle of WX_PLACEMENT_AUTO_CELLS cells and more (WX_OPT_PLACEMENT_SEARCH tries; 0: never)
+  int place_tries = 6;
+  bool place_done = false, place_busy = false;
+  float place_first_ms = 0.f, place_kept_ms = 0.f;
   // the pair kernel's exact path (wx_march2.h, Dry2Fix): control words, the list of recorded cells, the host-visible length of the last list
   int *pair_ctl = nullptr;
   int2 *pair_cells = nullptr;
@@ -1113,7 +1118,7 @@ int wx_kernel_count(void) { return K_COUNT; }
 const char *wx_kernel_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }
 
 // process-wide defaults of the options a handle takes at creation (wx_set_option(NULL, ...))
-static int g_opt_kernel_set = 1, g_opt_dry_kernel = 1, g_opt_row_bands = 1, g_opt_fix_cap = 0;
+static int g_opt_kernel_set = 1, g_opt_dry_kernel = 1, g_opt_row_bands = 1, g_opt_fix_cap = 0, g_opt_place_tries = 6;
 
 int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_droplets, wx_sim **out)
 {
@@ -1145,6 +1150,7 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   s->dry_march = g_opt_dry_kernel;
   s->bands_mode = g_opt_row_bands;
   s->fix_cap_request = g_opt_fix_cap;
+  s->place_tries = g_opt_place_tries;
   const size_t n = ncell(s);
   int rc = WX_OK;
   { // everything allocated below, to the byte (plus the splat grids of handles with droplets)
@@ -1571,10 +1577,22 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
   } tail_reset{s};
   s->prof_tail = nullptr;
   s->prof_chain = true;
+  // Where the planes lie in physical memory is worth +-8 % of the iteration (include/wxsim.h, "Placement tuning"): big whole-domain handles
+  // look for a good set of allocations once, before their first iteration (state and counters are untouched; round-5 verdict: a host that
+  // follows INTEGRATION.md should not have to know). A failed search (no room for two more copies of the state) is not an error of the step.
+  if (!s->place_done && !s->place_busy && n_iter > 0) {
+    s->place_done = true;
+    if (s->place_tries > 0 && s->halo == 0 && ncell(s) >= WX_PLACEMENT_AUTO_CELLS && !s->blocks.empty()) {
+      const std::string err_keep = s->err;
+      if (wx_tune_placement(s, s->place_tries, 20, nullptr, nullptr) != WX_OK) {
+        s->err = err_keep;
+        (void)hipGetLastError();
+      }
+    }
+  }
   settle_edges(s); // (the previous call ended with an edges-first iteration that no halo pack followed)
   const unsigned mask = s->p.pass_mask;
   const bool precip = (mask & WX_PASS_PRECIPITATION) && s->p.enablePrecipitation && s->n_drops > 0;
-  const size_t n = ncell(s);
   // the marching kernel implements the full grid-pass set; any other pass_mask (but the dry one) runs the per-pass kernels
   const bool fused = s->fused && (mask & 0x3Fu) == 0x3Fu;
   const bool dry = s->fused && (mask & 0x3Fu) == WX_PASS_DRY;
@@ -1720,6 +1738,7 @@ int wx_set_option(wx_sim *s, int option, int value)
     case WX_OPT_DRY_KERNEL: g_opt_dry_kernel = value != 0; return WX_OK;
     case WX_OPT_ROW_BANDS: if (value < 0 || value > 2) return WX_E_INVALID; g_opt_row_bands = value; return WX_OK;
     case WX_OPT_FIX_CAP: if (value < 0) return WX_E_INVALID; g_opt_fix_cap = value; return WX_OK;
+    case WX_OPT_PLACEMENT_SEARCH: if (value < 0 || value > 64) return WX_E_INVALID; g_opt_place_tries = value; return WX_OK;
     default: return WX_E_INVALID;
     }
   }
@@ -1746,6 +1765,10 @@ int wx_set_option(wx_sim *s, int option, int value)
   case WX_OPT_DRY_PAIRS:
     if (int rc = wx_sync(s)) return rc;
     s->dry_pairs = value != 0;
+    return WX_OK;
+  case WX_OPT_PLACEMENT_SEARCH:
+    if (value < 0 || value > 64) return fail(s, WX_E_INVALID, "wx_set_option: WX_OPT_PLACEMENT_SEARCH takes 0 (never) .. 64 tries");
+    s->place_tries = value;
     return WX_OK;
   case WX_OPT_WATER0_ON_DEMAND:
     if (int rc = materialize_water0(s)) return rc;
@@ -1963,6 +1986,11 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
   if (s->pool_remote) return fail(s, WX_E_STATE, "wx_tune_placement: not on slab handles with particles (the exchange period would advance)");
   if (int rc = materialize_water0(s)) return rc; // (the probes' iterations overwrite the inputs it is made from)
   if (int rc = wx_sync(s)) return rc;
+  struct Busy { // (the probes call wx_step: no search inside the search; whoever calls, the handle's one search is this one)
+    wx_sim *s;
+    explicit Busy(wx_sim *s_) : s(s_) { s->place_busy = true; s->place_done = true; }
+    ~Busy() { s->place_busy = false; }
+  } busy(s);
   TuneSnap snap;
   if (s->blocks.empty() || !snap_take(s, snap)) return fail(s, WX_E_STATE, "wx_tune_placement: the handle's planes are not in registered blocks");
   hipEvent_t e0, e1;
@@ -2088,8 +2116,21 @@ int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before,
   s->profiling = was_profiling;
   if (ms_before) *ms_before = first_ms;
   if (ms_after) *ms_after = best_ms;
+  if (rc == WX_OK) {
+    s->place_first_ms = first_ms;
+    s->place_kept_ms = best_ms;
+  }
   if (rc != WX_OK && s->err.empty()) s->err = "wx_tune_placement: device error";
   return rc;
+}
+
+// the handle's placement search (explicit or the implicit one of the first wx_step): 1 and the two iteration times if one has run, else 0
+int wx_placement_info(const wx_sim *s, float *ms_first, float *ms_kept)
+{
+  if (!s) return WX_E_INVALID;
+  if (ms_first) *ms_first = s->place_first_ms;
+  if (ms_kept) *ms_kept = s->place_kept_ms;
+  return s->place_kept_ms > 0.f ? 1 : 0;
 }
 
 // largest |velocity component| that sent a cell to the exact path since the last call (0: none reached 0.9); resets it
@@ -2165,10 +2206,13 @@ int wx_slab_set_vx_bound(wx_sim *s, float v_measured)
 }
 
 // the state as it lies in base_0, for kernels that do not track while they run and for states that came from outside
-static void vx_scan_enqueue(wx_sim *s, hipStream_t st)
+// check: the state is the product of iterations of the CURRENT exchange period (kernels that do not track, or velocities a host wrote
+// through wx_device_ptr): a |vx| that reaches the period's bound is reported like the marching kernels report theirs (cone_violation ->
+// WX_E_STATE at the next blocking call), never silent. Without it: a freshly uploaded state, from which the bound is about to be set.
+static void vx_scan_enqueue(wx_sim *s, hipStream_t st, bool check)
 {
   const VxTrack t = vx_track(s);
-  hipLaunchKernelGGL(k_vx_scan, dim3(1024), dim3(256), 0, st, s->X, s->Y, t.zone_l, t.zone_r, s->base[0], VxTrack{t.max_bits, t.violation, 0.0f, 0, 0});
+  hipLaunchKernelGGL(k_vx_scan, dim3(1024), dim3(256), 0, st, s->X, s->Y, t.zone_l, t.zone_r, s->base[0], VxTrack{t.max_bits, t.violation, check ? t.limit : 0.0f, 0, 0});
 }
 
 int wx_slab_vx_take(wx_sim *s, float *vmax)
@@ -2178,7 +2222,7 @@ int wx_slab_vx_take(wx_sim *s, float *vmax)
   if (!s->uploaded) return fail(s, WX_E_STATE, "wx_slab_vx_take before wx_upload");
   settle_edges(s);
   wait_unpacked(s);
-  if (s->vx_stale || s->vx_untracked) vx_scan_enqueue(s, s->stream);
+  if (s->vx_stale || s->vx_untracked) vx_scan_enqueue(s, s->stream, !s->vx_stale);
   int bits = 0;
   HIPCHK(s, hipMemcpyAsync(&bits, &s->state->vx_max_bits, 4, hipMemcpyDeviceToHost, s->stream));
   HIPCHK(s, hipMemsetAsync(&s->state->vx_max_bits, 0, 4, s->stream));
@@ -2518,7 +2562,9 @@ void *wx_device_ptr(wx_sim *s, int field)
   const void *ptr;
   int ch, el;
   if (field_info(s, field, &ptr, &ch, &el)) return nullptr;
-  if (field == WX_FIELD_BASE_CUR) s->vx_stale = true; // (the caller may write velocities through the pointer: devtools.seed_flow does)
+  // (the caller may write velocities through the pointer: devtools.seed_flow does. Rank-LOCAL knowledge: it must not change which collectives
+  // this rank enqueues -- ADVICE round 5 -- so it only makes the next exchange's roll look at the state, with the period's bound checked)
+  if (field == WX_FIELD_BASE_CUR) s->vx_untracked = true;
   return const_cast<void *>(ptr);
 }
 

@@ -36,7 +36,7 @@ EXPORTS = [
     "wx_set_option", "wx_water_free", "wx_slab_assert_water_free", "wx_tune_placement",
     "wx_comm_unique_id", "wx_comm_init", "wx_exchange", "wx_slab_step", "wx_group_create", "wx_group_destroy", "wx_group_last_error",
     "wx_group_count", "wx_group_transport", "wx_group_slab", "wx_group_agree", "wx_group_step", "wx_group_sync", "wx_group_set_option",
-    "wx_group_exchange", "wx_slab_vx_take", "wx_slab_set_vx_bound", "wx_slab_cone", "wx_slab_period", "wx_pair_stats",
+    "wx_group_exchange", "wx_slab_vx_take", "wx_slab_set_vx_bound", "wx_slab_cone", "wx_slab_period", "wx_pair_stats", "wx_placement_info",
 ]
 
 
@@ -125,6 +125,7 @@ def lib() -> C.CDLL:
     L.wx_setup_columns.argtypes = [vp] + [vp] * 8
     L.wx_init_droplets.argtypes = [vp, C.c_uint32]
     L.wx_fastest_velocity.argtypes = [vp, C.POINTER(C.c_float)]
+    L.wx_placement_info.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.wx_pair_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.wx_slab_vx_take.argtypes = [vp, C.POINTER(C.c_float)]
     L.wx_slab_set_vx_bound.argtypes = [vp, C.c_float]
@@ -202,6 +203,7 @@ class Handle:
         self.X_owned, self.Y, self.n_droplets, self.halo = X, Y, n_droplets, halo
         self.X = L.wx_local_width(h)
         self.generation = 0  # bumped whenever device pointers obtained earlier become invalid (tune_placement)
+        self._stepped = False
 
     @classmethod
     def _borrowed(cls, ptr, X_owned: int, Y: int, halo: int, owner, n_droplets: int = 0) -> "Handle":
@@ -212,6 +214,7 @@ class Handle:
         self.X_owned, self.Y, self.n_droplets, self.halo = X_owned, Y, n_droplets, halo
         self.X = lib().wx_local_width(self._h)
         self.generation = 0
+        self._stepped = False
         return self
 
     def _chk(self, rc: int):
@@ -270,6 +273,9 @@ class Handle:
         """n iterations; ``overlap`` (slab handles with a comm stream): OVERLAP_EDGES_FIRST -- edge strips of the last iteration
         first, so that the halo can be packed and sent while the interior computes; OVERLAP_EDGES_LAST -- interior strips of the
         first iteration first, the edge strips once the ghost columns have arrived (wx_step_overlap)."""
+        if not self._stepped and n > 0:  # (the first step of a big whole-domain handle may move the planes: WX_OPT_PLACEMENT_SEARCH)
+            self._stepped = True
+            self.generation += 1
         if overlap:
             self._chk(lib().wx_step_overlap(self._h, int(n), int(overlap)))
         else:
@@ -295,6 +301,7 @@ class Handle:
         self._chk(lib().wx_slab_assert_water_free(self._h, 1 if agreed else 0))
 
     OPT_SPLAT_ORDER, OPT_CHECK_LAUNCHES, OPT_KERNEL_SET, OPT_DRY_KERNEL, OPT_ROW_BANDS, OPT_FIX_CAP, OPT_POOL_EXACT, OPT_EXCHANGE_OVERLAP, OPT_SPLIT_LAUNCH, OPT_DRY_PAIRS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+    OPT_PLACEMENT_SEARCH = 12  # tries of the handle's one placement search, run inside the first step of big whole-domain handles (0: never)
     OPT_WATER0_ON_DEMAND = 11  # waterTexture_0 made when asked for (default 1) instead of stored by every frame's last iteration
 
     def set_option(self, option: int, value: int):
@@ -441,6 +448,11 @@ class Handle:
         v = C.c_float(0)
         self._chk(lib().wx_fastest_velocity(self._h, C.byref(v)))
         return float(v.value)
+
+    def placement_info(self):
+        """(ms per iteration on the first allocations, on the kept ones) of the handle's placement search, or None if none has run."""
+        a, b = C.c_float(0), C.c_float(0)
+        return (float(a.value), float(b.value)) if lib().wx_placement_info(self._h, C.byref(a), C.byref(b)) == 1 else None
 
     def pair_stats(self):
         """(cells recomputed by the pair kernel's exact path, pairs repeated whole) since the last call; resets both; synchronises."""

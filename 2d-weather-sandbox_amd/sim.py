@@ -8,6 +8,7 @@ module-scope GL objects, ``draw()`` (app.js:5686) runs ``guiControls.IterPerFram
 from __future__ import annotations
 
 import datetime as _dt
+import sys
 from typing import Any, Dict, Optional
 
 import numpy as np
@@ -65,6 +66,8 @@ class WeatherSim:
         self._pass_mask = int(pass_mask)
         self._manual_sun = sun_angle_deg
         self._inactive_pushed = False
+        self._placement_told = False
+        self.verbose = True
         # startSimulation(): clock from the saved month / time of day (app.js:3902-3910)
         self.sim_datetime = initial_sim_datetime(float(self.gui["month"]), float(self.gui["timeOfDay"]), bool(self.gui.get("dayNightCycle")))
         self.brush = {"userInputType": -1, "userInputValues": (0.0, 0.0, 0.0, 0.0), "userInputMove": (0.0, 0.0)}
@@ -144,6 +147,11 @@ class WeatherSim:
         if self.gui.get("dayNightCycle") and self._manual_sun is None:
             self.update_sunlight(TIME_PER_ITERATION * n)
         self._h.step(n)
+        if not self._placement_told:  # the engine looked for a fast placement of its planes inside the first step of a big grid: say so once
+            self._placement_told = True
+            pi = self._h.placement_info()
+            if pi is not None and self.verbose:
+                print(f"[wxsim] placement search: {pi[0]:.4f} ms / iteration on the first allocations, {pi[1]:.4f} kept", file=sys.stderr)
 
     def sync(self):
         self._h.sync()

@@ -568,6 +568,12 @@ def main():
         ms0, ms1 = stepper.tune_placement(a.tune, 30)
         placement = {"tries": a.tune, "ms_per_iteration_first_allocation": ms0, "ms_per_iteration_kept": ms1,
                      "applies_to": "value, at_rest and frame_1 (all measured after the search, on the kept placement)"}
+    elif world == 1:  # --tune 0: a whole-domain handle of 8 Mi cells and more searches by itself inside its first wx_step (WX_OPT_PLACEMENT_SEARCH, 6 tries)
+        step(a.frame)
+        pi = stepper.placement_info()
+        if pi is not None:
+            placement = {"tries": "implicit: 6, inside the handle's first wx_step (WX_OPT_PLACEMENT_SEARCH; what a host that never calls wx_tune_placement gets)",
+                         "ms_per_iteration_first_allocation": pi[0], "ms_per_iteration_kept": pi[1]}
     at_rest = None
     if world == 1 and a.flow > 0 and not a.no_extras and not a.particles:  # the still start state first (round 2's definition)
         run_frames(step, a.warmup, a.frame)

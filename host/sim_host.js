@@ -368,7 +368,13 @@ WeatherSim.prototype.frame = function(nIter) {
   if (this.gui.dayNightCycle && this.manualSun == null) this.updateSunlight(TIME_PER_ITERATION * n);
   if (this.slabs) this.addon.groupStep(this.group, n); // every slab: n iterations + the halo exchanges that fall into them
   else this.addon.step(this.h, n);
+  if (!this.placementTold && !this.slabs) { // the engine looked for a fast placement of its planes inside the first step of a big grid: say so once
+    this.placementTold = true;
+    const pi = this.addon.placementInfo(this.h);
+    if (pi && this.verbose !== false) console.error(`[wxsim] placement search: ${pi[0].toFixed(4)} ms / iteration on the first allocations, ${pi[1].toFixed(4)} kept`);
+  }
 };
+WeatherSim.prototype.placementInfo = function() { return this.slabs ? null : this.addon.placementInfo(this.h); };
 WeatherSim.prototype.sync = function() { if (this.slabs) this.addon.groupSync(this.group); else this.addon.sync(this.h); };
 // engine options with no counterpart in app.js: deterministic particle splats (option 1), per-launch checks (option 2), and the
 // search for a fast placement of the handle's planes in device memory (returns [ms before, ms after]; the state is unchanged)

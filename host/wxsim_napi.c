@@ -28,6 +28,8 @@ static struct {
   int (*sync)(wx_sim *);
   int (*set_option)(wx_sim *, int, int);
   int (*tune_placement)(wx_sim *, int, int, float *, float *);
+  int (*placement_info)(const wx_sim *, float *, float *);
+  int (*pair_stats)(wx_sim *, int64_t *, int64_t *);
   int64_t (*get_iter)(const wx_sim *);
   int (*set_iter)(wx_sim *, int64_t);
   int (*read_rect)(wx_sim *, int, int, int, int, int, void *, int);
@@ -358,6 +360,47 @@ static napi_value TunePlacement(napi_env env, napi_callback_info info)
   NAPI_CALL(env, napi_create_array_with_length(env, 2, &arr));
   NAPI_CALL(env, napi_create_double(env, before, &v0));
   NAPI_CALL(env, napi_create_double(env, after, &v1));
+  NAPI_CALL(env, napi_set_element(env, arr, 0, v0));
+  NAPI_CALL(env, napi_set_element(env, arr, 1, v1));
+  return arr;
+}
+
+/* placementInfo(h) -> [msFirst, msKept] of the handle's placement search (tunePlacement, or the implicit one inside the first step of a
+ * big whole-domain handle: WX_OPT_PLACEMENT_SEARCH), or null if none has run */
+static napi_value PlacementInfo(napi_env env, napi_callback_info info)
+{
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  float first = 0.f, kept = 0.f;
+  napi_value arr, v0, v1;
+  if (L.placement_info(s, &first, &kept) != 1) {
+    NAPI_CALL(env, napi_get_null(env, &arr));
+    return arr;
+  }
+  NAPI_CALL(env, napi_create_array_with_length(env, 2, &arr));
+  NAPI_CALL(env, napi_create_double(env, first, &v0));
+  NAPI_CALL(env, napi_create_double(env, kept, &v1));
+  NAPI_CALL(env, napi_set_element(env, arr, 0, v0));
+  NAPI_CALL(env, napi_set_element(env, arr, 1, v1));
+  return arr;
+}
+
+/* pairStats(h) -> [cellsRecomputed, pairsRepeated]: wx_pair_stats (the dry pair kernel's exact path since the last call) */
+static napi_value PairStats(napi_env env, napi_callback_info info)
+{
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  wx_sim *s = get_handle(env, a[0]);
+  if (!s) return NULL;
+  int64_t fixed = 0, repeated = 0;
+  int rc = L.pair_stats(s, &fixed, &repeated);
+  if (rc) return throw_wx(env, s, rc, "wx_pair_stats");
+  napi_value arr, v0, v1;
+  NAPI_CALL(env, napi_create_array_with_length(env, 2, &arr));
+  NAPI_CALL(env, napi_create_double(env, (double)fixed, &v0));
+  NAPI_CALL(env, napi_create_double(env, (double)repeated, &v1));
   NAPI_CALL(env, napi_set_element(env, arr, 0, v0));
   NAPI_CALL(env, napi_set_element(env, arr, 1, v1));
   return arr;
@@ -807,7 +850,7 @@ static int load_lib(napi_env env)
   SYM(group_create, "wx_group_create") SYM(group_destroy, "wx_group_destroy") SYM(group_last_error, "wx_group_last_error") SYM(group_count, "wx_group_count")
   SYM(group_transport, "wx_group_transport") SYM(group_slab, "wx_group_slab") SYM(group_agree, "wx_group_agree") SYM(group_step, "wx_group_step")
   SYM(group_sync, "wx_group_sync") SYM(local_width, "wx_local_width") SYM(group_set_option, "wx_group_set_option") SYM(group_exchange, "wx_group_exchange")
-  SYM(pool_flags, "wx_pool_flags")
+  SYM(pool_flags, "wx_pool_flags") SYM(placement_info, "wx_placement_info") SYM(pair_stats, "wx_pair_stats")
 #undef SYM
   return 0;
 }
@@ -824,6 +867,7 @@ static napi_value Init(napi_env env, napi_value exports)
     {"abiVersion", 0, AbiVersion, 0, 0, 0, napi_default, 0}, {"setupColumns", 0, SetupColumns, 0, 0, 0, napi_default, 0}, {"setupTerrain", 0, SetupTerrain, 0, 0, 0, napi_default, 0}, {"initDroplets", 0, InitDroplets, 0, 0, 0, napi_default, 0},
     {"streamFrame", 0, StreamFrame, 0, 0, 0, napi_default, 0}, {"streamWait", 0, StreamWait, 0, 0, 0, napi_default, 0},
     {"setOption", 0, SetOption, 0, 0, 0, napi_default, 0},   {"tunePlacement", 0, TunePlacement, 0, 0, 0, napi_default, 0},
+    {"placementInfo", 0, PlacementInfo, 0, 0, 0, napi_default, 0}, {"pairStats", 0, PairStats, 0, 0, 0, napi_default, 0},
     {"groupCreate", 0, GroupCreate, 0, 0, 0, napi_default, 0}, {"groupSlab", 0, GroupSlab, 0, 0, 0, napi_default, 0},
     {"groupInfo", 0, GroupInfo, 0, 0, 0, napi_default, 0},     {"groupAgree", 0, GroupAgree, 0, 0, 0, napi_default, 0},
     {"groupStep", 0, GroupStep, 0, 0, 0, napi_default, 0},     {"groupSync", 0, GroupSync, 0, 0, 0, napi_default, 0},

@@ -247,6 +247,14 @@ int wx_sync(wx_sim *s);
  * instead of being stored by every frame's last iteration: 16 of the 36 display-side bytes per cell. Applies to the marching wet kernel
  * without particles; 0 = always stored by the iteration itself. Bit-identical either way (tests/test_gpu_parity.py). */
 #define WX_OPT_WATER0_ON_DEMAND 11
+/* (ABI 11) WX_OPT_PLACEMENT_SEARCH: the number of further allocation sets the handle's ONE placement search tries (default 6; 0 = never).
+ * A whole-domain handle of WX_PLACEMENT_AUTO_CELLS cells or more runs wx_tune_placement(s, tries, 20, ..) by itself inside its first
+ * wx_step (a quarter of a second at 16384 x 2048; state, counters and results untouched; skipped silently if the device has no room for
+ * two more copies of the state) unless the host has called wx_tune_placement before -- see "Placement tuning" below. Device pointers
+ * taken before that first step are invalid after it. Slab handles never search by themselves (their hosts call wx_tune_placement). With
+ * s == NULL: the default of handles created afterwards (tests switch the search off). */
+#define WX_OPT_PLACEMENT_SEARCH 12
+#define WX_PLACEMENT_AUTO_CELLS (8u << 20)
 int wx_set_option(wx_sim *s, int option, int value);
 
 /* iterNum global (app.js:440) */
@@ -286,12 +294,21 @@ int wx_stream_wait(wx_sim *s);
  * iteration time on the allocation the handle had and on the winner. Needs three times the handle's memory while it runs (more is used
  * if free: rejected candidates are kept until the end so that the allocator does not hand the same memory out again). */
 int wx_tune_placement(wx_sim *s, int tries, int iters_per_try, float *ms_before, float *ms_after);
+/* (ABI 11) Returns 1 and the two iteration times [ms] of the handle's placement search -- the host's call above or the implicit one of
+ * the first wx_step (WX_OPT_PLACEMENT_SEARCH) -- if one has run, else 0. Either pointer may be NULL. */
+int wx_placement_info(const wx_sim *s, float *ms_first, float *ms_kept);
 
 /* ---- plumbing for hosts that own device memory / streams (PyTorch, multi-GPU halo exchange) ---- */
 int wx_set_stream(wx_sim *s, void *hip_stream);     /* NULL = legacy default stream */
 void *wx_device_ptr(wx_sim *s, int field);          /* device address of a field's current storage; WX_FIELD_LIGHT_0/1, WX_FIELD_EMITTED and
                                                      * WX_FIELD_PRECIP_FB are stored in another form (planes / on demand / three channels): the
-                                                     * pointer is to the RGBA texture made at the time of the call, valid until the next wx_step */
+                                                     * pointer is to the RGBA texture made at the time of the call, valid until the next wx_step.
+                                                     * Slabs: velocities written through WX_FIELD_BASE_CUR are looked at by the next exchange
+                                                     * (a |vx| beyond the current period's bound is REPORTED, WX_E_STATE); only wx_upload /
+                                                     * wx_setup_* re-size the first period -- and on the slabs of an initialised ring those are
+                                                     * COLLECTIVE: every rank calls them alike before the next wx_slab_step / wx_exchange (the
+                                                     * ranks all-gather their |vx| once after an upload: a rank that skipped it would pair the
+                                                     * ring's later collectives off by one) */
 int wx_local_width(const wx_sim *s);                /* X_owned + 2*halo */
 /* Halo exchange of the state carried across iterations (base_0, wall_0, water_1, both light textures; with particles also
  * the feedback and deposition textures):

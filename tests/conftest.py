@@ -20,7 +20,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
-    return wxpkg.load_package()
+    p = wxpkg.load_package()
+    try:  # (the implicit placement search of big whole-domain handles -- a quarter of a second and more per handle -- only where a test asks for it)
+        p.engine.lib().wx_set_option(None, p.engine.Handle.OPT_PLACEMENT_SEARCH, 0)
+    except Exception:
+        pass
+    return p
 
 
 @pytest.fixture(scope="session")

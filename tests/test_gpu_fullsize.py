@@ -63,6 +63,8 @@ def _uniforms(pkg, Y, **kw):
 def _run_pair(pkg, oracle, E, X, Y, state, u, steps, fields):
     base, water, wall = state
     h = E.Handle(X, Y, 0)
+    if X * Y <= (64 << 20):  # (the shipped default, which conftest switches off for the suite's other handles; the 32768 x 4096 grids skip it for time)
+        h.set_option(h.OPT_PLACEMENT_SEARCH, 3)
     h.upload(base, water, wall)
     h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
     o = oracle.OracleSim(X, Y, 0)
@@ -74,6 +76,8 @@ def _run_pair(pkg, oracle, E, X, Y, state, u, steps, fields):
         o.step(n)
         _assert_equal(h, o, fields)
     assert h.iter == o.iter == sum(steps)
+    # (ABI 11) whole-domain handles of 8 Mi cells and more looked for a good placement inside their first step -- and nothing above noticed
+    assert (h.placement_info() is not None) == ((8 << 20) <= X * Y <= (64 << 20)), h.placement_info()
     b = h.read_rect("BASE_CUR")
     assert np.isfinite(b).all() and np.abs(b[..., :2]).max() > 1e-3  # something moved
     h.close()
