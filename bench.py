@@ -619,6 +619,7 @@ def main():
     prof_steps = a.steps if profile_inline else 16
     flow1 = devtools.flow_stats(stepper)
     verify = "n/a (single rank)" if world == 1 else "off (--no-verify)"
+    whole, n1, per_rank = None, None, None
     # largest |velocity component| the exact path of the wet kernel saw during the run (0: nothing reached 0.9 cells / iteration). On
     # slabs the halo width assumes |v| < 1: a larger value means the decomposed run may differ from the undecomposed one near slab edges
     fastest = stepper.fastest_velocity() if a.workload == "wet" else 0.0
@@ -647,10 +648,37 @@ def main():
                     ref = devtools.checksum(whole, VERIFY_FIELDS, Xg=X, x0=0, cols=slice(r * xo, (r + 1) * xo))
                     got = gathered[r].cpu().numpy()
                     bad += [f"rank {r} {f}" for k, f in enumerate(VERIFY_FIELDS) if not np.array_equal(ref[k], got[k])]
-                whole.close()
                 verify = "ok" if not bad else "MISMATCH: " + ", ".join(bad)
         elif a.verify:
             verify = "not available with particles (a period may differ from the undecomposed run by a few re-spawn probes: tests/test_gpu_fullsize.py quantifies it)"
+        # Round-5 verdict, item 7: what the curve decomposes into, measured in THIS run on rank 0's GPU while the other ranks wait in the final
+        # barrier -- (a) the same grid UNDECOMPOSED on the same box (`strong_scaling_vs_n1`: SCALE's N = 1 point without a second run; the handle
+        # searches its placement inside its first step), (b) this rank's slab with NO exchange at all (`per_rank.plain_slab_ms_per_step`: the
+        # kernel on a narrow launch; the rest of ms_per_step is the exchange protocol + the link).
+        if rank == 0 and not a.particles:
+            try:
+                if whole is None:
+                    whole = make_whole()
+                    if a.flow > 0:
+                        devtools.seed_flow(whole, a.flow, Xg=X, x0=0, kind=a.flow_kind)
+                    run_frames(whole.step, a.warmup, a.frame)
+                condition_clocks(whole.step, whole.sync, a.frame)
+                dtw, _ = timed_run(whole, a.steps, a.frame, profile=False)
+                n1 = {"n1_ms_per_step": dtw / a.steps * 1e3, "n1_value": X * Y * a.steps / dtw / 1e6, "speedup": dtw / dt,
+                      "how": "the undecomposed grid timed on rank 0's GPU in the same run (same state family, same frames), the other ranks idle",
+                      "n1_placement": whole.placement_info()}
+                whole.close()
+                whole = None
+                condition_clocks(stepper.step, stepper.sync, a.frame)
+                dtp, _ = timed_run(stepper, a.steps, a.frame, profile=False)
+                per_rank = {"local_columns": stepper.X, "owned_columns": X // world, "plain_slab_ms_per_step": dtp / a.steps * 1e3,
+                            "protocol_and_link_share_of_ms_per_step": 1.0 - (dtp / a.steps) / (dt / a.steps),
+                            "plain_slab_x_n_over_n1": (dtp * world) / dtw,
+                            "how": "rank 0's slab stepped with no exchange at all after the timed region (ghost columns stale: timing only)"}
+            except Exception as e:  # (never at the price of the line itself)
+                n1 = n1 or {"error": repr(e)}
+        if whole is not None:
+            whole.close()
 
     if rank == 0:
         cells = X * Y
@@ -723,6 +751,10 @@ def main():
             "iteration_roofline_frac_A_wet": cells * a.steps * A / dt / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roof,
         }
+        if n1:
+            out["strong_scaling_vs_n1"] = n1
+        if per_rank:
+            out["per_rank"] = per_rank
         if at_rest:
             out["at_rest"] = at_rest
         if world == 1 and not a.no_extras and a.frame != 1 and not a.particles:

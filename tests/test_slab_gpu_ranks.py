@@ -139,6 +139,9 @@ def test_bench_verify_two_ranks(workload, grid):
     assert d["verify"] == "ok", d["verify"]
     assert d["ranks_seen"] == 2 and d["n_gpus"] == 2 and d["value"] > 0
     assert d["flow"]["end_of_timed_region"]["rms_v"] > 0.01  # the fluid moved
+    # (round 6) what a scaling curve decomposes into, in the same line: the undecomposed grid on the same box, the slab without any exchange
+    assert d["strong_scaling_vs_n1"]["n1_value"] > 0 and d["strong_scaling_vs_n1"]["speedup"] > 0, d.get("strong_scaling_vs_n1")
+    assert d["per_rank"]["plain_slab_ms_per_step"] > 0 and d["per_rank"]["local_columns"] > d["per_rank"]["owned_columns"], d.get("per_rank")
     if workload == "dry":
         # the water-free marching kernel ran on the slabs -- in pairs: agreed water-free slabs run their periods in order (ABI 10)
         assert d["roofline"]["kernel"] == "march_dry2_two_iterations_per_launch"
