@@ -1112,6 +1112,11 @@ extern "C" {
 
 int wx_abi_version(void) { return WX_ABI_VERSION; }
 
+#ifndef WX_FAST_ARITH
+#define WX_FAST_ARITH 0
+#endif
+int wx_arith(void) { return WX_FAST_ARITH ? WX_ARITH_FAST : WX_ARITH_EXACT; }
+
 const char *wx_last_error(const wx_sim *s) { return s ? s->err.c_str() : g_create_error.c_str(); }
 
 int wx_kernel_count(void) { return K_COUNT; }

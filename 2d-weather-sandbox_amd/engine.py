@@ -16,7 +16,10 @@ from .params import WxParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.environ.get("WXSIM_LIB") or os.path.join(CSRC, "libwxsim.so")  # WXSIM_LIB: tuning variants
+# WXSIM_LIB: another build of the same sources -- the tolerance build FAST_LIB_PATH (`make -C csrc fast`, SURVEY Appendix A's opt-in fast
+# arithmetic; lib().wx_arith() says which one is loaded) or a tuning variant. The default is the parity build.
+FAST_LIB_PATH = os.path.join(CSRC, "libwxsim_fast.so")
+LIB_PATH = os.environ.get("WXSIM_LIB") or os.path.join(CSRC, "libwxsim.so")
 
 FIELD_IDS = {
     "BASE_CUR": 0, "BASE_DISP": 1, "WATER_0": 2, "WATER_CUR": 3, "WALL_CUR": 4, "WALL_DISP": 5,
@@ -36,18 +39,22 @@ EXPORTS = [
     "wx_set_option", "wx_water_free", "wx_slab_assert_water_free", "wx_tune_placement",
     "wx_comm_unique_id", "wx_comm_init", "wx_exchange", "wx_slab_step", "wx_group_create", "wx_group_destroy", "wx_group_last_error",
     "wx_group_count", "wx_group_transport", "wx_group_slab", "wx_group_agree", "wx_group_step", "wx_group_sync", "wx_group_set_option",
-    "wx_group_exchange", "wx_slab_vx_take", "wx_slab_set_vx_bound", "wx_slab_cone", "wx_slab_period", "wx_pair_stats", "wx_placement_info",
+    "wx_group_exchange", "wx_slab_vx_take", "wx_slab_set_vx_bound", "wx_slab_cone", "wx_slab_period", "wx_pair_stats", "wx_placement_info", "wx_arith",
 ]
 
 
-def build(force: bool = False) -> str:
-    """Compile libwxsim.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+def build(force: bool = False, fast: bool = False) -> str:
+    """Compile libwxsim.so (``fast``: the tolerance build libwxsim_fast.so) for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(os.path.dirname(_HERE), "include", "wxsim.h"))
-    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs)
+    fast = fast or os.path.abspath(LIB_PATH) == os.path.abspath(FAST_LIB_PATH)
+    target = FAST_LIB_PATH if fast else os.path.join(CSRC, "libwxsim.so")
+    if os.path.abspath(LIB_PATH) not in (os.path.abspath(target),) and not fast:
+        return LIB_PATH  # (a tuning variant named by WXSIM_LIB: built by its own make target)
+    stale = (not os.path.exists(target)) or any(os.path.getmtime(f) > os.path.getmtime(target) for f in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "-s", "libwxsim.so"])
-    return LIB_PATH
+        subprocess.check_call(["make", "-C", CSRC, "-s", os.path.basename(target)])
+    return target
 
 
 _lib: Optional[C.CDLL] = None
@@ -77,6 +84,7 @@ def lib() -> C.CDLL:
     L.wx_last_error.argtypes = [vp]
     L.wx_last_error.restype = C.c_char_p
     L.wx_abi_version.restype = i32
+    L.wx_arith.restype = i32
     L.wx_upload.argtypes = [vp, vp, vp, vp, vp]
     L.wx_set_params.argtypes = [vp, C.POINTER(WxParams), vp, vp, vp, vp]
     L.wx_step.argtypes = [vp, i32]

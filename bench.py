@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--flow-kind", choices=["eddies", "noise"], default="eddies",
                     help="eddies: smooth divergence-free eddies of 50..400 cells (a developed flow; default); noise: white noise per cell (worst case for the ring reads)")
     ap.add_argument("--no-north-star", action="store_true", help="skip the 32768 x 4096 dry north-star measurement (N=1)")
+    ap.add_argument("--no-arith-fast", action="store_true", help="skip the side measurement of the opt-in tolerance build (csrc/libwxsim_fast.so) reported as the EXTRA key `arith_fast` (N=1)")
     ap.add_argument("--no-extras", action="store_true", help="skip at_rest / frame-1 / hbm_ceiling side measurements (N=1)")
     ap.add_argument("--tune", type=int, default=20, help="wx_tune_placement: further device allocations to try for the handle's planes (0: keep the first)")
     ap.add_argument("--dry-pairs", type=int, default=1, choices=[0, 1], help="dry stencil: WX_OPT_DRY_PAIRS (two iterations per launch; round 5 prototype)")
@@ -168,7 +169,7 @@ def pmc_traffic(a, kernel, X=None, Y=None, workload=None):
             nfr = max(1, int(a.frame))
             cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--steps", str(nfr), "--warmup", str(nfr),
                    "--X", str(X or a.X), "--Y", str(Y or a.Y), "--workload", workload or a.workload, "--no-cpu-baseline", "--no-pmc",
-                   "--no-north-star", "--no-extras", "--frame", str(a.frame), "--flow", str(a.flow), "--flow-kind", a.flow_kind, "--tune", "0", "--dry-pairs", str(a.dry_pairs)]
+                   "--no-north-star", "--no-extras", "--no-arith-fast", "--frame", str(a.frame), "--flow", str(a.flow), "--flow-kind", a.flow_kind, "--tune", "0", "--dry-pairs", str(a.dry_pairs)]
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
@@ -186,6 +187,32 @@ def pmc_traffic(a, kernel, X=None, Y=None, workload=None):
         return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, vals["SQ_INSTS_VALU"], vals["SQ_LDS_BANK_CONFLICT"]
     except Exception:
         return None, None, None
+
+
+def arith_fast_entry(a):
+    """EXTRA key (round-5 verdict, item 3): the same headline workload and the north-star stencil on the opt-in TOLERANCE build
+    (csrc/libwxsim_fast.so: FMA contraction, 1-ulp reciprocal / sqrt -- SURVEY.md Appendix A; gated by tests/test_fast_arith.py against the
+    reference's own outputs and the rounding envelope, NOT bit-identical to the oracle). A process holds one libwxsim, so this re-runs the
+    script with WXSIM_LIB pointing at that build; the line's `value` is and stays the exact build."""
+    fast = os.path.join(ROOT, "2d-weather-sandbox_amd", "csrc", "libwxsim_fast.so")
+    if not os.path.exists(fast) or os.environ.get("WXSIM_LIB"):
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(a.steps), "--warmup", str(a.warmup), "--X", str(a.X), "--Y", str(a.Y), "--workload", a.workload,
+           "--frame", str(a.frame), "--flow", str(a.flow), "--flow-kind", a.flow_kind, "--tune", str(min(a.tune, 6)), "--no-cpu-baseline", "--no-pmc", "--no-extras", "--no-arith-fast"]
+    if a.no_north_star:
+        cmd.append("--no-north-star")
+    try:
+        out = subprocess.run(cmd, env=dict(os.environ, WXSIM_LIB=fast), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True).stdout.decode()
+        d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        res = {"arith": d.get("arith"), "library": "csrc/libwxsim_fast.so (-ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt)", "value": d["value"], "unit": d["unit"],
+               "ms_per_step": d["ms_per_step"], "roofline_frac": d["roofline"]["frac"] if d.get("roofline") else None, "placement": d.get("placement"),
+               "gate": "tests/test_fast_arith.py: reference-output tests + drift inside 8 x the 1-ulp envelope at configs[1] / [2] size; masks bit-exact; NOT bit-identical to the oracle"}
+        ns = d.get("north_star_dry")
+        if ns:
+            res["north_star_dry"] = {"value": ns["value"], "ms_per_step": ns["ms_per_step"], "roofline_frac": ns["roofline"]["frac"]}
+        return res
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def run_frames(step, n, frame):
@@ -740,6 +767,7 @@ def main():
         A = 36 if a.workload == "dry" else 72
         out = {
             "metric": "Mcell-steps/s", "value": value, "unit": "Mcell-steps/s", "n_gpus": world, "steps": a.steps,
+            "arith": "fast (tolerance build, NOT the parity build)" if pkg.engine.lib().wx_arith() == 1 else "exact",
             "warmup": a.warmup, "clock_conditioning": {"untimed_iterations_after_warmup": conditioning_iters, "min_seconds": CONDITION_S,
                                                        "why": "sustained clocks need ~40 ms of load after any idle phase (profiles/r04_driver_gap.txt)"},
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -775,6 +803,14 @@ def main():
             out["north_star_dry"] = north_star_dry(a, pkg)
         if world == 1 and not a.no_extras and not a.no_north_star and a.workload == "wet" and not a.particles and (X, Y) == (16384, 2048):
             out["configs"] = other_configs(a, pkg)
+        if world == 1 and not a.no_arith_fast and not a.particles:
+            fa = arith_fast_entry(a)
+            if fa:
+                if "value" in fa:
+                    fa["vs_exact"] = fa["value"] / out["value"]
+                    if "north_star_dry" in fa and "north_star_dry" in out:
+                        fa["north_star_dry"]["vs_exact"] = fa["north_star_dry"]["value"] / out["north_star_dry"]["value"]
+                out["arith_fast"] = fa
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -145,6 +145,14 @@ int wx_slab_period(const wx_sim *s);
 void wx_destroy(wx_sim *s);
 const char *wx_last_error(const wx_sim *s); /* also valid with s == NULL for create failures */
 int wx_abi_version(void);
+/* (ABI 11) Which arithmetic this library was built with. WX_ARITH_EXACT (libwxsim.so, the default and the one every parity claim is about):
+ * no FMA contraction, correctly rounded division and sqrt -- bit-identical to the CPU oracle. WX_ARITH_FAST (libwxsim_fast.so, `make -C
+ * csrc fast`; SURVEY.md Appendix A's opt-in tolerance build): contraction allowed, 1-ulp hardware reciprocal / sqrt -- the freedom a GL
+ * driver takes with the reference's shaders (common.glsl:177-180, advectionShader.frag:111-131); masks stay bit-exact, float fields stay
+ * inside the calibrated rounding envelope of the exact build (tests/test_fast_arith.py). A host picks one by the file it loads. */
+#define WX_ARITH_EXACT 0
+#define WX_ARITH_FAST 1
+int wx_arith(void);
 
 /* Replaces setupTextures() app.js:5189-5234 (the same data goes into BOTH _0 and _1) and
  * setupPrecipitationBuffers() app.js:4915-5002. Host arrays are copied; the caller keeps ownership.

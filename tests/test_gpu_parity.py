@@ -5,6 +5,8 @@ operations in a fixed order, see csrc/wx_cells.h); particle feedback to fp32 sum
 against the SwiftShader goldens the calibrated envelope of tests/test_oracle_golden.py (the goldens were
 rendered with SwiftShader's own fragCoord interpolation, which the product does not imitate).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -110,11 +112,14 @@ def test_reference_raw_save_1000_iterations(pkg, golden, E, fused):
     h = E.Handle(X, Y, 0)
     h.upload(g["in_base"], g["in_water"], g["in_wall"])
     h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+    # the envelope is what two EXACT runs differ by when their inputs differ in the last bit: the parity build must be inside it; the opt-in
+    # tolerance build (tests/test_fast_arith.py runs this test on it), whose every operation may round differently, inside a small multiple
+    factor = float(os.environ.get("WX_TEST_ENVELOPE_FACTOR", "1")) if E.lib().wx_arith() == 1 else 1.0
     done = 0
     for it in (1, 10, 50, 200, 1000):
         h.step(it - done)
         done = it
-        e = env[it]
+        e = {k: v * factor for k, v in env[it].items()}
         assert np.array_equal(h.read_rect("WALL_CUR"), g[f"it{it}_wall_cur"]), f"wall masks must be bit-exact (iteration {it})"
         b, rb = h.read_rect("BASE_CUR"), g[f"it{it}_base_cur"]
         assert np.abs(b[..., :2] - rb[..., :2]).max() <= e["v"], it
@@ -149,7 +154,9 @@ def test_lightning_vs_reference(pkg, golden, E):
         h.step(1)
         d, rd, rfb, rl = h.read_particles(), g[f"it{k}_drops"], g[f"it{k}_precip_fb"], g[f"it{k}_lightning"]
         flip = np.abs(d - rd).max(1) > 2.5e-7  # spawn threshold fract(pow(cloud * 10, 2)): one driver-pow ulp flips ~1 droplet in 1000
-        assert flip.sum() <= 2, (k, int(flip.sum()))
+        # (the opt-in tolerance build -- tests/test_fast_arith.py runs this test on it -- rounds twice as many operations differently: 4
+        # per iteration; the run's total stays below one droplet-iteration in 1000 for both builds, asserted at the end)
+        assert flip.sum() <= (4 if E.lib().wx_arith() == 1 else 2), (k, int(flip.sum()))
         flipped += int(flip.sum())
         assert np.array_equal((d[:, 2] >= 0)[~flip], (rd[:, 2] >= 0)[~flip]), k
         fb = h.read_rect("PRECIP_FB", 0, 0, 2, 1)
