@@ -474,6 +474,25 @@ __device__ __forceinline__ float precip_T(const Geo &g, size_t t, const float4 *
   return (wb.y == 0 && wb.x == 1) ? t_in[t] : base_in[t].w;
 }
 
+// baseTexture_1 (post-advection base: what the display samples, app.js:6081-6110) of the marching wet kernel's display iteration, rows
+// [y0, y0 + rows): the pressure pass (pressure_cell, wx_cells.h) leaves vx and vy alone, changes P everywhere and T only directly above a land
+// surface cell -- so the iteration stores its post-advection P (p_disp) and, in rows that hold such a cell, its post-advection T (t_disp:
+// the plane the droplets read through precip_T), and the texel is (vx, vy of the post-pressure texture, p_disp, precip_T). Bit-identical
+// to the texture the iteration stored whole until round 5 (tests/test_gpu_parity.py).
+__global__ void k_base_disp_assemble(int X, int Y, int y0, int rows, const float4 *__restrict__ base_cur, const float *__restrict__ p_disp, const float *__restrict__ t_disp,
+                                     const char4 *__restrict__ wall_cur, float4 *__restrict__ out)
+{
+  const size_t n = (size_t)rows * X, off = (size_t)y0 * X;
+  Geo g{};
+  g.X = X;
+  g.Y = Y;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t t = off + i;
+    const float4 b = base_cur[t];
+    out[t] = make_float4(b.x, b.y, p_disp[t], precip_T(g, t, base_cur, t_disp, wall_cur));
+  }
+}
+
 // one droplet of the pool: transform-feedback update + its deposit. Returns true for a droplet that stays inactive (the reference
 // blends +1 per such droplet into texel (0,0), precipitationShader.vert:158-159: counted by the caller).
 __device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const Uni &u, int n_drops, const float *__restrict__ drops_in,

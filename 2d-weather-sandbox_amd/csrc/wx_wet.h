@@ -118,10 +118,11 @@ struct WetOut {
   char4 *wall;
   float4 *water;     // post-advection
   LightPlanes light;
-  float4 *base_disp; // optional (OPT_OUT): post-advection base (baseTexture_1)
+  float *p_disp;     // optional (OPT_OUT): post-advection PRESSURE -- all of baseTexture_1 (what the display samples) that the post-pressure base texture and
+                     // t_disp do not already hold: pressure_cell changes P everywhere and T directly above land only (k_base_disp_assemble makes the RGBA texels on demand)
   float4 *water0;    // optional (OPT_OUT): post-boundary water (waterTexture_0); NULL = not stored (made on demand)
   float *curl;       // optional (OPT_OUT)
-  float *t_disp;     // optional (runtime): post-advection temperature for the droplets
+  float *t_disp;     // optional (runtime): post-advection temperature where the pressure pass changes it, for the droplets and for baseTexture_1 on demand
 #ifdef WX_WET_TIMING
   unsigned long long *cycles; // (tuning builds) per wave: s_memtime at start / end
 #endif
@@ -250,7 +251,7 @@ __device__ __noinline__ void wet_output_cell_exact(const FullCtx *__restrict__ c
   out->light.x[gi] = l.x;
   out->light.y[gi] = l.y;
   out->light.zw[gi] = make_float2(l.z, l.w);
-  if (opt_out) out->base_disp[gi] = o0.b;
+  if (opt_out) out->p_disp[gi] = o0.b.z;
   if (out->t_disp) out->t_disp[gi] = o0.b.w;
 }
 
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
       st_row(out.light.x + e, so4, st_l.x);
       st_row(out.light.y + e, so4, st_l.y);
       st_row(out.light.zw + e, so8, make_float2(st_l.z, st_l.w));
-      if (OPT_OUT) st_row(out.base_disp + e, so16, st_ab);
+      if (OPT_OUT) st_row(out.p_disp + e, so4, st_ab.z);
 #ifndef WX_ABL_NO_TDISP
       // post-advection temperature for the droplets: only rows in which the pressure pass changed it (k_precipitation's precip_T makes
       // the same test per texel and reads the post-pressure T everywhere else)
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
     st_row(out.light.x + e, so4, st_l.x);
     st_row(out.light.y + e, so4, st_l.y);
     st_row(out.light.zw + e, so8, make_float2(st_l.z, st_l.w));
-    if (OPT_OUT) st_row(out.base_disp + e, so16, st_ab);
+    if (OPT_OUT) st_row(out.p_disp + e, so4, st_ab.z);
     if (out.t_disp && st_td) st_row(out.t_disp + e, so4, st_ab.w);
   }
   {
@@ -1237,7 +1238,7 @@ __global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx
         out.light.x[gi] = l.x;
         out.light.y[gi] = l.y;
         out.light.zw[gi] = make_float2(l.z, l.w);
-        if (OPT_OUT) out.base_disp[gi] = o.b;
+        if (OPT_OUT) out.p_disp[gi] = o.b.z;
         if (out.t_disp) out.t_disp[gi] = o.b.w;
       }
     }

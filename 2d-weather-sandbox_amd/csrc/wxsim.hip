@@ -147,7 +147,9 @@ struct wx_sim {
   // says which copy is current; the other kernels, readback and streaming use the interleaved light[] buffers.
   LightPlanes lp[3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}; // [2]: spare of the marching kernel
   bool light_planar = false;
-  float *tdisp = nullptr;   // post-advection temperature for the droplets (marching wet kernel, instead of the whole base_disp)
+  float *tdisp = nullptr;   // post-advection temperature where the pressure pass changes it (marching wet kernel): for the droplets, and for baseTexture_1 on demand
+  float *pdisp = nullptr;   // post-advection pressure of the display iteration (marching wet kernel): baseTexture_1 is assembled from base_0, this and tdisp when asked for
+  bool disp_lazy = false;   // BASE_DISP has to be assembled (field_info): the last display iteration was the marching wet kernel's
   bool wall_veg_ok = false; // no negative vegetation byte anywhere (advection would clamp it: the one wall change it can make unasked)
   FullCtx *full_ctx = nullptr;
   std::vector<void *> alloc_pads;          // (WX_ALLOC_PADS experiment: pads between the planes' allocations)
@@ -778,7 +780,11 @@ int iterate_march_wet(wx_sim *s, bool opt_out, bool precip, int edge_mode = 0)
            s->zero_row, s->sg.TXn};
   // (waterTexture_0 on demand: see water0_pending; with particles the feedback textures the boundary stage read are gone after the iteration)
   const bool lazy_w0 = opt_out && !precip && !fb && s->lazy_water0;
-  WetOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->base[2], lazy_w0 ? nullptr : s->water[0], s->curl, precip ? s->tdisp : nullptr};
+  // (round 6) the display iteration stores 4 instead of 16 bytes per cell of baseTexture_1: the post-advection PRESSURE (+ the temperature in rows
+  // directly above land, as for the droplets) -- vx, vy and T everywhere else are the post-pressure texture's (pressure_cell, wx_cells.h); the
+  // RGBA texels are assembled when a reader asks for WX_FIELD_BASE_DISP (k_base_disp_assemble)
+  WetOut out{s->base[1], s->wall[1], s->water[2], light_dst, s->pdisp, lazy_w0 ? nullptr : s->water[0], s->curl, (precip || opt_out) ? s->tdisp : nullptr};
+  if (opt_out) s->disp_lazy = true;
   if (opt_out) {
     s->water0_pending = lazy_w0;
     s->w0_even = s->even;
@@ -976,6 +982,7 @@ static bool dry_runs_in_order(const wx_sim *s)
 // edge_mode: as iterate_march_wet (marching kernel only)
 int iterate_dry(wx_sim *s, bool write_disp, int edge_mode = 0)
 {
+  if (write_disp) s->disp_lazy = false; // (the dry kernels store baseTexture_1 whole, into base[2])
   const bool water = dry_has_water(s);
   DryIn in{s->base[0], s->wall[0], s->water[1]};
   DryOut out{s->base[1], s->wall[1], s->water[2], s->base[2]};
@@ -1088,6 +1095,7 @@ int iterate_dry_pair(wx_sim *s, bool write_disp)
       (void)hipGetLastError();
     }
   }
+  if (write_disp) s->disp_lazy = false;
   DryIn in{s->base[0], s->wall[0], s->water[1]};
   DryOut out{s->base[1], s->wall[1], s->water[2], s->base[2]};
   {
@@ -1181,7 +1189,8 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
   if (rc == WX_OK) rc = dalloc(s, &s->snd_W, (size_t)Y + 8);
   if (rc == WX_OK) rc = dalloc(s, &s->snd_Vel, (size_t)Y + 8);
   if (rc == WX_OK) rc = dalloc(s, &s->state, 1);
-  if (rc == WX_OK && n_droplets > 0) rc = dalloc(s, &s->tdisp, n);
+  if (rc == WX_OK) rc = dalloc(s, &s->tdisp, n);
+  if (rc == WX_OK) rc = dalloc(s, &s->pdisp, n);
   for (int i = 0; i < 3 && rc == WX_OK; i++) {
     if ((rc = dalloc(s, &s->lp[i].x, n))) break;
     if ((rc = dalloc(s, &s->lp[i].y, n))) break;
@@ -1305,6 +1314,7 @@ void wx_destroy(wx_sim *s)
   dfree(s, s->pool_flips);
   dfree(s, s->pool_best);
   dfree(s, s->tdisp);
+  dfree(s, s->pdisp);
   for (int i = 0; i < 3; i++) {
     dfree(s, s->lp[i].x);
     dfree(s, s->lp[i].y);
@@ -1894,7 +1904,7 @@ struct TuneSnap { // host-side state that iterations change; the rotating plane 
   Ref base[3], water[3], light[2], wall[2], drops[2], lpx[3], lpy[3], lpzw[3];
   int even, drop_cur, splat_par, period_j, air_from_row;
   int64_t iter;
-  bool ran_fused, light_planar, fb_dirty, water_trivial, local_water_free, wall_veg_ok, ghost_check, emit_lit, fix_check, wet_shape_valid, halo_base_only, water0_pending;
+  bool ran_fused, light_planar, fb_dirty, water_trivial, local_water_free, wall_veg_ok, ghost_check, emit_lit, fix_check, wet_shape_valid, halo_base_only, water0_pending, disp_lazy;
   Uni emit_uni;
 };
 bool snap_take(const wx_sim *s, TuneSnap &t)
@@ -1908,7 +1918,7 @@ bool snap_take(const wx_sim *s, TuneSnap &t)
   for (int i = 0; i < 3; i++) { t.base[i] = ref(s->base[i]); t.water[i] = ref(s->water[i]); t.lpx[i] = ref(s->lp[i].x); t.lpy[i] = ref(s->lp[i].y); t.lpzw[i] = ref(s->lp[i].zw); }
   for (int i = 0; i < 2; i++) { t.light[i] = ref(s->light[i]); t.wall[i] = ref(s->wall[i]); t.drops[i] = ref(s->drops[i]); }
   t.even = s->even; t.drop_cur = s->drop_cur; t.splat_par = s->splat_par; t.period_j = s->period_j; t.air_from_row = s->air_from_row; t.iter = s->iter;
-  t.ran_fused = s->ran_fused; t.light_planar = s->light_planar; t.fb_dirty = s->fb_dirty; t.water_trivial = s->water_trivial; t.local_water_free = s->local_water_free; t.wall_veg_ok = s->wall_veg_ok; t.halo_base_only = s->halo_base_only; t.water0_pending = s->water0_pending;
+  t.ran_fused = s->ran_fused; t.light_planar = s->light_planar; t.fb_dirty = s->fb_dirty; t.water_trivial = s->water_trivial; t.local_water_free = s->local_water_free; t.wall_veg_ok = s->wall_veg_ok; t.halo_base_only = s->halo_base_only; t.water0_pending = s->water0_pending; t.disp_lazy = s->disp_lazy;
   t.ghost_check = s->ghost_check; t.emit_lit = s->emit_lit; t.fix_check = s->fix_check; t.wet_shape_valid = s->wet_shape_valid; t.emit_uni = s->emit_uni;
   return ok;
 }
@@ -1921,7 +1931,7 @@ void snap_put(wx_sim *s, const TuneSnap &t) // (into the block set the handle po
   }
   for (int i = 0; i < 2; i++) { s->light[i] = (float4 *)at(t.light[i]); s->wall[i] = (char4 *)at(t.wall[i]); s->drops[i] = (float *)at(t.drops[i]); }
   s->even = t.even; s->drop_cur = t.drop_cur; s->splat_par = t.splat_par; s->period_j = t.period_j; s->air_from_row = t.air_from_row; s->iter = t.iter;
-  s->ran_fused = t.ran_fused; s->light_planar = t.light_planar; s->fb_dirty = t.fb_dirty; s->water_trivial = t.water_trivial; s->local_water_free = t.local_water_free; s->wall_veg_ok = t.wall_veg_ok; s->halo_base_only = t.halo_base_only; s->water0_pending = t.water0_pending;
+  s->ran_fused = t.ran_fused; s->light_planar = t.light_planar; s->fb_dirty = t.fb_dirty; s->water_trivial = t.water_trivial; s->local_water_free = t.local_water_free; s->wall_veg_ok = t.wall_veg_ok; s->halo_base_only = t.halo_base_only; s->water0_pending = t.water0_pending; s->disp_lazy = t.disp_lazy;
   s->ghost_check = t.ghost_check; s->emit_lit = t.emit_lit; s->fix_check = t.fix_check; s->wet_shape_valid = t.wet_shape_valid; s->emit_uni = t.emit_uni;
 }
 // every registered pointer of the handle moves from the current block set to `to` (same block, same offset)
@@ -2333,7 +2343,14 @@ static int field_info(wx_sim *s, int field, const void **ptr, int *channels, int
 {
   switch (field) {
   case WX_FIELD_BASE_CUR: *ptr = s->base[0]; *channels = 4; *elem = 4; return 0;
-  case WX_FIELD_BASE_DISP: *ptr = s->ran_fused ? s->base[2] : s->base[1]; *channels = 4; *elem = 4; return 0;
+  case WX_FIELD_BASE_DISP:
+    if (s->ran_fused && s->disp_lazy) { // the marching wet kernel's display iteration: the rows asked for, assembled now (wx_wet.h, WetOut::p_disp)
+      const int r0 = h > 0 ? y0 : 0, rows = h > 0 ? h : s->Y;
+      const size_t cnt = (size_t)rows * s->X;
+      hipLaunchKernelGGL(k_base_disp_assemble, dim3((unsigned)std::min<size_t>(4096, (cnt + 255) / 256)), dim3(256), 0, s->stream, s->X, s->Y, r0, rows, s->base[0], s->pdisp, s->tdisp,
+                         s->wall[0], s->base[2]);
+    }
+    *ptr = s->ran_fused ? s->base[2] : s->base[1]; *channels = 4; *elem = 4; return 0;
   case WX_FIELD_WATER_0:
     if (int rc = materialize_water0(s)) return rc < -1 ? rc : WX_E_DEVICE; // (not -1: that means "unknown field" to the callers)
     *ptr = s->water[0]; *channels = 4; *elem = 4; return 0;

@@ -308,8 +308,9 @@ int wx_placement_info(const wx_sim *s, float *ms_first, float *ms_kept);
 
 /* ---- plumbing for hosts that own device memory / streams (PyTorch, multi-GPU halo exchange) ---- */
 int wx_set_stream(wx_sim *s, void *hip_stream);     /* NULL = legacy default stream */
-void *wx_device_ptr(wx_sim *s, int field);          /* device address of a field's current storage; WX_FIELD_LIGHT_0/1, WX_FIELD_EMITTED and
-                                                     * WX_FIELD_PRECIP_FB are stored in another form (planes / on demand / three channels): the
+void *wx_device_ptr(wx_sim *s, int field);          /* device address of a field's current storage; WX_FIELD_LIGHT_0/1, WX_FIELD_EMITTED,
+                                                     * WX_FIELD_PRECIP_FB and (after the marching wet kernel, round 6) WX_FIELD_BASE_DISP are
+                                                     * stored in another form (planes / on demand / three channels / post-advection P only): the
                                                      * pointer is to the RGBA texture made at the time of the call, valid until the next wx_step.
                                                      * Slabs: velocities written through WX_FIELD_BASE_CUR are looked at by the next exchange
                                                      * (a |vx| beyond the current period's bound is REPORTED, WX_E_STATE); only wx_upload /
