@@ -66,7 +66,8 @@ template <int K> __device__ __forceinline__ M2Fp<K> make_fp(const M2Acc<K> &a, i
 #define WX_MARCH2_MINWAVES 4
 #endif
 // The second iteration's exact path. ctl: {entries, arrival ticket of the fix pass, what the host's hint word was last told, epoch of the
-// pair that has to be repeated whole, pairs repeated whole, -, cells recomputed (64 bits)}; the fix pass leaves the first two at 0.
+// pair that has to be repeated whole, pairs repeated whole, -, cells recomputed (64 bits), two grid barriers (counter, release word)}; the fix
+// pass leaves the first two at 0.
 struct Dry2Fix {
   int *ctl;
   int2 *cells;         // second-iteration advection cells (column, row) with a back-trace of 0.9 cells or more, recorded by the wave that owns them
@@ -75,7 +76,7 @@ struct Dry2Fix {
   int *hint;           // host-visible word (pinned, mapped; may be NULL): the length of the last list, read (stale) by the host to size the next fix launch
   const int *hint_host;
 };
-enum { D2_COUNT = 0, D2_TICKET = 1, D2_TOLD = 2, D2_REDO_EPOCH = 3, D2_N_REDO = 4, D2_FIXED = 6 };
+enum { D2_COUNT = 0, D2_TICKET = 1, D2_TOLD = 2, D2_REDO_EPOCH = 3, D2_N_REDO = 4, D2_FIXED = 6, D2_BAR0 = 8, D2_BAR1 = 10, D2_WORDS = 12 };
 // WRITE_DISP: also store the post-advection base of the SECOND iteration (baseTexture_1 of the last iteration of a frame: display side)
 template <bool QUIET, bool WRITE_DISP>
 __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows, int n_full, int n_half,
@@ -312,26 +313,19 @@ struct Dry2StageAcc {
   __device__ __forceinline__ float4 water_off(int, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
 };
 
+// the entries [first, n) in steps of `stride`, one wavefront each; returns true if one of them left the stage (the whole pair has to be repeated)
+struct Dry2FixOut {
+  float x[8], y[8], P[8], T[8];
+  char4 w[8];
+};
 template <bool QUIET, bool WRITE_DISP>
-__global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_fix(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, Dry2Fix fix)
+__device__ __forceinline__ bool dry2_fix_entries(const Geo &g, const FullCtx *__restrict__ ctx, const DryIn &in, const DryOut &out, const int2 *__restrict__ cells, int first, int stride,
+                                                 int n, Dry2FixStage &st, Dry2FixOut &o, int lane)
 {
-  __shared__ Dry2FixStage st;
-  __shared__ float o_x[8], o_y[8], o_P[8], o_T[8];
-  __shared__ char4 o_w[8];
-  int *ctl = fix.ctl;
-  const int total = ctl[D2_COUNT], lane = threadIdx.x;
-  if (total == 0) { // the usual case: one load, and out (the host's hint word is set back once)
-    if (blockIdx.x == 0 && lane == 0 && fix.hint && ctl[D2_TOLD] != 0) {
-      ctl[D2_TOLD] = 0;
-      __hip_atomic_store(fix.hint, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return;
-  }
   const int X = g.X, Y = g.Y;
-  const int n = total <= fix.cap ? total : 0; // (an overflowed list: the whole pair is repeated, nothing to do here)
-  bool whole = total > fix.cap;
-  for (int e = blockIdx.x; e < n; e += gridDim.x) {
-    const int2 c = fix.cells[e];
+  bool whole = false;
+  for (int e = first; e < n; e += stride) {
+    const int2 c = cells[e];
     for (int i = lane; i < F2N; i += 64) { // the pair's inputs
       const int sy = i / F2W, sx = i - sy * F2W;
       const size_t gi = fidx(wrapmod(c.x - F2C + sx, X), wrapmod(c.y - F2C + sy, Y), X);
@@ -359,9 +353,9 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_fix(Geo g, const
       char4 awl;
       advection_cell<true, false, false, QUIET>(ctx->u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, gx, gy, a, ab, aw, awl);
       if (left) { // a footprint outside the stage: the exact path of the one-iteration kernels
-        const AdvOut o = advection_cell_dry_global(ctx, in, false, gx, gy);
-        ab = o.b;
-        awl = o.wl;
+        const AdvOut ao = advection_cell_dry_global(ctx, in, false, gx, gy);
+        ab = ao.b;
+        awl = ao.wl;
       }
       st.a1x[i] = ab.x;
       st.a1y[i] = ab.y;
@@ -392,11 +386,11 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_fix(Geo g, const
       float4 ab, aw;
       char4 awl;
       advection_cell<true, false, false, QUIET>(ctx->u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, wrapmod(c.x + ox, X), wrapmod(c.y + oy, Y), a, ab, aw, awl);
-      o_x[lane] = ab.x;
-      o_y[lane] = ab.y;
-      o_P[lane] = ab.z;
-      o_T[lane] = ab.w;
-      o_w[lane] = awl;
+      o.x[lane] = ab.x;
+      o.y[lane] = ab.y;
+      o.P[lane] = ab.z;
+      o.T[lane] = ab.w;
+      o.w[lane] = awl;
     }
     wave_fence();
     if (__any(left2)) {
@@ -405,37 +399,53 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_fix(Geo g, const
       // lane 0: (0, 0) <- left (-1, 0) = 3, below (0, -1) = 4;  lane 1: (1, 0) <- left (0, 0) = 0, below (1, -1) = 5;
       // lane 2: (0, 1) <- left (-1, 1) = 6, below (0, 0) = 0
       const int il = lane == 0 ? 3 : (lane == 1 ? 0 : 6), id = lane == 0 ? 4 : (lane == 1 ? 5 : 0);
-      const float4 ab = make_float4(o_x[lane], o_y[lane], o_P[lane], o_T[lane]);
-      const float4 p = pressure_cell(ab, o_x[il], o_y[id], o_T[id], o_w[id].x, o_w[id].y);
+      const float4 ab = make_float4(o.x[lane], o.y[lane], o.P[lane], o.T[lane]);
+      const float4 p = pressure_cell(ab, o.x[il], o.y[id], o.T[id], o.w[id].x, o.w[id].y);
       const size_t gi = fidx(wrapmod(c.x + (lane == 1 ? 1 : 0), X), wrapmod(c.y + (lane == 2 ? 1 : 0), Y), X);
       out.base[gi] = p;
       if (WRITE_DISP) out.base_disp[gi] = ab;
     }
     wave_fence(); // the stage is rewritten by the next entry
   }
-  if (whole && lane == 0 && atomicMax(ctl + D2_REDO_EPOCH, fix.epoch) < fix.epoch) atomicAdd(ctl + D2_N_REDO, 1);
-  // the list is empty again for the next pair: reset by the LAST workgroup to get here (every workgroup has read the count by then)
-  if (lane == 0 && atomicAdd(ctl + D2_TICKET, 1) == (int)gridDim.x - 1) {
-    ctl[D2_TICKET] = 0;
-    ctl[D2_TOLD] = total;
-    atomicAdd(reinterpret_cast<unsigned long long *>(ctl + D2_FIXED), (unsigned long long)n);
-    __hip_atomic_store(ctl + D2_COUNT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (fix.hint) __hip_atomic_store(fix.hint, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  return whole;
+}
+// the list is empty again for the next pair (the caller: the LAST workgroup to get here -- every workgroup has read the count by then)
+__device__ __forceinline__ void dry2_list_reset(const Dry2Fix &fix, int total, int n)
+{
+  int *ctl = fix.ctl;
+  ctl[D2_TICKET] = 0;
+  ctl[D2_TOLD] = total;
+  atomicAdd(reinterpret_cast<unsigned long long *>(ctl + D2_FIXED), (unsigned long long)n);
+  __hip_atomic_store(ctl + D2_COUNT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (fix.hint) __hip_atomic_store(fix.hint, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// ---- the repeat of a WHOLE pair (a second-iteration back-trace of three cells or more, or an overflowed list): ONE iteration per launch, ----
-// ---- persistent, predicated ----
-// Launched twice behind every pair's fix pass (inputs -> scratch -> the pair's output buffer) with a small grid; while the epoch word is not
-// this pair's -- almost always -- every workgroup leaves after one scalar load. When it runs it walks the pair's own (segment, strip) items
-// with the same cell functions as k_march_dry (its exact out-of-line path included: THIS iteration's inputs are in global memory), so the
-// repeated pair equals two launches of k_march_dry bit for bit. Not tuned: it runs when the state is blowing up.
+// The WIDE fix pass: launched in front of k_dry2_post only while the host's (stale) hint word says that the lists hold entries -- up to
+// 4096 workgroups of one wave. (The occupancy bound is k_march_dry's: the kernels share the out-of-line exact path advection_cell_dry_global,
+// and the compiler gives a shared callee the LOOSEST register budget among its callers -- an unbounded one here would double the
+// registers of every marching kernel.)
 template <bool QUIET, bool WRITE_DISP>
-__global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry_redo(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows, int n_full,
-                                                                            int n_half, int band_h, int n_seg, VxTrack vx, const int *__restrict__ ctl, int epoch)
+__global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_fix(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, Dry2Fix fix)
 {
-  if (ctl[D2_REDO_EPOCH] != epoch) return;
-  __shared__ March2Ring rg;
+  __shared__ Dry2FixStage st;
+  __shared__ Dry2FixOut o;
+  int *ctl = fix.ctl;
+  const int total = ctl[D2_COUNT], lane = threadIdx.x;
+  if (total == 0) return; // (k_dry2_post behind this launch sets the hint word back)
+  const int n = total <= fix.cap ? total : 0; // (an overflowed list: the whole pair is repeated, nothing to do here)
+  const bool whole = dry2_fix_entries<QUIET, WRITE_DISP>(g, ctx, in, out, fix.cells, blockIdx.x, gridDim.x, n, st, o, lane) || total > fix.cap;
+  if (whole && lane == 0 && atomicMax(ctl + D2_REDO_EPOCH, fix.epoch) < fix.epoch) atomicAdd(ctl + D2_N_REDO, 1);
+  if (lane == 0 && atomicAdd(ctl + D2_TICKET, 1) == (int)gridDim.x - 1) dry2_list_reset(fix, total, n);
+}
+
+// ---- the repeat of a WHOLE pair (a second-iteration back-trace of three cells or more, or an overflowed list): one iteration of the ----
+// ---- one-iteration stencil over the pair's own (segment, strip) items, grid-stride ----
+// The same cell functions as k_march_dry (its exact out-of-line path included: THIS iteration's inputs are in global memory), so the repeated
+// pair equals two launches of k_march_dry bit for bit. Not tuned: it runs when the state is blowing up.
+template <bool QUIET, bool WRITE_DISP>
+__device__ __forceinline__ void march_dry_redo_items(const Geo &g, const FullCtx *__restrict__ ctx, const DryIn &in, const DryOut &out, int n_strips, int seg_rows, int n_full, int n_half,
+                                                     int band_h, int n_seg, const VxTrack &vx, March2Ring &rg)
+{
   CUni &u = as_constant(ctx->u);
   const CFloatP initial_T = as_constant(ctx->initial_T), snd_T = as_constant(ctx->snd_T), snd_W = as_constant(ctx->snd_W), snd_Vel = as_constant(ctx->snd_Vel);
   const int X = g.X, Y = g.Y, lane = threadIdx.x;
@@ -526,6 +536,76 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry_redo(Geo g
   }
 }
 
+// a barrier of the whole (co-resident) grid, reusable without a reset between launches: the last workgroup to arrive clears the counter
+// and publishes the launch's own number; the others poll for it (bounded: a grid that cannot be resident traps instead of hanging)
+__device__ __forceinline__ void dry2_grid_barrier(int *cnt, int *rel, int epoch, int lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (lane == 0) {
+    if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rel, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      unsigned spins = 0;
+      while (__hip_atomic_load(rel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > 40000000u) __builtin_trap();
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  wave_fence();
+#endif
+}
+
+// ---- k_dry2_post: everything that may have to follow a pair, in ONE launch (round 6: the fix pass and the two predicated repeat launches ----
+// ---- were three dependent launches of ~5 us each behind every pair -- a quarter of a 4096 x 1024 pair) ----
+// A small co-resident grid (D2_POST_GRID workgroups of one wave). Quiet pair -- list empty, epoch word not this pair's --: one scalar load
+// per workgroup, and out. Entries on the list (the host's hint word was stale: a flow that has just produced its first fast cells; with a
+// non-zero hint the wide k_dry2_fix runs in front and leaves the list empty): fixed here, grid-stride. The pair has to be repeated whole
+// (decided by either fix pass): iteration 1 from the pair's inputs into the scratch buffer -> grid barrier -> iteration 2 into the pair's
+// output (+ display field).
+constexpr int D2_POST_GRID = 512;
+template <bool QUIET, bool WRITE_DISP>
+__global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_post(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, Dry2Fix fix, float4 *__restrict__ scratch, int n_strips,
+                                                                      int seg_rows, int n_full, int n_half, int band_h, int n_seg, VxTrack vx)
+{
+  __shared__ union Mem {
+    Dry2FixStage st;
+    March2Ring rg;
+    __device__ Mem() {}
+  } m;
+  __shared__ Dry2FixOut o;
+  int *ctl = fix.ctl;
+  const int lane = threadIdx.x;
+  const int total = ctl[D2_COUNT];
+  bool redo = ctl[D2_REDO_EPOCH] == fix.epoch;
+  if (total == 0 && !redo) { // the usual case (the host's hint word is set back once)
+    if (blockIdx.x == 0 && lane == 0 && fix.hint && ctl[D2_TOLD] != 0) {
+      ctl[D2_TOLD] = 0;
+      __hip_atomic_store(fix.hint, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  if (total > 0) {
+    const int n = total <= fix.cap ? total : 0;
+    const bool whole = dry2_fix_entries<QUIET, WRITE_DISP>(g, ctx, in, out, fix.cells, blockIdx.x, gridDim.x, n, m.st, o, lane) || total > fix.cap;
+    if (whole && lane == 0 && atomicMax(ctl + D2_REDO_EPOCH, fix.epoch) < fix.epoch) atomicAdd(ctl + D2_N_REDO, 1);
+    dry2_grid_barrier(ctl + D2_BAR0, ctl + D2_BAR0 + 1, fix.epoch, lane); // every workgroup has read the count and raised what it had to raise
+    if (blockIdx.x == 0 && lane == 0) dry2_list_reset(fix, total, n);
+    redo = __hip_atomic_load(ctl + D2_REDO_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fix.epoch;
+  }
+  if (!redo) return;
+  DryIn in2 = in;
+  in2.base = scratch;
+  DryOut out1 = out;
+  out1.base = scratch;
+  march_dry_redo_items<QUIET, false>(g, ctx, in, out1, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vx, m.rg);
+  dry2_grid_barrier(ctl + D2_BAR1, ctl + D2_BAR1 + 1, fix.epoch, lane);
+  march_dry_redo_items<QUIET, WRITE_DISP>(g, ctx, in2, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vx, m.rg);
+}
+
 // Unit segment height of a row band: 3/16 of the band -- five full segments + 1/2 + 1/4 per band. One handle each, interleaved,
 // ms per iteration (profiles/r05_dry_pairs.txt): 32768 x 4096 (512-row bands) 48 rows 0.694, 64 0.688, 96 0.674, 128 0.690 (one iteration
 // per launch 0.947); 16384 x 2048 (256-row bands) 24 rows 0.191, 32 0.188, 48 0.181, 64 0.189 (0.250); 4096 x 1024 (128-row bands) 16 rows
@@ -573,11 +653,11 @@ inline void launch_march_dry2(const Geo &g, const Uni &u, const FullCtx *ctx, co
   }
 #undef WX_LAUNCH_M2
   if (wx_tune_env("WX_MARCH2_NOREDO")) return; // (timing experiments)
-  // the fix pass: one wavefront per recorded cell; a corner of the chip while the lists are empty (the host's stale hint word), room for four
-  // times the last list otherwise, at most 4096 workgroups of one wave (the list is walked grid-stride: any size is correct)
-  {
-    const int last = fix.hint_host ? *(volatile const int *)fix.hint_host : -1;
-    const dim3 fgrid(last < 0 ? 1024 : (last > 0 ? std::min(4096, std::max(64, 4 * last)) : 32));
+  // While the host's (stale) hint word says that the lists hold entries: the wide fix pass -- one wavefront per recorded cell, room for four
+  // times the last list, at most 4096 workgroups of one wave (the list is walked grid-stride: any size is correct).
+  const int last = fix.hint_host ? *(volatile const int *)fix.hint_host : -1;
+  if (last != 0) {
+    const dim3 fgrid(last < 0 ? 1024 : std::min(4096, std::max(64, 4 * last)));
 #define WX_LAUNCH_F(Q, D) hipLaunchKernelGGL((k_dry2_fix<Q, D>), fgrid, dim3(64), 0, stream, g, ctx, in, out, fix)
     if (quiet) {
       if (write_disp) WX_LAUNCH_F(true, true); else WX_LAUNCH_F(true, false);
@@ -586,21 +666,15 @@ inline void launch_march_dry2(const Geo &g, const Uni &u, const FullCtx *ctx, co
     }
 #undef WX_LAUNCH_F
   }
-  // the predicated repeat of the whole pair: inputs -> scratch -> the pair's output buffer (+ the display field of the second iteration)
-  const dim3 rgrid(std::min<unsigned>(grid.x, 2048u));
-  DryIn in2 = in;
-  in2.base = scratch;
-  DryOut out1 = out;
-  out1.base = scratch;
-#define WX_LAUNCH_R(Q, D, I, O) hipLaunchKernelGGL((k_march_dry_redo<Q, D>), rgrid, dim3(64), 0, stream, g, ctx, I, O, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vt, fix.ctl, fix.epoch)
+  // ... and ONE launch for everything else that may have to follow: entries the hint did not announce, the repeat of the whole pair
+  // (inputs -> scratch -> the pair's output buffer + the display field of the second iteration)
+#define WX_LAUNCH_P(Q, D) hipLaunchKernelGGL((k_dry2_post<Q, D>), dim3(D2_POST_GRID), dim3(64), 0, stream, g, ctx, in, out, fix, scratch, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vt)
   if (quiet) {
-    WX_LAUNCH_R(true, false, in, out1);
-    if (write_disp) WX_LAUNCH_R(true, true, in2, out); else WX_LAUNCH_R(true, false, in2, out);
+    if (write_disp) WX_LAUNCH_P(true, true); else WX_LAUNCH_P(true, false);
   } else {
-    WX_LAUNCH_R(false, false, in, out1);
-    if (write_disp) WX_LAUNCH_R(false, true, in2, out); else WX_LAUNCH_R(false, false, in2, out);
+    if (write_disp) WX_LAUNCH_P(false, true); else WX_LAUNCH_P(false, false);
   }
-#undef WX_LAUNCH_R
+#undef WX_LAUNCH_P
 }
 
 } // namespace wx

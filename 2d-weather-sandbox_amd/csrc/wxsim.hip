@@ -1080,8 +1080,8 @@ int iterate_dry_pair(wx_sim *s, bool write_disp)
     size_t cap = std::min<size_t>(std::max<size_t>(ncell(s) / 64, 1u << 16), 1u << 20);
     if (s->fix_cap_request > 0) cap = (size_t)s->fix_cap_request; // (WX_OPT_FIX_CAP; tests: provoke the overflow -> the whole pair is repeated)
     if (const char *e = wx_tune_env("WX_MARCH2_FIX_CAP")) cap = (size_t)atoi(e); // (0: every recorded cell repeats the whole pair -- round 5's behaviour, for A/B timing)
-    if (hipMalloc((void **)&s->pair_ctl, 32) != hipSuccess || hipMalloc((void **)&s->pair_cells, std::max<size_t>(cap, 1) * sizeof(int2)) != hipSuccess ||
-        hipMemsetAsync(s->pair_ctl, 0, 32, s->stream) != hipSuccess)
+    if (hipMalloc((void **)&s->pair_ctl, D2_WORDS * sizeof(int)) != hipSuccess || hipMalloc((void **)&s->pair_cells, std::max<size_t>(cap, 1) * sizeof(int2)) != hipSuccess ||
+        hipMemsetAsync(s->pair_ctl, 0, D2_WORDS * sizeof(int), s->stream) != hipSuccess)
       return fail(s, WX_E_NOMEM, "wx_step: %zu bytes for the pair kernel's exact-path list", cap * sizeof(int2));
     s->pair_cap = (int)cap;
     s->pair_epoch = 0;
