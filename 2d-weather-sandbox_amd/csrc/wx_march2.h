@@ -66,7 +66,7 @@ template <int K> __device__ __forceinline__ M2Fp<K> make_fp(const M2Acc<K> &a, i
 #define WX_MARCH2_MINWAVES 4
 #endif
 // The second iteration's exact path. ctl: {entries, arrival ticket of the fix pass, what the host's hint word was last told, epoch of the
-// pair that has to be repeated whole, pairs repeated whole, -, cells recomputed (64 bits), two grid barriers (counter, release word)}; the fix
+// pair that has to be repeated whole, pairs repeated whole, the pair whose list the hint word was last told about, cells recomputed (64 bits), two grid barriers (counter, release word)}; the fix
 // pass leaves the first two at 0.
 struct Dry2Fix {
   int *ctl;
@@ -76,7 +76,7 @@ struct Dry2Fix {
   int *hint;           // host-visible word (pinned, mapped; may be NULL): the length of the last list, read (stale) by the host to size the next fix launch
   const int *hint_host;
 };
-enum { D2_COUNT = 0, D2_TICKET = 1, D2_TOLD = 2, D2_REDO_EPOCH = 3, D2_N_REDO = 4, D2_FIXED = 6, D2_BAR0 = 8, D2_BAR1 = 10, D2_WORDS = 12 };
+enum { D2_COUNT = 0, D2_TICKET = 1, D2_TOLD = 2, D2_REDO_EPOCH = 3, D2_N_REDO = 4, D2_TOLD_EPOCH = 5, D2_FIXED = 6, D2_BAR0 = 8, D2_BAR1 = 10, D2_WORDS = 12 };
 // WRITE_DISP: also store the post-advection base of the SECOND iteration (baseTexture_1 of the last iteration of a frame: display side)
 template <bool QUIET, bool WRITE_DISP>
 __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows, int n_full, int n_half,
@@ -125,6 +125,9 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
   float vx_seen = 0.f;
   unsigned h_big1 = 0, h_big2 = 0; // bit k: "some |v| >= 0.9" in the velocity row k steps back (bit 0 = the row this step produced)
   unsigned h_nw = 0;               // bit k: input row r-k holds no wall cell
+  unsigned h_bad1 = 0;             // bit k: some lane of the first iteration's advection row k steps back was tainted (see there)
+  int rec_tr = -1;                 // the tile row (of this segment) whose tiles rec_mask says are on the exact-path list already
+  unsigned rec_mask = 0;
 
   const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
   int r = y_lo - 4;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
       rg.vx[0][s1][lane] = v.x;
       rg.vy[0][s1][lane] = v.y;
       vx_seen = fmaxf(vx_seen, fabsf(v.x));
-      h_big1 |= __any(fmaxf(fabsf(v.x), fabsf(v.y)) >= 0.9f) ? 1u : 0u;
+      h_big1 |= __any(!(fabsf(v.x) < 0.9f) || !(fabsf(v.y) < 0.9f)) ? 1u : 0u; // (NaN counts as fast)
     }
     march_fence();
     float4 b2 = make_float4(0.f, 0.f, 0.f, 0.f); // pressure_1 of row r-2 = the second iteration's input row
@@ -174,22 +177,30 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
       float4 ab, aw;
       char4 awl;
       bool fast = true;
+      h_bad1 <<= 1;
       if (h_big1 & 7u) {
-        const float m = fmaxf(fmaxf(fmaxf(fabsf(rg.vx[0][yc & 3][lr]), fabsf(rg.vx[0][yc & 3][lr - 1])), fmaxf(fabsf(rg.vx[0][(yc + 1) & 3][lr]), fabsf(rg.vx[0][(yc + 1) & 3][lr - 1]))),
-                              fmaxf(fmaxf(fabsf(rg.vy[0][yc & 3][lr]), fabsf(rg.vy[0][(yc - 1) & 3][lr])), fmaxf(fabsf(rg.vy[0][yc & 3][lr + 1]), fabsf(rg.vy[0][(yc - 1) & 3][lr + 1]))));
-        fast = m < 0.9f;
+        const float q0 = rg.vx[0][yc & 3][lr], q1 = rg.vx[0][yc & 3][lr - 1], q2 = rg.vx[0][(yc + 1) & 3][lr], q3 = rg.vx[0][(yc + 1) & 3][lr - 1];
+        const float q4 = rg.vy[0][yc & 3][lr], q5 = rg.vy[0][(yc - 1) & 3][lr], q6 = rg.vy[0][yc & 3][lr + 1], q7 = rg.vy[0][(yc - 1) & 3][lr + 1];
+        const float m = fmaxf(fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3))), fmaxf(fmaxf(fabsf(q4), fabsf(q5)), fmaxf(fabsf(q6), fabsf(q7))));
+        const float sn = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)); // (fmaxf drops a NaN operand; the sum keeps it)
+        fast = m < 0.9f && sn == sn;
+        h_bad1 |= __any(!fast) ? 1u : 0u;
       }
+      const M2Acc<0> a{rg, lr, yc};
       if (fast) {
-        const M2Acc<0> a{rg, lr, yc};
         if ((h_nw & 14u) == 14u) // no wall cell in input rows r-1 .. r-3
           advection_cell<true, true, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
         else
           advection_cell<true, false, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
-      } else { // the first iteration's inputs are in global memory: the exact out-of-line path of k_march_dry
-        const AdvOut o = advection_cell_dry_global(ctx, in, false, col, y);
-        ab = o.b;
-        aw = o.w;
-        awl = o.wl;
+      } else {
+        // A back-trace of 0.9 cells or more leaves the ring. The one-iteration kernel takes its out-of-line path through global memory here --
+        // a serial chase per lane that made a wave crossing a vortex the straggler of its launch (+20 % on the pair kernel with a few
+        // thousand such cells). The pair kernel TAINTS instead: the cell's post-advection texel is NaN, every second-iteration value that
+        // depends on it becomes NaN by arithmetic alone (+, -, x of the cell functions; the two places where a NaN could be dropped --
+        // fmaxf in the speed tests -- test for it), and every second-iteration cell that is fast OR tainted puts its tile on the exact-path
+        // list: k_dry2_fix recomputes BOTH iterations for those from the pair's inputs. Nothing tainted is ever kept.
+        ab = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+        awl = a.wall(0, 0); // (the wall texture is constant in a pair: the caller checked)
       }
       if (r >= y_lo) {
         b2 = pressure_cell(ab, wave_from_left(ab.x), a1_vy, a1_T, a1_w.x, a1_w.y);
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
         rg.vx[1][s3][lane] = v.x;
         rg.vy[1][s3][lane] = v.y;
         vx_seen = fmaxf(vx_seen, fabsf(v.x));
-        h_big2 |= __any(lane >= 2 && lane <= 61 && fmaxf(fabsf(v.x), fabsf(v.y)) >= 0.9f) ? 1u : 0u;
+        h_big2 |= __any(lane >= 2 && lane <= 61 && (!(fabsf(v.x) < 0.9f) || !(fabsf(v.y) < 0.9f))) ? 1u : 0u; // (NaN -- a tainted input, below -- counts as fast)
       }
     }
     march_fence();
@@ -217,16 +228,11 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
       char4 awl;
       bool fast2 = true;
       if (h_big2 & 7u) {
-        const float m = fmaxf(fmaxf(fmaxf(fabsf(rg.vx[1][yc & 3][lr]), fabsf(rg.vx[1][yc & 3][lr - 1])), fmaxf(fabsf(rg.vx[1][(yc + 1) & 3][lr]), fabsf(rg.vx[1][(yc + 1) & 3][lr - 1]))),
-                              fmaxf(fmaxf(fabsf(rg.vy[1][yc & 3][lr]), fabsf(rg.vy[1][(yc - 1) & 3][lr])), fmaxf(fabsf(rg.vy[1][yc & 3][lr + 1]), fabsf(rg.vy[1][(yc - 1) & 3][lr + 1]))));
-        fast2 = m < 0.9f;
-        // No exact path here (the inputs of this iteration exist in no texture): the cell keeps a placeholder, and the wave that OWNS it as an
-        // output cell records it -- k_dry2_fix recomputes the three output cells it feeds (its own, the right neighbour's pressure: vx of the
-        // left cell, the upper neighbour's: vy, T, wall of the lower cell), whichever wave owns those. Rare path: one returning atomic per lane.
-        if (!fast2 && lane_out && r - 4 >= y_lo) {
-          const int at = atomicAdd(fix.ctl + D2_COUNT, 1);
-          if (at < fix.cap) fix.cells[at] = make_int2(c_out, r - 4);
-        }
+        const float q0 = rg.vx[1][yc & 3][lr], q1 = rg.vx[1][yc & 3][lr - 1], q2 = rg.vx[1][(yc + 1) & 3][lr], q3 = rg.vx[1][(yc + 1) & 3][lr - 1];
+        const float q4 = rg.vy[1][yc & 3][lr], q5 = rg.vy[1][(yc - 1) & 3][lr], q6 = rg.vy[1][yc & 3][lr + 1], q7 = rg.vy[1][(yc - 1) & 3][lr + 1];
+        const float m = fmaxf(fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3))), fmaxf(fmaxf(fabsf(q4), fabsf(q5)), fmaxf(fabsf(q6), fabsf(q7))));
+        const float sn = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7));
+        fast2 = m < 0.9f && sn == sn;
       }
       const M2Acc<1> a{rg, lr, yc};
       if (fast2) {
@@ -237,6 +243,32 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
       } else { // placeholder (the post-velocity texel)
         ab = a.base(0, 0);
         awl = a.wall(0, 0);
+      }
+      if ((h_big2 & 7u) | (h_bad1 & 0xffu)) { // (wave-uniform; clean flows never get here)
+        // No exact path here for a fast cell (the inputs of this iteration exist in no texture), and nothing to keep of a cell whose
+        // footprints touched a tainted texel of the first iteration (a NaN among its four post-advection values): the wave that OWNS such a
+        // cell as an output cell records the 8 x 8 TILE it lies in (8 of the strip's columns x 8 rows counted from the segment's first) --
+        // once per tile: k_dry2_fix recomputes the 9 x 9 output cells such a tile's cells feed (their own, the right neighbour's pressure: vx
+        // of the left cell, the upper neighbour's: vy, T, wall of the lower cell), whichever waves own those. Rare path, wave-uniform.
+        const float chk = (ab.x + ab.y) + (ab.z + ab.w);
+        const unsigned long long badmask = __ballot((!fast2 || chk != chk) && lane_out && r - 4 >= y_lo);
+        if (badmask) {
+          const int tr = (r - 4 - y_lo) >> 3;
+          unsigned gm = 0;
+          for (int gq = 0; gq < M2OUT / 8; gq++) gm |= ((badmask >> (M2LO + 8 * gq)) & 0xffull) ? (1u << gq) : 0u;
+          if (tr != rec_tr) rec_mask = 0;
+          const unsigned fresh = gm & ~rec_mask;
+          rec_tr = tr;
+          rec_mask |= gm;
+          if (fresh && lane == 0) {
+            int at = atomicAdd(fix.ctl + D2_COUNT, __popc(fresh));
+            for (int gq = 0; gq < M2OUT / 8; gq++)
+              if ((fresh >> gq) & 1u) {
+                if (at < fix.cap) fix.cells[at] = make_int2(strip * M2OUT + 8 * gq, y_lo + 8 * tr);
+                at++;
+              }
+          }
+        }
       }
       if (r >= y_lo + 4) {
         st_p = pressure_cell(ab, wave_from_left(ab.x), a2_vy, a2_T, a2_w.x, a2_w.y);
@@ -261,31 +293,31 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
   vx_track_commit(vx, vx_seen, lane, strip);
 }
 
-// ---- k_dry2_fix: the second iteration's exact path -- one wavefront per recorded cell ----
-// Entry (X0, Y0): advection_2 of that cell had a back-trace of 0.9 cells or more. It feeds the OUTPUT cells (X0, Y0), (X0 + 1, Y0) [pressure:
-// vx of the left cell] and (X0, Y0 + 1) [pressure: vy, T, wall of the lower cell]; those three need advection_2 of seven cells
-// ([-1, 1] x [-1, 1] without two corners). The wave rebuilds what they read from the pair's untouched INPUTS, stage by stage through
-// LDS, the way the passes follow each other (offsets relative to the entry, one 18 x 18 frame [-8, 9] for every stage):
-//   base_0 / wall      [-8, 9]   loaded once
-//   velocity_1         [-8, 8]   velocity_cell
-//   advection_1        [-5, 5]   advection_cell on the stage (back-traces shorter than three cells stay inside; the others take the
-//                                one-iteration kernels' exact path from global memory, advection_cell_dry_global: any length)
-//   pressure_1         [-4, 5]   = the second iteration's input
-//   velocity_2         [-4, 4]
-//   advection_2        7 cells   advection_cell on the stage: covers back-traces shorter than three cells
-//   pressure_2         3 cells   stored (+ the display field)
-// Same cell functions on the same operands as the marching loop: the same values. A second-iteration footprint that leaves the stage
-// (|v| >= 3: the state is blowing up) raises the epoch word, and the predicated one-iteration launches behind the fix pass repeat the
-// whole pair, as does a list that overflowed. Recomputing an output is idempotent, so the order of the entries does not matter.
-constexpr int F2W = 18, F2N = F2W * F2W, F2C = 8; // stage width, cells, stage coordinate of the entry
+// ---- k_dry2_fix: the second iteration's exact path -- one wavefront per recorded TILE ----
+// Entry (X0, Y0): origin of an 8 x 8 tile holding cells whose advection_2 had a back-trace of 0.9 cells or more. Such a cell (x, y) feeds
+// the OUTPUT cells (x, y), (x + 1, y) [pressure: vx of the left cell] and (x, y + 1) [pressure: vy, T, wall of the lower cell]: the tile's
+// cells feed the 9 x 9 outputs [0, 8]^2 (offsets from the origin), which need advection_2 on [-1, 8]^2. The wave rebuilds what those read
+// from the pair's untouched INPUTS, stage by stage through LDS, the way the passes follow each other -- one 25 x 25 frame [-8, 16]:
+//   base_0 / wall      [-8, 16]   loaded once
+//   velocity_1         [-8, 15]   velocity_cell
+//   advection_1        [-5, 12]   advection_cell on the stage (back-traces shorter than three cells stay inside; the others take the
+//                                 one-iteration kernels' exact path from global memory, advection_cell_dry_global: any length)
+//   pressure_1         [-4, 12]   = the second iteration's input
+//   velocity_2         [-4, 11]
+//   advection_2        [-1, 8]    advection_cell on the stage: covers back-traces shorter than three cells
+//   pressure_2         [0, 8]     stored (+ the display field)
+// Same cell functions on the same operands as the marching loop: the same values (for the cells of the tile that were NOT fast, too:
+// recomputing an output is idempotent, and the order of the entries does not matter). A second-iteration footprint that leaves the
+// stage (|v| >= 3: the state is blowing up) raises the epoch word, and the whole pair is repeated, as it is when the list overflowed.
+// (Round 6 began with one wavefront per CELL: a vortex ring of a thousand fast cells is forty tiles, and a tile costs three cells.)
+constexpr int F2W = 25, F2N = F2W * F2W, F2C = 8; // stage width, cells, stage coordinate of the tile's origin
+constexpr int F2T = 8;                            // tile edge
 struct Dry2FixStage {
-  float b0x[F2N], b0y[F2N], b0P[F2N], b0T[F2N];
+  float b0x[F2N], b0y[F2N], b0P[F2N], b0T[F2N]; // (b0x / b0y hold velocity_2 once velocity_1 is made)
   char4 w[F2N];
-  float v1x[F2N], v1y[F2N];
+  float v1x[F2N], v1y[F2N];                     // (... and pressure_1's P / T once advection_1 is made)
   float a1x[F2N], a1y[F2N], a1P[F2N], a1T[F2N];
   char4 a1w[F2N];
-  float b1P[F2N], b1T[F2N];
-  float v2x[F2N], v2y[F2N];
 };
 // post-velocity base of one iteration on the stage: (vx, vy) valid on [lo, hi]^2, P / T / wall wherever those are
 struct Dry2StageAcc {
@@ -314,15 +346,17 @@ struct Dry2StageAcc {
 };
 
 // the entries [first, n) in steps of `stride`, one wavefront each; returns true if one of them left the stage (the whole pair has to be repeated)
+constexpr int F2A = F2T + 2; // advection_2 is made on an (F2T + 2)^2 block
 struct Dry2FixOut {
-  float x[8], y[8], P[8], T[8];
-  char4 w[8];
+  float x[F2A * F2A], y[F2A * F2A], P[F2A * F2A], T[F2A * F2A];
+  char4 w[F2A * F2A];
 };
 template <bool QUIET, bool WRITE_DISP>
 __device__ __forceinline__ bool dry2_fix_entries(const Geo &g, const FullCtx *__restrict__ ctx, const DryIn &in, const DryOut &out, const int2 *__restrict__ cells, int first, int stride,
-                                                 int n, Dry2FixStage &st, Dry2FixOut &o, int lane)
+                                                 int n, Dry2FixStage &st, Dry2FixOut &o, int lane, const VxTrack &vx)
 {
   const int X = g.X, Y = g.Y;
+  float *const b1P = st.v1x, *const b1T = st.v1y, *const v2x = st.b0x, *const v2y = st.b0y; // (the planes that take over dead ones)
   bool whole = false;
   for (int e = first; e < n; e += stride) {
     const int2 c = cells[e];
@@ -337,18 +371,18 @@ __device__ __forceinline__ bool dry2_fix_entries(const Geo &g, const FullCtx *__
       st.w[i] = in.wall[gi];
     }
     wave_fence();
-    for (int k = lane; k < 17 * 17; k += 64) { // velocity_1 on [0, 16]^2
-      const int sy = k / 17, sx = k - sy * 17, i = sy * F2W + sx;
+    for (int k = lane; k < 24 * 24; k += 64) { // velocity_1 on [0, 23]^2
+      const int sy = k / 24, sx = k - sy * 24, i = sy * F2W + sx;
       const float4 v = velocity_cell(ctx->u, make_float4(st.b0x[i], st.b0y[i], st.b0P[i], st.b0T[i]), st.b0P[i + 1], st.b0P[i + F2W], st.w[i].y);
       st.v1x[i] = v.x;
       st.v1y[i] = v.y;
     }
     wave_fence();
-    for (int k = lane; k < 11 * 11; k += 64) { // advection_1 on [3, 13]^2
-      const int sy = 3 + k / 11, sx = 3 + k % 11, i = sy * F2W + sx;
+    for (int k = lane; k < 18 * 18; k += 64) { // advection_1 on [3, 20]^2
+      const int sy = 3 + k / 18, sx = 3 + k % 18, i = sy * F2W + sx;
       const int gx = wrapmod(c.x - F2C + sx, X), gy = wrapmod(c.y - F2C + sy, Y);
       bool left = false;
-      const Dry2StageAcc a{st.v1x, st.v1y, st.b0P, st.b0T, st.w, sx, sy, 0, 16, &left};
+      const Dry2StageAcc a{st.v1x, st.v1y, st.b0P, st.b0T, st.w, sx, sy, 0, 23, &left};
       float4 ab, aw;
       char4 awl;
       advection_cell<true, false, false, QUIET>(ctx->u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, gx, gy, a, ab, aw, awl);
@@ -363,47 +397,50 @@ __device__ __forceinline__ bool dry2_fix_entries(const Geo &g, const FullCtx *__
       st.a1T[i] = ab.w;
       st.a1w[i] = awl;
     }
-    wave_fence();
-    for (int k = lane; k < 10 * 10; k += 64) { // pressure_1 on [4, 13]^2: the second iteration's input
-      const int sy = 4 + k / 10, sx = 4 + k % 10, i = sy * F2W + sx;
+    wave_fence(); // (velocity_1 is dead from here on: its planes take pressure_1)
+    for (int k = lane; k < 17 * 17; k += 64) { // pressure_1 on [4, 20]^2: the second iteration's input
+      const int sy = 4 + k / 17, sx = 4 + k % 17, i = sy * F2W + sx;
       const float4 p = pressure_cell(make_float4(st.a1x[i], st.a1y[i], st.a1P[i], st.a1T[i]), st.a1x[i - 1], st.a1y[i - F2W], st.a1T[i - F2W], st.a1w[i - F2W].x,
                                      st.a1w[i - F2W].y);
-      st.b1P[i] = p.z;
-      st.b1T[i] = p.w;
+      b1P[i] = p.z;
+      b1T[i] = p.w;
     }
     wave_fence();
-    for (int k = lane; k < 9 * 9; k += 64) { // velocity_2 on [4, 12]^2
-      const int sy = 4 + k / 9, sx = 4 + k % 9, i = sy * F2W + sx;
-      const float4 v = velocity_cell(ctx->u, make_float4(st.a1x[i], st.a1y[i], st.b1P[i], st.b1T[i]), st.b1P[i + 1], st.b1P[i + F2W], st.w[i].y);
-      st.v2x[i] = v.x;
-      st.v2y[i] = v.y;
+    for (int k = lane; k < 16 * 16; k += 64) { // velocity_2 on [4, 19]^2 (into the planes of base_0's velocities, dead since velocity_1)
+      const int sy = 4 + k / 16, sx = 4 + k % 16, i = sy * F2W + sx;
+      const float4 v = velocity_cell(ctx->u, make_float4(st.a1x[i], st.a1y[i], b1P[i], b1T[i]), b1P[i + 1], b1P[i + F2W], st.w[i].y);
+      v2x[i] = v.x;
+      v2y[i] = v.y;
     }
     wave_fence();
+    // (slabs size their exchange periods by the largest |vx| they produce: the marching loop could not see the second iteration's velocity
+    // where its input was tainted -- fmaxf drops NaN -- so the tile's own 64 cells report theirs here)
+    vx_track_commit(vx, fabsf(v2x[(F2C + (lane >> 3)) * F2W + F2C + (lane & 7)]), lane, c.x / M2OUT);
     bool left2 = false;
-    if (lane < 7) { // advection_2: lanes 0..2 the output cells themselves, 3..6 the neighbours below / left of them
-      const int ox = lane == 1 || lane == 5 ? 1 : (lane == 3 || lane == 6 ? -1 : 0), oy = lane == 2 || lane == 6 ? 1 : (lane == 4 || lane == 5 ? -1 : 0);
-      const Dry2StageAcc a{st.v2x, st.v2y, st.b1P, st.b1T, st.w, F2C + ox, F2C + oy, 4, 12, &left2};
+    for (int k = lane; k < F2A * F2A; k += 64) { // advection_2 on [7, 16]^2
+      const int oy = k / F2A, ox = k - oy * F2A, sy = F2C - 1 + oy, sx = F2C - 1 + ox;
+      const Dry2StageAcc a{v2x, v2y, b1P, b1T, st.w, sx, sy, 4, 19, &left2};
       float4 ab, aw;
       char4 awl;
-      advection_cell<true, false, false, QUIET>(ctx->u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, wrapmod(c.x + ox, X), wrapmod(c.y + oy, Y), a, ab, aw, awl);
-      o.x[lane] = ab.x;
-      o.y[lane] = ab.y;
-      o.P[lane] = ab.z;
-      o.T[lane] = ab.w;
-      o.w[lane] = awl;
+      advection_cell<true, false, false, QUIET>(ctx->u, g, ctx->initial_T, ctx->snd_T, ctx->snd_W, ctx->snd_Vel, wrapmod(c.x - F2C + sx, X), wrapmod(c.y - F2C + sy, Y), a, ab, aw, awl);
+      o.x[k] = ab.x;
+      o.y[k] = ab.y;
+      o.P[k] = ab.z;
+      o.T[k] = ab.w;
+      o.w[k] = awl;
     }
     wave_fence();
     if (__any(left2)) {
       whole = true;
-    } else if (lane < 3) {
-      // lane 0: (0, 0) <- left (-1, 0) = 3, below (0, -1) = 4;  lane 1: (1, 0) <- left (0, 0) = 0, below (1, -1) = 5;
-      // lane 2: (0, 1) <- left (-1, 1) = 6, below (0, 0) = 0
-      const int il = lane == 0 ? 3 : (lane == 1 ? 0 : 6), id = lane == 0 ? 4 : (lane == 1 ? 5 : 0);
-      const float4 ab = make_float4(o.x[lane], o.y[lane], o.P[lane], o.T[lane]);
-      const float4 p = pressure_cell(ab, o.x[il], o.y[id], o.T[id], o.w[id].x, o.w[id].y);
-      const size_t gi = fidx(wrapmod(c.x + (lane == 1 ? 1 : 0), X), wrapmod(c.y + (lane == 2 ? 1 : 0), Y), X);
-      out.base[gi] = p;
-      if (WRITE_DISP) out.base_disp[gi] = ab;
+    } else {
+      for (int k = lane; k < (F2T + 1) * (F2T + 1); k += 64) { // pressure_2 of the 9 x 9 outputs: (1 + i, 1 + j) of the advection_2 block
+        const int oy = k / (F2T + 1), ox = k - oy * (F2T + 1), q = (oy + 1) * F2A + (ox + 1);
+        const float4 ab = make_float4(o.x[q], o.y[q], o.P[q], o.T[q]);
+        const float4 p = pressure_cell(ab, o.x[q - 1], o.y[q - F2A], o.T[q - F2A], o.w[q - F2A].x, o.w[q - F2A].y);
+        const size_t gi = fidx(wrapmod(c.x + ox, X), wrapmod(c.y + oy, Y), X);
+        out.base[gi] = p;
+        if (WRITE_DISP) out.base_disp[gi] = ab;
+      }
     }
     wave_fence(); // the stage is rewritten by the next entry
   }
@@ -415,7 +452,8 @@ __device__ __forceinline__ void dry2_list_reset(const Dry2Fix &fix, int total, i
   int *ctl = fix.ctl;
   ctl[D2_TICKET] = 0;
   ctl[D2_TOLD] = total;
-  atomicAdd(reinterpret_cast<unsigned long long *>(ctl + D2_FIXED), (unsigned long long)n);
+  ctl[D2_TOLD_EPOCH] = fix.epoch; // (k_dry2_post of the same pair must not take the word back: it finds the list empty because it was just consumed)
+  atomicAdd(reinterpret_cast<unsigned long long *>(ctl + D2_FIXED), (unsigned long long)n * ((F2T + 1) * (F2T + 1))); // (output cells recomputed: 9 x 9 per tile)
   __hip_atomic_store(ctl + D2_COUNT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (fix.hint) __hip_atomic_store(fix.hint, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -425,7 +463,7 @@ __device__ __forceinline__ void dry2_list_reset(const Dry2Fix &fix, int total, i
 // and the compiler gives a shared callee the LOOSEST register budget among its callers -- an unbounded one here would double the
 // registers of every marching kernel.)
 template <bool QUIET, bool WRITE_DISP>
-__global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_fix(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, Dry2Fix fix)
+__global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_fix(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, Dry2Fix fix, VxTrack vx)
 {
   __shared__ Dry2FixStage st;
   __shared__ Dry2FixOut o;
@@ -433,7 +471,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_fix(Geo g, const
   const int total = ctl[D2_COUNT], lane = threadIdx.x;
   if (total == 0) return; // (k_dry2_post behind this launch sets the hint word back)
   const int n = total <= fix.cap ? total : 0; // (an overflowed list: the whole pair is repeated, nothing to do here)
-  const bool whole = dry2_fix_entries<QUIET, WRITE_DISP>(g, ctx, in, out, fix.cells, blockIdx.x, gridDim.x, n, st, o, lane) || total > fix.cap;
+  const bool whole = dry2_fix_entries<QUIET, WRITE_DISP>(g, ctx, in, out, fix.cells, blockIdx.x, gridDim.x, n, st, o, lane, vx) || total > fix.cap;
   if (whole && lane == 0 && atomicMax(ctl + D2_REDO_EPOCH, fix.epoch) < fix.epoch) atomicAdd(ctl + D2_N_REDO, 1);
   if (lane == 0 && atomicAdd(ctl + D2_TICKET, 1) == (int)gridDim.x - 1) dry2_list_reset(fix, total, n);
 }
@@ -582,7 +620,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_post(Geo g, cons
   const int total = ctl[D2_COUNT];
   bool redo = ctl[D2_REDO_EPOCH] == fix.epoch;
   if (total == 0 && !redo) { // the usual case (the host's hint word is set back once)
-    if (blockIdx.x == 0 && lane == 0 && fix.hint && ctl[D2_TOLD] != 0) {
+    if (blockIdx.x == 0 && lane == 0 && fix.hint && ctl[D2_TOLD] != 0 && ctl[D2_TOLD_EPOCH] != fix.epoch) {
       ctl[D2_TOLD] = 0;
       __hip_atomic_store(fix.hint, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -590,7 +628,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_post(Geo g, cons
   }
   if (total > 0) {
     const int n = total <= fix.cap ? total : 0;
-    const bool whole = dry2_fix_entries<QUIET, WRITE_DISP>(g, ctx, in, out, fix.cells, blockIdx.x, gridDim.x, n, m.st, o, lane) || total > fix.cap;
+    const bool whole = dry2_fix_entries<QUIET, WRITE_DISP>(g, ctx, in, out, fix.cells, blockIdx.x, gridDim.x, n, m.st, o, lane, vx) || total > fix.cap;
     if (whole && lane == 0 && atomicMax(ctl + D2_REDO_EPOCH, fix.epoch) < fix.epoch) atomicAdd(ctl + D2_N_REDO, 1);
     dry2_grid_barrier(ctl + D2_BAR0, ctl + D2_BAR0 + 1, fix.epoch, lane); // every workgroup has read the count and raised what it had to raise
     if (blockIdx.x == 0 && lane == 0) dry2_list_reset(fix, total, n);
@@ -658,7 +696,7 @@ inline void launch_march_dry2(const Geo &g, const Uni &u, const FullCtx *ctx, co
   const int last = fix.hint_host ? *(volatile const int *)fix.hint_host : -1;
   if (last != 0) {
     const dim3 fgrid(last < 0 ? 1024 : std::min(4096, std::max(64, 4 * last)));
-#define WX_LAUNCH_F(Q, D) hipLaunchKernelGGL((k_dry2_fix<Q, D>), fgrid, dim3(64), 0, stream, g, ctx, in, out, fix)
+#define WX_LAUNCH_F(Q, D) hipLaunchKernelGGL((k_dry2_fix<Q, D>), fgrid, dim3(64), 0, stream, g, ctx, in, out, fix, vt)
     if (quiet) {
       if (write_disp) WX_LAUNCH_F(true, true); else WX_LAUNCH_F(true, false);
     } else {

@@ -2169,7 +2169,8 @@ int wx_pair_stats(wx_sim *s, int64_t *cells_recomputed, int64_t *pairs_repeated)
   int ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (s->pair_ctl) {
     HIPCHK(s, hipMemcpyAsync(ctl, s->pair_ctl, 32, hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(s, hipMemsetAsync(s->pair_ctl + D2_N_REDO, 0, 16, s->stream)); // {pairs repeated, -, cells recomputed (64 bits)}
+    HIPCHK(s, hipMemsetAsync(s->pair_ctl + D2_N_REDO, 0, 4, s->stream));
+    HIPCHK(s, hipMemsetAsync(s->pair_ctl + D2_FIXED, 0, 8, s->stream));
     HIPCHK(s, hipStreamSynchronize(s->stream));
   }
   int64_t fixed;

@@ -245,10 +245,11 @@ int wx_sync(wx_sim *s);
 /* WX_OPT_DRY_PAIRS (round 5; default 1): the water-free dry stencil (pass_mask WX_PASS_DRY, no water anywhere, no brush, wall texture
  *   constant) runs TWO iterations per launch wherever two are left in a wx_step call and neither is a split iteration -- the second
  *   iteration's input never leaves the wavefront (csrc/wx_march2.h): 18 instead of 36 bytes per cell-step, 0.71 instead of 0.86 ms per
- *   iteration at 32768 x 4096. Same results bit for bit: a second-iteration cell whose back-trace is 0.9 cells or more (no exact path
- *   inside the march: its inputs exist in no texture) is recorded and recomputed from the pair's untouched inputs by a small fix kernel
- *   behind the pair (round 6: one wavefront per cell; wx_pair_stats); only a back-trace of three cells or more -- or an overflowing list --
- *   makes two predicated one-iteration launches repeat the whole pair. 0 = one iteration per launch. */
+ *   iteration at 32768 x 4096. Same results bit for bit: cells whose back-trace is 0.9 cells or more (no exact path inside the march) are
+ *   handled by tiles -- first-iteration ones taint what depends on them (NaN), second-iteration cells that are fast or tainted put their
+ *   8 x 8 tile on a list, and a small fix kernel behind the pair recomputes both iterations for those tiles from the pair's untouched
+ *   inputs (round 6; wx_pair_stats); only a back-trace of three cells or more -- or an overflowing list -- makes one further launch repeat
+ *   the whole pair with the one-iteration stencil. 0 = one iteration per launch. */
 #define WX_OPT_DRY_PAIRS 10
 /* (ABI 10) 1 (default): waterTexture_0 -- the post-boundary water of a step's last iteration, which only saves read (app.js:6587-6589) --
  * is made when somebody asks for WX_FIELD_WATER_0 (per-pass kernels on the retained inputs of that iteration, with its parameters)
@@ -463,10 +464,10 @@ int wx_group_sync(wx_group *g);
  * wx_slab_set_vx_bound above); the value is a diagnostic of the flow, nothing more. */
 int wx_fastest_velocity(wx_sim *s, float *cells_per_iteration);
 
-/* (ABI 11) The pair kernel's exact path (WX_OPT_DRY_PAIRS) since the last call: how many second-iteration cells k_dry2_fix recomputed
- * (back-traces of 0.9 .. 3 cells: one wavefront per cell, a few microseconds each) and how many pairs were repeated WHOLE with the
+/* (ABI 11) The pair kernel's exact path (WX_OPT_DRY_PAIRS) since the last call: how many output cells k_dry2_fix recomputed (81 per
+ * recorded 8 x 8 tile of cells with back-traces of 0.9 .. 3 cells in either iteration: one wavefront per tile) and how many pairs were repeated WHOLE with the
  * one-iteration kernel (a second-iteration back-trace of three cells or more, or more recorded cells than the list holds: 1/64 of the
- * grid's cells, 64 Ki .. 1 Mi entries, WX_OPT_FIX_CAP). Either pointer may be NULL. Resets both; synchronises the handle's stream. The
+ * grid's cells, 64 Ki .. 1 Mi tiles, WX_OPT_FIX_CAP). Either pointer may be NULL. Resets both; synchronises the handle's stream. The
  * reference has no velocity clamp (advectionShader.frag:85-99); results are bit-identical to one iteration per launch whatever these say. */
 int wx_pair_stats(wx_sim *s, int64_t *cells_recomputed, int64_t *pairs_repeated);
 
