@@ -604,7 +604,9 @@ __device__ __forceinline__ void dry2_grid_barrier(int *cnt, int *rel, int epoch,
 // non-zero hint the wide k_dry2_fix runs in front and leaves the list empty): fixed here, grid-stride. The pair has to be repeated whole
 // (decided by either fix pass): iteration 1 from the pair's inputs into the scratch buffer -> grid barrier -> iteration 2 into the pair's
 // output (+ display field).
-constexpr int D2_POST_GRID = 512;
+// (128: the barrier needs every workgroup of the launch resident at once, and up to eight slab handles may share one device in the group
+// tests -- 8 x 128 workgroups of 32 KB of LDS fit the chip's 1 280 slots together, so no two such launches can starve each other)
+constexpr int D2_POST_GRID = 128;
 template <bool QUIET, bool WRITE_DISP>
 __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_post(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, Dry2Fix fix, float4 *__restrict__ scratch, int n_strips,
                                                                       int seg_rows, int n_full, int n_half, int band_h, int n_seg, VxTrack vx)
