@@ -77,8 +77,31 @@ struct Dry2Fix {
   const int *hint_host;
 };
 enum { D2_COUNT = 0, D2_TICKET = 1, D2_TOLD = 2, D2_REDO_EPOCH = 3, D2_N_REDO = 4, D2_TOLD_EPOCH = 5, D2_FIXED = 6, D2_BAR0 = 8, D2_BAR1 = 10, D2_WORDS = 12 };
+// the tiles (8 of the strip's columns x 8 rows counted from the segment's first) of the lanes in `badmask`, each once per wave
+// (rec: (tile row << 8) | mask of the tiles of that row already recorded; returns the new value)
+__device__ __forceinline__ int dry2_record_tiles(unsigned long long badmask, int tr, int y_lo, int strip, int lane, int rec, const Dry2Fix &fix)
+{
+  int rec_tr = rec >> 8;
+  unsigned rec_mask = (unsigned)rec & 0xffu;
+  unsigned gm = 0;
+  for (int gq = 0; gq < M2OUT / 8; gq++) gm |= ((badmask >> (M2LO + 8 * gq)) & 0xffull) ? (1u << gq) : 0u;
+  if (tr != rec_tr) rec_mask = 0;
+  const unsigned fresh = gm & ~rec_mask;
+  rec_tr = tr;
+  rec_mask |= gm;
+  if (fresh && lane == 0) {
+    int at = atomicAdd(fix.ctl + D2_COUNT, __popc(fresh));
+    for (int gq = 0; gq < M2OUT / 8; gq++)
+      if ((fresh >> gq) & 1u) {
+        if (at < fix.cap) fix.cells[at] = make_int2(strip * M2OUT + 8 * gq, y_lo + 8 * tr);
+        at++;
+      }
+  }
+  return (rec_tr << 8) | (int)rec_mask;
+}
 // WRITE_DISP: also store the post-advection base of the SECOND iteration (baseTexture_1 of the last iteration of a frame: display side)
-template <bool QUIET, bool WRITE_DISP>
+// TAINT: how a FIRST-iteration back-trace of 0.9 cells or more is handled -- see the loop. Same results either way; the host picks.
+template <bool QUIET, bool WRITE_DISP, bool TAINT>
 __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, int n_strips, int seg_rows, int n_full, int n_half,
                                                                         int band_h, int n_seg, VxTrack vx, Dry2Fix fix)
 {
@@ -126,8 +149,7 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
   unsigned h_big1 = 0, h_big2 = 0; // bit k: "some |v| >= 0.9" in the velocity row k steps back (bit 0 = the row this step produced)
   unsigned h_nw = 0;               // bit k: input row r-k holds no wall cell
   unsigned h_bad1 = 0;             // bit k: some lane of the first iteration's advection row k steps back was tainted (see there)
-  int rec_tr = -1;                 // the tile row (of this segment) whose tiles rec_mask says are on the exact-path list already
-  unsigned rec_mask = 0;
+  int rec = -256;                  // (tile row of this segment << 8) | the 7-bit mask of its tiles that are on the exact-path list already
 
   const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
   int r = y_lo - 4;
@@ -167,7 +189,7 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
       rg.vx[0][s1][lane] = v.x;
       rg.vy[0][s1][lane] = v.y;
       vx_seen = fmaxf(vx_seen, fabsf(v.x));
-      h_big1 |= __any(!(fabsf(v.x) < 0.9f) || !(fabsf(v.y) < 0.9f)) ? 1u : 0u; // (NaN counts as fast)
+      h_big1 |= __any(fmaxf(fabsf(v.x), fabsf(v.y)) >= 0.9f) ? 1u : 0u;
     }
     march_fence();
     float4 b2 = make_float4(0.f, 0.f, 0.f, 0.f); // pressure_1 of row r-2 = the second iteration's input row
@@ -177,14 +199,20 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
       float4 ab, aw;
       char4 awl;
       bool fast = true;
-      h_bad1 <<= 1;
+      if (TAINT) h_bad1 <<= 1;
       if (h_big1 & 7u) {
-        const float q0 = rg.vx[0][yc & 3][lr], q1 = rg.vx[0][yc & 3][lr - 1], q2 = rg.vx[0][(yc + 1) & 3][lr], q3 = rg.vx[0][(yc + 1) & 3][lr - 1];
-        const float q4 = rg.vy[0][yc & 3][lr], q5 = rg.vy[0][(yc - 1) & 3][lr], q6 = rg.vy[0][yc & 3][lr + 1], q7 = rg.vy[0][(yc - 1) & 3][lr + 1];
-        const float m = fmaxf(fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3))), fmaxf(fmaxf(fabsf(q4), fabsf(q5)), fmaxf(fabsf(q6), fabsf(q7))));
-        const float sn = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)); // (fmaxf drops a NaN operand; the sum keeps it)
-        fast = m < 0.9f && sn == sn;
-        h_bad1 |= __any(!fast) ? 1u : 0u;
+        if (!TAINT) {
+          const float m = fmaxf(fmaxf(fmaxf(fabsf(rg.vx[0][yc & 3][lr]), fabsf(rg.vx[0][yc & 3][lr - 1])), fmaxf(fabsf(rg.vx[0][(yc + 1) & 3][lr]), fabsf(rg.vx[0][(yc + 1) & 3][lr - 1]))),
+                                fmaxf(fmaxf(fabsf(rg.vy[0][yc & 3][lr]), fabsf(rg.vy[0][(yc - 1) & 3][lr])), fmaxf(fabsf(rg.vy[0][yc & 3][lr + 1]), fabsf(rg.vy[0][(yc - 1) & 3][lr + 1]))));
+          fast = m < 0.9f;
+        } else {
+          const float q0 = rg.vx[0][yc & 3][lr], q1 = rg.vx[0][yc & 3][lr - 1], q2 = rg.vx[0][(yc + 1) & 3][lr], q3 = rg.vx[0][(yc + 1) & 3][lr - 1];
+          const float q4 = rg.vy[0][yc & 3][lr], q5 = rg.vy[0][(yc - 1) & 3][lr], q6 = rg.vy[0][yc & 3][lr + 1], q7 = rg.vy[0][(yc - 1) & 3][lr + 1];
+          const float m = fmaxf(fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3))), fmaxf(fmaxf(fabsf(q4), fabsf(q5)), fmaxf(fabsf(q6), fabsf(q7))));
+          const float sn = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)); // (fmaxf drops a NaN operand; the sum keeps it)
+          fast = m < 0.9f && sn == sn;
+          h_bad1 |= __any(!fast) ? 1u : 0u;
+        }
       }
       const M2Acc<0> a{rg, lr, yc};
       if (fast) {
@@ -192,15 +220,20 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
           advection_cell<true, true, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
         else
           advection_cell<true, false, false, QUIET>(u, g, initial_T, snd_T, snd_W, snd_Vel, col, y, a, ab, aw, awl);
-      } else {
-        // A back-trace of 0.9 cells or more leaves the ring. The one-iteration kernel takes its out-of-line path through global memory here --
-        // a serial chase per lane that made a wave crossing a vortex the straggler of its launch (+20 % on the pair kernel with a few
-        // thousand such cells). The pair kernel TAINTS instead: the cell's post-advection texel is NaN, every second-iteration value that
-        // depends on it becomes NaN by arithmetic alone (+, -, x of the cell functions; the two places where a NaN could be dropped --
-        // fmaxf in the speed tests -- test for it), and every second-iteration cell that is fast OR tainted puts its tile on the exact-path
-        // list: k_dry2_fix recomputes BOTH iterations for those from the pair's inputs. Nothing tainted is ever kept.
+      } else if (TAINT) {
+        // A back-trace of 0.9 cells or more leaves the ring. The one-iteration kernel takes its out-of-line path through global memory here
+        // (and so does the plain instantiation below) -- a serial chase per lane that makes a wave crossing a vortex the straggler of its
+        // launch (+20 % on the pair kernel with a few thousand such cells). The TAINT instantiation, which the host launches while the
+        // exact-path lists are not empty, taints instead: the cell's post-advection texel is NaN, every second-iteration value that depends
+        // on it becomes NaN by arithmetic alone (+, -, x of the cell functions; the places where a NaN could be dropped -- fmaxf in the
+        // speed tests -- test for it), and every second-iteration cell that is fast OR tainted puts its tile on the exact-path list:
+        // k_dry2_fix recomputes BOTH iterations for those from the pair's inputs. Nothing tainted is ever kept.
         ab = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
         awl = a.wall(0, 0); // (the wall texture is constant in a pair: the caller checked)
+      } else { // the first iteration's inputs are in global memory: the exact out-of-line path of k_march_dry
+        const AdvOut o = advection_cell_dry_global(ctx, in, false, col, y);
+        ab = o.b;
+        awl = o.wl;
       }
       if (r >= y_lo) {
         b2 = pressure_cell(ab, wave_from_left(ab.x), a1_vy, a1_T, a1_w.x, a1_w.y);
@@ -218,7 +251,7 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
         rg.vx[1][s3][lane] = v.x;
         rg.vy[1][s3][lane] = v.y;
         vx_seen = fmaxf(vx_seen, fabsf(v.x));
-        h_big2 |= __any(lane >= 2 && lane <= 61 && (!(fabsf(v.x) < 0.9f) || !(fabsf(v.y) < 0.9f))) ? 1u : 0u; // (NaN -- a tainted input, below -- counts as fast)
+        h_big2 |= __any(lane >= 2 && lane <= 61 && fmaxf(fabsf(v.x), fabsf(v.y)) >= 0.9f) ? 1u : 0u; // (fmaxf drops a NaN: tainted rows are covered by h_bad1 below)
       }
     }
     march_fence();
@@ -227,12 +260,34 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
       float4 ab, aw;
       char4 awl;
       bool fast2 = true;
-      if (h_big2 & 7u) {
-        const float q0 = rg.vx[1][yc & 3][lr], q1 = rg.vx[1][yc & 3][lr - 1], q2 = rg.vx[1][(yc + 1) & 3][lr], q3 = rg.vx[1][(yc + 1) & 3][lr - 1];
-        const float q4 = rg.vy[1][yc & 3][lr], q5 = rg.vy[1][(yc - 1) & 3][lr], q6 = rg.vy[1][yc & 3][lr + 1], q7 = rg.vy[1][(yc - 1) & 3][lr + 1];
-        const float m = fmaxf(fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3))), fmaxf(fmaxf(fabsf(q4), fabsf(q5)), fmaxf(fabsf(q6), fabsf(q7))));
-        const float sn = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7));
-        fast2 = m < 0.9f && sn == sn;
+      if ((h_big2 & 7u) | (TAINT ? (h_bad1 & 0xffu) : 0u)) { // (some velocity of rows y-1 .. y+1 is large, or a first-iteration cell of the last rows was tainted)
+        if (!TAINT) {
+          const float m = fmaxf(fmaxf(fmaxf(fabsf(rg.vx[1][yc & 3][lr]), fabsf(rg.vx[1][yc & 3][lr - 1])), fmaxf(fabsf(rg.vx[1][(yc + 1) & 3][lr]), fabsf(rg.vx[1][(yc + 1) & 3][lr - 1]))),
+                                fmaxf(fmaxf(fabsf(rg.vy[1][yc & 3][lr]), fabsf(rg.vy[1][(yc - 1) & 3][lr])), fmaxf(fabsf(rg.vy[1][yc & 3][lr + 1]), fabsf(rg.vy[1][(yc - 1) & 3][lr + 1]))));
+          fast2 = m < 0.9f;
+        } else {
+          const float q0 = rg.vx[1][yc & 3][lr], q1 = rg.vx[1][yc & 3][lr - 1], q2 = rg.vx[1][(yc + 1) & 3][lr], q3 = rg.vx[1][(yc + 1) & 3][lr - 1];
+          const float q4 = rg.vy[1][yc & 3][lr], q5 = rg.vy[1][(yc - 1) & 3][lr], q6 = rg.vy[1][yc & 3][lr + 1], q7 = rg.vy[1][(yc - 1) & 3][lr + 1];
+          const float m = fmaxf(fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3))), fmaxf(fmaxf(fabsf(q4), fabsf(q5)), fmaxf(fabsf(q6), fabsf(q7))));
+          const float sn = ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7));
+          fast2 = m < 0.9f && sn == sn;
+        }
+        // No exact path here for a fast cell (the inputs of this iteration exist in no texture): it keeps a placeholder, and the wave that
+        // OWNS it as an output cell records the 8 x 8 TILE it lies in (8 of the strip's columns x 8 rows counted from the segment's first):
+        // k_dry2_fix recomputes the 9 x 9 output cells such a tile's cells feed (their own, the right neighbour's pressure: vx of the left
+        // cell, the upper neighbour's: vy, T, wall of the lower cell), whichever waves own those. Rare path. The TAINT instantiation
+        // records a tile once per wave; the plain one -- which runs only until the host has heard of the first entries -- lane by lane
+        // (duplicates are harmless: recomputing an output is idempotent), in the very shape of round 5's code: anything else in this branch
+        // cost the clean flow 2-3 % through the compiler's layout of the loop around it.
+        if (!TAINT) {
+          if (!fast2 && lane_out && r - 4 >= y_lo) {
+            const int at = atomicAdd(fix.ctl + D2_COUNT, 1);
+            if (at < fix.cap) fix.cells[at] = make_int2(strip * M2OUT + ((lane - M2LO) & ~7), y_lo + ((r - 4 - y_lo) & ~7));
+          }
+        } else {
+          const unsigned long long badmask = __ballot(!fast2 && lane_out && r - 4 >= y_lo);
+          if (badmask) rec = dry2_record_tiles(badmask, (r - 4 - y_lo) >> 3, y_lo, strip, lane, rec, fix);
+        }
       }
       const M2Acc<1> a{rg, lr, yc};
       if (fast2) {
@@ -244,31 +299,11 @@ __global__ __launch_bounds__(64, WX_MARCH2_MINWAVES) void k_march_dry2(Geo g, co
         ab = a.base(0, 0);
         awl = a.wall(0, 0);
       }
-      if ((h_big2 & 7u) | (h_bad1 & 0xffu)) { // (wave-uniform; clean flows never get here)
-        // No exact path here for a fast cell (the inputs of this iteration exist in no texture), and nothing to keep of a cell whose
-        // footprints touched a tainted texel of the first iteration (a NaN among its four post-advection values): the wave that OWNS such a
-        // cell as an output cell records the 8 x 8 TILE it lies in (8 of the strip's columns x 8 rows counted from the segment's first) --
-        // once per tile: k_dry2_fix recomputes the 9 x 9 output cells such a tile's cells feed (their own, the right neighbour's pressure: vx
-        // of the left cell, the upper neighbour's: vy, T, wall of the lower cell), whichever waves own those. Rare path, wave-uniform.
+      if (TAINT && (h_bad1 & 0xffu)) { // (wave-uniform: a first-iteration cell of the last rows was tainted) nothing to keep of a cell whose footprints
+        // touched a tainted texel -- a NaN among its four post-advection values: its tile goes to the list like a fast cell's
         const float chk = (ab.x + ab.y) + (ab.z + ab.w);
-        const unsigned long long badmask = __ballot((!fast2 || chk != chk) && lane_out && r - 4 >= y_lo);
-        if (badmask) {
-          const int tr = (r - 4 - y_lo) >> 3;
-          unsigned gm = 0;
-          for (int gq = 0; gq < M2OUT / 8; gq++) gm |= ((badmask >> (M2LO + 8 * gq)) & 0xffull) ? (1u << gq) : 0u;
-          if (tr != rec_tr) rec_mask = 0;
-          const unsigned fresh = gm & ~rec_mask;
-          rec_tr = tr;
-          rec_mask |= gm;
-          if (fresh && lane == 0) {
-            int at = atomicAdd(fix.ctl + D2_COUNT, __popc(fresh));
-            for (int gq = 0; gq < M2OUT / 8; gq++)
-              if ((fresh >> gq) & 1u) {
-                if (at < fix.cap) fix.cells[at] = make_int2(strip * M2OUT + 8 * gq, y_lo + 8 * tr);
-                at++;
-              }
-          }
-        }
+        const unsigned long long badmask = __ballot(chk != chk && lane_out && r - 4 >= y_lo);
+        if (badmask) rec = dry2_record_tiles(badmask, (r - 4 - y_lo) >> 3, y_lo, strip, lane, rec, fix);
       }
       if (r >= y_lo + 4) {
         st_p = pressure_cell(ab, wave_from_left(ab.x), a2_vy, a2_T, a2_w.x, a2_w.y);
@@ -482,7 +517,7 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_fix(Geo g, const
 // pair equals two launches of k_march_dry bit for bit. Not tuned: it runs when the state is blowing up.
 template <bool QUIET, bool WRITE_DISP>
 __device__ __forceinline__ void march_dry_redo_items(const Geo &g, const FullCtx *__restrict__ ctx, const DryIn &in, const DryOut &out, int n_strips, int seg_rows, int n_full, int n_half,
-                                                     int band_h, int n_seg, const VxTrack &vx, March2Ring &rg)
+                                                     int band_h, int n_seg, const VxTrack &vx, March2Ring &rg, int nwg)
 {
   CUni &u = as_constant(ctx->u);
   const CFloatP initial_T = as_constant(ctx->initial_T), snd_T = as_constant(ctx->snd_T), snd_W = as_constant(ctx->snd_W), snd_Vel = as_constant(ctx->snd_Vel);
@@ -490,7 +525,7 @@ __device__ __forceinline__ void march_dry_redo_items(const Geo &g, const FullCtx
   const int total = n_strips * n_seg;
   const int lr = lane < 1 ? 1 : (lane > 62 ? 62 : lane), lright = lane < 63 ? lane + 1 : 63;
   const int *__restrict__ wall_raw = reinterpret_cast<const int *>(in.wall);
-  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+  for (int item = blockIdx.x; item < total; item += nwg) {
     float vx_seen = 0.f;
     const int seg = item / n_strips, strip = item - seg * n_strips;
     const int c_out = strip * M2OUT + lane - M2LO, col = wrapmod(c_out, X);
@@ -576,12 +611,12 @@ __device__ __forceinline__ void march_dry_redo_items(const Geo &g, const FullCtx
 
 // a barrier of the whole (co-resident) grid, reusable without a reset between launches: the last workgroup to arrive clears the counter
 // and publishes the launch's own number; the others poll for it (bounded: a grid that cannot be resident traps instead of hanging)
-__device__ __forceinline__ void dry2_grid_barrier(int *cnt, int *rel, int epoch, int lane)
+__device__ __forceinline__ void dry2_grid_barrier(int *cnt, int *rel, int epoch, int lane, int nwg)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   if (lane == 0) {
-    if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+    if (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
       __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(rel, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -606,7 +641,10 @@ __device__ __forceinline__ void dry2_grid_barrier(int *cnt, int *rel, int epoch,
 // output (+ display field).
 // (128: the barrier needs every workgroup of the launch resident at once, and up to eight slab handles may share one device in the group
 // tests -- 8 x 128 workgroups of 32 KB of LDS fit the chip's 1 280 slots together, so no two such launches can starve each other)
-constexpr int D2_POST_GRID = 128;
+#ifndef WX_POST_GRID
+#define WX_POST_GRID 512
+#endif
+constexpr int D2_POST_GRID = WX_POST_GRID, D2_POST_ACTIVE = 128;
 template <bool QUIET, bool WRITE_DISP>
 __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_post(Geo g, const FullCtx *__restrict__ ctx, DryIn in, DryOut out, Dry2Fix fix, float4 *__restrict__ scratch, int n_strips,
                                                                       int seg_rows, int n_full, int n_half, int band_h, int n_seg, VxTrack vx)
@@ -628,11 +666,15 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_post(Geo g, cons
     }
     return;
   }
+  // (only the first D2_POST_ACTIVE workgroups work: the barriers need every participant resident at once; the rest of the grid is there
+  // for the quiet case only, see launch_march_dry2)
+  const int nwg = min((int)gridDim.x, D2_POST_ACTIVE);
+  if ((int)blockIdx.x >= nwg) return;
   if (total > 0) {
     const int n = total <= fix.cap ? total : 0;
-    const bool whole = dry2_fix_entries<QUIET, WRITE_DISP>(g, ctx, in, out, fix.cells, blockIdx.x, gridDim.x, n, m.st, o, lane, vx) || total > fix.cap;
+    const bool whole = dry2_fix_entries<QUIET, WRITE_DISP>(g, ctx, in, out, fix.cells, blockIdx.x, nwg, n, m.st, o, lane, vx) || total > fix.cap;
     if (whole && lane == 0 && atomicMax(ctl + D2_REDO_EPOCH, fix.epoch) < fix.epoch) atomicAdd(ctl + D2_N_REDO, 1);
-    dry2_grid_barrier(ctl + D2_BAR0, ctl + D2_BAR0 + 1, fix.epoch, lane); // every workgroup has read the count and raised what it had to raise
+    dry2_grid_barrier(ctl + D2_BAR0, ctl + D2_BAR0 + 1, fix.epoch, lane, nwg); // every workgroup has read the count and raised what it had to raise
     if (blockIdx.x == 0 && lane == 0) dry2_list_reset(fix, total, n);
     redo = __hip_atomic_load(ctl + D2_REDO_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fix.epoch;
   }
@@ -641,9 +683,9 @@ __global__ __launch_bounds__(64, WX_MARCH_MINWAVES) void k_dry2_post(Geo g, cons
   in2.base = scratch;
   DryOut out1 = out;
   out1.base = scratch;
-  march_dry_redo_items<QUIET, false>(g, ctx, in, out1, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vx, m.rg);
-  dry2_grid_barrier(ctl + D2_BAR1, ctl + D2_BAR1 + 1, fix.epoch, lane);
-  march_dry_redo_items<QUIET, WRITE_DISP>(g, ctx, in2, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vx, m.rg);
+  march_dry_redo_items<QUIET, false>(g, ctx, in, out1, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vx, m.rg, nwg);
+  dry2_grid_barrier(ctl + D2_BAR1, ctl + D2_BAR1 + 1, fix.epoch, lane, nwg);
+  march_dry_redo_items<QUIET, WRITE_DISP>(g, ctx, in2, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vx, m.rg, nwg);
 }
 
 // Unit segment height of a row band: 3/16 of the band -- five full segments + 1/2 + 1/4 per band. One handle each, interleaved,
@@ -685,17 +727,25 @@ inline void launch_march_dry2(const Geo &g, const Uni &u, const FullCtx *ctx, co
   }
   const dim3 grid(8 * ((n_strips * n_seg + 7) / 8));
   const bool quiet = !(u.userInputType >= 1) && !(u.airplaneValues[3] < 0.0f || u.airplaneValues[3] > 0.9f);
-#define WX_LAUNCH_M2(Q, D) hipLaunchKernelGGL((k_march_dry2<Q, D>), grid, dim3(64), 0, stream, g, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vt, fix)
+  // The host's (stale) hint word -- the length of the last exact-path list it has heard of -- picks the instantiation: clean flows run the plain
+  // one (first-iteration fast cells, should one appear, take the inline path through global memory), flows with fast cells the TAINT one
+  // (no inline path: those cells go to the list with what depends on them). Identical results; an A/B switch in the debug build.
+  const int last = fix.hint_host ? *(volatile const int *)fix.hint_host : -1;
+  bool taint = last > 0;
+  if (const char *e = wx_tune_env("WX_MARCH2_TAINT")) taint = atoi(e) != 0;
+#define WX_LAUNCH_M2(Q, D, T) hipLaunchKernelGGL((k_march_dry2<Q, D, T>), grid, dim3(64), 0, stream, g, ctx, in, out, n_strips, seg_rows, n_full, n_half, band_h, n_seg, vt, fix)
+#define WX_LAUNCH_M2T(Q, D) \
+  do { if (taint) WX_LAUNCH_M2(Q, D, true); else WX_LAUNCH_M2(Q, D, false); } while (0)
   if (quiet) {
-    if (write_disp) WX_LAUNCH_M2(true, true); else WX_LAUNCH_M2(true, false);
+    if (write_disp) WX_LAUNCH_M2T(true, true); else WX_LAUNCH_M2T(true, false);
   } else {
-    if (write_disp) WX_LAUNCH_M2(false, true); else WX_LAUNCH_M2(false, false);
+    if (write_disp) WX_LAUNCH_M2T(false, true); else WX_LAUNCH_M2T(false, false);
   }
+#undef WX_LAUNCH_M2T
 #undef WX_LAUNCH_M2
   if (wx_tune_env("WX_MARCH2_NOREDO")) return; // (timing experiments)
   // While the host's (stale) hint word says that the lists hold entries: the wide fix pass -- one wavefront per recorded cell, room for four
   // times the last list, at most 4096 workgroups of one wave (the list is walked grid-stride: any size is correct).
-  const int last = fix.hint_host ? *(volatile const int *)fix.hint_host : -1;
   if (last != 0) {
     const dim3 fgrid(last < 0 ? 1024 : std::min(4096, std::max(64, 4 * last)));
 #define WX_LAUNCH_F(Q, D) hipLaunchKernelGGL((k_dry2_fix<Q, D>), fgrid, dim3(64), 0, stream, g, ctx, in, out, fix, vt)
