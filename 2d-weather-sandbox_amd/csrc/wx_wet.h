@@ -1498,7 +1498,8 @@ inline void launch_wet_fix(float iterNum, const FullCtx *ctx, const WetIn &in, c
   // four entries per workgroup with room for four times the last list (its length varies from iteration to iteration: room for twice
   // cost the particle flow 6 us, 21 -> 27), 32 .. 512 workgroups (wgs: the edge group of a slab -- a few strips -- asks for 64); the
   // list is walked grid-stride, so any size is correct
-  const int want = last < 0 ? 512 : (last > 0 ? std::min(512, std::max(32, last)) : 32);
+  int want = last < 0 ? 512 : (last > 0 ? std::min(512, std::max(32, last)) : 32);
+  if (const char *e = wx_tune_env("WX_FIX_WGS")) want = atoi(e) > 0 ? atoi(e) : want; // (tuning)
   const dim3 grid(wgs > 0 ? wgs : want), block(256);
   if (opt_out)
     hipLaunchKernelGGL((k_wet_fix<true>), grid, block, 0, stream, ctx, iterNum, in, out, fix.count, fix.cells, fix.cap, overflow, fix.hint);
