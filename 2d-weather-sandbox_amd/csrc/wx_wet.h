@@ -1196,7 +1196,11 @@ __global__ __launch_bounds__(256) void k_wet_fix(const FullCtx *__restrict__ ctx
   __shared__ WetFixStage stages[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   WetPatch &pt = patches[wave];
-  const int total = *count, n = total < cap ? total : cap;
+  // An OVERFLOWED list is not consumed at all: an appender whose 1-3 entries straddle cap writes none of them (k_march_wet, `at + n_add <=
+  // fix.cap`), so up to two slots below cap may hold whatever the allocation held before -- coordinates nobody checked (found by
+  // tools/fuzz_parity.py: a memory access fault a few cases after a handle whose list had overflowed). The overflow is reported and the results
+  // since are invalid either way (wx_step's next blocking call fails with WX_E_STATE).
+  const int total = *count, n = total <= cap ? total : 0;
   if (total == 0) {
     // The usual case, and a launch that is pure latency on a small grid (5 us of a 20 us iteration at 100 x 100): nothing to recompute and
     // nothing to reset -- one load, and out. count[2] remembers what the host's hint word was last told: it is set back once.

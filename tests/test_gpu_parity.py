@@ -509,6 +509,37 @@ def test_exact_path_overflow_is_reported(pkg, E, monkeypatch):
     h.close()
 
 
+def test_exact_path_overflow_never_consumes_unwritten_list_slots(pkg, E):
+    """An appender whose 1-3 entries straddle the end of the exact-path list writes none of them, so the slots just below the capacity may
+    hold whatever the allocation held before; the fix pass must not take coordinates from there (tools/fuzz_parity.py found a memory access
+    fault a few cases after a handle whose list had overflowed). Device memory is poisoned first; capacities that 1-3-entry appends straddle."""
+    import torch
+    X, Y = 384, 128
+    base, water, wall = pkg.synth.terrain_grid(X, Y)
+    base[40:110, :, 1] = 1.5
+    base[40:110, :, 0] = -1.2
+    gui = pkg.params.merge_settings(None)
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+    for cap in (1000, 1001, 1002, 4099):
+        poison = [torch.full((1 << 20,), 0x7F7F7F7F, dtype=torch.int32, device="cuda") for _ in range(16)]
+        torch.cuda.synchronize()
+        del poison
+        torch.cuda.empty_cache()  # (back to the driver: the handle's hipMalloc may now be handed these pages)
+        h = E.Handle(X, Y, 0)
+        h.set_option(h.OPT_KERNEL_SET, 1)
+        h.set_option(h.OPT_FIX_CAP, cap)
+        h.upload(base, water, wall)
+        h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u), u["initial_T"])
+        h.step(2)
+        with pytest.raises(E.WxError) as ei:
+            h.sync()
+        assert ei.value.code == -5
+        h.close()
+    t = torch.zeros(16, device="cuda") + 1.0  # the device is still there
+    assert float(t.sum()) == 16.0
+
+
 def test_particles_vs_oracle(pkg, oracle, golden, E, fused):
     g, u = golden("precip64")
     u = dict(u, quad_scale=0, enablePrecipitation=1)
