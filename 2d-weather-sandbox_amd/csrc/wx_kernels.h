@@ -694,7 +694,11 @@ __device__ __forceinline__ bool precip_droplet(const int i, const Geo &g, const 
       drops_out[5 * (size_t)i + 4] = fmaxf(newDensity, 0.0f);
     }
     if (sp.stamp) { // what the exchange needs to know: did the status flip, and did I have the droplet in my owned columns
-      if ((m0 >= 0.0f) != (newM0 >= 0.0f)) sp.flips[i] |= (unsigned short)(1u << (sp.stamp - 1));
+      // ... or was the record of an inactive droplet rewritten without a flip: a droplet that spawns inside a cell it cannot live in (a wall
+      // cell that holds cloud water: water.x > 1000) retires in the same iteration with NEW seeds (-2 - x, y, :199-203), and the other ranks
+      // must probe with those from now on (found by tools/fuzz_parity.py --mode group on grids a few dozen rows high, where the wall rows at
+      // the top are a tenth of the domain). Its event ends inactive, so the 600-iteration count leaves it out as the reference does (:158).
+      if ((m0 >= 0.0f) != (newM0 >= 0.0f) || (spawned && newM0 < 0.0f)) sp.flips[i] |= (unsigned short)(1u << (sp.stamp - 1));
       sp.owned_once[i] = (unsigned char)((sp.owned_once[i] & 0x80) | sp.stamp | (claim ? 0x80 : 0));
     }
   }

@@ -3,7 +3,9 @@
 BIT, on randomly drawn cases -- grid size (tiny, ragged, a strip / a tile / a band border away from the launch shapes' corners), terrain,
 flow speed (up to several cells per iteration: the exact paths), humidity / cloud / smoke / snow, settings (every slider inside the range
 the reference's GUI offers), pass mask (all passes / the dry stencil), brush tool and airplane inputs, droplets in deterministic splat
-order, the way a host cuts its iterations into steps, dry pairs on / off, row bands, waterTexture_0 on demand / stored.
+order, the way a host cuts its iterations into steps, dry pairs on / off, row bands, waterTexture_0 on demand / stored. --mode group: the same
+scenes cut into 2 .. 8 column slabs on this one GPU (the library's own halo exchange, random halo widths, overlapped / split / in-order
+protocol, droplet pool in exact mode) against the undecomposed handle, bit for bit.
 
     python tools/fuzz_parity.py [--seed S] [--cases N] [--seconds T] [--max-cells C]
 
@@ -175,12 +177,89 @@ def run_case(pkg, E, wx_oracle, c):
     return bad, info
 
 
+def draw_group(rng, c):
+    """Extra draws of --mode group (after draw_case, so the scene sequence of a seed is the same in both modes)."""
+    n = int(rng.choice([2, 2, 3, 4, 4, 5, 6, 8]))
+    if c["drops"]:  # wx_create_slab: with particles halo and owned width are multiples of 64 (splat tiles), owned + 2 halo <= X
+        halo = 64
+        xo = max(64 if n > 2 else 128, -(-c["X"] // n // 64) * 64)
+    else:  # (a halo narrower than the flow's dependency cone is refused by the first step: reported, not a mismatch)
+        lo = 6 if c["sigma"] <= 0.2 and not c["vortices"] else (12 if c["sigma"] <= 0.45 else 24)
+        halo = int(rng.choice([h for h in (6, 12, 18, 24, 42, 48, 64) if h >= lo]))
+        xo = max(halo, -(-c["X"] // n))
+    c["X"] = n * xo
+    c.update(nslab=n, halo=halo, overlap=int(rng.random() < 0.6), split=int(rng.random() < 0.25), pool_exact=1, kernel_set=1)
+    c["steps"] = [int(v) for v in rng.integers(1, 2 * max(1, halo // 6) + 3, size=int(rng.integers(1, 4)))]
+    return c
+
+
+def run_group_case(pkg, E, c):
+    """N slabs on this one GPU (wx_group_*: the library's own halo exchange, device-to-device copies) against the undecomposed handle, bit
+    for bit -- SURVEY 8e's determinism check on random scenes, slab counts, halo widths, call boundaries, overlap / split-launch modes."""
+    X, Y = c["X"], c["Y"]
+    base, water, wall, u, drops = build_case(pkg, c)
+    nd = 0 if drops is None else len(drops)
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    g = whole = None
+    bad = []
+    try:
+        g = E.Group(c["nslab"], X, Y, halo=c["halo"], devices=[0] * c["nslab"], transport=E.TRANSPORT_LOCAL, n_droplets=nd)
+        whole = E.Handle(X, Y, nd)
+        g.upload(base, water, wall, drops)
+        whole.upload(base, water, wall, drops)
+        g.set_params(p, u["initial_T"])
+        whole.set_params(p, u["initial_T"])
+        for hh in g.slabs + [whole]:
+            hh.iter = c["iter0"]
+        opts = [(E.Handle.OPT_DRY_PAIRS, c["pairs"]), (E.Handle.OPT_ROW_BANDS, c["bands"]), (E.Handle.OPT_DRY_KERNEL, c["dry_kernel"])]
+        if nd:
+            opts.append((E.Handle.OPT_SPLAT_ORDER, 1))
+        for k, v in opts:
+            g.set_option(k, v)
+            whole.set_option(k, v)
+        g.set_option(E.Handle.OPT_EXCHANGE_OVERLAP, c["overlap"])
+        g.set_option(E.Handle.OPT_SPLIT_LAUNCH, c["split"])
+        if nd:
+            g.set_option(E.Handle.OPT_POOL_EXACT, c["pool_exact"])
+        fields = ["BASE_CUR", "WATER_CUR", "WALL_CUR"] + ([] if c["dry"] else ["LIGHT_0", "LIGHT_1", "BASE_DISP", "WATER_0"]) + (["PRECIP_DEP"] if nd else [])
+        done = 0
+        for n in c["steps"]:
+            g.step(n)
+            whole.step(n)
+            done += n
+            for f in fields:
+                a, b = g.read(f), whole.read_rect(f)
+                if not np.array_equal(a, b, equal_nan=True):
+                    ne = (a != b) & ~(np.isnan(a.astype(np.float64)) & np.isnan(b.astype(np.float64)))
+                    ys, xs = np.nonzero(ne.any(axis=-1))
+                    bad.append({"field": f, "after_iterations": done, "values": int(ne.sum()), "first": [int(xs[0]), int(ys[0])]})
+            if bad:
+                break
+        if nd and not bad:
+            g.exchange()
+            g.sync()
+            d, d_ref = g.particles(), whole.read_particles()
+            if not np.array_equal(d, d_ref, equal_nan=True):
+                bad.append({"field": "DROPS", "after_iterations": done, "values": int((d != d_ref).sum())})
+        wb = whole.read_rect("BASE_CUR")
+        info = {"blown_up": not bool(np.isfinite(wb).all() and np.abs(wb[..., :2]).max() < 1e4), "fastest": float(np.abs(wb[..., :2]).max())}
+    except E.WxError as e:  # reported: the exact path's list overflowed / a slab outran the |vx| bound its period was sized for (a blown-up state)
+        return [], {"error": str(e)}
+    finally:
+        if g is not None:
+            g.close()
+        if whole is not None:
+            whole.close()
+    return bad, info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cases", type=int, default=100000)
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--max-cells", type=int, default=600000)
+    ap.add_argument("--mode", choices=["oracle", "group"], default="oracle", help="oracle: one handle against the CPU oracle; group: N slabs against one handle")
     ap.add_argument("--only", type=int, default=-1, help="run only case K of the seed's sequence")
     ap.add_argument("--first", type=int, default=0, help="skip the cases before this one (they are still drawn: same sequence)")
     ap.add_argument("--last", type=int, default=1 << 30)
@@ -199,6 +278,8 @@ def main():
     failures, ran, reported = [], 0, 0
     for k in range(a.cases):
         c = draw_case(rng, a.max_cells)
+        if a.mode == "group":
+            c = draw_group(rng, c)
         if (a.only >= 0 and k != a.only) or k < a.first:
             continue
         if k > a.last:
@@ -208,7 +289,7 @@ def main():
         if a.override:
             c.update(json.loads(a.override))
         t1 = time.time()
-        bad, info = run_case(pkg, E, wx_oracle, c)
+        bad, info = run_case(pkg, E, wx_oracle, c) if a.mode == "oracle" else run_group_case(pkg, E, c)
         ran += 1
         reported += 1 if info.get("error") else 0
         if bad and info.get("blown_up"):  # NaN / inf / |v| > 1e4 cells per iteration (the reference blows up the same way): float -> int conversions out of range differ between CPU and GPU
@@ -216,11 +297,11 @@ def main():
             bad = []
         tag = "MISMATCH" if bad else ("reported: " + info["error"][:60] if info.get("error") else "ok")
         print(f"case {k:4d} {c['X']:5d}x{c['Y']:<5d} {'dry' if c['dry'] else 'wet'} sigma {c['sigma']:.2f} steps {c['steps']} drops {c['drops']:4d} brush "
-              f"{c['brush']['type'] if c['brush'] else '-':>2} pairs {c['pairs']} bands {c['bands']} set {c['kernel_set']}{c['dry_kernel']} fastest {info.get('fastest')}  {time.time() - t1:.1f}s  {tag}", flush=True)
+              f"{c['brush']['type'] if c['brush'] else '-':>2} pairs {c['pairs']} bands {c['bands']} set {c['kernel_set']}{c['dry_kernel']}{' slabs %d halo %d overlap %d split %d' % (c['nslab'], c['halo'], c['overlap'], c['split']) if a.mode == 'group' else ''} fastest {info.get('fastest')}  {time.time() - t1:.1f}s  {tag}", flush=True)
         if bad:
             failures.append({"case": k, "recipe": c, "mismatches": bad})
             print(json.dumps(failures[-1]), flush=True)
-    print(json.dumps({"seed": a.seed, "cases_run": ran, "mismatching_cases": len(failures), "cases_ending_in_a_reported_error": reported,
+    print(json.dumps({"mode": a.mode, "seed": a.seed, "cases_run": ran, "mismatching_cases": len(failures), "cases_ending_in_a_reported_error": reported,
                       "seconds": round(time.time() - t0, 1)}))
     sys.exit(1 if failures else 0)
 
