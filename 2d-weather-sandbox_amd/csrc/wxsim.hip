@@ -1691,7 +1691,7 @@ int wx_step_overlap(wx_sim *s, int n_iter, unsigned flags)
         if (s->pool_remote) { // slab: the grid of this iteration is valid on the owned columns + (halo - 6*(j+1)) ghost columns; the
           // feedback texture is exact where every droplet within a sprite radius (6 px) was processed, so the owned columns
           // need 6 valid ghost columns even in the last iteration of a period
-          const int margin = s->halo - s->cone - (s->cone + 3) * s->period_j; // >= 6: checked before the loop
+          const int margin = s->halo - s->cone - (s->cone + 3) * s->period_j; // >= cone + 1 (wx_slab_period): checked before the loop
           sp = SlabP{s->halo - margin, s->X - s->halo + margin, s->halo, s->X - s->halo, s->seam, s->period_j + 1, s->pool_remote, s->pool_flips, s->pool_owned, s->pool_exact};
           d_in = d_out = s->drops[0]; // the partitioned pool is updated in place
         }
@@ -2197,9 +2197,14 @@ int wx_slab_cone(const wx_sim *s) { return s ? s->cone : 0; }
 int wx_slab_period(const wx_sim *s)
 {
   if (!s || s->halo <= 0) return 0;
-  if (s->pool_remote) { // with particles: the sprite radius (6) stays valid in the last iteration; `cone` for the first, cone + 3 for every further one
-    if (s->halo < 6 + s->cone) return 0;
-    return std::min(15, 1 + (s->halo - 6 - s->cone) / (s->cone + 3)); // (at most 15: the flip history is a 16-bit mask)
+  if (s->pool_remote) { // with particles: `cone` columns for the first iteration, cone + 3 for every further one, and in the LAST one the zone in
+    // which droplets are processed must still reach every droplet that ENDS the iteration within a sprite radius of the owned columns: it is
+    // tested on the position a droplet starts from and deposits where it arrives, up to floor|vx| + 1 = cone - 5 columns further -- a margin
+    // of 5.5 + |vx| < cone + 1 columns (round 6, tools/fuzz_parity.py --mode group: with jets of 2 cells / iteration the margin of 6 left
+    // one sprite column at a slab's edge undeposited; for |vx| < 1 and the halos particles allow -- multiples of 64 -- the period is
+    // WX_SLAB_PERIOD_PARTICLES(halo) as before)
+    if (s->halo < 2 * s->cone + 1) return 0;
+    return std::min(15, 1 + (s->halo - 2 * s->cone - 1) / (s->cone + 3)); // (at most 15: the flip history is a 16-bit mask)
   }
   return s->halo / s->cone;
 }
@@ -2212,7 +2217,7 @@ int wx_slab_set_vx_bound(wx_sim *s, float v_measured)
   // 0.6 cells / iteration that still is less than one cell
   const float bound = v_measured * 1.25f + 0.25f;
   const int cone = WX_SLAB_CONE + (bound >= 1.0f ? (int)floorf(bound) : 0);
-  if (s->halo > 0 && (cone > s->halo || (s->pool_remote && 6 + cone > s->halo)))
+  if (s->halo > 0 && (cone > s->halo || (s->pool_remote && 2 * cone + 1 > s->halo)))
     return fail(s, WX_E_STATE, "|vx| up to %.2f cells / iteration needs %d ghost columns per iteration; the handle has %d: a wider halo (wx_create_slab) is needed for this flow",
                 v_measured, cone, s->halo);
   s->vx_known = v_measured;

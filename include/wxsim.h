@@ -116,7 +116,9 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
  * where it is, and the next boundary pass feeds that deposit through advection and pressure (3 more) -- 9 columns per iteration, after 6
  * for the first (whose feedback texture came with the exchange). Iteration j (0-based) of a period is exact on the owned columns +
  * halo - 6 - 9j ghost columns, droplets are processed there, and the owned columns need a sprite radius of that left in the last
- * iteration: WX_SLAB_PERIOD_PARTICLES(halo) iterations per exchange (at most 15: the flip history is a 16-bit mask).
+ * iteration: WX_SLAB_PERIOD_PARTICLES(halo) iterations per exchange (at most 15: the flip history is a 16-bit mask). (For flows of one
+ * cell per iteration and more wx_slab_period() is the authority: the cone is 6 + floor|vx|, and the last iteration keeps cone + 1 columns
+ * instead of 6 -- a droplet is tested where it starts from and deposits where it arrives.)
  * (Rounds 2-3 assumed 6 per iteration throughout, which the measured spread -- 6 to 7 columns -- satisfied in every test but the
  * worst case does not.) */
 #define WX_SLAB_CONE 6
