@@ -32,10 +32,12 @@ SLIDERS = {"vorticity": (0.0, 0.010), "dragMultiplier": (0.0, 1.0), "wind": (-1.
            "greenhouseGases": (0.0, 0.01), "waterGreenHouseEffect": (0.0, 0.01), "IR_rate": (0.0, 10.0), "soundingForcing": (0.0, 0.001)}
 
 
-def draw_case(rng, max_cells):
+def draw_case(rng, max_cells, big=False):
     c = {}
     kind = rng.choice(["tiny", "small", "small", "mid", "wide", "tall"])
-    if kind == "tiny":
+    if big:  # (--big: the launch shapes of grids that fill the chip -- row bands per XCD, several rounds of segments, tail segments)
+        X, Y = int(rng.integers(1000, 9000)), int(rng.integers(512, 2100))
+    elif kind == "tiny":
         X, Y = int(rng.integers(2, 70)), int(rng.integers(4, 40))
     elif kind == "small":
         X, Y = int(rng.integers(40, 400)), int(rng.integers(12, 200))
@@ -75,6 +77,8 @@ def draw_case(rng, max_cells):
     c["dry_kernel"] = int(rng.random() < 0.8)  # the dry stencil: row-marching (default) / LDS-tiled
     c["water0_on_demand"] = int(rng.random() < 0.7)
     c["data_seed"] = int(rng.integers(0, 2**31))
+    c["brush_toggle"] = bool(rng.random() < 0.5)  # the brush is held down in every other step only (a host's mouse-up / mouse-down between frames)
+    c["subrect"] = bool(rng.random() < 0.3)  # also read a random sub-rectangle of every field (wx_read_rect's x / y / w / h)
     return c
 
 
@@ -146,9 +150,21 @@ def run_case(pkg, E, wx_oracle, c):
         h.set_option(h.OPT_WATER0_ON_DEMAND, c["water0_on_demand"])
         if nd:
             h.set_option(h.OPT_SPLAT_ORDER, 1)
-        for n in c["steps"]:
+        rng = np.random.default_rng(c["data_seed"] ^ 0x5EED)
+        for k_step, n in enumerate(c["steps"]):
+            if c.get("brush_toggle") and c["brush"] and k_step > 0:  # mouse up / down between two steps: new parameters on both sides
+                u2 = dict(u, userInputType=(c["brush"]["type"] if k_step % 2 == 0 else -1))
+                h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u2), u["initial_T"])
+                o.set_params(u2)
             h.step(n)
             o.step(n)
+            if c.get("subrect"):
+                x0, y0 = int(rng.integers(0, X)), int(rng.integers(0, Y))
+                w, hh = int(rng.integers(1, X - x0 + 1)), int(rng.integers(1, Y - y0 + 1))
+                for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR") + (() if c["dry"] else ("LIGHT_1", "BASE_DISP")):
+                    a, b = h.read_rect(f, x0, y0, w, hh), o.field(f)[y0:y0 + hh, x0:x0 + w]
+                    if not np.array_equal(a, b, equal_nan=True):
+                        bad.append({"field": f + " sub-rectangle", "rect": [x0, y0, w, hh], "after_iterations": h.iter - c["iter0"]})
             fields = list(GRID_FIELDS if not c["dry"] else ["BASE_CUR", "BASE_DISP", "WATER_CUR", "WATER_0", "WALL_CUR"])
             for f in fields:
                 a, b = h.read_rect(f), o.field(f)
@@ -184,7 +200,7 @@ def draw_group(rng, c):
         halo = 64
         xo = max(64 if n > 2 else 128, -(-c["X"] // n // 64) * 64)
     else:  # (a halo narrower than the flow's dependency cone is refused by the first step: reported, not a mismatch)
-        lo = 6 if c["sigma"] <= 0.2 and not c["vortices"] else (12 if c["sigma"] <= 0.45 else 24)
+        lo = 6 if c["sigma"] <= 0.05 and not c["vortices"] else (12 if c["sigma"] <= 0.3 and not c["vortices"] else 24)
         halo = int(rng.choice([h for h in (6, 12, 18, 24, 42, 48, 64) if h >= lo]))
         xo = max(halo, -(-c["X"] // n))
     c["X"] = n * xo
@@ -259,6 +275,7 @@ def main():
     ap.add_argument("--cases", type=int, default=100000)
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--max-cells", type=int, default=600000)
+    ap.add_argument("--big", action="store_true", help="grids of 1000-9000 x 512-2100 cells (use with --max-cells 8000000)")
     ap.add_argument("--mode", choices=["oracle", "group"], default="oracle", help="oracle: one handle against the CPU oracle; group: N slabs against one handle")
     ap.add_argument("--only", type=int, default=-1, help="run only case K of the seed's sequence")
     ap.add_argument("--first", type=int, default=0, help="skip the cases before this one (they are still drawn: same sequence)")
@@ -277,7 +294,7 @@ def main():
     t0 = time.time()
     failures, ran, reported = [], 0, 0
     for k in range(a.cases):
-        c = draw_case(rng, a.max_cells)
+        c = draw_case(rng, a.max_cells, a.big)
         if a.mode == "group":
             c = draw_group(rng, c)
         if (a.only >= 0 and k != a.only) or k < a.first:
