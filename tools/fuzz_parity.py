@@ -204,7 +204,7 @@ def draw_group(rng, c):
         halo = int(rng.choice([h for h in (6, 12, 18, 24, 42, 48, 64) if h >= lo]))
         xo = max(halo, -(-c["X"] // n))
     c["X"] = n * xo
-    c.update(nslab=n, halo=halo, overlap=int(rng.random() < 0.6), split=int(rng.random() < 0.25), pool_exact=1, kernel_set=1)
+    c.update(nslab=n, halo=halo, overlap=int(rng.random() < 0.6), split=int(rng.random() < 0.25), pool_exact=1, kernel_set=int(rng.random() < 0.9))
     c["steps"] = [int(v) for v in rng.integers(1, 2 * max(1, halo // 6) + 3, size=int(rng.integers(1, 4)))]
     return c
 
@@ -227,7 +227,7 @@ def run_group_case(pkg, E, c):
         whole.set_params(p, u["initial_T"])
         for hh in g.slabs + [whole]:
             hh.iter = c["iter0"]
-        opts = [(E.Handle.OPT_DRY_PAIRS, c["pairs"]), (E.Handle.OPT_ROW_BANDS, c["bands"]), (E.Handle.OPT_DRY_KERNEL, c["dry_kernel"])]
+        opts = [(E.Handle.OPT_DRY_PAIRS, c["pairs"]), (E.Handle.OPT_ROW_BANDS, c["bands"]), (E.Handle.OPT_DRY_KERNEL, c["dry_kernel"]), (E.Handle.OPT_KERNEL_SET, c["kernel_set"])]
         if nd:
             opts.append((E.Handle.OPT_SPLAT_ORDER, 1))
         for k, v in opts:
