@@ -78,6 +78,7 @@ def draw_case(rng, max_cells, big=False):
     c["water0_on_demand"] = int(rng.random() < 0.7)
     c["data_seed"] = int(rng.integers(0, 2**31))
     c["brush_toggle"] = bool(rng.random() < 0.5)  # the brush is held down in every other step only (a host's mouse-up / mouse-down between frames)
+    c["pieces"] = bool(rng.random() < 0.3)  # steps cut into two pieces, the first with WX_OVERLAP_MORE_TO_COME
     c["subrect"] = bool(rng.random() < 0.3)  # also read a random sub-rectangle of every field (wx_read_rect's x / y / w / h)
     return c
 
@@ -130,6 +131,32 @@ def build_case(pkg, c):
 
 
 def run_case(pkg, E, wx_oracle, c):
+    """One case on its own."""
+    g = case_steps(pkg, E, wx_oracle, c)
+    while True:
+        try:
+            next(g)
+        except StopIteration as e:
+            return e.value
+
+
+def run_interleaved(pkg, E, wx_oracle, cases):
+    """Several handles alive at once, their steps in turn (state that a handle shares with the process -- work lists, hint words, scratch
+    sized by another handle -- would show here). Returns the (bad, info) of every case."""
+    gens = [case_steps(pkg, E, wx_oracle, c) for c in cases]
+    out = [None] * len(gens)
+    while any(o is None for o in out):
+        for i, g in enumerate(gens):
+            if out[i] is None:
+                try:
+                    next(g)
+                except StopIteration as e:
+                    out[i] = e.value
+    return out
+
+
+def case_steps(pkg, E, wx_oracle, c):
+    """Generator: yields after every step of the case; its return value is (mismatches, info)."""
     X, Y = c["X"], c["Y"]
     base, water, wall, u, drops = build_case(pkg, c)
     nd = 0 if drops is None else len(drops)
@@ -156,8 +183,16 @@ def run_case(pkg, E, wx_oracle, c):
                 u2 = dict(u, userInputType=(c["brush"]["type"] if k_step % 2 == 0 else -1))
                 h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u2), u["initial_T"])
                 o.set_params(u2)
-            h.step(n)
+            pieces = [n]
+            if c.get("pieces") and n > 1:  # the step cut into pieces whose all but the last skip the display-side stores (WX_OVERLAP_MORE_TO_COME)
+                k1 = int(rng.integers(1, n))
+                pieces = [k1, n - k1]
+            for i_p, k_p in enumerate(pieces):
+                h.step(k_p, 4 if i_p + 1 < len(pieces) else 0)
             o.step(n)
+            yield
+            if not c["dry"] and not np.array_equal(h.read_rect("CURL"), o.field("CURL"), equal_nan=True):
+                bad.append({"field": "CURL", "after_iterations": h.iter - c["iter0"]})
             if c.get("subrect"):
                 x0, y0 = int(rng.integers(0, X)), int(rng.integers(0, Y))
                 w, hh = int(rng.integers(1, X - x0 + 1)), int(rng.integers(1, Y - y0 + 1))
@@ -275,6 +310,7 @@ def main():
     ap.add_argument("--cases", type=int, default=100000)
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--max-cells", type=int, default=600000)
+    ap.add_argument("--interleave", action="store_true", help="oracle mode: half of the cases run with a second handle alive, steps in turn")
     ap.add_argument("--big", action="store_true", help="grids of 1000-9000 x 512-2100 cells (use with --max-cells 8000000)")
     ap.add_argument("--mode", choices=["oracle", "group"], default="oracle", help="oracle: one handle against the CPU oracle; group: N slabs against one handle")
     ap.add_argument("--only", type=int, default=-1, help="run only case K of the seed's sequence")
@@ -291,6 +327,7 @@ def main():
     import wx_oracle
     wx_oracle.build()
     rng = np.random.default_rng(a.seed)
+    rng_il = np.random.default_rng(a.seed + 1000003)  # (companions come from a sequence of their own: --seed S --only K still reproduces case K alone)
     t0 = time.time()
     failures, ran, reported = [], 0, 0
     for k in range(a.cases):
@@ -306,7 +343,14 @@ def main():
         if a.override:
             c.update(json.loads(a.override))
         t1 = time.time()
-        bad, info = run_case(pkg, E, wx_oracle, c) if a.mode == "oracle" else run_group_case(pkg, E, c)
+        if a.mode == "oracle" and a.interleave and rng_il.random() < 0.5 and a.only < 0:  # this case and a second small one, handles alive together
+            c2 = draw_case(rng_il, min(a.max_cells, 60000))
+            (bad, info), (bad2, info2) = run_interleaved(pkg, E, wx_oracle, [c, c2])
+            if bad2 and not info2.get("blown_up"):
+                failures.append({"case": k, "interleaved_with": c, "recipe": c2, "mismatches": bad2})
+                print("MISMATCH in the interleaved companion:", json.dumps(failures[-1]), flush=True)
+        else:
+            bad, info = run_case(pkg, E, wx_oracle, c) if a.mode == "oracle" else run_group_case(pkg, E, c)
         ran += 1
         reported += 1 if info.get("error") else 0
         if bad and info.get("blown_up"):  # NaN / inf / |v| > 1e4 cells per iteration (the reference blows up the same way): float -> int conversions out of range differ between CPU and GPU
