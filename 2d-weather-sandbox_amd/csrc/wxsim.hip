@@ -2428,7 +2428,7 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
   wait_unpacked(s); // ghost columns written on the comm stream are part of what a readback sees
   if (int rc = validate_ghost_flag(s)) return rc;
   if (field == WX_FIELD_EMITTED) {
-    if (w <= 0 || h <= 0 || x < 0 || y < 0 || x + w > s->X || y + h > s->Y)
+    if (w <= 0 || h <= 0 || x < 0 || y < 0 || (long long)x + w > s->X || (long long)y + h > s->Y)
       return fail(s, WX_E_RANGE, "wx_read_rect: rect (%d,%d %dx%d) outside %dx%d (no wrap)", x, y, w, h, s->X, s->Y);
     if (dtype != WX_DTYPE_F16 && dtype != WX_DTYPE_F32) return fail(s, WX_E_INVALID, "wx_read_rect: emittedLight is RGBA16F: WX_DTYPE_F16 or WX_DTYPE_F32");
     const int rc = emitted_rect(s, x, y, w, h);
@@ -2446,14 +2446,15 @@ int wx_read_rect(wx_sim *s, int field, int x, int y, int w, int h, void *dst, in
     for (size_t i = 0; i < tmp.size(); i++) d[i] = __half2float(tmp[i]);
     return WX_OK;
   }
+  // (the rectangle first: fields that are made on demand are made for the rows asked for -- rows outside the grid would be written outside it)
+  if (w <= 0 || h <= 0 || x < 0 || y < 0 || (long long)x + w > s->X || (long long)y + h > s->Y)
+    return fail(s, WX_E_RANGE, "wx_read_rect: rect (%d,%d %dx%d) outside %dx%d (no wrap)", x, y, w, h, s->X, s->Y);
   const void *ptr;
   int ch, el;
   if (int rc = field_info(s, field, &ptr, &ch, &el, y, h)) {
     if (rc != -1) return rc; // (a field that is made on demand could not be made: the message is set)
     return fail(s, WX_E_INVALID, "wx_read_rect: unknown field %d", field);
   }
-  if (w <= 0 || h <= 0 || x < 0 || y < 0 || x + w > s->X || y + h > s->Y)
-    return fail(s, WX_E_RANGE, "wx_read_rect: rect (%d,%d %dx%d) outside %dx%d (no wrap)", x, y, w, h, s->X, s->Y);
   const bool is_wall = (el == 1);
   if (is_wall ? (dtype != WX_DTYPE_I8 && dtype != WX_DTYPE_I32) : (dtype != WX_DTYPE_F32))
     return fail(s, WX_E_INVALID, "wx_read_rect: dtype %d does not fit field %d", dtype, field);
@@ -2476,7 +2477,7 @@ int wx_read_particles(wx_sim *s, int first, int count, float *dst)
 {
   if (!s || !dst) return WX_E_INVALID;
   DeviceScope dev_scope(s);
-  if (first < 0 || count < 0 || first + count > s->n_drops) return fail(s, WX_E_RANGE, "wx_read_particles: [%d, %d) outside 0..%d", first, first + count, s->n_drops);
+  if (first < 0 || count < 0 || (long long)first + count > s->n_drops) return fail(s, WX_E_RANGE, "wx_read_particles: [%d, %d) outside 0..%d", first, first + count, s->n_drops);
   if (count == 0) return WX_OK;
   wait_unpacked(s); // (a pool exchange still running on the side stream)
   HIPCHK(s, hipMemcpyAsync(dst, s->drops[s->drop_cur] + 5 * (size_t)first, (size_t)count * 20, hipMemcpyDeviceToHost, s->stream));
@@ -2506,7 +2507,7 @@ int wx_stream_frame(wx_sim *s, int x, int y, int w, int h, void *host_dst)
 {
   if (!s || !host_dst) return WX_E_INVALID;
   if (!s->uploaded) return fail(s, WX_E_STATE, "wx_stream_frame before wx_upload");
-  if (w <= 0 || h <= 0 || x < 0 || y < 0 || x + w > s->X || y + h > s->Y)
+  if (w <= 0 || h <= 0 || x < 0 || y < 0 || (long long)x + w > s->X || (long long)y + h > s->Y)
     return fail(s, WX_E_RANGE, "wx_stream_frame: rect (%d,%d %dx%d) outside %dx%d (no wrap)", x, y, w, h, s->X, s->Y);
   if (!s->copy_stream) {
     HIPCHK(s, hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
