@@ -304,6 +304,53 @@ def run_group_case(pkg, E, c):
     return bad, info
 
 
+def run_setup_case(pkg, E, c):
+    """--mode setup: the device-side initialisers (wx_setup_columns from 1-D descriptors, wx_setup_terrain with the shader's terrain noise on
+    the device, wx_init_droplets) against the host generator + wx_upload: bit-identical textures (setup_terrain: all but the handful of
+    columns whose height sits on a row boundary in the last bit of sin()), and the same run afterwards."""
+    S = pkg.synth
+    X, Y = c["X"], max(16, c["Y"])  # (wx_setup_terrain: at least 16 rows)
+    snap = int([1, 2, 4][c["data_seed"] % 3])
+    cloud = bool(c["cloud"])
+    desc = S.terrain_columns(X, Y, seed=c["tseed"], height_mult=c["tmult"], snap=snap, cloud_deck=cloud)
+    base, water, wall = S.terrain_grid(X, Y, seed=c["tseed"], height_mult=c["tmult"], snap=snap)
+    if cloud:
+        S.add_cloud_deck(water, wall)
+    gui = pkg.params.merge_settings(None)
+    gui["sunAngle"] = c["sun"]
+    u = pkg.params.uniforms_from_gui(gui, Y, quad_scale=0)
+    u["enablePrecipitation"] = 0
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    a, b, t = E.Handle(X, Y, 0), E.Handle(X, Y, 0), E.Handle(X, Y, 0)
+    bad = []
+    try:
+        a.upload(base, water, wall)
+        b.setup_columns(desc)
+        t.setup_terrain(S.sounding_rows(Y, cloud_deck=cloud), seed=c["tseed"], height_mult=c["tmult"], snap=snap, sim_height=float(gui["simHeight"]))
+        for hh in (a, b):
+            hh.set_params(p, u["initial_T"])
+        terr = np.zeros(X, bool)
+        for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR"):
+            terr |= (b.read_rect(f) != t.read_rect(f)).any(axis=(0, 2))
+        if terr.sum() > max(4, X // 200):
+            bad.append({"field": "terrain", "what": "setup_terrain vs setup_columns: %d of %d columns differ" % (int(terr.sum()), X)})
+        for when in ("after setup", "after 5 iterations"):
+            for f in ("BASE_CUR", "WATER_CUR", "WATER_0", "WALL_CUR", "LIGHT_0"):
+                if not np.array_equal(a.read_rect(f), b.read_rect(f)):
+                    bad.append({"field": f, "what": "setup_columns vs upload, " + when})
+            if bad:
+                break
+            a.step(5)
+            b.step(5)
+        info = {"blown_up": False, "fastest": 0.0, "terrain_columns_differing": int(terr.sum())}
+    except E.WxError as e:
+        return [], {"error": str(e)}
+    finally:
+        for hh in (a, b, t):
+            hh.close()
+    return bad, info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
@@ -312,7 +359,7 @@ def main():
     ap.add_argument("--max-cells", type=int, default=600000)
     ap.add_argument("--interleave", action="store_true", help="oracle mode: half of the cases run with a second handle alive, steps in turn")
     ap.add_argument("--big", action="store_true", help="grids of 1000-9000 x 512-2100 cells (use with --max-cells 8000000)")
-    ap.add_argument("--mode", choices=["oracle", "group"], default="oracle", help="oracle: one handle against the CPU oracle; group: N slabs against one handle")
+    ap.add_argument("--mode", choices=["oracle", "group", "setup"], default="oracle", help="oracle: one handle against the CPU oracle; group: N slabs against one handle")
     ap.add_argument("--only", type=int, default=-1, help="run only case K of the seed's sequence")
     ap.add_argument("--first", type=int, default=0, help="skip the cases before this one (they are still drawn: same sequence)")
     ap.add_argument("--last", type=int, default=1 << 30)
@@ -350,7 +397,7 @@ def main():
                 failures.append({"case": k, "interleaved_with": c, "recipe": c2, "mismatches": bad2})
                 print("MISMATCH in the interleaved companion:", json.dumps(failures[-1]), flush=True)
         else:
-            bad, info = run_case(pkg, E, wx_oracle, c) if a.mode == "oracle" else run_group_case(pkg, E, c)
+            bad, info = run_case(pkg, E, wx_oracle, c) if a.mode == "oracle" else (run_group_case(pkg, E, c) if a.mode == "group" else run_setup_case(pkg, E, c))
         ran += 1
         reported += 1 if info.get("error") else 0
         if bad and info.get("blown_up"):  # NaN / inf / |v| > 1e4 cells per iteration (the reference blows up the same way): float -> int conversions out of range differ between CPU and GPU
@@ -358,7 +405,7 @@ def main():
             bad = []
         tag = "MISMATCH" if bad else ("reported: " + info["error"][:60] if info.get("error") else "ok")
         print(f"case {k:4d} {c['X']:5d}x{c['Y']:<5d} {'dry' if c['dry'] else 'wet'} sigma {c['sigma']:.2f} steps {c['steps']} drops {c['drops']:4d} brush "
-              f"{c['brush']['type'] if c['brush'] else '-':>2} pairs {c['pairs']} bands {c['bands']} set {c['kernel_set']}{c['dry_kernel']}{' slabs %d halo %d overlap %d split %d' % (c['nslab'], c['halo'], c['overlap'], c['split']) if a.mode == 'group' else ''} fastest {info.get('fastest')}  {time.time() - t1:.1f}s  {tag}", flush=True)
+              f"{c['brush']['type'] if c['brush'] else '-':>2} pairs {c['pairs']} bands {c['bands']} set {c['kernel_set']}{c['dry_kernel']}{' slabs %d halo %d overlap %d split %d' % (c['nslab'], c['halo'], c['overlap'], c['split']) if a.mode == 'group' else ''} fastest {info.get('fastest')}{' terrain columns differing %s' % info.get('terrain_columns_differing') if a.mode == 'setup' else ''}  {time.time() - t1:.1f}s  {tag}", flush=True)
         if bad:
             failures.append({"case": k, "recipe": c, "mismatches": bad})
             print(json.dumps(failures[-1]), flush=True)
