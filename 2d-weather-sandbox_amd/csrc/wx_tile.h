@@ -218,12 +218,19 @@ struct VxTrack {
   int *violation;  // float bits of a |vx| that reached `limit` (0: none)
   float limit;     // |vx| the current period's ghost columns allow (cone - 5); <= 0: whole-domain handle, nothing to check
   int zone_l, zone_r; // strips [0, zone_l) and [zone_r, n) are watched (zone_l >= zone_r: all of them)
+  float limit_in;  // the strips in between consume no ghost column -- until |vx| spans the two halo widths that separate them from the ghost
+                   // columns: a jet that fast (2 * halo - 8 cells / iteration: a state that has blown up) is a violation too (0: not checked)
 };
 __device__ __forceinline__ void vx_track_commit(const VxTrack &t, float lane_max, int lane, int strip = 0)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (t.zone_l < t.zone_r && strip >= t.zone_l && strip < t.zone_r) return; // (wave-uniform)
   float m = lane_max;
+  if (t.zone_l < t.zone_r && strip >= t.zone_l && strip < t.zone_r) { // (wave-uniform) an interior strip
+    if (!(t.limit_in > 0.0f)) return;
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0 && t.violation != nullptr && m >= t.limit_in) atomicMax(t.violation, __float_as_int(m));
+    return;
+  }
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if (lane == 0 && t.max_bits != nullptr && m >= 0.5f) {
     atomicMax(t.max_bits, __float_as_int(m)); // (bit patterns of positive floats order like ints)
@@ -235,14 +242,23 @@ __device__ __forceinline__ void vx_track_commit(const VxTrack &t, float lane_max
 // (columns [0, col_l) and [col_r, X) of every row; col_l >= col_r: all columns)
 __global__ void k_vx_scan(int X, int Y, int col_l, int col_r, const float4 *__restrict__ base, VxTrack t)
 {
-  float m = 0.0f;
+  float m = 0.0f, m_in = 0.0f;
   const size_t n = (size_t)X * Y;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int x = (int)(i % (size_t)X);
-    if (col_l >= col_r || x < col_l || x >= col_r) m = fmaxf(m, fabsf(base[i].x));
+    const float v = fabsf(base[i].x);
+    if (col_l >= col_r || x < col_l || x >= col_r)
+      m = fmaxf(m, v);
+    else
+      m_in = fmaxf(m_in, v);
   }
   t.zone_l = t.zone_r = 0;
   vx_track_commit(t, m, threadIdx.x & 63);
+  if (t.limit_in > 0.0f) { // the columns in between: only against the interior limit
+    t.zone_l = 0;
+    t.zone_r = 1;
+    vx_track_commit(t, m_in, threadIdx.x & 63, 0);
+  }
 }
 
 // comm stream: wait until the edge strips of the launch that carries `want` arrivals (cumulative) are done

@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(64 * WX_WET_WPB, WX_WET_MINWAVES) void k_march_wet(
   {
 #if WX_WET_ARGS_MEM && defined(__HIP_DEVICE_COMPILE__)
     const __attribute__((address_space(4))) VxTrack &vc = *(const __attribute__((address_space(4))) VxTrack *)(ka_c + offsetof(KArgs, vx));
-    vx_track_commit(VxTrack{vc.max_bits, vc.violation, vc.limit, vc.zone_l, vc.zone_r}, vx_seen, lane, strip);
+    vx_track_commit(VxTrack{vc.max_bits, vc.violation, vc.limit, vc.zone_l, vc.zone_r, vc.limit_in}, vx_seen, lane, strip);
 #else
     vx_track_commit(vx_arg, vx_seen, lane, strip);
 #endif

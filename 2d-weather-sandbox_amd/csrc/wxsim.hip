@@ -737,7 +737,7 @@ static VxTrack vx_track(wx_sim *s)
   if (s->halo > 0) s->vx_check = true;
   // slabs watch three halo widths from either edge of the local array (in columns here; the launch functions turn them into strips)
   const int zl = s->halo > 0 ? 3 * s->halo : 0, zr = s->halo > 0 ? s->X - 3 * s->halo : 0;
-  return VxTrack{&s->state->vx_max_bits, &s->state->cone_violation, s->halo > 0 ? (float)(s->cone - 5) : 0.0f, zl, zr};
+  return VxTrack{&s->state->vx_max_bits, &s->state->cone_violation, s->halo > 0 ? (float)(s->cone - 5) : 0.0f, zl, zr, s->halo > 0 ? (float)std::max(1, 2 * s->halo - 8) : 0.0f};
 }
 
 // stream / events / second exact-path list of the concurrent edge group (created by the first split iteration)
@@ -1843,7 +1843,8 @@ static int validate_ghost_flag(wx_sim *s)
       HIPCHK(s, hipMemsetAsync(&s->state->cone_violation, 0, 4, s->stream));
       return fail(s, WX_E_STATE, "|vx| reached %.3f cells / iteration in an exchange period sized for |vx| < %d (%d ghost columns per iteration): the flow accelerated "
                                  "faster than the margin of wx_slab_set_vx_bound allows, ghost columns were consumed faster than assumed and the slab may differ "
-                                 "from the undecomposed run since", v, s->cone - 5, s->cone);
+                                 "from the undecomposed run since (a velocity of 2 * halo - 8 = %d cells / iteration and more is reported wherever it occurs: from three halo widths "
+                                 "inside the slab it reaches the ghost columns)", v, s->cone - 5, s->cone, std::max(1, 2 * s->halo - 8));
     }
   }
   if (s->sync_words && s->split_check) { // did a device-side hand-off of a split iteration give up polling?
@@ -2233,7 +2234,7 @@ int wx_slab_set_vx_bound(wx_sim *s, float v_measured)
 static void vx_scan_enqueue(wx_sim *s, hipStream_t st, bool check)
 {
   const VxTrack t = vx_track(s);
-  hipLaunchKernelGGL(k_vx_scan, dim3(1024), dim3(256), 0, st, s->X, s->Y, t.zone_l, t.zone_r, s->base[0], VxTrack{t.max_bits, t.violation, check ? t.limit : 0.0f, 0, 0});
+  hipLaunchKernelGGL(k_vx_scan, dim3(1024), dim3(256), 0, st, s->X, s->Y, t.zone_l, t.zone_r, s->base[0], VxTrack{t.max_bits, t.violation, check ? t.limit : 0.0f, 0, 0, check ? t.limit_in : 0.0f});
 }
 
 int wx_slab_vx_take(wx_sim *s, float *vmax)

@@ -225,6 +225,43 @@ def test_slab_outrunning_its_vx_bound_is_reported(pkg):
     h.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("wet", [True, False])
+def test_interior_jet_faster_than_the_slab_can_follow_is_reported(pkg, wet):
+    """The strips three halo widths and more from a slab's edges are not watched for |vx| -- they consume no ghost column -- until a
+    velocity spans the two halo widths between them and the ghost columns (a state that has blown up: tools/fuzz_parity.py --mode group met
+    2 600 cells / iteration under a brush). Such a jet is a violation like any other: WX_E_STATE, not a silent difference."""
+    E = pkg.engine
+    X, Y, halo, nslab = 2048, 64, 12, 2
+    base, water, wall, u = _scene(pkg, X, Y)
+    if not wet:
+        u = pkg.params.uniforms_from_gui(pkg.params.merge_settings(None), Y, quad_scale=0, pass_mask=pkg.params.PASS_DRY)
+        u["enablePrecipitation"] = 0
+        base, water, wall = pkg.synth.dry_grid(X, Y, flow_sigma=0.05)
+    p = pkg.params.fill_struct(pkg.params.WxParams(), u)
+    # a quiet flow passes ...
+    g = E.Group(nslab, X, Y, halo=halo, devices=[0] * nslab, transport=E.TRANSPORT_LOCAL)
+    calm = base.copy()
+    calm[..., 0] *= 0.1
+    g.upload(calm, water, wall)
+    g.set_params(p, u["initial_T"])
+    g.step(3)
+    g.read("BASE_CUR")
+    g.close()
+    # ... a jet of 40 cells / iteration in the middle of slab 0 (500 columns from either of its edges; 2 * halo - 8 = 16) does not
+    jet = calm.copy()
+    jet[40:44, 500:506, 0] = np.where(wall[40:44, 500:506, 1] != 0, 40.0, 0.0)
+    g = E.Group(nslab, X, Y, halo=halo, devices=[0] * nslab, transport=E.TRANSPORT_LOCAL)
+    with pytest.raises(E.WxError) as ei:
+        g.upload(jet, water, wall)
+        g.set_params(p, u["initial_T"])
+        g.step(3)
+        g.sync()
+        g.read("BASE_CUR")
+    assert ei.value.code == -5, ei.value
+    g.close()
+
+
 def _particle_scene(pkg, X, Y, N, seed=4):
     """A cloud deck over terrain, droplets everywhere incl. on the slab edges and at the domain edge, a drift that carries them across."""
     base, water, wall = pkg.synth.terrain_grid(X, Y)
