@@ -135,7 +135,8 @@ int wx_create_slab(int X_global, int Y, int x0, int X_owned, int halo, int n_dro
  *                                reaches 1 -- WX_E_STATE if the halo is too thin for it
  *   wx_slab_cone(s), wx_slab_period(s)   ghost columns per iteration / iterations per exchange under the current bound (with particles:
  *                                cone for the first iteration, cone + 3 for every further one, a sprite radius left in the last)
- * A |vx| that reaches the bound inside a period is REPORTED by the next blocking call (WX_E_STATE), never silent. wx_slab_step /
+ * A |vx| that reaches the bound inside a period is REPORTED by the next blocking call (WX_E_STATE), never silent; so is a velocity of
+ * 2 * halo - 8 cells / iteration and more anywhere in the slab (beyond that even the strips three halo widths from the edges read ghost columns). wx_slab_step /
  * wx_group_step do all of this themselves without a host round trip inside a period: the maxima travel with the exchange (one word per
  * slab, all-gathered) and size the period after the next; slab.py's host-driven exchange all-reduces them. Hosts that drive
  * wx_step_overlap / wx_halo_* themselves call the three functions once per period. */
