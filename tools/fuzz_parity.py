@@ -79,6 +79,7 @@ def draw_case(rng, max_cells, big=False):
     c["data_seed"] = int(rng.integers(0, 2**31))
     c["brush_toggle"] = bool(rng.random() < 0.5)  # the brush is held down in every other step only (a host's mouse-up / mouse-down between frames)
     c["pieces"] = bool(rng.random() < 0.3)  # steps cut into two pieces, the first with WX_OVERLAP_MORE_TO_COME
+    c["reupload"] = bool(rng.random() < 0.2)  # after the first step the current state is uploaded again (a host that edits the state: new ping-pong copies, on slabs a fresh exchange period and |vx| scan)
     c["subrect"] = bool(rng.random() < 0.3)  # also read a random sub-rectangle of every field (wx_read_rect's x / y / w / h)
     return c
 
@@ -183,6 +184,10 @@ def case_steps(pkg, E, wx_oracle, c):
                 u2 = dict(u, userInputType=(c["brush"]["type"] if k_step % 2 == 0 else -1))
                 h.set_params(pkg.params.fill_struct(pkg.params.WxParams(), u2), u["initial_T"])
                 o.set_params(u2)
+            if c.get("reupload") and k_step == 1 and not nd:
+                st = [o.field(f) for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR")]
+                h.upload(*st)
+                o.upload(*st)
             pieces = [n]
             if c.get("pieces") and n > 1:  # the step cut into pieces whose all but the last skip the display-side stores (WX_OVERLAP_MORE_TO_COME)
                 k1 = int(rng.integers(1, n))
@@ -274,7 +279,16 @@ def run_group_case(pkg, E, c):
             g.set_option(E.Handle.OPT_POOL_EXACT, c["pool_exact"])
         fields = ["BASE_CUR", "WATER_CUR", "WALL_CUR"] + ([] if c["dry"] else ["LIGHT_0", "LIGHT_1", "BASE_DISP", "WATER_0"]) + (["PRECIP_DEP"] if nd else [])
         done = 0
-        for n in c["steps"]:
+        for k_step, n in enumerate(c["steps"]):
+            if c.get("reupload") and k_step == 1 and not nd:
+                st = [whole.read_rect(f) for f in ("BASE_CUR", "WATER_CUR", "WALL_CUR")]
+                g.upload(*st)
+                whole.upload(*st)
+            if c.get("brush_toggle") and c["brush"] and k_step > 0:  # mouse up / down between two steps
+                u2 = dict(u, userInputType=(c["brush"]["type"] if k_step % 2 == 0 else -1))
+                p2 = pkg.params.fill_struct(pkg.params.WxParams(), u2)
+                g.set_params(p2, u["initial_T"])
+                whole.set_params(p2, u["initial_T"])
             g.step(n)
             whole.step(n)
             done += n
