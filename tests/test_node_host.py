@@ -46,8 +46,10 @@ def test_addon_builds_loads_and_fails_loudly_without_gpu(pkg):
 
 @needs_node
 @pytest.mark.gpu
-def test_node_host_end_to_end_equals_python_host(pkg, golden, tmp_path):
-    """save in -> N iterations through JS/N-API/C-ABI/HIP -> save out == the same run through the Python host."""
+@pytest.mark.parametrize("sun_fixed", [True, False], ids=["sun-fixed", "day-night-cycle"])
+def test_node_host_end_to_end_equals_python_host(pkg, golden, tmp_path, sun_fixed):
+    """save in -> N iterations through JS/N-API/C-ABI/HIP -> save out == the same run through the Python host; with the clock running
+    (dayNightCycle: updateSunlight before every frame, app.js:6510-6561) both hosts push a new sun per frame and still end bit for bit alike."""
     g, u = golden("save100qa_precip")
     settings = {"vorticity": 0.007, "dragMultiplier": 0.01, "wind": -0.0001, "globalDrying": 1e-05, "evapHeat": 1.9, "meltingHeat": 0.6,
                 "waterWeight": 0.5, "subZeroThreshold": 0.01, "spawnChance": 2e-05, "freezingRate": 0.0025, "meltingRate": 0.0025,
@@ -58,11 +60,11 @@ def test_node_host_end_to_end_equals_python_host(pkg, golden, tmp_path):
     pkg.codec.save(src, sf)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
     n = 60
-    out = subprocess.check_output([NODE, os.path.join(ROOT, "host", "sim_host.js"), src, str(n), dst, "--sun-fixed"])
+    out = subprocess.check_output([NODE, os.path.join(ROOT, "host", "sim_host.js"), src, str(n), dst] + (["--sun-fixed"] if sun_fixed else []))
     info = json.loads(out.decode().strip().split("\n")[-1])
     assert info["iterNum"] == n
     got = pkg.codec.load(dst)
-    sim = pkg.WeatherSim.from_save(sf, sun_angle_deg=settings["sunAngle"])
+    sim = pkg.WeatherSim.from_save(sf, sun_angle_deg=settings["sunAngle"]) if sun_fixed else pkg.WeatherSim.from_save(sf)
     left = n
     while left > 0:
         k = min(left, 26)
