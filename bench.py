@@ -361,7 +361,7 @@ def fast_cells_entry(a, h, X, Y, n, clean):
     return {"flow": "the moving fluid + 8 fresh vortices of 1.3 cells / iteration (radius 20) before each of three timed runs", "steps_per_run": n,
             "value": X * Y / worst["ms_per_step"] / 1e3, "unit": "Mcell-steps/s", "ms_per_step": worst["ms_per_step"],
             "vs_clean_flow": worst["ms_per_step"] / clean["ms_per_step"], "runs": runs,
-            "exact_path": "k_dry2_fix: one wavefront per recorded second-iteration cell (csrc/wx_march2.h); bit-identical to one iteration per launch"}
+            "exact_path": "k_dry2_fix: one wavefront per recorded 8 x 8 tile (fast or NaN-tainted second-iteration cells; both iterations rebuilt for the tile from the pair's inputs, csrc/wx_march2.h); bit-identical to one iteration per launch"}
 
 
 def measure_handle(h, cells, steps, warmup, frame, algo_bytes=None, events_in_timed_region=True):
