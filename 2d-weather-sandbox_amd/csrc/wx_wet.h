@@ -1325,8 +1325,11 @@ inline WetLaunch wet_launch_shape(const Geo &g, int air_from_row, int bands_mode
   // Round 5, the reference's own sizes (tools/ref_sizes_bands.py, profiles/r05_ref_sizes.txt): NARROW grids below 512 rows gain from the
   // bands too -- 2500 x 300 (the reference's default: 45 strips) 45.3 -> 36.9 us per iteration, 5000 x 400 65.4 -> 60.0 -- while wide low
   // ones lose (16000 x 300: 120.5 -> 142.6): bands also for grids of fewer than 128 strips that are at least 128 rows high.
+  // Round 6 (tools/ref_sizes_minrows.py, profiles/r06_ref_sizes_minrows.txt): the border re-measured on 17 sizes -- 7200 x 256 / x 448
+  // (129 strips) -15 / -8 % with bands, 8000 x 300 ... 500 (143 strips) -5 % (x 350: +2.5 %), 10000 x 480 (179) +9 %, 12000 and 16000
+  // columns even or worse: fewer than 146 strips. The minimum segment height below is at its optimum for every reference size.
   const int strips_all = (g.X + WOUT - 1) / WOUT;
-  bool bands = bands_mode >= 2 ? g.Y >= 16 : (bands_mode != 0 && WX_WET_BANDS && (g.Y >= 8 * 64 || (strips_all < 128 && g.Y >= 128)));
+  bool bands = bands_mode >= 2 ? g.Y >= 16 : (bands_mode != 0 && WX_WET_BANDS && (g.Y >= 8 * 64 || (strips_all < 146 && g.Y >= 128)));
   if (const char *e = wx_tune_env("WX_WET_BANDS")) bands = atoi(e) >= 2 ? g.Y >= 16 : (atoi(e) != 0 && g.Y >= 8 * 64); // (2: tests force it on small grids)
   const int Y = bands ? (g.Y + 7) / 8 : g.Y; // (bands: the shape of ONE band; the kernel clips it to the band's own height)
   w.segs.bands = bands ? 1 : 0;

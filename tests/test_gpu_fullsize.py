@@ -102,10 +102,10 @@ def test_config2_wet_16384x2048_vs_oracle(pkg, oracle, E):
     _run_pair(pkg, oracle, E, X, Y, _wet_state(pkg, X, Y, 31), _uniforms(pkg, Y), (1, 4), FIELDS_WET)
 
 
-@pytest.mark.parametrize("X,Y,bands", [(10781, 523, "1"), (10781, 523, "0"), (11000, 800, "1"), (2150, 1030, None)])
+@pytest.mark.parametrize("X,Y,bands", [(10781, 523, "1"), (10781, 523, "0"), (11000, 800, "1"), (2150, 1030, None), (7990, 301, None)])
 def test_wet_launch_shapes_on_ragged_grids_vs_oracle(pkg, oracle, E, monkeypatch, X, Y, bands):
     """The launch shapes of the marching wet kernel on grids that divide into nothing: row bands per XCD (wide grids; heights not
-    divisible by 8, last strip ragged), column blocks with the short tail, and a narrow slab-like grid -- with long back-traces
+    divisible by 8, last strip ragged), column blocks with the short tail, a narrow slab-like grid, and a wide LOW grid that takes the bands by the default rule (143 strips, round 6) -- with long back-traces
     (|v| > 0.9: the recorded-mask exact tail crosses segment and band borders). Bit-exact against the oracle."""
     if bands is not None:
         monkeypatch.setenv("WX_WET_BANDS", bands)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 GRIDS = [(16384, 2048), (32768, 4096), (4192, 4096), (2144, 2048), (8240, 2048), (4096, 1024), (10781, 523), (11000, 800), (2150, 1030),
-         (1000, 600), (256, 96), (100, 100), (64, 8), (2, 4), (130, 50), (4100, 20), (512, 512), (57, 511), (56, 513)]
+         (1000, 600), (2500, 300), (7990, 301), (8000, 500), (10000, 480), (256, 96), (100, 100), (64, 8), (2, 4), (130, 50), (4100, 20), (512, 512), (57, 511), (56, 513)]
 
 
 @pytest.fixture(scope="module")
@@ -60,6 +60,8 @@ def test_default_shape_has_a_short_tail_on_the_metric_grid(harness):
     lens = [b - a for a, b in zip(s["start"], s["start"][1:])]
     assert lens[-1] < lens[-2] < lens[0] and lens[0] >= 48  # full segments first, the shortest last
     assert sh[(256, 96)]["bands"] == 0  # low grids keep the column blocks
+    # grids below 512 rows: bands while they are at least 128 rows high and fewer than 146 strips wide (profiles/r06_ref_sizes_minrows.txt)
+    assert sh[(2500, 300)]["bands"] == 1 and sh[(7990, 301)]["bands"] == 1 and sh[(8000, 500)]["bands"] == 1 and sh[(10000, 480)]["bands"] == 0
 
 
 def test_halved_shape_covers_the_same_rows(harness):
